@@ -1,0 +1,75 @@
+// common.h -- shared helpers for the gfx950 kernels of libcloudaae_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CLOUDAAE_API extern "C" __attribute__((visibility("default")))
+
+namespace cloudaae {
+
+// thread-local description of the last failure (read by cloudaae_last_error)
+void set_error(const char *fmt, ...);
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Every C-ABI entry point returns 0 or a hipError_t value; kernels are launched
+// on the caller's stream and never synchronise.
+#define CLOUDAAE_CHECK_LAUNCH(name)                                              \
+    do {                                                                         \
+        hipError_t e__ = hipGetLastError();                                      \
+        if (e__ != hipSuccess) {                                                 \
+            cloudaae::set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return (int)e__;                                                     \
+        }                                                                        \
+    } while (0)
+
+#define CLOUDAAE_CHECK_HIP(expr, name)                                           \
+    do {                                                                         \
+        hipError_t e__ = (expr);                                                 \
+        if (e__ != hipSuccess) {                                                 \
+            cloudaae::set_error("%s: %s", name, hipGetErrorString(e__));         \
+            return (int)e__;                                                     \
+        }                                                                        \
+    } while (0)
+
+#define CLOUDAAE_REQUIRE(cond, name, msg)                                        \
+    do {                                                                         \
+        if (!(cond)) {                                                           \
+            cloudaae::set_error("%s: %s", name, msg);                            \
+            return (int)hipErrorInvalidValue;                                    \
+        }                                                                        \
+    } while (0)
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+// ---- wave64 helpers ------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+} // namespace cloudaae

@@ -1,0 +1,336 @@
+// knn.hip -- fused pairwise distance + k-smallest selection (gfx950).
+//
+// Replaces tf_util.pairwise_xyz_distance + tf_util.knn (reference
+// utils/tf_util.py:597-632), which materialise a [B,N,N] fp32 matrix (134 MB per
+// layer at B=32, N=1024) and then run top_k over it.  Here the matrix never
+// exists: a lane owns one query point (its features and its sorted k-list live in
+// registers), the cloud's points stream through LDS as broadcast reads, and only
+// the [B,N,k] int32 indices are written.
+//
+// Numerics = oracle_knn (oracle/cloudaae_oracle.c):
+//   D[i][j] = (|x_i|^2 + (-2 * <x_i,x_j>)) + |x_j|^2             (tf_util.py:618)
+//   <,>   : channel-ordered fp32 fma chain from +0 (what v_mfma_f32 computes)
+//   |.|^2 : sequential un-fused sum of rounded squares
+//   order : ascending D, ties -> lower j (TopKV2)
+// A workgroup is 4 waves x 64 queries; wave w scans candidate quarter w in
+// ascending j, then wave 0 merges the four sorted lists in wave order with the
+// same stable insertion, which preserves the tie rule.
+#include "common.h"
+#include "../../include/cloudaae_hip.h"
+
+namespace cloudaae {
+
+constexpr int KNN_WAVES = 4;
+constexpr int KNN_THREADS = 64 * KNN_WAVES;
+
+template <int K>
+struct TopK {
+    float d[K];
+    int i[K];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            d[p] = __builtin_inff();
+            i[p] = 0;
+        }
+    }
+    // stable: the newcomer only passes entries that are strictly larger
+    __device__ __forceinline__ void insert(float nd, int ni)
+    {
+        if (nd < d[K - 1]) {
+            d[K - 1] = nd;
+            i[K - 1] = ni;
+#pragma unroll
+            for (int p = K - 1; p > 0; --p) {
+                const bool sw = d[p] < d[p - 1];
+                const float a = d[p - 1], b = d[p];
+                const int ia = i[p - 1], ib = i[p];
+                d[p - 1] = sw ? b : a;
+                d[p] = sw ? a : b;
+                i[p - 1] = sw ? ib : ia;
+                i[p] = sw ? ia : ib;
+            }
+        }
+    }
+};
+
+template <int K>
+__device__ __forceinline__ void merge_and_store(TopK<K> &top, float *mbuf_d, int *mbuf_i, int wave,
+                                                int lane, bool valid, int k, int *dst)
+{
+    // lists of waves 1..3 go through LDS, [wave-1][p][lane]; the buffer aliases
+    // the scan buffers, so every wave must have finished scanning first
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            mbuf_d[((wave - 1) * K + p) * 64 + lane] = top.d[p];
+            mbuf_i[((wave - 1) * K + p) * 64 + lane] = top.i[p];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 0; w < KNN_WAVES - 1; ++w) {
+#pragma unroll
+            for (int p = 0; p < K; ++p)
+                top.insert(mbuf_d[(w * K + p) * 64 + lane], mbuf_i[(w * K + p) * 64 + lane]);
+        }
+        if (valid) {
+#pragma unroll
+            for (int p = 0; p < K; ++p)
+                if (p < k)
+                    dst[p] = top.i[p];
+        }
+    }
+}
+
+// ---- C = 3 (xyz slice of a [*, ld] row) -----------------------------------
+constexpr int KNN3_CHUNK = 256;  // candidates per wave per LDS refill
+
+template <int K>
+__global__ __launch_bounds__(KNN_THREADS) void knn3_kernel(int n, int ld, int k,
+                                                           const float *__restrict__ x,
+                                                           int *__restrict__ nn_idx)
+{
+    // scan buffer (x, y, z, |.|^2 per candidate) and merge buffer share LDS
+    constexpr int SCAN_BYTES = KNN_WAVES * KNN3_CHUNK * 16;
+    constexpr int MERGE_BYTES = (KNN_WAVES - 1) * K * 64 * 8;
+    __shared__ __attribute__((aligned(16))) char smem[SCAN_BYTES > MERGE_BYTES ? SCAN_BYTES : MERGE_BYTES];
+    float4v(*cand)[KNN3_CHUNK] = reinterpret_cast<float4v(*)[KNN3_CHUNK]>(smem);
+    float *mbuf_d = reinterpret_cast<float *>(smem);
+    int *mbuf_i = reinterpret_cast<int *>(smem) + (KNN_WAVES - 1) * K * 64;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cloud = blockIdx.y;
+    const float *X = x + (size_t)cloud * n * ld;
+    const int i = blockIdx.x * 64 + lane;
+    const bool valid = i < n;
+    const int ii = valid ? i : 0;
+    const float qx = X[(size_t)ii * ld], qy = X[(size_t)ii * ld + 1], qz = X[(size_t)ii * ld + 2];
+    float sqi;
+    {
+        const float a = qx * qx, b = qy * qy, c = qz * qz;
+        sqi = 0.0f + a;
+        sqi = sqi + b;
+        sqi = sqi + c;
+    }
+    TopK<K> top;
+    top.init();
+
+    const int per = (n + KNN_WAVES - 1) / KNN_WAVES;
+    const int j_begin = min(wave * per, n), j_end = min(j_begin + per, n);
+    const int rounds = (per + KNN3_CHUNK - 1) / KNN3_CHUNK;  // same for all waves
+    for (int r = 0; r < rounds; ++r) {
+        const int c0 = j_begin + r * KNN3_CHUNK;
+        const int cnt = max(0, min(KNN3_CHUNK, j_end - c0));
+        __syncthreads();
+        for (int s = lane; s < cnt; s += 64) {
+            const float *row = X + (size_t)(c0 + s) * ld;
+            const float cx = row[0], cy = row[1], cz = row[2];
+            const float a = cx * cx, b = cy * cy, c = cz * cz;
+            float sq = 0.0f + a;
+            sq = sq + b;
+            sq = sq + c;
+            cand[wave][s] = float4v{cx, cy, cz, sq};
+        }
+        __syncthreads();
+        for (int s = 0; s < cnt; ++s) {
+            const float4v c = cand[wave][s];
+            float inner = fmaf(qx, c.x, 0.0f);
+            inner = fmaf(qy, c.y, inner);
+            inner = fmaf(qz, c.z, inner);
+            const float m2 = -2.0f * inner;
+            const float t = sqi + m2;
+            const float d = t + c.w;
+            top.insert(d, c0 + s);
+        }
+    }
+    merge_and_store<K>(top, mbuf_d, mbuf_i, wave, lane, valid, k,
+                       nn_idx + ((size_t)cloud * n + ii) * k);
+}
+
+// ---- C = 64 ---------------------------------------------------------------
+constexpr int KNN64_CHUNK = 32;  // candidates per wave per LDS refill (8 KiB)
+
+template <int K>
+__global__ __launch_bounds__(KNN_THREADS) void knn64_kernel(int n, int ld, int k,
+                                                            const float *__restrict__ x,
+                                                            int *__restrict__ nn_idx)
+{
+    // scan buffers (candidate rows + their |.|^2) and merge buffer share LDS
+    constexpr int ROW_BYTES = KNN_WAVES * KNN64_CHUNK * 16 * 16;
+    constexpr int SCAN_BYTES = ROW_BYTES + KNN_WAVES * KNN64_CHUNK * 4;
+    constexpr int MERGE_BYTES = (KNN_WAVES - 1) * K * 64 * 8;
+    __shared__ __attribute__((aligned(16))) char smem[SCAN_BYTES > MERGE_BYTES ? SCAN_BYTES : MERGE_BYTES];
+    float4v(*cand)[KNN64_CHUNK * 16] = reinterpret_cast<float4v(*)[KNN64_CHUNK * 16]>(smem);
+    float(*csq)[KNN64_CHUNK] = reinterpret_cast<float(*)[KNN64_CHUNK]>(smem + ROW_BYTES);
+    float *mbuf_d = reinterpret_cast<float *>(smem);
+    int *mbuf_i = reinterpret_cast<int *>(smem) + (KNN_WAVES - 1) * K * 64;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cloud = blockIdx.y;
+    const float *X = x + (size_t)cloud * n * ld;
+    const int i = blockIdx.x * 64 + lane;
+    const bool valid = i < n;
+    const int ii = valid ? i : 0;
+
+    float4v q[16];
+    float sqi = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        q[g] = *reinterpret_cast<const float4v *>(X + (size_t)ii * ld + 4 * g);
+        const float a = q[g].x * q[g].x, b = q[g].y * q[g].y, c = q[g].z * q[g].z,
+                    d = q[g].w * q[g].w;
+        sqi = sqi + a;
+        sqi = sqi + b;
+        sqi = sqi + c;
+        sqi = sqi + d;
+    }
+    TopK<K> top;
+    top.init();
+
+    const int per = (n + KNN_WAVES - 1) / KNN_WAVES;
+    const int j_begin = min(wave * per, n), j_end = min(j_begin + per, n);
+    const int rounds = (per + KNN64_CHUNK - 1) / KNN64_CHUNK;
+    const int half = lane & 1, cslot = lane >> 1;  // two lanes stage one candidate row
+    for (int r = 0; r < rounds; ++r) {
+        const int c0 = j_begin + r * KNN64_CHUNK;
+        const int cnt = max(0, min(KNN64_CHUNK, j_end - c0));
+        __syncthreads();
+        {
+            // lane pair (2c, 2c+1) loads channels [0,32) / [32,64) of candidate c and
+            // continues ONE sequential |.|^2 sum across the pair (oracle order)
+            float part = 0.0f;
+            float4v v[8];
+            const bool ok = cslot < cnt;
+            const float *row = X + (size_t)(ok ? c0 + cslot : 0) * ld + 32 * half;
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                v[g] = ok ? *reinterpret_cast<const float4v *>(row + 4 * g) : float4v{0, 0, 0, 0};
+            const float first = 0.0f;
+            float lo = first;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float a = v[g].x * v[g].x, b = v[g].y * v[g].y, c = v[g].z * v[g].z,
+                            d = v[g].w * v[g].w;
+                lo = lo + a;
+                lo = lo + b;
+                lo = lo + c;
+                lo = lo + d;
+            }
+            // the odd lane restarts from the even lane's partial sum
+            const float carry = __shfl(lo, lane & ~1, 64);
+            part = carry;
+            if (half) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float a = v[g].x * v[g].x, b = v[g].y * v[g].y, c = v[g].z * v[g].z,
+                                d = v[g].w * v[g].w;
+                    part = part + a;
+                    part = part + b;
+                    part = part + c;
+                    part = part + d;
+                }
+                csq[wave][cslot] = part;
+            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                cand[wave][cslot * 16 + half * 8 + g] = v[g];
+        }
+        __syncthreads();
+        for (int s = 0; s < cnt; ++s) {
+            float inner = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float4v c = cand[wave][s * 16 + g];
+                inner = fmaf(q[g].x, c.x, inner);
+                inner = fmaf(q[g].y, c.y, inner);
+                inner = fmaf(q[g].z, c.z, inner);
+                inner = fmaf(q[g].w, c.w, inner);
+            }
+            const float m2 = -2.0f * inner;
+            const float t = sqi + m2;
+            const float d = t + csq[wave][s];
+            top.insert(d, c0 + s);
+        }
+    }
+    merge_and_store<K>(top, mbuf_d, mbuf_i, wave, lane, valid, k,
+                       nn_idx + ((size_t)cloud * n + ii) * k);
+}
+
+// ---- any other channel count (model variants outside the named configs) ----
+// one lane per query, features re-read from global per candidate; slow, exact.
+template <int K>
+__global__ __launch_bounds__(KNN_THREADS) void knn_generic_kernel(int n, int c, int ld, int k,
+                                                                  const float *__restrict__ x,
+                                                                  int *__restrict__ nn_idx)
+{
+    const int cloud = blockIdx.y;
+    const float *X = x + (size_t)cloud * n * ld;
+    const int i = blockIdx.x * KNN_THREADS + threadIdx.x;
+    if (i >= n)
+        return;
+    float sqi = 0.0f;
+    for (int ch = 0; ch < c; ++ch) {
+        const float v = X[(size_t)i * ld + ch];
+        const float v2 = v * v;
+        sqi = sqi + v2;
+    }
+    TopK<K> top;
+    top.init();
+    for (int j = 0; j < n; ++j) {
+        float inner = 0.0f, sqj = 0.0f;
+        for (int ch = 0; ch < c; ++ch) {
+            const float v = X[(size_t)j * ld + ch];
+            const float v2 = v * v;
+            sqj = sqj + v2;
+            inner = fmaf(X[(size_t)i * ld + ch], v, inner);
+        }
+        const float m2 = -2.0f * inner;
+        const float t = sqi + m2;
+        top.insert(t + sqj, j);
+    }
+    for (int p = 0; p < k && p < K; ++p)
+        nn_idx[((size_t)cloud * n + i) * k + p] = top.i[p];
+}
+
+template <int K>
+static void launch_knn(int b, int n, int c, int ld, int k, const float *x, int *nn_idx,
+                       hipStream_t s)
+{
+    if (c == 3)
+        hipLaunchKernelGGL(knn3_kernel<K>, dim3(ceil_div(n, 64), b), dim3(KNN_THREADS), 0, s, n, ld,
+                           k, x, nn_idx);
+    else if (c == 64 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0)
+        hipLaunchKernelGGL(knn64_kernel<K>, dim3(ceil_div(n, 64), b), dim3(KNN_THREADS), 0, s, n,
+                           ld, k, x, nn_idx);
+    else
+        hipLaunchKernelGGL(knn_generic_kernel<K>, dim3(ceil_div(n, KNN_THREADS), b),
+                           dim3(KNN_THREADS), 0, s, n, c, ld, k, x, nn_idx);
+}
+
+} // namespace cloudaae
+
+using namespace cloudaae;
+
+CLOUDAAE_API int cloudaae_knn(int b, int n, int c, int ld, int k, const float *x, int *nn_idx,
+                              cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_knn";
+    CLOUDAAE_REQUIRE(b >= 0 && n >= 0 && c > 0 && ld >= c, name, "bad size");
+    CLOUDAAE_REQUIRE(k >= 1 && k <= 32, name, "k must be in [1,32]");
+    CLOUDAAE_REQUIRE(b <= 65535, name, "batch > 65535");
+    if (b == 0 || n == 0)
+        return 0;
+    CLOUDAAE_REQUIRE(k <= n, name, "k > number of points (tf.nn.top_k would reject it)");
+    hipStream_t s = (hipStream_t)stream;
+    if (k <= 10)
+        launch_knn<10>(b, n, c, ld, k, x, nn_idx, s);
+    else if (k <= 20)
+        launch_knn<20>(b, n, c, ld, k, x, nn_idx, s);
+    else
+        launch_knn<32>(b, n, c, ld, k, x, nn_idx, s);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}

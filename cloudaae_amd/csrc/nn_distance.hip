@@ -1,0 +1,239 @@
+// nn_distance.hip -- Chamfer nearest-neighbour forward/backward for gfx950.
+//
+// Replaces NmDistanceKernelLauncher / NmDistanceGradKernelLauncher
+// (reference tf_ops/nn_distance/tf_nndistance_g.cu:128-131,152-157) and computes
+// exactly what the reference CPU op does (tf_nndistance.cpp:21-43,126-163):
+//   dist = min_k ((dx*dx + dy*dy) + dz*dz), un-fused fp32, strict '<', first
+//   minimum wins.
+//
+// Design (not the reference's 512-point smem tiles with the running minimum
+// round-tripping through global memory):
+//   * one launch covers both directions; a workgroup owns 256*Q queries of one
+//     cloud and streams the whole other cloud through LDS in chunks, laid out
+//     as quads [x0..x3 | y0..y3 | z0..z3] so one ds_read_b128 per coordinate is
+//     a broadcast read of four candidates and the arithmetic is v_pk_*_f32 on
+//     candidate pairs;
+//   * the hot loop tracks only the minimum VALUE per 16-candidate tile (squared
+//     distances are >= +0, so their bit patterns order as unsigned integers:
+//     v_min3_u32, no NaN canonicalisation) plus the tile in which the running
+//     minimum last improved; the arg-min is recovered afterwards by rescanning
+//     that one tile -- first index whose distance equals the minimum, which is
+//     the reference's first-wins rule;
+//   * results stay in registers; each output is written once.
+// Build flags matter: -ffp-contract=off keeps mul/add un-fused (bit-parity with
+// the CPU reference).
+#include "common.h"
+#include "../../include/cloudaae_hip.h"
+
+namespace cloudaae {
+
+constexpr int NN_THREADS = 256;
+constexpr int NN_CHUNK = 1024;  // candidates per LDS chunk (12 KiB)
+constexpr int NN_TILE = 16;     // candidates per min-tracking tile
+
+__device__ __forceinline__ unsigned umin3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned t = a < b ? a : b;
+    return t < c ? t : c;
+}
+
+// un-fused squared distance of one candidate, same association as the oracle
+__device__ __forceinline__ float sqdist(float cx, float cy, float cz, float qx, float qy, float qz)
+{
+    const float dx = cx - qx, dy = cy - qy, dz = cz - qz;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+template <int Q>
+__global__ __launch_bounds__(NN_THREADS) void nn_distance_kernel(
+    int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    float *__restrict__ dist1, int *__restrict__ idx1, float *__restrict__ dist2,
+    int *__restrict__ idx2, int tiles1)
+{
+    __shared__ float4v lds[NN_CHUNK / 4 * 3];
+
+    const int tid = threadIdx.x;
+    const int cloud = blockIdx.y;
+    const bool second = (int)blockIdx.x >= tiles1;
+    const int tile = second ? (int)blockIdx.x - tiles1 : (int)blockIdx.x;
+    const int nq = second ? m : n;   // queries in this direction
+    const int nc = second ? n : m;   // candidates
+    const float *from = (second ? xyz2 : xyz1) + (size_t)cloud * nq * 3;
+    const float *to = (second ? xyz1 : xyz2) + (size_t)cloud * nc * 3;
+    float *dist = (second ? dist2 : dist1) + (size_t)cloud * nq;
+    int *idx = (second ? idx2 : idx1) + (size_t)cloud * nq;
+
+    float qx[Q], qy[Q], qz[Q];
+    unsigned best[Q];
+    int btile[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int j = tile * (NN_THREADS * Q) + q * NN_THREADS + tid;
+        const bool ok = j < nq;
+        qx[q] = ok ? from[3 * j] : 0.0f;
+        qy[q] = ok ? from[3 * j + 1] : 0.0f;
+        qz[q] = ok ? from[3 * j + 2] : 0.0f;
+        best[q] = 0x7f800000u;  // +inf
+        btile[q] = 0;
+    }
+
+    float *lds_f = reinterpret_cast<float *>(lds);
+    for (int c0 = 0; c0 < nc; c0 += NN_CHUNK) {
+        const int cnt = min(NN_CHUNK, nc - c0);
+        const int padded = (cnt + NN_TILE - 1) / NN_TILE * NN_TILE;
+        __syncthreads();
+        for (int f = tid; f < padded * 3; f += NN_THREADS) {
+            const int k = f / 3, a = f - 3 * k;
+            const float v = k < cnt ? to[(size_t)(c0 + k) * 3 + a] : __builtin_inff();
+            lds_f[(k >> 2) * 12 + a * 4 + (k & 3)] = v;
+        }
+        __syncthreads();
+        const int ntile = padded / NN_TILE;
+        for (int t = 0; t < ntile; ++t) {
+            unsigned tmin[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                tmin[q] = 0x7f800000u;
+#pragma unroll
+            for (int g = 0; g < NN_TILE / 4; ++g) {
+                const float4v X = lds[(t * (NN_TILE / 4) + g) * 3 + 0];
+                const float4v Y = lds[(t * (NN_TILE / 4) + g) * 3 + 1];
+                const float4v Z = lds[(t * (NN_TILE / 4) + g) * 3 + 2];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const float2v x0 = {X.x, X.y}, x1 = {X.z, X.w};
+                    const float2v y0 = {Y.x, Y.y}, y1 = {Y.z, Y.w};
+                    const float2v z0 = {Z.x, Z.y}, z1 = {Z.z, Z.w};
+                    const float2v dx0 = x0 - qx[q], dx1 = x1 - qx[q];
+                    const float2v dy0 = y0 - qy[q], dy1 = y1 - qy[q];
+                    const float2v dz0 = z0 - qz[q], dz1 = z1 - qz[q];
+                    const float2v d0 = dx0 * dx0 + dy0 * dy0 + dz0 * dz0;
+                    const float2v d1 = dx1 * dx1 + dy1 * dy1 + dz1 * dz1;
+                    tmin[q] = umin3(tmin[q], __float_as_uint(d0.x), __float_as_uint(d0.y));
+                    tmin[q] = umin3(tmin[q], __float_as_uint(d1.x), __float_as_uint(d1.y));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const bool better = tmin[q] < best[q];
+                best[q] = better ? tmin[q] : best[q];
+                btile[q] = better ? (c0 / NN_TILE + t) : btile[q];
+            }
+        }
+    }
+
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int j = tile * (NN_THREADS * Q) + q * NN_THREADS + tid;
+        if (j >= nq)
+            continue;
+        if (nc == 0) {  // tf_nndistance.cpp:28-29: best = 0, besti = 0 survive an empty loop
+            dist[j] = 0.0f;
+            idx[j] = 0;
+            continue;
+        }
+        const int base = btile[q] * NN_TILE;
+        int arg = base;
+        for (int s = NN_TILE - 1; s >= 0; --s) {
+            const int k = base + s;
+            if (k < nc) {
+                const float d = sqdist(to[3 * (size_t)k], to[3 * (size_t)k + 1],
+                                       to[3 * (size_t)k + 2], qx[q], qy[q], qz[q]);
+                arg = (__float_as_uint(d) == best[q]) ? k : arg;
+            }
+        }
+        dist[j] = __uint_as_float(best[q]);
+        idx[j] = arg;
+    }
+}
+
+// Backward: one thread per point and direction.  grad_a[j] += 2 g (a_j - b_t),
+// grad_b[t] -= same (tf_nndistance.cpp:131-161).  Both sweeps run concurrently
+// and accumulate with hardware fp32 atomics into zero-filled outputs, i.e. the
+// summation ORDER differs from the reference's sequential CPU sweep (as does the
+// reference's own GPU kernel, tf_nndistance_g.cu:143-148).
+__global__ __launch_bounds__(256) void nn_distance_grad_kernel(
+    int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    const float *__restrict__ grad_dist1, const int *__restrict__ idx1,
+    const float *__restrict__ grad_dist2, const int *__restrict__ idx2,
+    float *__restrict__ grad_xyz1, float *__restrict__ grad_xyz2, int blocks1)
+{
+    const int cloud = blockIdx.y;
+    const bool second = (int)blockIdx.x >= blocks1;
+    const int blk = second ? (int)blockIdx.x - blocks1 : (int)blockIdx.x;
+    const int j = blk * 256 + (int)threadIdx.x;
+    const int na = second ? m : n, nb = second ? n : m;
+    if (j >= na)
+        return;
+    const float *A = (second ? xyz2 : xyz1) + (size_t)cloud * na * 3;
+    const float *B = (second ? xyz1 : xyz2) + (size_t)cloud * nb * 3;
+    float *gA = second ? grad_xyz2 : grad_xyz1;
+    float *gB = second ? grad_xyz1 : grad_xyz2;
+    const int t = (second ? idx2 : idx1)[(size_t)cloud * na + j];
+    const float g = (second ? grad_dist2 : grad_dist1)[(size_t)cloud * na + j] * 2;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float v = g * (A[3 * j + a] - B[3 * (size_t)t + a]);
+        if (gA)
+            atomicAdd(&gA[((size_t)cloud * na + j) * 3 + a], v);
+        if (gB)
+            atomicAdd(&gB[((size_t)cloud * nb + t) * 3 + a], -v);
+    }
+}
+
+} // namespace cloudaae
+
+using namespace cloudaae;
+
+CLOUDAAE_API int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2,
+                                      float *dist1, int *idx1, float *dist2, int *idx2,
+                                      cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_nn_distance";
+    CLOUDAAE_REQUIRE(b >= 0 && n >= 0 && m >= 0, name, "negative size");
+    if (b == 0 || (n == 0 && m == 0))
+        return 0;
+    CLOUDAAE_REQUIRE(b <= 65535, name, "batch > 65535");
+    hipStream_t s = (hipStream_t)stream;
+    // queries per lane: enough workgroups to fill 256 CUs first, then amortise
+    // LDS reads over more queries
+    const long long total = (long long)b * ((long long)n + m);
+    const int Q = total >= 4LL * 256 * 1024 ? 4 : (total >= 256LL * 1024 ? 2 : 1);
+    const int t1 = ceil_div(n, NN_THREADS * Q), t2 = ceil_div(m, NN_THREADS * Q);
+    dim3 grid(t1 + t2, b), block(NN_THREADS);
+    if (Q == 4)
+        hipLaunchKernelGGL(nn_distance_kernel<4>, grid, block, 0, s, n, m, xyz1, xyz2, dist1, idx1,
+                           dist2, idx2, t1);
+    else if (Q == 2)
+        hipLaunchKernelGGL(nn_distance_kernel<2>, grid, block, 0, s, n, m, xyz1, xyz2, dist1, idx1,
+                           dist2, idx2, t1);
+    else
+        hipLaunchKernelGGL(nn_distance_kernel<1>, grid, block, 0, s, n, m, xyz1, xyz2, dist1, idx1,
+                           dist2, idx2, t1);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_nn_distance_grad(int b, int n, const float *xyz1, int m,
+                                           const float *xyz2, const float *grad_dist1,
+                                           const int *idx1, const float *grad_dist2,
+                                           const int *idx2, float *grad_xyz1, float *grad_xyz2,
+                                           cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_nn_distance_grad";
+    CLOUDAAE_REQUIRE(b >= 0 && n >= 0 && m >= 0, name, "negative size");
+    CLOUDAAE_REQUIRE(b <= 65535, name, "batch > 65535");
+    hipStream_t s = (hipStream_t)stream;
+    // the callee zero-fills, as tf_nndistance_g.cu:153-154 does
+    if (grad_xyz1 && (size_t)b * n)
+        CLOUDAAE_CHECK_HIP(hipMemsetAsync(grad_xyz1, 0, sizeof(float) * (size_t)b * n * 3, s), name);
+    if (grad_xyz2 && (size_t)b * m)
+        CLOUDAAE_CHECK_HIP(hipMemsetAsync(grad_xyz2, 0, sizeof(float) * (size_t)b * m * 3, s), name);
+    if (b == 0 || n == 0 || m == 0)
+        return 0;
+    const int b1 = ceil_div(n, 256), b2 = ceil_div(m, 256);
+    hipLaunchKernelGGL(nn_distance_grad_kernel, dim3(b1 + b2, b), dim3(256), 0, s, n, m, xyz1, xyz2,
+                       grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2, b1);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}

@@ -1,0 +1,297 @@
+// sampling.hip -- farthest point sampling, point gather and its gradient (gfx950).
+//
+// Replaces farthestpointsamplingLauncher / gatherpointLauncher /
+// scatteraddpointLauncher (reference tf_ops/sampling/tf_sampling_g.cu:203-211).
+//
+// FPS is `m-1` dependent rounds; the cost is the per-round latency, so the
+// design keeps everything a round touches on chip: one 512-thread workgroup per
+// cloud, each thread owns points k = t, t+512, ... with their coordinates AND
+// running minimum distance in registers (the reference round-trips the running
+// minimum through a global `temp` array, tf_sampling_g.cu:139,144), the cloud is
+// mirrored in LDS only to fetch the last pick's coordinates, and the arg-max is
+// a single order-independent u64 max-reduction per round:
+//      key = bits(d2) << 32 | (511 - t) << 23 | p          (k = t + 512 p)
+// d2 >= 0, so its bit pattern orders like the float.  The largest key is the
+// reference's winner -- max value, then lowest k mod 512, then lowest k -- which
+// its thread-strided scan + left-biased tree (:130-165) produces.  One barrier
+// per round (ping-pong LDS slots).
+#include "common.h"
+#include "../../include/cloudaae_hip.h"
+
+namespace cloudaae {
+
+constexpr int FPS_THREADS = 512;
+constexpr int FPS_WAVES = FPS_THREADS / 64;
+
+__device__ __forceinline__ float fps_sqdist(float x2, float y2, float z2, float x1, float y1, float z1)
+{
+    // tf_sampling_g.cu:142, un-fused, left to right
+    const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// PPT = points per thread held in registers (n <= 512*PPT).
+// LDS_XYZ: cloud mirrored in dynamic LDS (12 n bytes) for the last-pick fetch.
+template <int PPT, bool LDS_XYZ>
+__global__ __launch_bounds__(FPS_THREADS) void fps_reg_kernel(int n, int m,
+                                                              const float *__restrict__ inp,
+                                                              int *__restrict__ out)
+{
+    extern __shared__ float lds_xyz[];
+    __shared__ unsigned long long slot[2][FPS_WAVES];
+
+    const int t = threadIdx.x;
+    const int cloud = blockIdx.x;
+    const float *P = inp + (size_t)cloud * n * 3;
+    int *O = out + (size_t)cloud * m;
+
+    float px[PPT], py[PPT], pz[PPT], run[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        const int k = t + FPS_THREADS * p;
+        const bool ok = k < n;
+        px[p] = ok ? P[3 * k] : 0.0f;
+        py[p] = ok ? P[3 * k + 1] : 0.0f;
+        pz[p] = ok ? P[3 * k + 2] : 0.0f;
+        run[p] = 1e38f;  // tf_sampling_g.cu:117
+    }
+    if (LDS_XYZ) {
+        for (int f = t; f < n * 3; f += FPS_THREADS)
+            lds_xyz[f] = P[f];
+    }
+    if (t == 0)
+        O[0] = 0;
+    __syncthreads();
+
+    int last = 0;
+    for (int j = 1; j < m; ++j) {
+        float ox, oy, oz;
+        if (LDS_XYZ) {
+            ox = lds_xyz[3 * last];
+            oy = lds_xyz[3 * last + 1];
+            oz = lds_xyz[3 * last + 2];
+        } else {
+            ox = P[3 * last];
+            oy = P[3 * last + 1];
+            oz = P[3 * last + 2];
+        }
+        unsigned bestv = 0;
+        unsigned bestp = 0;
+        bool any = false;
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            const int k = t + FPS_THREADS * p;
+            if (k < n) {
+                const float d = fps_sqdist(px[p], py[p], pz[p], ox, oy, oz);
+                const float d2 = fminf(d, run[p]);
+                run[p] = d2;
+                const unsigned u = __float_as_uint(d2);
+                // strict '>' keeps the first maximum of this thread (:146)
+                if (!any || u > bestv) {
+                    bestv = u;
+                    bestp = p;
+                    any = true;
+                }
+            }
+        }
+        unsigned long long key = 0;
+        if (any)
+            key = ((unsigned long long)bestv << 32) |
+                  ((unsigned long long)(FPS_THREADS - 1 - t) << 23) | bestp;
+        key = wave_max_u64(key);
+        if ((t & 63) == 0)
+            slot[j & 1][t >> 6] = key;
+        __syncthreads();
+        unsigned long long w = slot[j & 1][0];
+#pragma unroll
+        for (int i = 1; i < FPS_WAVES; ++i) {
+            const unsigned long long o = slot[j & 1][i];
+            w = o > w ? o : w;
+        }
+        const unsigned lo = (unsigned)w;
+        last = (FPS_THREADS - 1 - (int)((lo >> 23) & 511u)) + FPS_THREADS * (int)(lo & 0x7fffffu);
+        if (t == 0)
+            O[j] = last;
+    }
+}
+
+// n > 16384: running minimum in the caller's `temp` (32*n floats, one row per
+// workgroup, as tf_sampling.cpp:115 sizes it); clouds strided over <= 32 groups.
+__global__ __launch_bounds__(FPS_THREADS) void fps_big_kernel(int b, int n, int m,
+                                                              const float *__restrict__ inp,
+                                                              float *__restrict__ temp,
+                                                              int *__restrict__ out)
+{
+    __shared__ unsigned long long slot[2][FPS_WAVES];
+    const int t = threadIdx.x;
+    float *run = temp + (size_t)blockIdx.x * n;
+    for (int cloud = blockIdx.x; cloud < b; cloud += gridDim.x) {
+        const float *P = inp + (size_t)cloud * n * 3;
+        int *O = out + (size_t)cloud * m;
+        for (int k = t; k < n; k += FPS_THREADS)
+            run[k] = 1e38f;
+        if (t == 0)
+            O[0] = 0;
+        __syncthreads();
+        int last = 0;
+        for (int j = 1; j < m; ++j) {
+            const float ox = P[3 * last], oy = P[3 * last + 1], oz = P[3 * last + 2];
+            unsigned bestv = 0, bestp = 0;
+            bool any = false;
+            unsigned p = 0;
+            for (int k = t; k < n; k += FPS_THREADS, ++p) {
+                const float d = fps_sqdist(P[3 * k], P[3 * k + 1], P[3 * k + 2], ox, oy, oz);
+                const float d2 = fminf(d, run[k]);
+                run[k] = d2;
+                const unsigned u = __float_as_uint(d2);
+                if (!any || u > bestv) {
+                    bestv = u;
+                    bestp = p;
+                    any = true;
+                }
+            }
+            unsigned long long key = 0;
+            if (any)
+                key = ((unsigned long long)bestv << 32) |
+                      ((unsigned long long)(FPS_THREADS - 1 - t) << 23) | bestp;
+            key = wave_max_u64(key);
+            if ((t & 63) == 0)
+                slot[j & 1][t >> 6] = key;
+            __syncthreads();
+            unsigned long long w = slot[j & 1][0];
+            for (int i = 1; i < FPS_WAVES; ++i) {
+                const unsigned long long o = slot[j & 1][i];
+                w = o > w ? o : w;
+            }
+            const unsigned lo = (unsigned)w;
+            last = (FPS_THREADS - 1 - (int)((lo >> 23) & 511u)) +
+                   FPS_THREADS * (int)(lo & 0x7fffffu);
+            if (t == 0)
+                O[j] = last;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_point_kernel(int n, int m,
+                                                           const float *__restrict__ inp,
+                                                           const int *__restrict__ idx,
+                                                           float *__restrict__ out)
+{
+    const int cloud = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m)
+        return;
+    const int a = idx[(size_t)cloud * m + j];
+    const float *src = inp + ((size_t)cloud * n + a) * 3;
+    float *dst = out + ((size_t)cloud * m + j) * 3;
+    dst[0] = src[0];
+    dst[1] = src[1];
+    dst[2] = src[2];
+}
+
+__global__ __launch_bounds__(256) void scatter_add_point_kernel(int n, int m,
+                                                                const float *__restrict__ out_g,
+                                                                const int *__restrict__ idx,
+                                                                float *__restrict__ inp_g)
+{
+    const int cloud = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m)
+        return;
+    const int a = idx[(size_t)cloud * m + j];
+    const float *src = out_g + ((size_t)cloud * m + j) * 3;
+    float *dst = inp_g + ((size_t)cloud * n + a) * 3;
+    atomicAdd(dst + 0, src[0]);
+    atomicAdd(dst + 1, src[1]);
+    atomicAdd(dst + 2, src[2]);
+}
+
+template <int PPT>
+static int launch_fps_reg(int b, int n, int m, const float *inp, int *out, hipStream_t s)
+{
+    const size_t lds = (size_t)n * 3 * sizeof(float);
+    if (lds <= 96 * 1024) {
+        // opt in to > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void *)fps_reg_kernel<PPT, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                set_error("cloudaae_farthest_point_sample: %s", hipGetErrorString(e));
+                return (int)e;
+            }
+        }
+        hipLaunchKernelGGL((fps_reg_kernel<PPT, true>), dim3(b), dim3(FPS_THREADS), lds, s, n, m,
+                           inp, out);
+    } else {
+        hipLaunchKernelGGL((fps_reg_kernel<PPT, false>), dim3(b), dim3(FPS_THREADS), 0, s, n, m,
+                           inp, out);
+    }
+    return 0;
+}
+
+} // namespace cloudaae
+
+using namespace cloudaae;
+
+CLOUDAAE_API int cloudaae_farthest_point_sample(int b, int n, int m, const float *inp, float *temp,
+                                                int *out, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_farthest_point_sample";
+    CLOUDAAE_REQUIRE(b >= 0 && n >= 0 && m >= 0, name, "negative size");
+    if (b == 0 || m == 0)
+        return 0;  // tf_sampling_g.cu:106-107
+    CLOUDAAE_REQUIRE(n > 0, name, "empty cloud");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = 0;
+    if (n <= 512)
+        rc = launch_fps_reg<1>(b, n, m, inp, out, s);
+    else if (n <= 1024)
+        rc = launch_fps_reg<2>(b, n, m, inp, out, s);
+    else if (n <= 2048)
+        rc = launch_fps_reg<4>(b, n, m, inp, out, s);
+    else if (n <= 4096)
+        rc = launch_fps_reg<8>(b, n, m, inp, out, s);
+    else if (n <= 8192)
+        rc = launch_fps_reg<16>(b, n, m, inp, out, s);
+    else if (n <= 16384)
+        rc = launch_fps_reg<32>(b, n, m, inp, out, s);
+    else {
+        CLOUDAAE_REQUIRE(temp != nullptr, name, "n > 16384 needs the 32*n float workspace");
+        hipLaunchKernelGGL(fps_big_kernel, dim3(b < 32 ? b : 32), dim3(FPS_THREADS), 0, s, b, n, m,
+                           inp, temp, out);
+    }
+    if (rc)
+        return rc;
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_gather_point(int b, int n, int m, const float *inp, const int *idx,
+                                       float *out, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_gather_point";
+    CLOUDAAE_REQUIRE(b >= 0 && n >= 0 && m >= 0 && b <= 65535, name, "bad size");
+    if (b == 0 || m == 0)
+        return 0;
+    hipLaunchKernelGGL(gather_point_kernel, dim3(ceil_div(m, 256), b), dim3(256), 0,
+                       (hipStream_t)stream, n, m, inp, idx, out);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_gather_point_grad(int b, int n, int m, const float *out_g, const int *idx,
+                                            float *inp_g, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_gather_point_grad";
+    CLOUDAAE_REQUIRE(b >= 0 && n >= 0 && m >= 0 && b <= 65535, name, "bad size");
+    hipStream_t s = (hipStream_t)stream;
+    if ((size_t)b * n)
+        CLOUDAAE_CHECK_HIP(hipMemsetAsync(inp_g, 0, sizeof(float) * (size_t)b * n * 3, s), name);
+    if (b == 0 || m == 0)
+        return 0;
+    hipLaunchKernelGGL(scatter_add_point_kernel, dim3(ceil_div(m, 256), b), dim3(256), 0, s, n, m,
+                       out_g, idx, inp_g);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}

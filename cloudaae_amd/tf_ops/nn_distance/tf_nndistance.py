@@ -1,0 +1,92 @@
+"""Chamfer nearest-neighbour op -- mirror of the reference's
+tf_ops/nn_distance/tf_nndistance.py:14-37 (`nn_distance` + its registered gradient),
+backed by cloudaae_nn_distance / cloudaae_nn_distance_grad (include/cloudaae_hip.h).
+"""
+import torch
+
+from ... import _lib
+from ..._lib import ptr, require, stream
+
+
+def _check_cloud(name, t):
+    # same conditions as the OP_REQUIREs of tf_nndistance.cpp:51-58
+    require(t.dim() == 3, "NnDistance requires %s be of shape (batch,#points,3)" % name)
+    require(t.shape[2] == 3, "NnDistance only accepts 3d point set %s" % name)
+    require(t.dtype == torch.float32, "NnDistance: %s must be float32" % name)
+
+
+class _NnDistance(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        _check_cloud("xyz1", xyz1)
+        _check_cloud("xyz2", xyz2)
+        require(xyz1.shape[0] == xyz2.shape[0],
+                "NnDistance expects xyz1 and xyz2 have same batch size")
+        xyz1 = xyz1.contiguous()
+        xyz2 = xyz2.contiguous()
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        dist1 = torch.empty((b, n), dtype=torch.float32, device=xyz1.device)
+        idx1 = torch.empty((b, n), dtype=torch.int32, device=xyz1.device)
+        dist2 = torch.empty((b, m), dtype=torch.float32, device=xyz1.device)
+        idx2 = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+        _lib.check(_lib.lib().cloudaae_nn_distance(b, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1),
+                                                   ptr(idx1), ptr(dist2), ptr(idx2), stream()),
+                   "cloudaae_nn_distance")
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        ctx.mark_non_differentiable(idx1, idx2)
+        return dist1, idx1, dist2, idx2
+
+    @staticmethod
+    def backward(ctx, grad_dist1, grad_idx1, grad_dist2, grad_idx2):
+        # grad_idx* are ignored, as in tf_nndistance.py:31-37
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        need1, need2 = ctx.needs_input_grad
+        if grad_dist1 is None:
+            grad_dist1 = torch.zeros((b, n), dtype=torch.float32, device=xyz1.device)
+        if grad_dist2 is None:
+            grad_dist2 = torch.zeros((b, m), dtype=torch.float32, device=xyz1.device)
+        g1 = torch.empty_like(xyz1) if need1 else None
+        g2 = torch.empty_like(xyz2) if need2 else None
+        _lib.check(_lib.lib().cloudaae_nn_distance_grad(
+            b, n, ptr(xyz1), m, ptr(xyz2), ptr(grad_dist1.contiguous()), ptr(idx1),
+            ptr(grad_dist2.contiguous()), ptr(idx2), ptr(g1), ptr(g2), stream()),
+            "cloudaae_nn_distance_grad")
+        return g1, g2
+
+
+def nn_distance(xyz1, xyz2):
+    """
+Computes the distance of nearest neighbors for a pair of point clouds
+input: xyz1: (batch_size,#points_1,3)  the first point cloud
+input: xyz2: (batch_size,#points_2,3)  the second point cloud
+output: dist1: (batch_size,#point_1)   distance from first to second
+output: idx1:  (batch_size,#point_1)   nearest neighbor from first to second
+output: dist2: (batch_size,#point_2)   distance from second to first
+output: idx2:  (batch_size,#point_2)   nearest neighbor from second to first
+    """
+    return _NnDistance.apply(xyz1, xyz2)
+
+
+def nn_distance_grad(xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2):
+    """The NnDistanceGrad op itself (tf_nndistance.cpp:10-18): (grad_xyz1, grad_xyz2)."""
+    _check_cloud("xyz1", xyz1)
+    _check_cloud("xyz2", xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    require(xyz2.shape[0] == b, "NnDistanceGrad expects xyz1 and xyz2 have same batch size")
+    require(tuple(grad_dist1.shape) == (b, n), "NnDistanceGrad requires grad_dist1 be of shape(batch,#points)")
+    require(tuple(idx1.shape) == (b, n), "NnDistanceGrad requires idx1 be of shape(batch,#points)")
+    require(tuple(grad_dist2.shape) == (b, m), "NnDistanceGrad requires grad_dist2 be of shape(batch,#points)")
+    require(tuple(idx2.shape) == (b, m), "NnDistanceGrad requires idx2 be of shape(batch,#points)")
+    require(idx1.dtype == torch.int32 and idx2.dtype == torch.int32, "idx must be int32")
+    xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
+    g1 = torch.empty_like(xyz1)
+    g2 = torch.empty_like(xyz2)
+    _lib.check(_lib.lib().cloudaae_nn_distance_grad(
+        b, n, ptr(xyz1), m, ptr(xyz2), ptr(grad_dist1.contiguous()), ptr(idx1.contiguous()),
+        ptr(grad_dist2.contiguous()), ptr(idx2.contiguous()), ptr(g1), ptr(g2), stream()),
+        "cloudaae_nn_distance_grad")
+    return g1, g2

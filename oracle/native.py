@@ -1,0 +1,189 @@
+"""ctypes/numpy front-end of the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  Nothing under cloudaae_amd/ does.
+
+  liboracle.so               our C restatement (oracle/cloudaae_oracle.c)
+  _ref/libref_nndistance.so  the reference's own Chamfer lines, when built
+                             (oracle/build_ref.sh); `ref_*` raise if absent.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_c_f = ctypes.POINTER(ctypes.c_float)
+_c_i = ctypes.POINTER(ctypes.c_int32)
+
+
+def build(quiet=True):
+    """Compile liboracle.so (and _ref when /root/reference exists)."""
+    subprocess.run(["make", "-C", _HERE, "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def _load(path):
+    if not os.path.exists(path):
+        return None
+    return ctypes.CDLL(path)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        p = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(p):
+            build()
+        _lib = ctypes.CDLL(p)
+    return _lib
+
+
+def ref():
+    """The reference-lines library, or None when it was not built."""
+    global _ref
+    if _ref is None:
+        _ref = _load(os.path.join(_HERE, "_ref", "libref_nndistance.so"))
+    return _ref
+
+
+def have_ref():
+    return ref() is not None
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_c_f)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_c_i)
+
+
+def max_threads():
+    return int(lib().oracle_max_threads())
+
+
+def nn_distance(xyz1, xyz2, threads=1):
+    """(dist1, idx1, dist2, idx2) -- tf_nndistance.cpp:21-43,79-80."""
+    xyz1, p1 = _f(xyz1)
+    xyz2, p2 = _f(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    d1 = np.zeros((b, n), np.float32)
+    i1 = np.zeros((b, n), np.int32)
+    d2 = np.zeros((b, m), np.float32)
+    i2 = np.zeros((b, m), np.int32)
+    lib().oracle_nn_distance(b, n, m, p1, p2, d1.ctypes.data_as(_c_f), i1.ctypes.data_as(_c_i),
+                             d2.ctypes.data_as(_c_f), i2.ctypes.data_as(_c_i), int(threads))
+    return d1, i1, d2, i2
+
+
+def nn_distance_grad(xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2, threads=1):
+    """(grad_xyz1, grad_xyz2) -- tf_nndistance.cpp:126-163."""
+    xyz1, p1 = _f(xyz1)
+    xyz2, p2 = _f(xyz2)
+    g1, pg1 = _f(grad_dist1)
+    g2, pg2 = _f(grad_dist2)
+    i1, pi1 = _i(idx1)
+    i2, pi2 = _i(idx2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    o1 = np.zeros((b, n, 3), np.float32)
+    o2 = np.zeros((b, m, 3), np.float32)
+    lib().oracle_nn_distance_grad(b, n, m, p1, p2, pg1, pi1, pg2, pi2,
+                                  o1.ctypes.data_as(_c_f), o2.ctypes.data_as(_c_f), int(threads))
+    return o1, o2
+
+
+def ref_nn_distance(xyz1, xyz2):
+    r = ref()
+    if r is None:
+        raise RuntimeError("oracle/_ref/libref_nndistance.so not built")
+    xyz1, p1 = _f(xyz1)
+    xyz2, p2 = _f(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    d1 = np.zeros((b, n), np.float32)
+    i1 = np.zeros((b, n), np.int32)
+    d2 = np.zeros((b, m), np.float32)
+    i2 = np.zeros((b, m), np.int32)
+    r.ref_nn_distance(b, n, m, p1, p2, d1.ctypes.data_as(_c_f), i1.ctypes.data_as(_c_i),
+                      d2.ctypes.data_as(_c_f), i2.ctypes.data_as(_c_i))
+    return d1, i1, d2, i2
+
+
+def ref_nn_distance_grad(xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2):
+    r = ref()
+    if r is None:
+        raise RuntimeError("oracle/_ref/libref_nndistance.so not built")
+    xyz1, p1 = _f(xyz1)
+    xyz2, p2 = _f(xyz2)
+    g1, pg1 = _f(grad_dist1)
+    g2, pg2 = _f(grad_dist2)
+    i1, pi1 = _i(idx1)
+    i2, pi2 = _i(idx2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    o1 = np.zeros((b, n, 3), np.float32)
+    o2 = np.zeros((b, m, 3), np.float32)
+    r.ref_nn_distance_grad(b, n, m, p1, p2, pg1, pi1, pg2, pi2,
+                           o1.ctypes.data_as(_c_f), o2.ctypes.data_as(_c_f))
+    return o1, o2
+
+
+def farthest_point_sample(npoint, inp, threads=1):
+    """idx [b, npoint] int32 -- tf_sampling_g.cu:105-170."""
+    inp, p = _f(inp)
+    b, n, _ = inp.shape
+    out = np.zeros((b, npoint), np.int32)
+    lib().oracle_farthest_point_sample(b, n, int(npoint), p, out.ctypes.data_as(_c_i), int(threads))
+    return out
+
+
+def gather_point(inp, idx):
+    inp, p = _f(inp)
+    idx, pi = _i(idx)
+    b, n, _ = inp.shape
+    m = idx.shape[1]
+    out = np.zeros((b, m, 3), np.float32)
+    lib().oracle_gather_point(b, n, m, p, pi, out.ctypes.data_as(_c_f))
+    return out
+
+
+def gather_point_grad(inp_shape, idx, out_g):
+    idx, pi = _i(idx)
+    out_g, pg = _f(out_g)
+    b, n, _ = inp_shape
+    m = idx.shape[1]
+    inp_g = np.zeros((b, n, 3), np.float32)
+    lib().oracle_gather_point_grad(b, n, m, pg, pi, inp_g.ctypes.data_as(_c_f))
+    return inp_g
+
+
+def knn(x, k, channels=None, threads=1, return_dist=False):
+    """nn_idx [b, n, k] int32 -- tf_util.py:597-632 on the first `channels` of x[b,n,ld]."""
+    x, p = _f(x)
+    b, n, ld = x.shape
+    c = ld if channels is None else int(channels)
+    idx = np.zeros((b, n, k), np.int32)
+    dist = np.zeros((b, n, k), np.float32) if return_dist else None
+    lib().oracle_knn(b, n, c, ld, int(k), p, idx.ctypes.data_as(_c_i),
+                     dist.ctypes.data_as(_c_f) if return_dist else None, int(threads))
+    return (idx, dist) if return_dist else idx
+
+
+def pairwise_distance(x, channels=None):
+    """D [n, n] of ONE cloud x[n, ld] -- tf_util.py:597-618."""
+    x, p = _f(x)
+    n, ld = x.shape
+    c = ld if channels is None else int(channels)
+    D = np.zeros((n, n), np.float32)
+    lib().oracle_pairwise_distance(n, c, ld, p, D.ctypes.data_as(_c_f))
+    return D

@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import native
+    native.lib()
+    return native
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The loaded HIP library on a GPU box; fails (never skips) if it is missing."""
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked test started without a GPU"
+    from cloudaae_amd import _lib
+    _lib.lib()
+    return _lib

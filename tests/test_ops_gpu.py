@@ -1,0 +1,175 @@
+"""GPU: tf_ops custom operators and kNN grouping through the C-ABI vs the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+CHAMFER = ["chamfer_seed0_1x5x6", "chamfer_rand_2x256x256", "chamfer_dup_ties_2x64x64",
+           "chamfer_ragged_3x77x1031"]
+
+
+@pytest.mark.parametrize("name", CHAMFER)
+def test_nn_distance_golden_bit_exact(hip, golden_dir, name):
+    from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
+    g = _load(golden_dir, name)
+    d1, i1, d2, i2 = tf_nndistance.nn_distance(_dev(g["xyz1"]), _dev(g["xyz2"]))
+    assert i1.dtype == torch.int32 and i2.dtype == torch.int32
+    assert np.array_equal(i1.cpu().numpy(), g["idx1"])
+    assert np.array_equal(i2.cpu().numpy(), g["idx2"])
+    assert np.array_equal(d1.cpu().numpy(), g["dist1"])  # bit-exact fp32
+    assert np.array_equal(d2.cpu().numpy(), g["dist2"])
+    gx1, gx2 = tf_nndistance.nn_distance_grad(_dev(g["xyz1"]), _dev(g["xyz2"]), _dev(g["grad_dist1"]),
+                                              i1, _dev(g["grad_dist2"]), i2)
+    # atomics: summation order differs from the sequential CPU sweep -> fp32 tolerance
+    np.testing.assert_allclose(gx1.cpu().numpy(), g["grad_xyz1"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gx2.cpu().numpy(), g["grad_xyz2"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 3, 1000), (3, 257, 255), (4, 1024, 4096),
+                                   (2, 4096, 4096), (2, 5000, 17), (40, 512, 300)])
+def test_nn_distance_vs_oracle(hip, oracle, b, n, m):
+    from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
+    rng = np.random.default_rng(b * 1000 + n + m)
+    a = (rng.standard_normal((b, n, 3)) * 0.05 + [0.1, -0.2, 0.9]).astype(np.float32)
+    c = (rng.standard_normal((b, m, 3)) * 0.05 + [0.1, -0.2, 0.9]).astype(np.float32)
+    if m > 40:
+        c[:, m // 2:m // 2 + 20] = c[:, :20]   # duplicated candidates: first must win
+    want = oracle.nn_distance(a, c, threads=8)
+    got = tf_nndistance.nn_distance(_dev(a), _dev(c))
+    for w, g_ in zip(want, got):
+        assert np.array_equal(w, g_.cpu().numpy())
+
+
+def test_nn_distance_autograd_and_empty(hip, oracle):
+    from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((2, 100, 3)).astype(np.float32)
+    c = rng.standard_normal((2, 90, 3)).astype(np.float32)
+    ta = _dev(a).requires_grad_(True)
+    tc = _dev(c).requires_grad_(True)
+    d1, i1, d2, i2 = tf_nndistance.nn_distance(ta, tc)
+    w1 = _dev(rng.standard_normal((2, 100)).astype(np.float32))
+    w2 = _dev(rng.standard_normal((2, 90)).astype(np.float32))
+    ((d1 * w1).sum() + (d2 * w2).sum()).backward()
+    o = oracle.nn_distance(a, c)
+    g1, g2 = oracle.nn_distance_grad(a, c, w1.cpu().numpy(), o[1], w2.cpu().numpy(), o[3])
+    np.testing.assert_allclose(ta.grad.cpu().numpy(), g1, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(tc.grad.cpu().numpy(), g2, rtol=1e-5, atol=1e-6)
+    # m == 0: dist 0 / idx 0 (tf_nndistance.cpp:28-29 survive an empty loop)
+    e = torch.zeros((2, 0, 3), device="cuda")
+    d1, i1, d2, i2 = tf_nndistance.nn_distance(_dev(a), e)
+    assert (d1 == 0).all() and (i1 == 0).all() and d2.shape == (2, 0)
+    # shape errors mirror the OP_REQUIREs
+    with pytest.raises(ValueError):
+        tf_nndistance.nn_distance(_dev(a)[:, :, :2], _dev(c))
+    with pytest.raises(ValueError):
+        tf_nndistance.nn_distance(_dev(a), _dev(c)[:1])
+
+
+def test_nn_distance_full_size_properties(hip):
+    """BASELINE config sizes (B=32, n=m=4096): size-independent properties."""
+    from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
+    gen = torch.Generator(device="cuda").manual_seed(100)
+    a = torch.randn((32, 4096, 3), generator=gen, device="cuda")
+    c = torch.randn((32, 4096, 3), generator=gen, device="cuda")
+    d1, i1, d2, i2 = tf_nndistance.nn_distance(a, c)
+    # (1) the reported distance is the distance to the reported index (un-fused formula)
+    nb = torch.gather(c, 1, i1.long()[:, :, None].expand(-1, -1, 3))
+    diff = nb - a
+    dd = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+    assert torch.equal(dd, d1)
+    # (2) swapping the clouds swaps the outputs
+    e1, j1, e2, j2 = tf_nndistance.nn_distance(c, a)
+    assert torch.equal(e1, d2) and torch.equal(j1, i2) and torch.equal(e2, d1) and torch.equal(j2, i1)
+    # (3) a cloud against itself: zero distance; index = first duplicate = itself for distinct points
+    z1, k1, _, _ = tf_nndistance.nn_distance(a, a)
+    assert (z1 == 0).all() and torch.equal(k1, torch.arange(4096, device="cuda", dtype=torch.int32).expand(32, -1))
+    # (4) brute force on a sample of rows (tf_nndistance.py:77-85)
+    rows = torch.randint(0, 4096, (64,), device="cuda")
+    D = ((a[:, rows, None, :] - c[:, None, :, :]) ** 2).sum(-1)
+    assert torch.equal(D.argmin(-1).int(), i1[:, rows]) or (D.min(-1).values - d1[:, rows]).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("name", ["fps_rand_2x1024_to_256", "fps_dup_2x700_to_128",
+                                  "fps_lattice_1x1500_to_300"])
+def test_fps_golden_bit_exact(hip, golden_dir, name):
+    from cloudaae_amd.tf_ops.sampling import tf_sampling
+    g = _load(golden_dir, name)
+    out = tf_sampling.farthest_point_sample(int(g["npoint"]), _dev(g["inp"]))
+    assert out.dtype == torch.int32
+    assert np.array_equal(out.cpu().numpy(), g["out"])
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 1, 4), (3, 100, 100), (2, 513, 64), (4, 4096, 1024),
+                                   (1, 9000, 50), (33, 2048, 128), (1, 20000, 40)])
+def test_fps_vs_oracle(hip, oracle, b, n, m):
+    from cloudaae_amd.tf_ops.sampling import tf_sampling
+    rng = np.random.default_rng(n + m)
+    p = rng.standard_normal((b, n, 3)).astype(np.float32)
+    if n > 200:
+        p[:, n // 2:n // 2 + 100] = p[:, :100]
+    want = oracle.farthest_point_sample(m, p, threads=8)
+    got = tf_sampling.farthest_point_sample(m, _dev(p)).cpu().numpy()
+    assert np.array_equal(want, got)
+
+
+def test_gather_point_and_grad(hip, oracle):
+    from cloudaae_amd.tf_ops.sampling import tf_sampling
+    rng = np.random.default_rng(4)
+    inp = rng.standard_normal((3, 300, 3)).astype(np.float32)
+    idx = rng.integers(0, 300, (3, 70)).astype(np.int32)
+    t = _dev(inp).requires_grad_(True)
+    out = tf_sampling.gather_point(t, _dev(idx))
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.gather_point(inp, idx))
+    og = rng.standard_normal((3, 70, 3)).astype(np.float32)
+    out.backward(_dev(og))
+    np.testing.assert_allclose(t.grad.cpu().numpy(), oracle.gather_point_grad(inp.shape, idx, og),
+                               rtol=1e-5, atol=1e-6)
+    # unique indices (what FPS produces): exact
+    perm = np.stack([rng.permutation(300)[:70] for _ in range(3)]).astype(np.int32)
+    g = tf_sampling.gather_point_grad(_dev(inp), _dev(perm), _dev(og))
+    assert np.array_equal(g.cpu().numpy(), oracle.gather_point_grad(inp.shape, perm, og))
+    # eval-path composition (evaluate_cloudAAE_ycbv.py:450)
+    sub = tf_sampling.gather_point(_dev(inp), tf_sampling.farthest_point_sample(32, _dev(inp)))
+    assert sub.shape == (3, 32, 3)
+
+
+@pytest.mark.parametrize("name", ["knn_xyz_dup_2x300_k10", "knn_feat64_2x257_k10",
+                                  "knn_feat64_2x257_k20"])
+def test_knn_golden_bit_exact(hip, golden_dir, name):
+    from cloudaae_amd.utils import tf_util
+    g = _load(golden_dir, name)
+    x = _dev(g["x"])
+    c = int(g["channels"])
+    adj = tf_util.pairwise_xyz_distance(x if c == 3 else x[:, :, None, :])
+    nn_idx = tf_util.knn(adj, k=int(g["k"]))
+    assert nn_idx.dtype == torch.int32
+    assert np.array_equal(nn_idx.cpu().numpy(), g["nn_idx"])
+
+
+@pytest.mark.parametrize("b,n,c,ld,k", [(2, 256, 3, 24, 10), (3, 1024, 3, 24, 10), (2, 1000, 3, 3, 20),
+                                        (2, 256, 64, 64, 10), (4, 1024, 64, 64, 10), (2, 777, 64, 64, 20),
+                                        (1, 4096, 64, 64, 20), (2, 130, 64, 64, 5), (2, 100, 16, 16, 7),
+                                        (1, 64, 3, 24, 32)])
+def test_knn_vs_oracle(hip, oracle, b, n, c, ld, k):
+    from cloudaae_amd import _lib
+    rng = np.random.default_rng(n * 7 + c + k)
+    x = np.maximum(rng.standard_normal((b, n, ld)), -0.5).astype(np.float32) * 0.1
+    x[:, n // 2:n // 2 + 30] = x[:, :30]      # duplicates -> exact ties
+    want = oracle.knn(x, k, channels=c, threads=8)
+    xd = _dev(x)
+    got = torch.empty((b, n, k), dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().cloudaae_knn(b, n, c, ld, k, _lib.ptr(xd), _lib.ptr(got), _lib.stream()), "knn")
+    assert np.array_equal(want, got.cpu().numpy())

@@ -1,0 +1,145 @@
+"""CPU: the oracle against the committed golden vectors and its own properties."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+CHAMFER = ["chamfer_seed0_1x5x6", "chamfer_rand_2x256x256", "chamfer_dup_ties_2x64x64",
+           "chamfer_ragged_3x77x1031"]
+
+
+@pytest.mark.parametrize("name", CHAMFER)
+def test_chamfer_oracle_matches_reference_lines(oracle, golden_dir, name):
+    # expected outputs were produced by the reference's own C++ lines (oracle/_ref)
+    g = _load(golden_dir, name)
+    d1, i1, d2, i2 = oracle.nn_distance(g["xyz1"], g["xyz2"])
+    assert np.array_equal(i1, g["idx1"]) and np.array_equal(i2, g["idx2"])
+    assert np.array_equal(d1, g["dist1"]) and np.array_equal(d2, g["dist2"])
+    gx1, gx2 = oracle.nn_distance_grad(g["xyz1"], g["xyz2"], g["grad_dist1"], i1, g["grad_dist2"], i2)
+    assert np.array_equal(gx1, g["grad_xyz1"]) and np.array_equal(gx2, g["grad_xyz2"])
+
+
+def test_chamfer_seed0_known_answer(oracle, golden_dir):
+    # the reference's only seeded input (tf_nndistance_cpu.py:28-46) and its brute-force matrix
+    g = _load(golden_dir, "chamfer_seed0_1x5x6")
+    np.random.seed(0)
+    assert np.array_equal(np.random.random((1, 5, 3)), g["pc1_f64"])
+    assert np.array_equal(np.random.random((1, 6, 3)), g["pc2_f64"])
+    D = g["brute_f64"]
+    d1, i1, d2, i2 = oracle.nn_distance(g["xyz1"], g["xyz2"])
+    assert np.array_equal(i1[0], D.argmin(1)) and np.array_equal(i2[0], D.argmin(0))
+    np.testing.assert_allclose(d1[0], D.min(1), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(d2[0], D.min(0), rtol=0, atol=1e-6)
+
+
+def test_chamfer_against_live_reference_lines(oracle):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference on this box)")
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((3, 130, 3)).astype(np.float32)
+    b = rng.standard_normal((3, 513, 3)).astype(np.float32)
+    b[:, 400:] = b[:, :113]
+    ours, ref = oracle.nn_distance(a, b), oracle.ref_nn_distance(a, b)
+    for x, y in zip(ours, ref):
+        assert np.array_equal(x, y)
+    g1 = rng.standard_normal((3, 130)).astype(np.float32)
+    g2 = rng.standard_normal((3, 513)).astype(np.float32)
+    og = oracle.nn_distance_grad(a, b, g1, ours[1], g2, ours[3])
+    rg = oracle.ref_nn_distance_grad(a, b, g1, ours[1], g2, ours[3])
+    assert np.array_equal(og[0], rg[0]) and np.array_equal(og[1], rg[1])
+    # OpenMP over the batch must not change the per-cloud order
+    og8 = oracle.nn_distance_grad(a, b, g1, ours[1], g2, ours[3], threads=4)
+    assert np.array_equal(og[0], og8[0]) and np.array_equal(og[1], og8[1])
+
+
+def test_chamfer_brute_force_semantics(oracle):
+    # tf_nndistance.py:77-85: squared L2 min / argmin
+    rng = np.random.default_rng(7)
+    a = rng.standard_normal((2, 50, 3)).astype(np.float32)
+    b = rng.standard_normal((2, 70, 3)).astype(np.float32)
+    d1, i1, d2, i2 = oracle.nn_distance(a, b)
+    D = ((a[:, :, None, :].astype(np.float64) - b[:, None, :, :]) ** 2).sum(-1)
+    assert np.array_equal(i1, D.argmin(2)) and np.array_equal(i2, D.argmin(1))
+    np.testing.assert_allclose(d1, D.min(2), atol=1e-5)
+
+
+def test_chamfer_empty_other_cloud(oracle):
+    a = np.ones((2, 4, 3), np.float32)
+    b = np.zeros((2, 0, 3), np.float32)
+    d1, i1, d2, i2 = oracle.nn_distance(a, b)
+    assert (d1 == 0).all() and (i1 == 0).all() and d2.shape == (2, 0)
+
+
+@pytest.mark.parametrize("name", ["fps_rand_2x1024_to_256", "fps_dup_2x700_to_128",
+                                  "fps_lattice_1x1500_to_300"])
+def test_fps_golden_and_property(oracle, golden_dir, name):
+    g = _load(golden_dir, name)
+    out = oracle.farthest_point_sample(int(g["npoint"]), g["inp"])
+    assert np.array_equal(out, g["out"])
+    # property: pick j is an arg-max of the running min distance to picks < j
+    P = g["inp"]
+    for c in range(P.shape[0]):
+        run = np.full(P.shape[1], 1e38, np.float32)
+        assert out[c, 0] == 0
+        for j in range(1, out.shape[1]):
+            d = P[c] - P[c, out[c, j - 1]]
+            d = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            run = np.minimum(run, d.astype(np.float32))
+            assert run[out[c, j]] == run.max()
+            # tie-break of tf_sampling_g.cu:130-165: lowest k mod 512, then lowest k
+            ties = np.flatnonzero(run == run.max())
+            want = min(ties, key=lambda k: (k % 512, k))
+            assert out[c, j] == want
+
+
+@pytest.mark.parametrize("name", ["knn_xyz_dup_2x300_k10", "knn_feat64_2x257_k10",
+                                  "knn_feat64_2x257_k20"])
+def test_knn_golden_and_stable_argsort(oracle, golden_dir, name):
+    g = _load(golden_dir, name)
+    k, c = int(g["k"]), int(g["channels"])
+    idx = oracle.knn(g["x"], k, channels=c)
+    assert np.array_equal(idx, g["nn_idx"])
+    for cl in range(g["x"].shape[0]):
+        D = oracle.pairwise_distance(g["x"][cl], channels=c)
+        assert np.array_equal(idx[cl], np.argsort(D, axis=1, kind="stable")[:, :k])
+
+
+def test_knn_formula_order(oracle):
+    # D = (sq_i + (-2*inner)) + sq_j with fp32 fma-chain inner (tf_util.py:613-618)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((40, 8)).astype(np.float32)
+    D = oracle.pairwise_distance(x)
+    sq = np.zeros(40, np.float32)
+    for ch in range(8):
+        sq = sq + x[:, ch] * x[:, ch]
+    inner = np.zeros((40, 40), np.float64)
+    for ch in range(8):  # fmaf = exact product + one rounding
+        inner = (x[:, None, ch].astype(np.float64) * x[None, :, ch].astype(np.float64) + inner
+                 ).astype(np.float32).astype(np.float64)
+    want = (sq[:, None] + (-2 * inner).astype(np.float32)).astype(np.float32) + sq[None, :]
+    assert np.array_equal(D, want.astype(np.float32))
+
+
+def test_gather_and_grad(oracle):
+    rng = np.random.default_rng(4)
+    inp = rng.standard_normal((2, 30, 3)).astype(np.float32)
+    idx = rng.integers(0, 30, (2, 12)).astype(np.int32)
+    out = oracle.gather_point(inp, idx)
+    assert np.array_equal(out, np.take_along_axis(inp, idx[:, :, None].astype(np.int64), 1))
+    og = rng.standard_normal((2, 12, 3)).astype(np.float32)
+    ig = oracle.gather_point_grad(inp.shape, idx, og)
+    want = np.zeros_like(inp)
+    for c in range(2):
+        for j in range(12):
+            want[c, idx[c, j]] += og[c, j]
+    assert np.array_equal(ig, want)
+
+
+def test_golden_files_present(golden_dir):
+    assert len(glob.glob(os.path.join(golden_dir, "*.npz"))) >= 10
