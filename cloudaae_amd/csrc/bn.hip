@@ -1,0 +1,320 @@
+// bn.hip -- batch normalisation (+ReLU, +pool over points) on dense [M,C] rows.
+//
+// Replaces batch_norm_template and its wrappers (reference utils/tf_util.py:473-570)
+// as used after every conv2d / fully_connected (tf_util.py:168-173, 354-357), and the
+// symmetric pooling over the point axis that follows dgcnn_agg / pn_conv5
+// (models/pointnet_ycb_23_decoder_4.py:419 mean, :684 and :59-60 max).
+//   training : mean, var = tf.nn.moments (biased variance) over all M rows;
+//              EMA shadows   s <- s - (s - stat) * (1 - decay)   (assign_moving_average,
+//              shadows start at 0, no zero-debias: tf_util.py:493-500)
+//   inference: mean, var = EMA shadows (tf_util.py:507-509)
+//   output   : tf.nn.batch_normalization with eps 1e-3 (tf_util.py:510):
+//              inv = gamma * rsqrt(var + eps);  z = y * inv + (beta - mean * inv)
+// Forward is a column reduction (fp64 partial sums, two-level, no atomics, so the
+// moments are deterministic), one tiny per-channel finalise, and one streaming
+// apply pass that can write the activation, its pool over groups of `pool_rows`
+// rows, or both.  Backward is the same shape.  All passes are HBM streaming:
+// a wave reads 64 consecutive channels of a row (256 B), four rows in flight per
+// workgroup.
+#include "bn_common.h"
+#include "../../include/cloudaae_hip.h"
+
+namespace cloudaae {
+
+// ---- forward: column sums ------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_colsum_kernel(int M, int C, const float *__restrict__ y,
+                                                       int ldy, double *__restrict__ partial, int parts)
+{
+    __shared__ double red[2][4][64];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    double s = 0.0, s2 = 0.0;
+    if (c < C) {
+        for (int r = blockIdx.y * 4 + rl; r < M; r += 4 * parts) {
+            const float v = y[(size_t)r * ldy + c];
+            s += (double)v;
+            s2 += (double)v * (double)v;
+        }
+    }
+    red[0][rl][lane] = s;
+    red[1][rl][lane] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    }
+}
+
+// ---- forward: apply (+ReLU), optional activation output, optional pooling ---------
+// grid (ceil(C/64), groups); block 64 channels x 4 row lanes; a group is
+// `rows` consecutive rows (the N points of one cloud when pooling, else a slab).
+template <int POOL>  // 0 none, 1 mean, 2 max
+__global__ __launch_bounds__(256) void bn_apply_kernel(int M, int C, const float *__restrict__ y,
+                                                      int ldy, const float *__restrict__ scale_shift,
+                                                      int relu, float *__restrict__ out, int ldo,
+                                                      int rows, float *__restrict__ pooled,
+                                                      float *__restrict__ ties)
+{
+    __shared__ float red[4][64];
+    __shared__ float redc[4][64];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rows;
+    const int r1 = min(M, r0 + rows);
+    float acc = POOL == 2 ? -__builtin_inff() : 0.0f;
+    float cnt = 0.0f;
+    if (c < C) {
+        const float sc = scale_shift[c], sh = scale_shift[C + c];
+        for (int r = r0 + rl; r < r1; r += 4) {
+            float z = y[(size_t)r * ldy + c] * sc + sh;
+            if (relu)
+                z = fmaxf(z, 0.0f);
+            if (out != nullptr)
+                out[(size_t)r * ldo + c] = z;
+            if (POOL == 1)
+                acc = acc + z;
+            if (POOL == 2) {
+                if (z > acc) {
+                    acc = z;
+                    cnt = 1.0f;
+                } else if (z == acc) {
+                    cnt += 1.0f;
+                }
+            }
+        }
+    }
+    if (POOL != 0) {
+        red[rl][lane] = acc;
+        redc[rl][lane] = cnt;
+        __syncthreads();
+        if (rl == 0 && c < C) {
+            if (POOL == 1) {
+                const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+                pooled[(size_t)blockIdx.y * C + c] = s / (float)(r1 - r0);
+            } else {
+                float m = red[0][lane], n = redc[0][lane];
+                for (int i = 1; i < 4; ++i) {
+                    if (red[i][lane] > m) {
+                        m = red[i][lane];
+                        n = redc[i][lane];
+                    } else if (red[i][lane] == m) {
+                        n += redc[i][lane];
+                    }
+                }
+                pooled[(size_t)blockIdx.y * C + c] = m;
+                if (ties != nullptr)
+                    ties[(size_t)blockIdx.y * C + c] = n;
+            }
+        }
+    }
+}
+
+// ---- backward ---------------------------------------------------------------------
+// upstream gradient of the activation at (r, c):
+//   dout[r][c]                                   (plain activation output)
+// + dpooled[g][c] / rows                         (mean pool, g = r / rows)
+// + dpooled[g][c] * [z == max] / ties            (max pool: tf.reduce_max shares
+//                                                 the gradient among equal maxima)
+// times the ReLU mask [z > 0].
+struct BnBwdArgs {
+    int M, C, ldy, lddo, rows, pool, relu, training;
+    const float *y, *dout, *dpooled, *pooled, *ties;
+    const float *gamma, *save_mean, *save_var, *scale_shift;
+};
+
+__device__ __forceinline__ float bn_upstream(const BnBwdArgs &a, int r, int c, float z)
+{
+    float g = 0.0f;
+    if (a.dout != nullptr)
+        g = a.dout[(size_t)r * a.lddo + c];
+    if (a.pool == 1) {
+        g += a.dpooled[(size_t)(r / a.rows) * a.C + c] / (float)a.rows;
+    } else if (a.pool == 2) {
+        const size_t gi = (size_t)(r / a.rows) * a.C + c;
+        if (z == a.pooled[gi])
+            g += a.dpooled[gi] / a.ties[gi];
+    }
+    if (a.relu && !(z > 0.0f))
+        g = 0.0f;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_colsum_kernel(BnBwdArgs a, double *__restrict__ partial,
+                                                           int parts)
+{
+    __shared__ double red[2][4][64];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    double s = 0.0, s2 = 0.0;
+    if (c < a.C) {
+        const float sc = a.scale_shift[c], sh = a.scale_shift[a.C + c];
+        const float mean = a.save_mean[c], rstd = bn_rsqrt(a.save_var[c] + BN_EPS);
+        for (int r = blockIdx.y * 4 + rl; r < a.M; r += 4 * parts) {
+            const float v = a.y[(size_t)r * a.ldy + c];
+            float z = v * sc + sh;
+            if (a.relu)
+                z = fmaxf(z, 0.0f);
+            const float dz = bn_upstream(a, r, c, z);
+            const float xh = (v - mean) * rstd;
+            s += (double)dz;
+            s2 += (double)dz * (double)xh;
+        }
+    }
+    red[0][rl][lane] = s;
+    red[1][rl][lane] = s2;
+    __syncthreads();
+    if (rl == 0 && c < a.C) {
+        partial[((size_t)blockIdx.y * 2 + 0) * a.C + c] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        partial[((size_t)blockIdx.y * 2 + 1) * a.C + c] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const float *__restrict__ m12,
+                                                          float *__restrict__ dy, int lddy, int slab)
+{
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    if (c >= a.C)
+        return;
+    const float sc = a.scale_shift[c], sh = a.scale_shift[a.C + c];
+    const float mean = a.save_mean[c], rstd = bn_rsqrt(a.save_var[c] + BN_EPS);
+    const float m1 = m12[c], m2 = m12[a.C + c];
+    const float gr = a.gamma[c] * rstd;
+    const int r0 = blockIdx.y * slab, r1 = min(a.M, r0 + slab);
+    for (int r = r0 + rl; r < r1; r += 4) {
+        const float v = a.y[(size_t)r * a.ldy + c];
+        float z = v * sc + sh;
+        if (a.relu)
+            z = fmaxf(z, 0.0f);
+        const float dz = bn_upstream(a, r, c, z);
+        const float xh = (v - mean) * rstd;
+        dy[(size_t)r * lddy + c] = gr * ((dz - m1) - xh * m2);
+    }
+}
+
+// plain column sums (bias gradients): out[c] (+)= sum_r x[r][c]
+__global__ void colsum_finalize_kernel(int C, const double *__restrict__ partial, int parts,
+                                       float *__restrict__ out, int accumulate)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C)
+        return;
+    double s = 0.0;
+    for (int p = 0; p < parts; ++p)
+        s += partial[((size_t)p * 2 + 0) * C + c];
+    out[c] = (accumulate ? out[c] : 0.0f) + (float)s;
+}
+
+static int bn_parts(int M)
+{
+    int p = M / 64;
+    if (p < 1)
+        p = 1;
+    if (p > BN_MAX_PARTS)
+        p = BN_MAX_PARTS;
+    return p;
+}
+
+} // namespace cloudaae
+
+using namespace cloudaae;
+
+CLOUDAAE_API long long cloudaae_bn_workspace_bytes(int C) { return (long long)(bn_ws_doubles(C) * sizeof(double)); }
+
+CLOUDAAE_API int cloudaae_bn_forward(int M, int C, const float *y, int ldy, const float *gamma,
+                                     const float *beta, int training, const float *decay,
+                                     float *ema_mean, float *ema_var, float *save_mean, float *save_var,
+                                     int relu, float *out, int ldo, int pool_rows, int pool_mode,
+                                     float *pooled, float *tie_count, void *workspace,
+                                     cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_bn_forward";
+    CLOUDAAE_REQUIRE(M > 0 && C > 0 && ldy >= C, name, "bad size");
+    CLOUDAAE_REQUIRE(workspace != nullptr && gamma && beta && save_mean && save_var, name, "null argument");
+    CLOUDAAE_REQUIRE(training || (ema_mean && ema_var), name, "inference needs the EMA statistics");
+    CLOUDAAE_REQUIRE(!training || !ema_mean || decay, name, "EMA update needs the decay scalar");
+    CLOUDAAE_REQUIRE(pool_mode >= 0 && pool_mode <= 2, name, "pool_mode must be 0 (none), 1 (mean) or 2 (max)");
+    CLOUDAAE_REQUIRE(pool_mode == 0 || (pool_rows > 0 && M % pool_rows == 0 && pooled), name,
+                     "pooling needs pool_rows | M and an output");
+    CLOUDAAE_REQUIRE(pool_mode != 0 || out != nullptr, name, "no output requested");
+    hipStream_t s = (hipStream_t)stream;
+    double *partial = (double *)workspace;
+    float *scale_shift = (float *)(partial + (size_t)BN_MAX_PARTS * 2 * C);
+    const int parts = bn_parts(M);
+    const int cb = ceil_div(C, 64);
+    if (training)
+        hipLaunchKernelGGL(bn_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, M, C, y, ldy, partial, parts);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, C, partial, parts,
+                       (double)M, training, decay, ema_mean, ema_var, gamma, beta, save_mean, save_var,
+                       scale_shift);
+    if (pool_mode == 0) {
+        const int slab = 64;
+        hipLaunchKernelGGL(bn_apply_kernel<0>, dim3(cb, ceil_div(M, slab)), dim3(256), 0, s, M, C, y, ldy,
+                           scale_shift, relu, out, ldo, slab, nullptr, nullptr);
+    } else {
+        CLOUDAAE_REQUIRE(M / pool_rows <= 65535, name, "too many pooling groups");
+        if (pool_mode == 1)
+            hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(cb, M / pool_rows), dim3(256), 0, s, M, C, y, ldy,
+                               scale_shift, relu, out, ldo, pool_rows, pooled, tie_count);
+        else
+            hipLaunchKernelGGL(bn_apply_kernel<2>, dim3(cb, M / pool_rows), dim3(256), 0, s, M, C, y, ldy,
+                               scale_shift, relu, out, ldo, pool_rows, pooled, tie_count);
+    }
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, const float *gamma,
+                                      const float *beta, const float *save_mean, const float *save_var,
+                                      int training, int relu, const float *dout, int lddo, int pool_rows,
+                                      int pool_mode, const float *dpooled, const float *pooled,
+                                      const float *tie_count, float *dy, int lddy, float *dgamma,
+                                      float *dbeta, int accumulate_param_grads, void *workspace,
+                                      cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_bn_backward";
+    CLOUDAAE_REQUIRE(M > 0 && C > 0 && ldy >= C, name, "bad size");
+    CLOUDAAE_REQUIRE(workspace && gamma && beta && save_mean && save_var && dy, name, "null argument");
+    CLOUDAAE_REQUIRE(pool_mode >= 0 && pool_mode <= 2, name, "bad pool_mode");
+    CLOUDAAE_REQUIRE(pool_mode == 0 || (pool_rows > 0 && M % pool_rows == 0 && dpooled), name,
+                     "pooled gradient needs pool_rows | M");
+    CLOUDAAE_REQUIRE(pool_mode != 2 || (pooled && tie_count), name, "max pool backward needs max and tie count");
+    CLOUDAAE_REQUIRE(dout != nullptr || pool_mode != 0, name, "no upstream gradient");
+    hipStream_t s = (hipStream_t)stream;
+    double *partial = (double *)workspace;
+    float *scratch = (float *)(partial + (size_t)BN_MAX_PARTS * 2 * C);
+    float *scale_shift = scratch, *m12 = scratch + 2 * (size_t)C;
+    hipLaunchKernelGGL(bn_scale_shift_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, C, gamma, beta,
+                       save_mean, save_var, scale_shift);
+    BnBwdArgs a;
+    a.M = M; a.C = C; a.ldy = ldy; a.lddo = lddo; a.rows = pool_rows > 0 ? pool_rows : 1;
+    a.pool = pool_mode; a.relu = relu; a.training = training;
+    a.y = y; a.dout = dout; a.dpooled = dpooled; a.pooled = pooled; a.ties = tie_count;
+    a.gamma = gamma; a.save_mean = save_mean; a.save_var = save_var; a.scale_shift = scale_shift;
+    const int parts = bn_parts(M);
+    const int cb = ceil_div(C, 64);
+    hipLaunchKernelGGL(bn_bwd_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, a, partial, parts);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, C, partial, parts,
+                       (double)M, training, dgamma, dbeta, accumulate_param_grads, m12);
+    const int slab = 64;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cb, ceil_div(M, slab)), dim3(256), 0, s, a, m12, dy, lddy,
+                       slab);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, float *out, int accumulate,
+                                     void *workspace, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_colsum_f32";
+    CLOUDAAE_REQUIRE(M > 0 && C > 0 && ldx >= C && workspace && out, name, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    double *partial = (double *)workspace;
+    const int parts = bn_parts(M);
+    hipLaunchKernelGGL(bn_colsum_kernel, dim3(ceil_div(C, 64), parts), dim3(256), 0, s, M, C, x, ldx, partial,
+                       parts);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, C, partial, parts, out,
+                       accumulate);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}

@@ -1,0 +1,298 @@
+// gemm.hip -- fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Serves every dense layer of the CloudAAE path: the 1x1 convolutions
+// (reference utils/tf_util.py:161-166: tf.nn.conv2d + bias_add on [B,N,k,C] rows)
+// and the fully connected layers (tf_util.py:349-352: tf.matmul + bias_add),
+// forward and both backward products:
+//     y  = x W + b            op(A) = A      op(B) = B
+//     dx = dy W^T             op(A) = A      op(B) = B^T
+//     dW = x^T dy             op(A) = A^T    op(B) = B
+// fp32 in, fp32 accumulate: the f32 MFMA is bitwise a k-ordered fmaf chain
+// (MI355X_MICROARCH.md, matrix cores), so without split-K the result is exactly
+//     c = fma(a[k], b[k], c), k ascending, from +0.
+//
+// Tiling is for wave64 / 32x32 MFMA tiles, not a warp-shaped port: a workgroup of
+// 4 waves owns a BM x BN tile, each wave a grid of 32x32 accumulator tiles (16
+// VGPRs each).  One MFMA consumes ONE fp32 per operand per lane (A[i=l&31][k=l>>5],
+// B[k=l>>5][j=l&31]) and takes 64 cycles, so operand traffic is tiny next to the
+// matrix pipe: operands sit in LDS in their natural global layout (k-contiguous
+// rows padded to an odd stride, or row-contiguous panels) and are fetched with
+// conflict-free ds_read_b32; no transposition pass is needed for any of the three
+// products.  The next K-slab's global loads are issued before the current slab's
+// MFMAs (register prefetch).  K can be split across workgroups (grid.z) when the
+// output has too few tiles to fill 256 CUs (dW products, tiny-batch FC layers);
+// slices then combine with hardware fp32 atomics.
+#include "common.h"
+#include "../../include/cloudaae_hip.h"
+
+namespace cloudaae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GEMM_BK = 16;
+constexpr int GEMM_THREADS = 256;
+
+enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_ATOMIC = 2 };
+
+// One operand panel: ROWS "outer" indices (m for A, n for B) x BK k-values.
+// KC = true : memory is [outer][k] (k contiguous)   -> LDS [ROWS][BK+1]
+// KC = false: memory is [k][outer] (outer contiguous)-> LDS [BK][ROWS]
+template <int ROWS, bool KC>
+struct Panel {
+    static constexpr int LDS_FLOATS = KC ? ROWS * (GEMM_BK + 1) : GEMM_BK * ROWS;
+    static constexpr int VECS = ROWS * GEMM_BK / 4;           // float4 per slab
+    static constexpr int PER_THREAD = (VECS + GEMM_THREADS - 1) / GEMM_THREADS;
+
+    float4v reg[PER_THREAD];
+
+    // global -> registers for the slab starting at k0; outer0 = first outer index
+    __device__ __forceinline__ void load(const float *__restrict__ P, int ld, int outer0, int nouter,
+                                         int k0, int kend, bool vec_ok)
+    {
+#pragma unroll
+        for (int it = 0; it < PER_THREAD; ++it) {
+            const int v = it * GEMM_THREADS + (int)threadIdx.x;
+            float4v r = {0.f, 0.f, 0.f, 0.f};
+            if (VECS % GEMM_THREADS == 0 || v < VECS) {
+                if (KC) {
+                    const int o = v / (GEMM_BK / 4), kq = v % (GEMM_BK / 4);
+                    const int go = outer0 + o, gk = k0 + kq * 4;
+                    if (go < nouter) {
+                        const float *src = P + (size_t)go * ld + gk;
+                        if (vec_ok && gk + 3 < kend) {
+                            r = *reinterpret_cast<const float4v *>(src);
+                        } else {
+                            if (gk + 0 < kend) r.x = src[0];
+                            if (gk + 1 < kend) r.y = src[1];
+                            if (gk + 2 < kend) r.z = src[2];
+                            if (gk + 3 < kend) r.w = src[3];
+                        }
+                    }
+                } else {
+                    const int kk = v / (ROWS / 4), oq = v % (ROWS / 4);
+                    const int gk = k0 + kk, go = outer0 + oq * 4;
+                    if (gk < kend) {
+                        const float *src = P + (size_t)gk * ld + go;
+                        if (vec_ok && go + 3 < nouter) {
+                            r = *reinterpret_cast<const float4v *>(src);
+                        } else {
+                            if (go + 0 < nouter) r.x = src[0];
+                            if (go + 1 < nouter) r.y = src[1];
+                            if (go + 2 < nouter) r.z = src[2];
+                            if (go + 3 < nouter) r.w = src[3];
+                        }
+                    }
+                }
+            }
+            reg[it] = r;
+        }
+    }
+
+    // registers -> LDS
+    __device__ __forceinline__ void stage(float *__restrict__ lds) const
+    {
+#pragma unroll
+        for (int it = 0; it < PER_THREAD; ++it) {
+            const int v = it * GEMM_THREADS + (int)threadIdx.x;
+            if (VECS % GEMM_THREADS == 0 || v < VECS) {
+                if (KC) {
+                    const int o = v / (GEMM_BK / 4), kq = v % (GEMM_BK / 4);
+                    float *dst = lds + o * (GEMM_BK + 1) + kq * 4;
+                    dst[0] = reg[it].x;
+                    dst[1] = reg[it].y;
+                    dst[2] = reg[it].z;
+                    dst[3] = reg[it].w;
+                } else {
+                    const int kk = v / (ROWS / 4), oq = v % (ROWS / 4);
+                    *reinterpret_cast<float4v *>(lds + kk * ROWS + oq * 4) = reg[it];
+                }
+            }
+        }
+    }
+
+    // MFMA operand of this lane: element (outer, kk) of the staged slab
+    static __device__ __forceinline__ float frag(const float *__restrict__ lds, int outer, int kk)
+    {
+        return KC ? lds[outer * (GEMM_BK + 1) + kk] : lds[kk * ROWS + outer];
+    }
+};
+
+// C[M,N] (+)= op(A)[M,K] * op(B)[K,N] (+ bias[N])
+// TA: A is stored [K][M] (lda >= M); else [M][K].  TB: B is stored [N][K]; else [K][N].
+template <int BM, int BN, int WM, int WN, bool TA, bool TB>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
+    int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+    float *__restrict__ C, int ldc, const float *__restrict__ bias, int epilogue, int kchunk,
+    int vecA, int vecB)
+{
+    static_assert(WM * WN * 64 == GEMM_THREADS, "4 waves");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;   // 32x32 tiles per wave
+    typedef Panel<BM, !TA> PA;
+    typedef Panel<BN, TB> PB;
+    __shared__ float ldsA[PA::LDS_FLOATS];
+    __shared__ float ldsB[PB::LDS_FLOATS];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * kchunk;
+    const int kend = min(K, kbeg + kchunk);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0.0f;
+
+    PA pa;
+    PB pb;
+    pa.load(A, lda, m0, M, kbeg, kend, vecA != 0);
+    pb.load(B, ldb, n0, N, kbeg, kend, vecB != 0);
+
+    const int fr = lane & 31, fk = lane >> 5;
+    for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
+        __syncthreads();            // previous slab fully consumed
+        pa.stage(ldsA);
+        pb.stage(ldsB);
+        __syncthreads();
+        if (k0 + GEMM_BK < kend) {  // prefetch the next slab behind the MFMAs
+            pa.load(A, lda, m0, M, k0 + GEMM_BK, kend, vecA != 0);
+            pb.load(B, ldb, n0, N, k0 + GEMM_BK, kend, vecB != 0);
+        }
+#pragma unroll
+        for (int s = 0; s < GEMM_BK / 2; ++s) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = PA::frag(ldsA, (wm * TM + i) * 32 + fr, 2 * s + fk);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = PB::frag(ldsB, (wn * TN + j) * 32 + fr, 2 * s + fk);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool add_bias = bias != nullptr && (epilogue != EPI_ATOMIC || blockIdx.z == 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + fr;
+        if (col >= N)
+            continue;
+        const float bv = add_bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row < M) {
+                    float *dst = C + (size_t)row * ldc + col;
+                    const float v = acc[i][j][r] + bv;
+                    if (epilogue == EPI_STORE)
+                        *dst = v;
+                    else if (epilogue == EPI_ACCUM)
+                        *dst = *dst + v;
+                    else
+                        atomicAdd(dst, v);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_cfg(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A,
+                       int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int epi,
+                       int kchunk, int vecA, int vecB)
+{
+    dim3 block(GEMM_THREADS);
+    if (!ta && !tb)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, M, N, K,
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+    else if (!ta && tb)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, M, N, K,
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+    else if (ta && !tb)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, M, N, K,
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, M, N, K,
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+}
+
+} // namespace cloudaae
+
+using namespace cloudaae;
+
+CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A,
+                                   int lda, const float *B, int ldb, float *C, int ldc,
+                                   const float *bias, int accumulate, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_gemm_f32";
+    CLOUDAAE_REQUIRE(M >= 0 && N >= 0 && K >= 0, name, "negative size");
+    if (M == 0 || N == 0)
+        return 0;
+    hipStream_t s = (hipStream_t)stream;
+    CLOUDAAE_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, name,
+                     "leading dimension too small");
+
+    // tile shape: small-batch FC rows -> 32-row tiles; narrow outputs -> 64 columns
+    int BM, BN;
+    if (M <= 32) {
+        BM = 32;
+        BN = 128;
+    } else if (N <= 64) {
+        BM = 128;
+        BN = 64;
+    } else {
+        BM = 128;
+        BN = 128;
+    }
+    const int tm = ceil_div(M, BM), tn = ceil_div(N, BN);
+    CLOUDAAE_REQUIRE(tm <= 65535, name, "M too large");
+    // split K until ~2 workgroups per CU exist, keeping >= 64 k per slice
+    int splits = 1;
+    const long long tiles = (long long)tm * tn;
+    if (tiles < 256 && K >= 128) {
+        splits = (int)((512 + tiles - 1) / tiles);
+        const int max_splits = K / 64 > 0 ? K / 64 : 1;
+        if (splits > max_splits)
+            splits = max_splits;
+        if (splits > 1024)
+            splits = 1024;
+        if (splits < 1)
+            splits = 1;
+    }
+    int kchunk = K > 0 ? ceil_div(ceil_div(K, splits), GEMM_BK) * GEMM_BK : GEMM_BK;
+    splits = K > 0 ? ceil_div(K, kchunk) : 1;
+    int epi = accumulate ? EPI_ACCUM : EPI_STORE;
+    if (splits > 1) {
+        epi = EPI_ATOMIC;
+        if (!accumulate)  // slices add into a zeroed output
+            CLOUDAAE_CHECK_HIP(hipMemset2DAsync(C, sizeof(float) * (size_t)ldc, 0,
+                                                sizeof(float) * (size_t)N, (size_t)M, s), name);
+    }
+    const bool a16 = ((uintptr_t)A & 15) == 0 && lda % 4 == 0;
+    const bool b16 = ((uintptr_t)B & 15) == 0 && ldb % 4 == 0;
+    const int vecA = a16 ? 1 : 0, vecB = b16 ? 1 : 0;
+    dim3 grid(tn, tm, splits);
+    const bool ta = trans_a != 0, tb = trans_b != 0;
+    if (BM == 32)
+        launch_cfg<32, 128, 1, 4>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
+                                  vecA, vecB);
+    else if (BN == 64)
+        launch_cfg<128, 64, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
+                                  vecA, vecB);
+    else
+        launch_cfg<128, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
+                                   vecA, vecB);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}

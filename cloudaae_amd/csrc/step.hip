@@ -1,0 +1,572 @@
+// step.hip -- the small kernels around the network in one training step (gfx950):
+// input assembly, loss terms, scalar bookkeeping and the optimiser.  All of them are
+// HBM-streaming or tiny; device-side scalars (step counter, beta powers, bn decay,
+// upstream loss gradients) keep the whole step free of host synchronisation, so it
+// can be captured in a hipGraph.
+//
+// Reference sites: train_cloudAAE_ycbv.py:194-273 (graph assembly), losses/*.py.
+#include "common.h"
+#include "../../include/cloudaae_hip.h"
+
+namespace cloudaae {
+
+// ---- input assembly: train_cloudAAE_ycbv.py:206-226 ---------------------------------
+// one workgroup per cloud: v = visible[:N] + noise; mean over N; pc = [v - mean, onehot]
+__global__ __launch_bounds__(256) void input_assemble_kernel(int P, int N, int num_class,
+                                                            const float *__restrict__ visible,
+                                                            const float *__restrict__ noise,
+                                                            const long long *__restrict__ class_id,
+                                                            float *__restrict__ pc, float *__restrict__ mean,
+                                                            float *__restrict__ noisy)
+{
+    __shared__ float red[3][4];
+    __shared__ float mu[3];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float *V = visible + (size_t)b * P * 3;
+    const float *Z = noise ? noise + (size_t)b * N * 3 : nullptr;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int j = t; j < N; j += 256) {
+        float x = V[3 * j], y = V[3 * j + 1], z = V[3 * j + 2];
+        if (Z) {
+            x = x + Z[3 * j];
+            y = y + Z[3 * j + 1];
+            z = z + Z[3 * j + 2];
+        }
+        sx += x;
+        sy += y;
+        sz += z;
+    }
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    sz = wave_sum(sz);
+    if ((t & 63) == 0) {
+        red[0][t >> 6] = sx;
+        red[1][t >> 6] = sy;
+        red[2][t >> 6] = sz;
+    }
+    __syncthreads();
+    if (t < 3) {
+        const float s = (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+        mu[t] = s / (float)N;
+        mean[(size_t)b * 3 + t] = mu[t];
+    }
+    __syncthreads();
+    const int C = 3 + num_class;
+    const long long cls = class_id ? class_id[b] : -1;
+    for (int j = t; j < N; j += 256) {
+        float x = V[3 * j], y = V[3 * j + 1], z = V[3 * j + 2];
+        if (Z) {
+            x = x + Z[3 * j];
+            y = y + Z[3 * j + 1];
+            z = z + Z[3 * j + 2];
+        }
+        if (noisy) {
+            noisy[((size_t)b * N + j) * 3 + 0] = x;
+            noisy[((size_t)b * N + j) * 3 + 1] = y;
+            noisy[((size_t)b * N + j) * 3 + 2] = z;
+        }
+        float *row = pc + ((size_t)b * N + j) * C;
+        row[0] = x - mu[0];
+        row[1] = y - mu[1];
+        row[2] = z - mu[2];
+        for (int c = 0; c < num_class; ++c)
+            row[3 + c] = (c == cls) ? 1.0f : 0.0f;
+    }
+}
+
+// out[b,r,:] = x[b,r,:] + v[b,:]   (train_cloudAAE_ycbv.py:232-233)
+__global__ void add_rowvec_kernel(long long total, int R, int D, const float *__restrict__ x,
+                                  const float *__restrict__ v, float *__restrict__ out)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / ((long long)R * D);
+        const int d = (int)(i % D);
+        out[i] = x[i] + v[b * D + d];
+    }
+}
+
+__global__ void add_kernel(long long n, const float *__restrict__ a, const float *__restrict__ b,
+                           float *__restrict__ out)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+
+// out[i] = scalar[0] * scale  (+ add[i])   -- gradient of a mean, broadcast
+__global__ void fill_scaled_kernel(long long n, const float *__restrict__ scalar, float scale,
+                                   const float *__restrict__ add, float *__restrict__ out)
+{
+    const float g = scalar[0] * scale;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        out[i] = add ? g + add[i] : g;
+}
+
+// two-level mean with fp64 partial sums (deterministic)
+constexpr int MEAN_BLOCKS = 256;
+__global__ __launch_bounds__(256) void mean_stage1_kernel(long long n, const float *__restrict__ x,
+                                                         double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double s = 0.0;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x)
+        s += (double)x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void mean_stage2_kernel(int parts, double n, const double *__restrict__ partial,
+                                                         float *__restrict__ out)
+{
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < parts; i += 256)
+        s += partial[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        out[0] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / n);
+}
+
+// ---- translation error: losses/trans_distance.py:4-9 --------------------------------
+__global__ void trans_error_kernel(int b, const float *__restrict__ pred, const float *__restrict__ label,
+                                   float *__restrict__ per)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b)
+        return;
+    const float dx = label[3 * i] - pred[3 * i], dy = label[3 * i + 1] - pred[3 * i + 1],
+                dz = label[3 * i + 2] - pred[3 * i + 2];
+    per[i] = sqrtf(dx * dx + dy * dy + dz * dz);
+}
+// d per / d pred = -(label - pred) / per
+__global__ void trans_error_grad_kernel(int b, const float *__restrict__ pred, const float *__restrict__ label,
+                                        const float *__restrict__ per, const float *__restrict__ gper,
+                                        float *__restrict__ dpred)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b)
+        return;
+    const float g = gper[i] / per[i];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        dpred[3 * i + a] = -(g * (label[3 * i + a] - pred[3 * i + a]));
+}
+
+// ---- SO(3) geodesic error in float64: losses/angular_distance_taylor.py:30-116 ------
+// forward-mode duals carry d/d(pred) through exactly the reference's op sequence, so
+// the gradient is what TF's autodiff of that graph yields (selected tf.where branch,
+// clip_by_value passing the gradient only inside the range).
+struct Dual {
+    double v, d[3];
+};
+__device__ __forceinline__ Dual dconst(double c) { return Dual{c, {0.0, 0.0, 0.0}}; }
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return Dual{a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2]}}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return Dual{a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2]}}; }
+__device__ __forceinline__ Dual operator-(Dual a) { return Dual{-a.v, {-a.d[0], -a.d[1], -a.d[2]}}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b)
+{
+    return Dual{a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2]}};
+}
+__device__ __forceinline__ Dual operator/(Dual a, Dual b)
+{
+    const double q = a.v / b.v;
+    return Dual{q, {(a.d[0] - q * b.d[0]) / b.v, (a.d[1] - q * b.d[1]) / b.v, (a.d[2] - q * b.d[2]) / b.v}};
+}
+__device__ __forceinline__ Dual operator/(Dual a, double c) { return Dual{a.v / c, {a.d[0] / c, a.d[1] / c, a.d[2] / c}}; }
+__device__ __forceinline__ Dual operator*(double c, Dual a) { return Dual{c * a.v, {c * a.d[0], c * a.d[1], c * a.d[2]}}; }
+__device__ __forceinline__ Dual dsqrt(Dual a)
+{
+    const double r = sqrt(a.v), k = 0.5 / r;
+    return Dual{r, {k * a.d[0], k * a.d[1], k * a.d[2]}};
+}
+__device__ __forceinline__ Dual dsin(Dual a)
+{
+    const double c = cos(a.v);
+    return Dual{sin(a.v), {c * a.d[0], c * a.d[1], c * a.d[2]}};
+}
+__device__ __forceinline__ Dual dcos(Dual a)
+{
+    const double s = -sin(a.v);
+    return Dual{cos(a.v), {s * a.d[0], s * a.d[1], s * a.d[2]}};
+}
+
+// exponential_map, angular_distance_taylor.py:30-66 (EPS = 1e-2 on theta^2)
+__device__ void exp_map(const Dual ax[3], Dual R[3][3])
+{
+    const Dual zero = dconst(0.0);
+    Dual ss[3][3] = {{zero, -ax[2], ax[1]}, {ax[2], zero, -ax[0]}, {-ax[1], ax[0], zero}};
+    const Dual tsq = (ax[0] * ax[0] + ax[1] * ax[1]) + ax[2] * ax[2];
+    Dual t1, t2;
+    if (tsq.v < 1e-2) {
+        const Dual p4 = tsq * tsq, p6 = (tsq * tsq) * tsq, p8 = ((tsq * tsq) * tsq) * tsq;
+        t1 = (((dconst(1.0) - (tsq / 6.0)) + (p4 / 120.0)) - (p6 / 5040.0)) + (p8 / 362880.0);
+        t2 = (((dconst(0.5) - (tsq / 24.0)) + (p4 / 720.0)) - (p6 / 40320.0)) + (p8 / 3628800.0);
+    } else {
+        const Dual th = dsqrt(tsq);
+        t1 = dsin(th) / th;
+        t2 = (dconst(1.0) - dcos(th)) / tsq;
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            Dual sq = zero;
+            for (int k = 0; k < 3; ++k)
+                sq = sq + ss[i][k] * ss[k][j];
+            R[i][j] = (dconst(i == j ? 1.0 : 0.0) + t1 * ss[i][j]) + t2 * sq;
+        }
+}
+
+__global__ void rotation_error_kernel(int b, const float *__restrict__ pred, const double *__restrict__ label,
+                                      double *__restrict__ per, double *__restrict__ jac)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b)
+        return;
+    Dual p[3], l[3];
+    for (int a = 0; a < 3; ++a) {
+        p[a] = dconst((double)pred[3 * i + a]);  // tf.cast(rot_pred, tf.float64), train...:249
+        p[a].d[a] = 1.0;
+        l[a] = dconst(label[3 * i + a]);
+    }
+    Dual Rp[3][3], Rl[3][3];
+    exp_map(p, Rp);
+    exp_map(l, Rl);
+    // R = R_label * R_pred^T ; only its trace is needed (angular_distance_taylor.py:113,77-84)
+    Dual tr = dconst(0.0);
+    for (int r = 0; r < 3; ++r) {
+        Dual e = dconst(0.0);
+        for (int k = 0; k < 3; ++k)
+            e = e + Rl[r][k] * Rp[r][k];
+        tr = tr + e;
+    }
+    Dual t = (tr - dconst(1.0)) / 2.0;
+    const double lim = 0.9999999;
+    if (t.v < -lim)
+        t = dconst(-lim);
+    else if (t.v > lim)
+        t = dconst(lim);
+    const double theta = acos(t.v);
+    const double k = -1.0 / sqrt(1.0 - t.v * t.v);
+    per[i] = theta;
+    if (jac) {
+        jac[3 * i + 0] = k * t.d[0];
+        jac[3 * i + 1] = k * t.d[1];
+        jac[3 * i + 2] = k * t.d[2];
+    }
+}
+
+// exponential_map alone (train_cloudAAE_ycbv.py:79-85: rotation matrix of the GT pose)
+__global__ void exp_map_kernel(int b, const double *__restrict__ axag, double *__restrict__ R)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b)
+        return;
+    Dual a[3], M[3][3];
+    for (int k = 0; k < 3; ++k)
+        a[k] = dconst(axag[3 * i + k]);
+    exp_map(a, M);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            R[9 * i + 3 * r + c] = M[r][c].v;
+}
+
+// loss = mean(per) (fp64 -> fp32, train...:253); dpred = gloss/b * jac (fp64 -> fp32)
+__global__ void rotation_reduce_kernel(int b, const double *__restrict__ per, float *__restrict__ loss)
+{
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < b; i += 256)
+        s += per[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        loss[0] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)b);
+}
+__global__ void rotation_grad_kernel(int b, const double *__restrict__ jac, const float *__restrict__ gloss,
+                                     float *__restrict__ dpred)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * b)
+        return;
+    dpred[i] = (float)((double)gloss[0] / (double)b * jac[i]);
+}
+
+// total = w0*a + w1*b + w2*c (train...:268) and its gradient fan-out
+__global__ void loss_mix_kernel(const float *a, const float *b, const float *c, float w0, float w1, float w2,
+                                float *out)
+{
+    out[0] = (w0 * a[0] + w1 * b[0]) + w2 * c[0];
+}
+__global__ void loss_mix_grad_kernel(const float *g, float w0, float w1, float w2, float *ga, float *gb, float *gc)
+{
+    ga[0] = g[0] * w0;
+    gb[0] = g[0] * w1;
+    gc[0] = g[0] * w2;
+}
+
+// ---- optimiser: tf.train.AdamOptimizer (train...:263-273), TF-1.x ApplyAdam form ----
+//   lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+//   m += (g - m) * (1 - beta1);  v += (g*g - v) * (1 - beta2)
+//   var -= lr_t * m / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void adam_tf_kernel(long long n, float *__restrict__ param,
+                                                     const float *__restrict__ grad, float *__restrict__ m,
+                                                     float *__restrict__ v, float lr, float beta1, float beta2,
+                                                     float eps, const float *__restrict__ b1p,
+                                                     const float *__restrict__ b2p, float gscale)
+{
+    const float lr_t = lr * sqrtf(1.0f - b2p[0]) / (1.0f - b1p[0]);
+    const float om1 = 1.0f - beta1, om2 = 1.0f - beta2;
+    const long long n4 = n / 4;
+    float4v *P4 = reinterpret_cast<float4v *>(param);
+    const float4v *G4 = reinterpret_cast<const float4v *>(grad);
+    float4v *M4 = reinterpret_cast<float4v *>(m);
+    float4v *V4 = reinterpret_cast<float4v *>(v);
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += 256LL * gridDim.x) {
+        float4v p = P4[i], g = G4[i] * gscale, mm = M4[i], vv = V4[i];
+        mm = mm + (g - mm) * om1;
+        vv = vv + (g * g - vv) * om2;
+        float4v den;
+        den.x = sqrtf(vv.x) + eps;
+        den.y = sqrtf(vv.y) + eps;
+        den.z = sqrtf(vv.z) + eps;
+        den.w = sqrtf(vv.w) + eps;
+        p = p - (mm * lr_t) / den;
+        P4[i] = p;
+        M4[i] = mm;
+        V4[i] = vv;
+    }
+    for (long long i = n4 * 4 + blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) {
+        const float g = grad[i] * gscale;
+        const float mm = m[i] + (g - m[i]) * om1;
+        const float vv = v[i] + (g * g - v[i]) * om2;
+        param[i] = param[i] - (mm * lr_t) / (sqrtf(vv) + eps);
+        m[i] = mm;
+        v[i] = vv;
+    }
+}
+__global__ void adam_advance_kernel(float *b1p, float *b2p, float beta1, float beta2)
+{
+    b1p[0] = b1p[0] * beta1;
+    b2p[0] = b2p[0] * beta2;
+}
+// tf.train.GradientDescentOptimizer: var -= lr * g
+__global__ __launch_bounds__(256) void sgd_kernel(long long n, float *__restrict__ param,
+                                                 const float *__restrict__ grad, float lr, float gscale)
+{
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x)
+        param[i] = param[i] - lr * (grad[i] * gscale);
+}
+
+// bn_decay(step) = min(clip, 1 - init * rate^floor(step*batch/decay_step))   (train...:194-202)
+__global__ void bn_decay_kernel(const float *step, float batch_size, float init, float decay_step, float rate,
+                                float clip, float *out)
+{
+    const float p = floorf(step[0] * batch_size / decay_step);
+    const float mom = init * powf(rate, p);
+    out[0] = fminf(clip, 1.0f - mom);
+}
+__global__ void increment_kernel(float *x, float by) { x[0] = x[0] + by; }
+
+static int stream_grid(long long n)
+{
+    long long g = (n + 255) / 256;
+    if (g > 2048)
+        g = 2048;
+    if (g < 1)
+        g = 1;
+    return (int)g;
+}
+
+} // namespace cloudaae
+
+using namespace cloudaae;
+
+CLOUDAAE_API int cloudaae_input_assemble(int b, int p, int n, int num_class, const float *visible,
+                                         const float *noise, const long long *class_id, float *pc,
+                                         float *mean, float *noisy, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_input_assemble";
+    CLOUDAAE_REQUIRE(b >= 0 && n > 0 && p >= n && num_class >= 0, name, "bad size (need n <= rows of visible)");
+    if (b == 0)
+        return 0;
+    hipLaunchKernelGGL(input_assemble_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, p, n, num_class,
+                       visible, noise, class_id, pc, mean, noisy);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_add_rowvec(int b, int r, int d, const float *x, const float *v, float *out,
+                                     cloudaae_stream_t stream)
+{
+    const long long total = (long long)b * r * d;
+    if (total == 0)
+        return 0;
+    hipLaunchKernelGGL(add_rowvec_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, total, r,
+                       d, x, v, out);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_add_rowvec");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_add_f32(long long n, const float *a, const float *b, float *out,
+                                  cloudaae_stream_t stream)
+{
+    if (n == 0)
+        return 0;
+    hipLaunchKernelGGL(add_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, n, a, b, out);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_add_f32");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_fill_scaled(long long n, const float *scalar, float scale, const float *add,
+                                      float *out, cloudaae_stream_t stream)
+{
+    if (n == 0)
+        return 0;
+    hipLaunchKernelGGL(fill_scaled_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, n, scalar,
+                       scale, add, out);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_fill_scaled");
+    return 0;
+}
+
+CLOUDAAE_API long long cloudaae_mean_workspace_bytes(void) { return (long long)MEAN_BLOCKS * sizeof(double); }
+
+CLOUDAAE_API int cloudaae_mean_f32(long long n, const float *x, float *out, void *workspace,
+                                   cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_mean_f32";
+    CLOUDAAE_REQUIRE(n > 0 && workspace, name, "empty input or no workspace");
+    hipStream_t s = (hipStream_t)stream;
+    int parts = stream_grid(n);
+    if (parts > MEAN_BLOCKS)
+        parts = MEAN_BLOCKS;
+    hipLaunchKernelGGL(mean_stage1_kernel, dim3(parts), dim3(256), 0, s, n, x, (double *)workspace);
+    hipLaunchKernelGGL(mean_stage2_kernel, dim3(1), dim3(256), 0, s, parts, (double)n, (const double *)workspace,
+                       out);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_trans_error(int b, const float *pred, const float *label, float *per,
+                                      cloudaae_stream_t stream)
+{
+    if (b == 0)
+        return 0;
+    hipLaunchKernelGGL(trans_error_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, (hipStream_t)stream, b, pred,
+                       label, per);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_trans_error");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_trans_error_grad(int b, const float *pred, const float *label, const float *per,
+                                           const float *gper, float *dpred, cloudaae_stream_t stream)
+{
+    if (b == 0)
+        return 0;
+    hipLaunchKernelGGL(trans_error_grad_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, (hipStream_t)stream, b,
+                       pred, label, per, gper, dpred);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_trans_error_grad");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_rotation_error(int b, const float *pred, const double *label, double *per,
+                                         double *jac, float *loss, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_rotation_error";
+    CLOUDAAE_REQUIRE(b > 0, name, "empty batch");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(rotation_error_kernel, dim3(ceil_div(b, 64)), dim3(64), 0, s, b, pred, label, per, jac);
+    if (loss)
+        hipLaunchKernelGGL(rotation_reduce_kernel, dim3(1), dim3(256), 0, s, b, per, loss);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_exponential_map(int b, const double *axag, double *rot, cloudaae_stream_t stream)
+{
+    if (b == 0)
+        return 0;
+    hipLaunchKernelGGL(exp_map_kernel, dim3(ceil_div(b, 64)), dim3(64), 0, (hipStream_t)stream, b, axag, rot);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_exponential_map");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_rotation_error_grad(int b, const double *jac, const float *gloss, float *dpred,
+                                              cloudaae_stream_t stream)
+{
+    if (b == 0)
+        return 0;
+    hipLaunchKernelGGL(rotation_grad_kernel, dim3(ceil_div(3 * b, 256)), dim3(256), 0, (hipStream_t)stream, b,
+                       jac, gloss, dpred);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_rotation_error_grad");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_loss_mix(const float *a, const float *b, const float *c, float w0, float w1, float w2,
+                                   float *out, cloudaae_stream_t stream)
+{
+    hipLaunchKernelGGL(loss_mix_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a, b, c, w0, w1, w2, out);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_loss_mix");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_loss_mix_grad(const float *g, float w0, float w1, float w2, float *ga, float *gb,
+                                        float *gc, cloudaae_stream_t stream)
+{
+    hipLaunchKernelGGL(loss_mix_grad_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, g, w0, w1, w2, ga, gb, gc);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_loss_mix_grad");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_adam_tf(long long n, float *param, const float *grad, float *m, float *v, float lr,
+                                  float beta1, float beta2, float eps, float *beta1_power, float *beta2_power,
+                                  float grad_scale, int advance, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_adam_tf";
+    CLOUDAAE_REQUIRE(n >= 0 && beta1_power && beta2_power, name, "bad argument");
+    CLOUDAAE_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0, name,
+                     "buffers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (n > 0)
+        hipLaunchKernelGGL(adam_tf_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, s, n, param, grad, m, v,
+                           lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale);
+    if (advance)
+        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, beta1_power, beta2_power, beta1, beta2);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_sgd(long long n, float *param, const float *grad, float lr, float grad_scale,
+                              cloudaae_stream_t stream)
+{
+    if (n == 0)
+        return 0;
+    hipLaunchKernelGGL(sgd_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, n, param, grad, lr,
+                       grad_scale);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_sgd");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_bn_decay_schedule(const float *step, float batch_size, float init, float decay_step,
+                                            float rate, float clip, float *out, cloudaae_stream_t stream)
+{
+    hipLaunchKernelGGL(bn_decay_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, batch_size, init,
+                       decay_step, rate, clip, out);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_bn_decay_schedule");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_increment(float *x, float by, cloudaae_stream_t stream)
+{
+    hipLaunchKernelGGL(increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, x, by);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_increment");
+    return 0;
+}

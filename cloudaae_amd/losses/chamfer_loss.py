@@ -1,0 +1,15 @@
+"""Chamfer loss -- mirror of the reference's losses/chamfer_loss.py:8-14."""
+from ..tf_ops.nn_distance import tf_nndistance
+from ..utils import _functions as F
+
+
+def get_loss(pred, label):
+    """ pred: BxNx3,
+        label: BxNx3,
+    returns (loss, loss_per_sample) where loss_per_sample = dists_forward + dists_backward is
+    [B,N] (elementwise, so both clouds must have the same number of points) and
+    loss = reduce_mean(loss_per_sample). """
+    dists_forward, _, dists_backward, _ = tf_nndistance.nn_distance(pred, label)
+    loss_per_sample = F.AddFn.apply(dists_forward, dists_backward)
+    loss = F.MeanFn.apply(loss_per_sample)
+    return loss, loss_per_sample

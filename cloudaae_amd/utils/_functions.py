@@ -1,0 +1,413 @@
+"""torch.autograd plumbing around the C-ABI kernels (no arithmetic happens here).
+
+Parameter gradients: a parameter tensor that belongs to a VariableStore carries its
+Variable in `_cloudaae_var`; its gradient is written by the kernel straight into the
+store's flat gradient buffer (first write of a backward pass stores, later ones add)
+and `None` is returned to autograd.  Foreign tensors get ordinary returned gradients.
+"""
+import torch
+
+from .. import _lib
+from .._lib import ptr, rows_ptr, require, stream
+
+L = _lib.lib
+
+
+def _ws(nbytes, device):
+    return torch.empty((int(nbytes) + 7) // 8, dtype=torch.float64, device=device)
+
+
+def _var(t):
+    return getattr(t, "_cloudaae_var", None)
+
+
+class _ParamGrad(object):
+    """Where the gradient of one parameter goes."""
+
+    def __init__(self, param, needed):
+        self.var = _var(param) if needed else None
+        self.needed = needed
+        self.own = None
+        if not needed:
+            self.buf, self.accumulate = None, 0
+        elif self.var is not None and self.var.grad is not None:
+            self.buf = self.var.grad
+            self.accumulate = 0 if self.var.fresh else 1
+        else:
+            self.own = torch.empty(param.shape, dtype=torch.float32, device=param.device)
+            self.buf, self.accumulate = self.own, 0
+
+    def done(self):
+        if self.var is not None and self.var.grad is not None:
+            self.var.fresh = False
+            if self.var.on_ready is not None:
+                self.var.on_ready()
+            return None
+        return self.own
+
+
+def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, accumulate=0):
+    _lib.check(L().cloudaae_gemm_f32(int(ta), int(tb), M, N, K, A, lda, B, ldb, C, ldc, bias, int(accumulate),
+                                     stream()), "cloudaae_gemm_f32")
+
+
+class LinearFn(torch.autograd.Function):
+    """y[M,N] = x[M,K] W[K,N] + b  (tf.matmul/conv2d-1x1 + bias_add)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        require(x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[0], "LinearFn: shape mismatch")
+        xp, ldx = rows_ptr(x)
+        M, K = x.shape
+        N = w.shape[1]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        gemm(0, 0, M, N, K, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        ctx.bvar = b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        M, K = x.shape
+        N = w.shape[1]
+        dy = dy.contiguous() if dy.stride(-1) != 1 else dy
+        dyp, lddy = rows_ptr(dy)
+        xp, ldx = rows_ptr(x)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
+            gemm(0, 1, M, K, N, dyp, lddy, ptr(w), N, ptr(dx), K)
+        gw = _ParamGrad(w, ctx.needs_input_grad[1])
+        if gw.needed:
+            gemm(1, 0, K, N, M, xp, ldx, dyp, lddy, ptr(gw.buf), N, None, gw.accumulate)
+        gb_ret = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = _ParamGrad(ctx.bvar, True)
+            ws = _ws(L().cloudaae_bn_workspace_bytes(N), x.device)
+            _lib.check(L().cloudaae_colsum_f32(M, N, dyp, lddy, ptr(gb.buf), gb.accumulate, ptr(ws), stream()),
+                       "cloudaae_colsum_f32")
+            gb_ret = gb.done()
+        return dx, gw.done(), gb_ret
+
+
+class ConcatLinearFn(torch.autograd.Function):
+    """Linear over the channel-concatenation of several [M,Ci] inputs
+    (models/pointnet_ycb_23_decoder_4.py:410: conv2d(tf.concat([net1..net4], -1))).
+    When the inputs are adjacent column slices of ONE row-major buffer (what the fused
+    encoder produces) no concat copy is made and the input gradients come back as
+    column slices of one [M, sum Ci] buffer."""
+
+    @staticmethod
+    def forward(ctx, w, b, *nets):
+        M = nets[0].shape[0]
+        widths = [t.shape[1] for t in nets]
+        Ktot = sum(widths)
+        require(w.shape[0] == Ktot, "ConcatLinearFn: weight rows != total input channels")
+        base = nets[0]
+        adjacent = base.stride(0) == Ktot and all(t.stride(1) == 1 for t in nets)
+        off = 0
+        for t, wd in zip(nets, widths):
+            adjacent = adjacent and t.shape[0] == M and t.stride(0) == Ktot and \
+                t.data_ptr() == base.data_ptr() + 4 * off
+            off += wd
+        if adjacent:
+            xp, ldx = base.data_ptr(), Ktot
+            ctx.cat = None
+        else:
+            cat = torch.cat([t.contiguous() for t in nets], dim=1)
+            xp, ldx = cat.data_ptr(), Ktot
+            ctx.cat = cat
+        N = w.shape[1]
+        y = torch.empty((M, N), dtype=torch.float32, device=w.device)
+        gemm(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None)
+        ctx.save_for_backward(w, *nets)
+        ctx.widths, ctx.xp, ctx.bvar = widths, xp, b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        w = ctx.saved_tensors[0]
+        nets = ctx.saved_tensors[1:]
+        M = nets[0].shape[0]
+        Ktot, N = w.shape
+        dy = dy.contiguous()
+        xp = ctx.cat.data_ptr() if ctx.cat is not None else ctx.xp
+        dcat = None
+        if any(ctx.needs_input_grad[2:]):
+            dcat = torch.empty((M, Ktot), dtype=torch.float32, device=w.device)
+            gemm(0, 1, M, Ktot, N, ptr(dy), N, ptr(w), N, ptr(dcat), Ktot)
+        gw = _ParamGrad(w, ctx.needs_input_grad[0])
+        if gw.needed:
+            gemm(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.accumulate)
+        gb_ret = None
+        if ctx.bvar is not None and ctx.needs_input_grad[1]:
+            gb = _ParamGrad(ctx.bvar, True)
+            ws = _ws(L().cloudaae_bn_workspace_bytes(N), w.device)
+            _lib.check(L().cloudaae_colsum_f32(M, N, ptr(dy), N, ptr(gb.buf), gb.accumulate, ptr(ws), stream()),
+                       "cloudaae_colsum_f32")
+            gb_ret = gb.done()
+        grads, off = [], 0
+        for i, wd in enumerate(ctx.widths):
+            grads.append(dcat[:, off:off + wd] if (dcat is not None and ctx.needs_input_grad[2 + i]) else None)
+            off += wd
+        return (gw.done(), gb_ret) + tuple(grads)
+
+
+class BatchNormFn(torch.autograd.Function):
+    """batch_norm_template (+ReLU) on rows [M,C], optionally pooled over groups of
+    `pool_rows` rows (mean/max over the points of a cloud)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, ema_mean, ema_var, decay, training, relu, pool_rows, pool_mode,
+                want_activation):
+        yp, ldy = rows_ptr(y)
+        M, C = y.shape
+        dev = y.device
+        save_mean = torch.empty(C, dtype=torch.float32, device=dev)
+        save_var = torch.empty(C, dtype=torch.float32, device=dev)
+        out = torch.empty((M, C), dtype=torch.float32, device=dev) if (want_activation or pool_mode == 0) else None
+        pooled = ties = None
+        if pool_mode != 0:
+            pooled = torch.empty((M // pool_rows, C), dtype=torch.float32, device=dev)
+            if pool_mode == 2:
+                ties = torch.empty_like(pooled)
+        ws = _ws(L().cloudaae_bn_workspace_bytes(C), dev)
+        _lib.check(L().cloudaae_bn_forward(
+            M, C, yp, ldy, ptr(gamma), ptr(beta), int(training), ptr(decay), ptr(ema_mean), ptr(ema_var),
+            ptr(save_mean), ptr(save_var), int(relu), ptr(out), C, int(pool_rows), int(pool_mode), ptr(pooled),
+            ptr(ties), ptr(ws), stream()), "cloudaae_bn_forward")
+        ctx.save_for_backward(y, gamma, beta, save_mean, save_var, pooled, ties)
+        ctx.cfg = (int(training), int(relu), int(pool_rows), int(pool_mode))
+        ctx.mark_non_differentiable(save_mean, save_var)
+        if pool_mode == 0:
+            return out, save_mean, save_var
+        if want_activation:
+            return pooled, out, save_mean, save_var
+        return pooled, save_mean, save_var
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        y, gamma, beta, save_mean, save_var, pooled, ties = ctx.saved_tensors
+        training, relu, pool_rows, pool_mode = ctx.cfg
+        M, C = y.shape
+        yp, ldy = rows_ptr(y)
+        if pool_mode == 0:
+            dout, dpooled = gouts[0], None
+        elif len(gouts) == 4:
+            dpooled, dout = gouts[0], gouts[1]
+        else:
+            dpooled, dout = gouts[0], None
+        if dout is not None:
+            dout = dout.contiguous()
+        if pool_mode != 0:
+            dpooled = torch.zeros_like(pooled) if dpooled is None else dpooled.contiguous()
+        if dout is None and pool_mode == 0:
+            return (None,) * 11
+        dy = torch.empty((M, C), dtype=torch.float32, device=y.device)
+        gg = _ParamGrad(gamma, ctx.needs_input_grad[1])
+        gb = _ParamGrad(beta, ctx.needs_input_grad[2])
+        acc = 1 if (gg.accumulate or gb.accumulate) else 0
+        if acc and not (gg.accumulate and gb.accumulate):   # mixed freshness: zero the fresh one
+            (gb if gg.accumulate else gg).buf.zero_()
+        ws = _ws(L().cloudaae_bn_workspace_bytes(C), y.device)
+        _lib.check(L().cloudaae_bn_backward(
+            M, C, yp, ldy, ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_var), training, relu, ptr(dout), C,
+            pool_rows, pool_mode, ptr(dpooled), ptr(pooled), ptr(ties), ptr(dy), C, ptr(gg.buf), ptr(gb.buf),
+            acc, ptr(ws), stream()), "cloudaae_bn_backward")
+        return (dy, gg.done(), gb.done()) + (None,) * 8
+
+
+class EdgeConvFn(torch.autograd.Function):
+    """Fused get_edge_feature + conv2d(1x1)+bias + batch norm + ReLU + pool over k."""
+
+    @staticmethod
+    def forward(ctx, x, nn_idx, w, b, gamma, beta, ema_mean, ema_var, decay, training, pool_mode, out_slot):
+        # x: [B, N, Cin] whose rows are contiguous (row stride may exceed Cin)
+        B, N, cin = x.shape
+        require(x.stride(2) == 1 and x.stride(0) == N * x.stride(1), "EdgeConvFn: x rows must be contiguous")
+        ldx = x.stride(1)
+        cout = w.shape[1]
+        require(w.shape[0] == 2 * cin, "EdgeConvFn: weights must be [2*Cin, Cout]")
+        require(nn_idx.dtype == torch.int32 and tuple(nn_idx.shape[:2]) == (B, N), "EdgeConvFn: nn_idx [B,N,k] int32")
+        k = nn_idx.shape[2]
+        dev = x.device
+        nn_idx = nn_idx.contiguous()
+        if out_slot is None:
+            out = torch.empty((B, N, cout), dtype=torch.float32, device=dev)
+        else:
+            # (buffer [B,N,Ctot], channel offset): the output is written in place as a
+            # column slice of a wider row-major buffer (saves the later concat copy).
+            # The view is created HERE so autograd sees a fresh output, not an input.
+            buf, off = out_slot
+            out = buf[:, :, off:off + cout]
+            require(tuple(out.shape) == (B, N, cout) and out.stride(2) == 1 and
+                    out.stride(0) == N * out.stride(1), "EdgeConvFn: bad output slot")
+        ldo = out.stride(1)
+        pq = torch.empty((B * N, 2 * cout), dtype=torch.float32, device=dev)
+        save_mean = torch.empty(cout, dtype=torch.float32, device=dev)
+        save_var = torch.empty(cout, dtype=torch.float32, device=dev)
+        ws = _ws(L().cloudaae_edgeconv_workspace_bytes(cout), dev)
+        _lib.check(L().cloudaae_edgeconv_forward(
+            B, N, k, cin, cout, x.data_ptr(), ldx, ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
+            int(training), ptr(decay), ptr(ema_mean), ptr(ema_var), int(pool_mode), ptr(pq), ptr(save_mean),
+            ptr(save_var), out.data_ptr(), ldo, ptr(ws), stream()), "cloudaae_edgeconv_forward")
+        ctx.save_for_backward(x, nn_idx, w, b, gamma, beta, pq, save_mean, save_var)
+        ctx.cfg = (int(training), int(pool_mode))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, nn_idx, w, b, gamma, beta, pq, save_mean, save_var = ctx.saved_tensors
+        training, pool_mode = ctx.cfg
+        B, N, cin = x.shape
+        cout = w.shape[1]
+        k = nn_idx.shape[2]
+        dev = x.device
+        if not (dout.stride(2) == 1 and dout.stride(0) == N * dout.stride(1)):
+            dout = dout.contiguous()
+        dpq = torch.empty((B * N, 2 * cout), dtype=torch.float32, device=dev)
+        dx = torch.empty((B, N, cin), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        gw = _ParamGrad(w, ctx.needs_input_grad[2])
+        gb = _ParamGrad(b, ctx.needs_input_grad[3])
+        gg = _ParamGrad(gamma, ctx.needs_input_grad[4])
+        gbe = _ParamGrad(beta, ctx.needs_input_grad[5])
+        # the kernel stores; shared (non-fresh) parameters would need accumulation
+        shared = [g for g in (gw, gb, gg, gbe) if g.needed and g.accumulate]
+        tmp = {}
+        for g in shared:
+            tmp[id(g)] = g.buf
+            g.buf = torch.empty_like(g.buf)
+        ws = _ws(L().cloudaae_edgeconv_workspace_bytes(cout), dev)
+        _lib.check(L().cloudaae_edgeconv_backward(
+            B, N, k, cin, cout, x.data_ptr(), x.stride(1), ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
+            training, pool_mode, ptr(pq), ptr(save_mean), ptr(save_var), dout.data_ptr(), dout.stride(1),
+            ptr(dpq), ptr(dx), cin, 0, ptr(gw.buf), ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), ptr(ws), stream()),
+            "cloudaae_edgeconv_backward")
+        for g in shared:
+            L().cloudaae_add_f32(g.buf.numel(), ptr(tmp[id(g)]), ptr(g.buf), ptr(tmp[id(g)]), stream())
+            g.buf = tmp[id(g)]
+        return (dx, None, gw.done(), gb.done(), gg.done(), gbe.done()) + (None,) * 6
+
+
+class AddRowVecFn(torch.autograd.Function):
+    """out[b,r,:] = x[b,r,:] + v[b,:]  (train_cloudAAE_ycbv.py:232-233); v carries no gradient path
+    to the parameters (it is a statistic of the input), so only dx is produced."""
+
+    @staticmethod
+    def forward(ctx, x, v):
+        x = x.contiguous()
+        v = v.contiguous()
+        B, R, D = x.shape
+        out = torch.empty_like(x)
+        _lib.check(L().cloudaae_add_rowvec(B, R, D, ptr(x), ptr(v), ptr(out), stream()), "cloudaae_add_rowvec")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        require(a.shape == b.shape, "AddFn: shapes differ (chamfer_loss.py:12 needs n == m)")
+        out = torch.empty_like(a)
+        _lib.check(L().cloudaae_add_f32(a.numel(), ptr(a), ptr(b), ptr(out), stream()), "cloudaae_add_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class MeanFn(torch.autograd.Function):
+    """tf.reduce_mean over all elements -> 0-dim fp32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        ws = _ws(L().cloudaae_mean_workspace_bytes(), x.device)
+        _lib.check(L().cloudaae_mean_f32(x.numel(), ptr(x), ptr(out), ptr(ws), stream()), "cloudaae_mean_f32")
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n = 1
+        for s in ctx.shape:
+            n *= s
+        out = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        _lib.check(L().cloudaae_fill_scaled(n, ptr(g.contiguous()), 1.0 / n, None, ptr(out), stream()),
+                   "cloudaae_fill_scaled")
+        return out
+
+
+class TransErrorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, label):
+        pred, label = pred.contiguous(), label.contiguous()
+        B = pred.shape[0]
+        per = torch.empty(B, dtype=torch.float32, device=pred.device)
+        _lib.check(L().cloudaae_trans_error(B, ptr(pred), ptr(label), ptr(per), stream()), "cloudaae_trans_error")
+        ctx.save_for_backward(pred, label, per)
+        return per
+
+    @staticmethod
+    def backward(ctx, gper):
+        pred, label, per = ctx.saved_tensors
+        d = torch.empty_like(pred)
+        _lib.check(L().cloudaae_trans_error_grad(pred.shape[0], ptr(pred), ptr(label), ptr(per),
+                                                 ptr(gper.contiguous()), ptr(d), stream()),
+                   "cloudaae_trans_error_grad")
+        return d, None
+
+
+class RotationErrorFn(torch.autograd.Function):
+    """(mean angle fp32, per-sample angle fp64); gradient flows through the mean only,
+    which is all the training graph uses (train_cloudAAE_ycbv.py:251-268)."""
+
+    @staticmethod
+    def forward(ctx, pred, label):
+        pred = pred.contiguous()
+        label = label.to(torch.float64).contiguous()
+        B = pred.shape[0]
+        per = torch.empty(B, dtype=torch.float64, device=pred.device)
+        jac = torch.empty((B, 3), dtype=torch.float64, device=pred.device)
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        _lib.check(L().cloudaae_rotation_error(B, ptr(pred), ptr(label), ptr(per), ptr(jac), ptr(loss), stream()),
+                   "cloudaae_rotation_error")
+        ctx.save_for_backward(jac)
+        ctx.mark_non_differentiable(per)
+        return loss, per
+
+    @staticmethod
+    def backward(ctx, gloss, gper):
+        (jac,) = ctx.saved_tensors
+        B = jac.shape[0]
+        d = torch.empty((B, 3), dtype=torch.float32, device=jac.device)
+        _lib.check(L().cloudaae_rotation_error_grad(B, ptr(jac), ptr(gloss.contiguous()), ptr(d), stream()),
+                   "cloudaae_rotation_error_grad")
+        return d, None
+
+
+class LossMixFn(torch.autograd.Function):
+    """total = w0*a + w1*b + w2*c on device scalars (train_cloudAAE_ycbv.py:268)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, w0, w1, w2):
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        _lib.check(L().cloudaae_loss_mix(ptr(a), ptr(b), ptr(c), w0, w1, w2, ptr(out), stream()),
+                   "cloudaae_loss_mix")
+        ctx.w = (w0, w1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ga, gb, gc = (torch.empty((), dtype=torch.float32, device=g.device) for _ in range(3))
+        _lib.check(L().cloudaae_loss_mix_grad(ptr(g.contiguous()), ctx.w[0], ctx.w[1], ctx.w[2], ptr(ga), ptr(gb),
+                                              ptr(gc), stream()), "cloudaae_loss_mix_grad")
+        return ga, gb, gc, None, None, None

@@ -1,12 +1,225 @@
 """Layer library -- mirror of the reference's utils/tf_util.py for the functions the
 CloudAAE scripts call (conv2d :111-179, fully_connected :321-365,
 batch_norm_* :473-570, pairwise_xyz_distance :597-618, knn :621-632,
-get_edge_feature :635-669), backed by libcloudaae_hip.so.
+get_edge_feature :635-669), hosted on torch tensors and backed by libcloudaae_hip.so.
+
+Same names, argument meaning and return values as the reference; differences that a
+torch host forces:
+  * `is_training` is a Python bool (TF: a bool placeholder); `bn_decay` is a float or
+    a 1-element device tensor (TF: float or float tensor);
+  * variables live in a VariableStore (utils/variables.py) under the reference's
+    scoped names instead of a TF graph collection;
+  * `activation_fn` is `tf_util.relu` or None.
+`edge_conv` is the fused form of get_edge_feature -> conv2d(bn) -> reduce_mean/max that
+the model builders use; the unfused functions remain available.
 """
 import torch
 
 from .. import _lib
 from .._lib import ptr, require, stream
+from . import _functions as F
+from .variables import VariableStore, default_store, reset_default_store, set_default_store  # noqa: F401
+
+relu = "relu"   # stands for tf.nn.relu in `activation_fn=`
+
+
+def variable_scope(name):
+    return default_store().variable_scope(name)
+
+
+def _variable_on_cpu(name, shape, initializer, use_fp16=False, trainable=None):
+    """tf_util.py:10-22.  (The reference pins variables to /cpu:0 and re-uploads them
+    every step; here they live in HBM, in the store's flat buffer.)"""
+    require(not use_fp16, "fp16 variables are not supported")
+    return default_store().get_variable(name, shape, initializer, trainable=(trainable is not False))
+
+
+def _variable_with_weight_decay(name, shape, stddev, wd, use_xavier=True, trainable=None, fan=None):
+    """tf_util.py:24-50.  Xavier-uniform (tf.contrib.layers.xavier_initializer) or
+    truncated normal.  The reference always passes weight_decay=0.0, which only adds a
+    constant-zero term to an unused collection; a non-zero value is rejected."""
+    if use_xavier:
+        fan_in, fan_out = fan
+        init = VariableStore.xavier_uniform(fan_in, fan_out)
+    else:
+        init = VariableStore.truncated_normal(stddev)
+    require(not wd, "weight decay is not used by the CloudAAE scripts and is not supported")
+    return _variable_on_cpu(name, shape, init, trainable=trainable)
+
+
+def _decay_tensor(bn_decay):
+    store = default_store()
+    if bn_decay is None:
+        return store.scalar(0.9)          # tf_util.py:493
+    if torch.is_tensor(bn_decay):
+        return bn_decay.reshape(1)
+    return store.scalar(float(bn_decay))
+
+
+def _bn_variables(num_channels):
+    """beta/gamma (tf_util.py:488-491) and the EMA shadows of the batch moments
+    (tf_util.py:493-500; TF names them .../bn/moments/Squeeze[_1]/ExponentialMovingAverage)."""
+    beta = _variable_on_cpu("beta", [num_channels], VariableStore.constant(0.0))
+    gamma = _variable_on_cpu("gamma", [num_channels], VariableStore.constant(1.0))
+    ema_mean = _variable_on_cpu("moments/Squeeze/ExponentialMovingAverage", [num_channels],
+                                VariableStore.constant(0.0), trainable=False)
+    ema_var = _variable_on_cpu("moments/Squeeze_1/ExponentialMovingAverage", [num_channels],
+                               VariableStore.constant(0.0), trainable=False)
+    return beta, gamma, ema_mean, ema_var
+
+
+def batch_norm_template(inputs, is_training, scope, moments_dims, bn_decay, _relu=False):
+    """ Batch normalization on convolutional maps and beyond... (tf_util.py:473-511)
+
+    Args:
+        inputs:        Tensor, k-D input ... x C could be BC or BHWC or BDHWC
+        is_training:   bool, true indicates training phase
+        scope:         string, variable scope
+        moments_dims:  a list of ints, indicating dimensions for moments calculation
+        bn_decay:      float or float tensor variable, controling moving average weight
+    Return:
+        normed:        batch-normalized maps
+    """
+    require(list(moments_dims) == list(range(inputs.dim() - 1)),
+            "moments_dims must be all axes but the last (as every reference call site has)")
+    C = inputs.shape[-1]
+    with variable_scope(scope):
+        beta, gamma, ema_mean, ema_var = _bn_variables(C)
+    x2 = inputs.reshape(-1, C)
+    out, _, _ = F.BatchNormFn.apply(x2, gamma.data, beta.data, ema_mean.data, ema_var.data,
+                                    _decay_tensor(bn_decay), bool(is_training), bool(_relu), 0, 0, True)
+    return out.reshape(inputs.shape)
+
+
+def batch_norm_for_fc(inputs, is_training, bn_decay, scope):
+    """tf_util.py:514-525"""
+    return batch_norm_template(inputs, is_training, scope, [0, ], bn_decay)
+
+
+def batch_norm_for_conv1d(inputs, is_training, bn_decay, scope):
+    """tf_util.py:528-539"""
+    return batch_norm_template(inputs, is_training, scope, [0, 1], bn_decay)
+
+
+def batch_norm_for_conv2d(inputs, is_training, bn_decay, scope):
+    """tf_util.py:544-555"""
+    return batch_norm_template(inputs, is_training, scope, [0, 1, 2], bn_decay)
+
+
+def _check_activation(activation_fn):
+    require(activation_fn in (relu, None), "activation_fn must be tf_util.relu or None")
+    return activation_fn == relu
+
+
+def conv2d(inputs,
+           num_output_channels,
+           kernel_size,
+           scope,
+           stride=[1, 1],
+           padding='SAME',
+           use_xavier=True,
+           stddev=1e-3,
+           weight_decay=0.0,
+           activation_fn=relu,
+           bn=False,
+           bn_decay=None,
+           is_training=None,
+           trainable=None):
+    """ 2D convolution with non-linear operation (tf_util.py:111-179).
+
+    Args:
+      inputs: 4-D tensor variable BxHxWxC
+      num_output_channels: int
+      kernel_size: a list of 2 ints -- [1,1] (every DGCNN call site) or [1,W] with
+                   padding 'VALID' on a BxHxWx1 input (PointNet's first layer,
+                   models/pointnet_ycb_23_decoder_4.py:39); both are a GEMM over rows
+      scope: string
+      ...
+    Returns:
+      Variable tensor BxHx1xCout / BxHxWxCout
+    """
+    require(inputs.dim() == 4, "conv2d: inputs must be BxHxWxC")
+    require(list(stride) == [1, 1], "conv2d: only stride [1,1] is used by CloudAAE")
+    kernel_h, kernel_w = kernel_size
+    B, H, W, Cin = inputs.shape
+    act = _check_activation(activation_fn)
+    with variable_scope(scope):
+        kernel = _variable_with_weight_decay('weights', [kernel_h, kernel_w, Cin, num_output_channels],
+                                             stddev=stddev, wd=weight_decay, use_xavier=use_xavier,
+                                             trainable=trainable,
+                                             fan=(kernel_h * kernel_w * Cin, kernel_h * kernel_w * num_output_channels))
+        biases = _variable_on_cpu('biases', [num_output_channels], VariableStore.constant(0.0),
+                                  trainable=trainable)
+        if kernel_h == 1 and kernel_w == 1:
+            rows = inputs.reshape(B * H * W, Cin)
+            out_shape = (B, H, W, num_output_channels)
+        else:
+            require(kernel_h == 1 and kernel_w == W and padding == 'VALID',
+                    "conv2d: only 1x1 and full-width [1,W] VALID kernels are supported")
+            rows = inputs.reshape(B * H, W * Cin)
+            out_shape = (B, H, 1, num_output_channels)
+        w2 = kernel.data.reshape(-1, num_output_channels)
+        w2._cloudaae_var = kernel
+        outputs = F.LinearFn.apply(rows, w2, biases.data)
+        if bn:
+            with variable_scope('bn'):
+                beta, gamma, ema_mean, ema_var = _bn_variables(num_output_channels)
+            outputs, _, _ = F.BatchNormFn.apply(outputs, gamma.data, beta.data, ema_mean.data, ema_var.data,
+                                                _decay_tensor(bn_decay), bool(is_training), act, 0, 0, True)
+        elif act:
+            outputs = _relu_rows(outputs)
+    return outputs.reshape(out_shape)
+
+
+def fully_connected(inputs,
+                    num_outputs,
+                    scope,
+                    use_xavier=True,
+                    stddev=1e-3,
+                    weight_decay=0.0,
+                    activation_fn=relu,
+                    bn=False,
+                    bn_decay=None,
+                    is_training=None,
+                    trainable=None):
+    """ Fully connected layer with non-linear operation (tf_util.py:321-365).
+
+    Args:
+      inputs: 2-D tensor BxN
+      num_outputs: int
+
+    Returns:
+      (outputs B x num_outputs, weights, biases)
+    """
+    require(inputs.dim() == 2, "fully_connected: inputs must be BxN")
+    act = _check_activation(activation_fn)
+    num_input_units = inputs.shape[-1]
+    with variable_scope(scope):
+        weights = _variable_with_weight_decay('weights', [num_input_units, num_outputs], stddev=stddev,
+                                              wd=weight_decay, use_xavier=use_xavier, trainable=trainable,
+                                              fan=(num_input_units, num_outputs))
+        biases = _variable_on_cpu('biases', [num_outputs], VariableStore.constant(0.0), trainable=trainable)
+        outputs = F.LinearFn.apply(inputs, weights.data, biases.data)
+        if bn:
+            with variable_scope('bn'):
+                beta, gamma, ema_mean, ema_var = _bn_variables(num_outputs)
+            outputs, _, _ = F.BatchNormFn.apply(outputs, gamma.data, beta.data, ema_mean.data, ema_var.data,
+                                                _decay_tensor(bn_decay), bool(is_training), act, 0, 0, True)
+        elif act:
+            outputs = _relu_rows(outputs)
+    return outputs, weights.data, biases.data
+
+
+def _relu_rows(x):
+    # ReLU without batch norm does not occur in the CloudAAE graphs (every activated layer
+    # has bn=True); route it through the BN kernel with identity statistics.
+    C = x.shape[-1]
+    dev = x.device
+    one = torch.ones(C, dtype=torch.float32, device=dev)
+    zero = torch.zeros(C, dtype=torch.float32, device=dev)
+    var = torch.full((C,), 1.0 - 1e-3, dtype=torch.float32, device=dev)   # rsqrt(var + eps) == 1
+    out, _, _ = F.BatchNormFn.apply(x.reshape(-1, C), one, zero, zero, var, None, False, True, 0, 0, True)
+    return out.reshape(x.shape)
 
 
 class PairwiseDistance(object):
@@ -16,7 +229,7 @@ class PairwiseDistance(object):
     never written."""
 
     def __init__(self, points, channels):
-        self.points = points      # [B, N, ld] contiguous fp32
+        self.points = points      # [B, N, ld] fp32 whose rows are contiguous
         self.channels = channels  # leading channels that form the metric
 
     @property
@@ -26,7 +239,7 @@ class PairwiseDistance(object):
 
 
 def pairwise_xyz_distance(point_cloud):
-    """Compute pairwise distance of a point cloud.
+    """Compute pairwise distance of a point cloud (tf_util.py:597-618).
 
     Args:
       point_cloud: tensor (batch_size, num_points, num_dims)  or
@@ -41,17 +254,21 @@ def pairwise_xyz_distance(point_cloud):
     require(point_cloud.dtype == torch.float32, "pairwise_xyz_distance: float32 expected")
     if point_cloud.dim() == 4:
         require(point_cloud.shape[2] == 1, "pairwise_xyz_distance: expected [B,N,1,C]")
-        pts = point_cloud.reshape(point_cloud.shape[0], point_cloud.shape[1], point_cloud.shape[3])
+        pts = point_cloud[:, :, 0, :]
         channels = pts.shape[2]
     else:
         require(point_cloud.dim() == 3, "pairwise_xyz_distance: expected [B,N,C]")
         pts = point_cloud
         channels = min(3, pts.shape[2])
-    return PairwiseDistance(pts.detach().contiguous(), channels)
+    pts = pts.detach()
+    B, N, _ = pts.shape
+    if not (pts.stride(2) == 1 and (B == 1 or pts.stride(0) == N * pts.stride(1))):
+        pts = pts.contiguous()
+    return PairwiseDistance(pts, channels)
 
 
 def knn(adj_matrix, k=9):
-    """Get KNN based on the pairwise distance.
+    """Get KNN based on the pairwise distance (tf_util.py:621-632).
     Args:
       pairwise distance: (batch_size, num_points, num_points)
       k: int
@@ -63,8 +280,94 @@ def knn(adj_matrix, k=9):
     require(isinstance(adj_matrix, PairwiseDistance),
             "knn expects the result of pairwise_xyz_distance")
     x = adj_matrix.points
-    b, n, ld = x.shape
+    b, n, _ = x.shape
+    ld = x.stride(1)
     nn_idx = torch.empty((b, n, int(k)), dtype=torch.int32, device=x.device)
-    _lib.check(_lib.lib().cloudaae_knn(b, n, adj_matrix.channels, ld, int(k), ptr(x), ptr(nn_idx),
+    _lib.check(_lib.lib().cloudaae_knn(b, n, adj_matrix.channels, ld, int(k), x.data_ptr(), ptr(nn_idx),
                                        stream()), "cloudaae_knn")
     return nn_idx
+
+
+def edge_conv(point_cloud, nn_idx, num_output_channels, scope, pool='mean', bn_decay=None, is_training=None,
+              out_slot=None):
+    """Fused  get_edge_feature(point_cloud, nn_idx, k)            (tf_util.py:635-669)
+              -> conv2d(., num_output_channels, [1,1], bn=True)   (tf_util.py:111-179)
+              -> tf.reduce_mean / tf.reduce_max(axis=-2, keep_dims=True)
+    i.e. one DGCNN block of models/pointnet_ycb_23_decoder_4.py:337-350 (mean) / :605-615 (max).
+    Variables are created under `scope` exactly as conv2d would ('weights' [1,1,2C,Cout],
+    'biases', 'bn/beta', 'bn/gamma').
+
+    Args:
+      point_cloud: (batch_size, num_points, num_dims) or (batch_size, num_points, 1, num_dims)
+      nn_idx: (batch_size, num_points, k) int32
+      pool: 'mean' or 'max'
+      out_slot: optional (buffer [B,N,Ctot], channel offset) to write the result into
+    Returns:
+      (batch_size, num_points, 1, num_output_channels)
+    """
+    require(pool in ('mean', 'max'), "pool must be 'mean' or 'max'")
+    x = point_cloud[:, :, 0, :] if point_cloud.dim() == 4 else point_cloud
+    B, N, C = x.shape
+    if not (x.stride(2) == 1 and (B == 1 or x.stride(0) == N * x.stride(1))):
+        x = x.contiguous()
+    with variable_scope(scope):
+        kernel = _variable_with_weight_decay('weights', [1, 1, 2 * C, num_output_channels], stddev=1e-3, wd=0.0,
+                                             use_xavier=True, fan=(2 * C, num_output_channels))
+        biases = _variable_on_cpu('biases', [num_output_channels], VariableStore.constant(0.0))
+        with variable_scope('bn'):
+            beta, gamma, ema_mean, ema_var = _bn_variables(num_output_channels)
+    w2 = kernel.data.reshape(2 * C, num_output_channels)
+    w2._cloudaae_var = kernel
+    out = F.EdgeConvFn.apply(x, nn_idx, w2, biases.data, gamma.data, beta.data, ema_mean.data, ema_var.data,
+                             _decay_tensor(bn_decay), bool(is_training), 1 if pool == 'mean' else 2, out_slot)
+    return out.unsqueeze(2)
+
+
+def conv2d_concat(inputs_list, num_output_channels, scope, bn_decay=None, is_training=None, pool=None):
+    """conv2d(tf.concat(inputs_list, axis=-1), C, [1,1], bn=True) followed, when `pool` is
+    'mean'/'max', by the reduction over the point axis (models/...:410-419 / :675-684) --
+    without the concat copy when the inputs are adjacent slices of one buffer, and without
+    writing the [B,N,1,C] activation when only the pooled embedding is consumed.
+    Returns (pooled [B,C] or None, lazy activation)."""
+    B, N = inputs_list[0].shape[0], inputs_list[0].shape[1]
+    rows = [t.reshape(B * N, t.shape[-1]) for t in inputs_list]
+    cin = sum(r.shape[1] for r in rows)
+    with variable_scope(scope):
+        kernel = _variable_with_weight_decay('weights', [1, 1, cin, num_output_channels], stddev=1e-3, wd=0.0,
+                                             use_xavier=True, fan=(cin, num_output_channels))
+        biases = _variable_on_cpu('biases', [num_output_channels], VariableStore.constant(0.0))
+        with variable_scope('bn'):
+            beta, gamma, ema_mean, ema_var = _bn_variables(num_output_channels)
+    w2 = kernel.data.reshape(cin, num_output_channels)
+    w2._cloudaae_var = kernel
+    y = F.ConcatLinearFn.apply(w2, biases.data, *rows)
+    mode = {None: 0, 'mean': 1, 'max': 2}[pool]
+    if mode == 0:
+        act, mean, var = F.BatchNormFn.apply(y, gamma.data, beta.data, ema_mean.data, ema_var.data,
+                                             _decay_tensor(bn_decay), bool(is_training), True, 0, 0, True)
+        return None, act.reshape(B, N, 1, num_output_channels)
+    pooled, mean, var = F.BatchNormFn.apply(y, gamma.data, beta.data, ema_mean.data, ema_var.data,
+                                            _decay_tensor(bn_decay), bool(is_training), True, N, mode, False)
+    return pooled, LazyActivation(y, mean, var, gamma.data, beta.data, (B, N, 1, num_output_channels))
+
+
+class LazyActivation(object):
+    """relu(batch_norm(y)) that is only written out when somebody asks for it
+    (end_points['layer_before_embedding'], models/...:418; nothing in the training graph
+    reads it, and at B=32, N=1024 it is a 134 MB tensor)."""
+
+    def __init__(self, y, mean, var, gamma, beta, shape):
+        self._y, self._mean, self._var, self._gamma, self._beta = y.detach(), mean, var, gamma.detach(), beta.detach()
+        self.shape = tuple(shape)
+
+    def tensor(self):
+        out, _, _ = F.BatchNormFn.apply(self._y, self._gamma, self._beta, self._mean, self._var, None, False, True,
+                                        0, 0, True)
+        return out.reshape(self.shape)
+
+
+def get_edge_feature(point_cloud, nn_idx, k):
+    """Construct edge feature for each point (tf_util.py:635-669): [c_i, n_ij - c_i].
+    Unfused form, kept for API completeness; the model builders use `edge_conv`.
+    TODO(next round): dedicated gather kernel; until then it fails loudly."""
+    raise NotImplementedError("get_edge_feature (unfused) is not built yet; use tf_util.edge_conv")

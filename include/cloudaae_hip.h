@@ -88,6 +88,111 @@ int cloudaae_gather_point_grad(int b, int n, int m, const float *out_g, const in
 int cloudaae_knn(int b, int n, int c, int ld, int k, const float *x, int *nn_idx,
                  cloudaae_stream_t stream);
 
+/* ---- utils/tf_util.py: dense layers ------------------------------------- */
+
+/* C[M,N] (+)= op(A)[M,K] op(B)[K,N] (+ bias[N]); fp32 in / fp32 accumulate on the
+ * matrix cores (v_mfma_f32_32x32x2_f32 = k-ordered fmaf chain).  Row-major.
+ * trans_a: A is stored [K][M]; trans_b: B is stored [N][K].  accumulate: add to C.
+ * Replaces tf.nn.conv2d 1x1 + bias_add (utils/tf_util.py:161-166) and tf.matmul +
+ * bias_add (utils/tf_util.py:349-352) and their two gradient products. */
+int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                      const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
+                      cloudaae_stream_t stream);
+
+/* batch_norm_template (utils/tf_util.py:473-511) on rows y[M,C] (+ ReLU), writing the
+ * activation out[M,C] and/or its pool over groups of pool_rows consecutive rows
+ * (pool_mode 0 none, 1 mean = models/pointnet_ycb_23_decoder_4.py:419, 2 max = :684,
+ * :59-60; tie_count[M/pool_rows,C] receives the number of equal maxima).
+ * training != 0: batch moments (biased variance), EMA shadows updated as
+ * s -= (s - stat) * (1 - decay[0]) when ema_mean != NULL; training == 0: moments =
+ * EMA shadows.  save_mean/save_var[C] receive the moments used.  eps = 1e-3.
+ * workspace: cloudaae_bn_workspace_bytes(C) bytes. */
+long long cloudaae_bn_workspace_bytes(int C);
+int cloudaae_bn_forward(int M, int C, const float *y, int ldy, const float *gamma, const float *beta,
+                        int training, const float *decay, float *ema_mean, float *ema_var,
+                        float *save_mean, float *save_var, int relu, float *out, int ldo, int pool_rows,
+                        int pool_mode, float *pooled, float *tie_count, void *workspace,
+                        cloudaae_stream_t stream);
+/* gradient of the above: upstream = dout[M,C] (may be NULL) and/or dpooled[M/pool_rows,C]
+ * (mean: /pool_rows; max: shared among equal maxima, as tf.reduce_max does);
+ * produces dy[M,C], dgamma[C], dbeta[C] (NULL = not wanted). */
+int cloudaae_bn_backward(int M, int C, const float *y, int ldy, const float *gamma, const float *beta,
+                         const float *save_mean, const float *save_var, int training, int relu,
+                         const float *dout, int lddo, int pool_rows, int pool_mode, const float *dpooled,
+                         const float *pooled, const float *tie_count, float *dy, int lddy, float *dgamma,
+                         float *dbeta, int accumulate_param_grads, void *workspace,
+                         cloudaae_stream_t stream);
+/* out[c] (+)= sum_r x[r][c] (bias gradients); workspace as for bn (same C). */
+int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, float *out, int accumulate, void *workspace,
+                        cloudaae_stream_t stream);
+
+/* ---- the DGCNN edge-convolution block, fused ---------------------------- */
+
+/* get_edge_feature + conv2d 1x1 + batch norm + ReLU + pool over k
+ * (utils/tf_util.py:635-669,111-179; models/pointnet_ycb_23_decoder_4.py:337-350):
+ * x[b*n, cin] (row stride ldx), nn_idx[b,n,k], weights[2*cin, cout] (the TF kernel
+ * [1,1,2cin,cout]), pool_mode 1 mean / 2 max -> out[b*n, cout] (row stride ldo).
+ * pq[b*n, 2*cout] is scratch that the backward pass reads again.  cout in {64,128}. */
+long long cloudaae_edgeconv_workspace_bytes(int cout);
+int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cout, const float *x, int ldx,
+                              const int *nn_idx, const float *weights, const float *biases,
+                              const float *gamma, const float *beta, int training, const float *decay,
+                              float *ema_mean, float *ema_var, int pool_mode, float *pq, float *save_mean,
+                              float *save_var, float *out, int ldo, void *workspace,
+                              cloudaae_stream_t stream);
+int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int cout, const float *x, int ldx,
+                               const int *nn_idx, const float *weights, const float *biases,
+                               const float *gamma, const float *beta, int training, int pool_mode,
+                               const float *pq, const float *save_mean, const float *save_var,
+                               const float *dout, int lddo, float *dpq, float *dx, int lddx,
+                               int accumulate_dx, float *dweights, float *dbiases, float *dgamma,
+                               float *dbeta, void *workspace, cloudaae_stream_t stream);
+
+/* ---- train_cloudAAE_ycbv.py:194-273: the step around the network --------- */
+
+/* :206-226  pc[b,n,3+num_class] = [visible[:, :n] + noise - mean, one_hot(class_id)],
+ * mean[b,3] over the n noisy points; noisy[b,n,3] optional; visible is [b,p,3], p >= n. */
+int cloudaae_input_assemble(int b, int p, int n, int num_class, const float *visible, const float *noise,
+                            const long long *class_id, float *pc, float *mean, float *noisy,
+                            cloudaae_stream_t stream);
+/* :232-233  out[b,r,:] = x[b,r,:] + v[b,:] */
+int cloudaae_add_rowvec(int b, int r, int d, const float *x, const float *v, float *out,
+                        cloudaae_stream_t stream);
+int cloudaae_add_f32(long long n, const float *a, const float *b, float *out, cloudaae_stream_t stream);
+/* out[i] = scalar[0] * scale (+ add[i]) : gradient of a mean */
+int cloudaae_fill_scaled(long long n, const float *scalar, float scale, const float *add, float *out,
+                         cloudaae_stream_t stream);
+long long cloudaae_mean_workspace_bytes(void);
+int cloudaae_mean_f32(long long n, const float *x, float *out, void *workspace, cloudaae_stream_t stream);
+/* losses/trans_distance.py:4-9 */
+int cloudaae_trans_error(int b, const float *pred, const float *label, float *per, cloudaae_stream_t stream);
+int cloudaae_trans_error_grad(int b, const float *pred, const float *label, const float *per,
+                              const float *gper, float *dpred, cloudaae_stream_t stream);
+/* losses/angular_distance_taylor.py:30-116 in float64: per[b] = geodesic angle,
+ * jac[b,3] = d per / d pred, loss = mean (fp32). */
+int cloudaae_rotation_error(int b, const float *pred, const double *label, double *per, double *jac,
+                            float *loss, cloudaae_stream_t stream);
+/* exponential_map (angular_distance_taylor.py:30-66): axag[b,3] f64 -> rot[b,3,3] f64 */
+int cloudaae_exponential_map(int b, const double *axag, double *rot, cloudaae_stream_t stream);
+int cloudaae_rotation_error_grad(int b, const double *jac, const float *gloss, float *dpred,
+                                 cloudaae_stream_t stream);
+/* :268  total = w0*a + w1*b + w2*c on device scalars */
+int cloudaae_loss_mix(const float *a, const float *b, const float *c, float w0, float w1, float w2,
+                      float *out, cloudaae_stream_t stream);
+int cloudaae_loss_mix_grad(const float *g, float w0, float w1, float w2, float *ga, float *gb, float *gc,
+                           cloudaae_stream_t stream);
+/* :263-273  tf.train.AdamOptimizer (ApplyAdam form) over a flat buffer; beta powers are
+ * device scalars (TF's beta1_power/beta2_power variables), multiplied when advance != 0. */
+int cloudaae_adam_tf(long long n, float *param, const float *grad, float *m, float *v, float lr,
+                     float beta1, float beta2, float eps, float *beta1_power, float *beta2_power,
+                     float grad_scale, int advance, cloudaae_stream_t stream);
+int cloudaae_sgd(long long n, float *param, const float *grad, float lr, float grad_scale,
+                 cloudaae_stream_t stream);
+/* :194-202  out[0] = min(clip, 1 - init * rate^floor(step[0]*batch_size/decay_step)) */
+int cloudaae_bn_decay_schedule(const float *step, float batch_size, float init, float decay_step,
+                               float rate, float clip, float *out, cloudaae_stream_t stream);
+int cloudaae_increment(float *x, float by, cloudaae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
