@@ -1,0 +1,148 @@
+"""bench.py -- throughput of the CloudAAE training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+A "step" is one pass of the hot path over one batch of synthetic input, i.e. one
+iteration of the reference's session loop (train_cloudAAE_ycbv.py:350-368): BN-decay
+schedule, input assembly, DGCNN encoder + decoder + pose heads, Chamfer / translation /
+SO(3) losses, backward, TF-Adam (+ gradient all-reduce for N > 1).  Workload at N=1 is
+BASELINE.json configs[1]: all 21 classes, batch 32, 1024 points, fp32.  For N > 1 the
+per-GPU batch stays 32 (weak scaling).  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     : the dominant kernel (the dgcnn_agg forward GEMM on the matrix cores),
+                 timed live with HIP events on the launch stream over the timed region
+  cpu_baseline : the CPU oracle's train step timed on this box's host cores on a bounded
+                 sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(num_point, sample_batch, steps=1):
+    """CPU oracle (oracle/model_oracle.py: torch-CPU restatement + C kNN/Chamfer, all host
+    cores) on a bounded sample of the same workload.  Checker code used as the reported
+    baseline only (kind "port": TensorFlow 1.12 cannot run in this image)."""
+    from oracle import model_oracle as MO
+    from oracle import native as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    V = MO.Vars(seed=0)
+    batch = MO.synthetic_batch(sample_batch, num_point, seed=123456789)
+    opt = MO.AdamTF()
+    warm = MO.synthetic_batch(2, num_point, seed=1)                # warm-up: allocations, thread pools
+    MO.train_step(warm, V, opt, 0, num_point, 2)
+    t0 = time.time()
+    for i in range(steps):
+        MO.train_step(batch, V, opt, i + 1, num_point, sample_batch)
+    dt = time.time() - t0
+    return {"value": round(sample_batch * steps / dt, 3), "unit": "clouds/s", "cores": min(cores, O.max_threads()),
+            "kind": "port",
+            "sample": "%d train step(s) of batch %d, N=%d (same graph, smaller batch), %.1f s"
+                      % (steps, sample_batch, num_point, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--per-gpu-batch", type=int, default=32)
+    ap.add_argument("--num-point", type=int, default=1024)
+    ap.add_argument("--cpu-batch", type=int, default=8, help="batch of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs torch.distributed.run (WORLD_SIZE is unset)" % args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from cloudaae_amd import train_cloudAAE_ycbv as T
+    from cloudaae_amd.utils import _functions as F
+
+    B = args.per_gpu_batch
+    N = args.num_point
+    graph = T.TrainGraph({"num_point": N, "gpu": local}, {"optimizer": "adam"},
+                         {"batch_size": B * world, "learning_rate": 0.0008})
+    el = T.synthetic_element(B, N, graph.device, seed=123456789, rank=rank)
+
+    for _ in range(args.warmup):
+        graph.train_step(el)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    F.TIMED_SITES["agg_fwd"] = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = graph.train_step(el)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    events = F.TIMED_SITES.pop("agg_fwd")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=graph.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(out["total_loss"])
+
+    if rank == 0:
+        ms = [a.elapsed_time(b) for a, b in events]
+        k_ms = sum(ms) / max(1, len(ms))
+        M, Nn, K = B * N, 1024, 320
+        flops = 2.0 * M * Nn * K                      # algorithmic flops of one dgcnn_agg forward launch
+        achieved = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        line = {
+            "metric": "point-clouds/sec (train step, N=%d)" % N,
+            "value": round(B * world * args.steps / elapsed, 2),
+            "unit": "clouds/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "CloudAAE train step: get_model_dgcnn_mean_6d, all 21 YCB classes, "
+                                   "batch %d/GPU, N=%d points, k=10, 4N-point Chamfer target, TF-Adam" % (B, N),
+                       "global_batch": B * world, "num_point": N, "parallelism": "dp%d" % world,
+                       "final_total_loss": round(loss, 4)},
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,2,2> dgcnn_agg forward "
+                                                     "[%d x 320] x [320 x 1024]" % M,
+                         "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launch_ms": round(k_ms, 4), "launches_timed": len(ms)},
+        }
+        if world == 1 and args.cpu_batch > 0:
+            line["cpu_baseline"] = cpu_baseline(N, args.cpu_batch)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

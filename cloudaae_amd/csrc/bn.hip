@@ -192,16 +192,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
     }
 }
 
-// plain column sums (bias gradients): out[c] (+)= sum_r x[r][c]
-__global__ void colsum_finalize_kernel(int C, const double *__restrict__ partial, int parts,
-                                       float *__restrict__ out, int accumulate)
+// plain column sums (bias gradients): out[c] (+)= sum_r x[r][c]; grid = ceil(C/64) x 256
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(int C, const double *__restrict__ partial,
+                                                             int parts, float *__restrict__ out, int accumulate)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C)
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    double s, s2;
+    bn_reduce_partials(partial, parts, C, c, pl, s, s2);
+    if (c >= C || pl != 0)
         return;
-    double s = 0.0;
-    for (int p = 0; p < parts; ++p)
-        s += partial[((size_t)p * 2 + 0) * C + c];
     out[c] = (accumulate ? out[c] : 0.0f) + (float)s;
 }
 
@@ -244,7 +243,7 @@ CLOUDAAE_API int cloudaae_bn_forward(int M, int C, const float *y, int ldy, cons
     const int cb = ceil_div(C, 64);
     if (training)
         hipLaunchKernelGGL(bn_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, M, C, y, ldy, partial, parts);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, C, partial, parts,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, C, partial, parts,
                        (double)M, training, decay, ema_mean, ema_var, gamma, beta, save_mean, save_var,
                        scale_shift);
     if (pool_mode == 0) {
@@ -294,7 +293,7 @@ CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, con
     const int parts = bn_parts(M);
     const int cb = ceil_div(C, 64);
     hipLaunchKernelGGL(bn_bwd_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, a, partial, parts);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, C, partial, parts,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, C, partial, parts,
                        (double)M, training, dgamma, dbeta, accumulate_param_grads, m12);
     const int slab = 64;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cb, ceil_div(M, slab)), dim3(256), 0, s, a, m12, dy, lddy,
@@ -313,7 +312,7 @@ CLOUDAAE_API int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, floa
     const int parts = bn_parts(M);
     hipLaunchKernelGGL(bn_colsum_kernel, dim3(ceil_div(C, 64), parts), dim3(256), 0, s, M, C, x, ldx, partial,
                        parts);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, C, partial, parts, out,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, C, partial, parts, out,
                        accumulate);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;

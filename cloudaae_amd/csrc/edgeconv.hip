@@ -24,7 +24,7 @@
 
 namespace cloudaae {
 
-constexpr int EC_MAX_PARTS = 1024;
+constexpr int EC_MAX_PARTS = 256;
 constexpr int EC_WAVES = 4;
 
 __host__ __device__ inline size_t ec_ws_doubles(int C) { return (size_t)EC_MAX_PARTS * 2 * C + 2 * (size_t)C; }
@@ -374,7 +374,7 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
         EC_DISPATCH(EC_STATS);
 #undef EC_STATS
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(cout, 256)), dim3(256), 0, s, cout, partial, grid,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(cout, 64)), dim3(256), 0, s, cout, partial, grid,
                        (double)P * (double)k, training, decay, ema_mean, ema_var, gamma, beta, save_mean,
                        save_var, scale_shift);
     if (pool_mode == 1) {
@@ -426,7 +426,7 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
         EC_DISPATCH(EC_BS);
 #undef EC_BS
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(cout, 256)), dim3(256), 0, s, cout, partial, grid,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(cout, 64)), dim3(256), 0, s, cout, partial, grid,
                        (double)P * (double)k, training, dgamma, dbeta, 0, m12);
     CLOUDAAE_CHECK_HIP(hipMemsetAsync(dpq, 0, sizeof(float) * (size_t)P * 2 * cout, s), name);
     if (dbiases)

@@ -18,6 +18,7 @@ def _check_cloud(name, t):
 class _NnDistance(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz1, xyz2):
+        ctx.set_materialize_grads(False)
         _check_cloud("xyz1", xyz1)
         _check_cloud("xyz2", xyz2)
         require(xyz1.shape[0] == xyz2.shape[0],

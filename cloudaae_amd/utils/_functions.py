@@ -46,9 +46,22 @@ class _ParamGrad(object):
         return self.own
 
 
-def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, accumulate=0):
+# bench.py times individual launches: TIMED_SITES[name] = [] switches a site on; each launch
+# of that site then appends a (start, end) HIP event pair recorded on the launch stream.
+TIMED_SITES = {}
+
+
+def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, accumulate=0, site=None):
+    rec = TIMED_SITES.get(site) if site is not None else None
+    if rec is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(L().cloudaae_gemm_f32(int(ta), int(tb), M, N, K, A, lda, B, ldb, C, ldc, bias, int(accumulate),
                                      stream()), "cloudaae_gemm_f32")
+    if rec is not None:
+        e1.record()
+        rec.append((e0, e1))
 
 
 class LinearFn(torch.autograd.Function):
@@ -121,7 +134,7 @@ class ConcatLinearFn(torch.autograd.Function):
             ctx.cat = cat
         N = w.shape[1]
         y = torch.empty((M, N), dtype=torch.float32, device=w.device)
-        gemm(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None)
+        gemm(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, site="agg_fwd")
         ctx.save_for_backward(w, *nets)
         ctx.widths, ctx.xp, ctx.bvar = widths, xp, b
         return y
@@ -162,6 +175,7 @@ class BatchNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, ema_mean, ema_var, decay, training, relu, pool_rows, pool_mode,
                 want_activation):
+        ctx.set_materialize_grads(False)
         yp, ldy = rows_ptr(y)
         M, C = y.shape
         dev = y.device
@@ -372,6 +386,7 @@ class RotationErrorFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pred, label):
+        ctx.set_materialize_grads(False)
         pred = pred.contiguous()
         label = label.to(torch.float64).contiguous()
         B = pred.shape[0]
@@ -387,6 +402,8 @@ class RotationErrorFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, gper):
         (jac,) = ctx.saved_tensors
+        if gloss is None:
+            return None, None
         B = jac.shape[0]
         d = torch.empty((B, 3), dtype=torch.float32, device=jac.device)
         _lib.check(L().cloudaae_rotation_error_grad(B, ptr(jac), ptr(gloss.contiguous()), ptr(d), stream()),
