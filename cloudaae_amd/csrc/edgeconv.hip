@@ -24,8 +24,9 @@
 
 namespace cloudaae {
 
-constexpr int EC_MAX_PARTS = 256;
-constexpr int EC_WAVES = 4;
+constexpr int EC_MAX_PARTS = 256;   // partial-sum rows of the statistics passes
+constexpr int EC_WAVES = 4;         // apply passes: 4 waves per workgroup, grid sized by the work
+constexpr int EC_STAT_WAVES = 16;   // statistics passes: 16 waves per workgroup (<= 256 workgroups)
 
 __host__ __device__ inline size_t ec_ws_doubles(int C) { return (size_t)EC_MAX_PARTS * 2 * C + 2 * (size_t)C; }
 
@@ -56,17 +57,17 @@ struct EcPoint {
         float u[CPL];
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
-            const int c = lane * CPL + e;
+            const int c = lane + 64 * e;
             u[e] = (row[c] - row[a.cout + c]) + a.bias[c];
         }
 #pragma unroll
         for (int j = 0; j < KCAP; ++j) {
             if (j < a.k) {
                 nb[j] = base + __shfl(mine, j, 64);
-                const float *q = a.pq + (size_t)nb[j] * a.ldpq + a.cout + lane * CPL;
+                const float *q = a.pq + (size_t)nb[j] * a.ldpq + a.cout + lane;
 #pragma unroll
                 for (int e = 0; e < CPL; ++e)
-                    y[j][e] = u[e] + q[e];
+                    y[j][e] = u[e] + q[64 * e];
             }
         }
     }
@@ -76,19 +77,19 @@ template <int CPL>
 __device__ __forceinline__ void ec_block_reduce_store(double (&s)[CPL], double (&s2)[CPL], double *partial,
                                                       int cout, int lane, int wave)
 {
-    __shared__ double red[2][EC_WAVES][64 * CPL];
+    __shared__ double red[2][EC_STAT_WAVES][64 * CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e) {
-        red[0][wave][lane * CPL + e] = s[e];
-        red[1][wave][lane * CPL + e] = s2[e];
+        red[0][wave][lane + 64 * e] = s[e];
+        red[1][wave][lane + 64 * e] = s2[e];
     }
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
-            const int c = lane * CPL + e;
+            const int c = lane + 64 * e;
             double a = red[0][0][c], b = red[1][0][c];
-            for (int w = 1; w < EC_WAVES; ++w) {
+            for (int w = 1; w < EC_STAT_WAVES; ++w) {
                 a += red[0][w][c];
                 b += red[1][w][c];
             }
@@ -99,14 +100,14 @@ __device__ __forceinline__ void ec_block_reduce_store(double (&s)[CPL], double (
 }
 
 template <int CPL, int KCAP>
-__global__ __launch_bounds__(64 * EC_WAVES) void ec_stats_kernel(EcArgs a, double *__restrict__ partial)
+__global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_stats_kernel(EcArgs a, double *__restrict__ partial)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double s[CPL], s2[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e)
         s[e] = s2[e] = 0.0;
-    for (int pt = blockIdx.x * EC_WAVES + wave; pt < a.P; pt += gridDim.x * EC_WAVES) {
+    for (int pt = blockIdx.x * EC_STAT_WAVES + wave; pt < a.P; pt += gridDim.x * EC_STAT_WAVES) {
         EcPoint<CPL, KCAP> p;
         p.load(a, pt, lane);
 #pragma unroll
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
     float sc[CPL], sh[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e) {
-        sc[e] = a.scale_shift[lane * CPL + e];
-        sh[e] = a.scale_shift[a.cout + lane * CPL + e];
+        sc[e] = a.scale_shift[lane + 64 * e];
+        sh[e] = a.scale_shift[a.cout + lane + 64 * e];
     }
     for (int pt = blockIdx.x * EC_WAVES + wave; pt < a.P; pt += gridDim.x * EC_WAVES) {
         EcPoint<CPL, KCAP> p;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
             }
 #pragma unroll
         for (int e = 0; e < CPL; ++e)
-            out[(size_t)pt * ldo + lane * CPL + e] = POOL == 2 ? acc[e] : acc[e] / (float)a.k;
+            out[(size_t)pt * ldo + lane + 64 * e] = POOL == 2 ? acc[e] : acc[e] / (float)a.k;
     }
 }
 
@@ -164,7 +165,7 @@ __device__ __forceinline__ void ec_upstream(const EcArgs &a, const EcPoint<CPL, 
     float g[CPL], zmax[CPL], ties[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e) {
-        g[e] = a.dout[(size_t)pt * a.lddo + lane * CPL + e];
+        g[e] = a.dout[(size_t)pt * a.lddo + lane + 64 * e];
         zmax[e] = -__builtin_inff();
         ties[e] = 0.0f;
     }
@@ -199,21 +200,21 @@ __device__ __forceinline__ void ec_upstream(const EcArgs &a, const EcPoint<CPL, 
 }
 
 template <int CPL, int KCAP, int POOL>
-__global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_stats_kernel(EcArgs a, double *__restrict__ partial)
+__global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_bwd_stats_kernel(EcArgs a, double *__restrict__ partial)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float sc[CPL], sh[CPL], mean[CPL], rstd[CPL];
     double s[CPL], s2[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e) {
-        const int c = lane * CPL + e;
+        const int c = lane + 64 * e;
         sc[e] = a.scale_shift[c];
         sh[e] = a.scale_shift[a.cout + c];
         mean[e] = a.save_mean[c];
         rstd[e] = bn_rsqrt(a.save_var[c] + BN_EPS);
         s[e] = s2[e] = 0.0;
     }
-    for (int pt = blockIdx.x * EC_WAVES + wave; pt < a.P; pt += gridDim.x * EC_WAVES) {
+    for (int pt = blockIdx.x * EC_STAT_WAVES + wave; pt < a.P; pt += gridDim.x * EC_STAT_WAVES) {
         EcPoint<CPL, KCAP> p;
         p.load(a, pt, lane);
         float dz[KCAP][CPL];
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(EcArgs a, c
     float sc[CPL], sh[CPL], mean[CPL], rstd[CPL], gr[CPL], m1[CPL], m2[CPL], bsum[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e) {
-        const int c = lane * CPL + e;
+        const int c = lane + 64 * e;
         sc[e] = a.scale_shift[c];
         sh[e] = a.scale_shift[a.cout + c];
         mean[e] = a.save_mean[c];
@@ -266,31 +267,31 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(EcArgs a, c
 #pragma unroll
         for (int j = 0; j < KCAP; ++j)
             if (j < a.k) {
-                float *tq = dpq + (size_t)p.nb[j] * a.ldpq + a.cout + lane * CPL;
+                float *tq = dpq + (size_t)p.nb[j] * a.ldpq + a.cout + lane;
 #pragma unroll
                 for (int e = 0; e < CPL; ++e) {
                     const float xh = (p.y[j][e] - mean[e]) * rstd[e];
                     const float dy = gr[e] * ((dz[j][e] - m1[e]) - xh * m2[e]);
                     S[e] = S[e] + dy;
-                    atomicAdd(tq + e, dy);
+                    atomicAdd(tq + 64 * e, dy);
                 }
             }
-        float *mine = dpq + (size_t)pt * a.ldpq + lane * CPL;
+        float *mine = dpq + (size_t)pt * a.ldpq + lane;
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
-            mine[e] = S[e];
-            atomicAdd(mine + a.cout + e, -S[e]);
+            mine[64 * e] = S[e];
+            atomicAdd(mine + a.cout + 64 * e, -S[e]);
             bsum[e] += S[e];
         }
     }
 #pragma unroll
     for (int e = 0; e < CPL; ++e)
-        redb[wave][lane * CPL + e] = bsum[e];
+        redb[wave][lane + 64 * e] = bsum[e];
     __syncthreads();
     if (wave == 0 && dbias != nullptr) {
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
-            const int c = lane * CPL + e;
+            const int c = lane + 64 * e;
             float t = redb[0][c];
             for (int w = 1; w < EC_WAVES; ++w)
                 t += redb[w][c];
@@ -299,14 +300,19 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(EcArgs a, c
     }
 }
 
-static int ec_grid(int P)
+static int ec_stat_grid(int P)
 {
-    int g = ceil_div(P, EC_WAVES * 4);  // ~4 points per wave at least
+    int g = ceil_div(P, EC_STAT_WAVES * 2);
     if (g > EC_MAX_PARTS)
         g = EC_MAX_PARTS;
-    if (g < 1)
-        g = 1;
-    return g;
+    return g < 1 ? 1 : g;
+}
+static int ec_apply_grid(int P)
+{
+    int g = ceil_div(P, EC_WAVES * 2);   // >= 2 points per wave
+    if (g > 4096)
+        g = 4096;
+    return g < 1 ? 1 : g;
 }
 
 // dispatch over (channels per lane, neighbour capacity, pool mode)
@@ -368,9 +374,9 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
     a.P = P; a.N = n; a.k = k; a.cout = cout; a.ldpq = 2 * cout;
     a.pq = pq; a.bias = biases; a.nn_idx = nn_idx; a.scale_shift = scale_shift;
     const int cpl = cout / 64, kcap = k <= 10 ? 10 : (k <= 20 ? 20 : 32);
-    const int grid = ec_grid(P);
+    const int grid = ec_stat_grid(P), agrid = ec_apply_grid(P);
     if (training) {
-#define EC_STATS(CPL_, KC_) hipLaunchKernelGGL((ec_stats_kernel<CPL_, KC_>), dim3(grid), dim3(64 * EC_WAVES), 0, s, a, partial)
+#define EC_STATS(CPL_, KC_) hipLaunchKernelGGL((ec_stats_kernel<CPL_, KC_>), dim3(grid), dim3(64 * EC_STAT_WAVES), 0, s, a, partial)
         EC_DISPATCH(EC_STATS);
 #undef EC_STATS
     }
@@ -378,11 +384,11 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
                        (double)P * (double)k, training, decay, ema_mean, ema_var, gamma, beta, save_mean,
                        save_var, scale_shift);
     if (pool_mode == 1) {
-#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 1>), dim3(grid), dim3(64 * EC_WAVES), 0, s, a, out, ldo)
+#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo)
         EC_DISPATCH(EC_APPLY);
 #undef EC_APPLY
     } else {
-#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 2>), dim3(grid), dim3(64 * EC_WAVES), 0, s, a, out, ldo)
+#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 2>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo)
         EC_DISPATCH(EC_APPLY);
 #undef EC_APPLY
     }
@@ -416,13 +422,13 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
     a.gamma = gamma; a.save_mean = save_mean; a.save_var = save_var; a.dout = dout; a.lddo = lddo;
     a.training = training;
     const int cpl = cout / 64, kcap = k <= 10 ? 10 : (k <= 20 ? 20 : 32);
-    const int grid = ec_grid(P);
+    const int grid = ec_stat_grid(P), agrid = ec_apply_grid(P);
     if (pool_mode == 1) {
-#define EC_BS(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_stats_kernel<CPL_, KC_, 1>), dim3(grid), dim3(64 * EC_WAVES), 0, s, a, partial)
+#define EC_BS(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_stats_kernel<CPL_, KC_, 1>), dim3(grid), dim3(64 * EC_STAT_WAVES), 0, s, a, partial)
         EC_DISPATCH(EC_BS);
 #undef EC_BS
     } else {
-#define EC_BS(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_stats_kernel<CPL_, KC_, 2>), dim3(grid), dim3(64 * EC_WAVES), 0, s, a, partial)
+#define EC_BS(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_stats_kernel<CPL_, KC_, 2>), dim3(grid), dim3(64 * EC_STAT_WAVES), 0, s, a, partial)
         EC_DISPATCH(EC_BS);
 #undef EC_BS
     }
@@ -432,11 +438,11 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
     if (dbiases)
         CLOUDAAE_CHECK_HIP(hipMemsetAsync(dbiases, 0, sizeof(float) * (size_t)cout, s), name);
     if (pool_mode == 1) {
-#define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 1>), dim3(grid), dim3(64 * EC_WAVES), 0, s, a, m12, dpq, dbiases)
+#define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, dpq, dbiases)
         EC_DISPATCH(EC_BA);
 #undef EC_BA
     } else {
-#define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 2>), dim3(grid), dim3(64 * EC_WAVES), 0, s, a, m12, dpq, dbiases)
+#define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 2>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, dpq, dbiases)
         EC_DISPATCH(EC_BA);
 #undef EC_BA
     }

@@ -28,6 +28,7 @@ from ._lib import ptr, require, stream
 from .losses import angular_distance_taylor, chamfer_loss, trans_distance
 from .utils import _functions as F
 from .utils import tf_util
+from .utils.grad_exchange import GradExchange
 from .utils.variables import reset_default_store
 
 NUM_CLASS = 21                      # train_cloudAAE_ycbv.py:29
@@ -120,20 +121,22 @@ class TrainGraph(object):
         with torch.no_grad():
             self._call_model(dummy, False)
         self.store.flatten()
-        if self.world > 1:     # identical initial weights on every rank
-            dist.broadcast(self.store.flat_params, src=0, group=self.pg)
         n = self.store.flat_params.numel()
         self.adam_m = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.adam_v = torch.zeros(n, dtype=torch.float32, device=self.device)
         # overlap bucket: the decoder output weights (12*N*1024 floats), first gradient of backward
-        self._early = None
+        early = None
         for name in ('dgcnn_output/weights', 'pn_output/weights'):
             v = self.store.vars.get(name)
-            if v is not None and self.world > 1:
+            if v is not None:
                 o = self.store.offsets[name]
-                self._early = (o, o + v.data.numel())
-                v.on_ready = self._early_ready
-        self._pending = []
+                early = (o, o + v.data.numel())
+        self.exchange = GradExchange(self.store.flat_grads, early, self.pg)
+        self.exchange.broadcast_params(self.store.flat_params)     # identical initial weights on every rank
+        if early is not None and self.world > 1:
+            for name in ('dgcnn_output/weights', 'pn_output/weights'):
+                if name in self.store.vars:
+                    self.store.vars[name].on_ready = self.exchange.early_ready
 
     def _call_model(self, pc, is_training):
         if self.is_pn:
@@ -182,25 +185,6 @@ class TrainGraph(object):
                     visiblePoints_org_final=visiblePoints_org_final, class_id=cls, input_pc=pc,
                     element_mean=element_mean, end_points=endpoint)
 
-    # -- gradient exchange --------------------------------------------------------------------
-    def _early_ready(self):
-        lo, hi = self._early
-        self._pending.append(dist.all_reduce(self.store.flat_grads[lo:hi], group=self.pg, async_op=True))
-
-    def _all_reduce_grads(self):
-        g = self.store.flat_grads
-        if self._early is None:
-            self._pending.append(dist.all_reduce(g, group=self.pg, async_op=True))
-        else:
-            lo, hi = self._early
-            if lo > 0:
-                self._pending.append(dist.all_reduce(g[:lo], group=self.pg, async_op=True))
-            if hi < g.numel():
-                self._pending.append(dist.all_reduce(g[hi:], group=self.pg, async_op=True))
-        for w in self._pending:
-            w.wait()
-        self._pending = []
-
     # -- one iteration of the loop at :344-368 ------------------------------------------------
     def train_step(self, element):
         L = _lib.lib()
@@ -212,10 +196,9 @@ class TrainGraph(object):
                                                 ptr(self.bn_decay), s), "cloudaae_bn_decay_schedule")
         out = self.forward(element, is_training=True)
         out['total_loss'].backward()
-        if self.world > 1:
-            self._all_reduce_grads()
+        self.exchange.finish()            # RCCL all-reduce of the flat gradient buffer (no-op for 1 rank)
         n = self.store.flat_params.numel()
-        scale = 1.0 / self.world
+        scale = self.exchange.scale
         if self.OPTIMIZER == 'adam':      # tf.train.AdamOptimizer(learning_rate), :266
             _lib.check(L.cloudaae_adam_tf(n, ptr(self.store.flat_params), ptr(self.store.flat_grads),
                                           ptr(self.adam_m), ptr(self.adam_v), self.BASE_LEARNING_RATE, 0.9,

@@ -1,0 +1,115 @@
+"""CPU: the N>1 path's host logic with world_size 2 over gloo -- flat-buffer gradient
+exchange (early bucket + remainder), averaging scale, parameter broadcast, batch sharding,
+and the VariableStore's flat layout.  No HIP compute is involved (there is no GPU here)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cloudaae_amd.utils.grad_exchange import GradExchange, shard_range
+        n = 1000
+        # (1) early bucket in the middle, sent before the rest
+        g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        ex = GradExchange(g, early=(100, 700))
+        ex.early_ready()
+        ex.early_ready()          # idempotent within a step
+        ex.finish()
+        want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
+        ok1 = torch.equal(g, want) and ex.scale == 1.0 / world
+        # (2) a second step on the same object, early hook never fired -> finish sends everything
+        g.copy_(torch.full((n,), float(rank + 1)))
+        ex.finish()
+        ok2 = torch.equal(g, torch.full((n,), float(sum(r + 1 for r in range(world)))))
+        # (3) no early range at all
+        h = torch.full((17,), float(rank))
+        ex2 = GradExchange(h)
+        ex2.finish()
+        ok3 = torch.equal(h, torch.full((17,), float(sum(range(world)))))
+        # (4) identical weights after broadcast
+        p = torch.full((5,), float(rank + 7))
+        ex2.broadcast_params(p)
+        ok4 = torch.equal(p, torch.full((5,), 7.0))
+        # (5) sharding + DP semantics: averaged shard gradients == gradient of the global mean
+        lo, hi = shard_range(8, world, rank)
+        x = torch.arange(8, dtype=torch.float32)
+        w = torch.tensor([0.5], requires_grad=True)
+        loss = ((w * x[lo:hi] - 1.0) ** 2).mean()
+        loss.backward()
+        gw = w.grad.clone()
+        GradExchange(gw).finish()
+        w2 = torch.tensor([0.5], requires_grad=True)
+        ((w2 * x - 1.0) ** 2).mean().backward()
+        ok5 = torch.allclose(gw / world, w2.grad, rtol=1e-6) and (hi - lo) == 8 // world
+        out[rank] = all([ok1, ok2, ok3, ok4, ok5])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_exchange_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
+def test_shard_range_errors():
+    from cloudaae_amd.utils.grad_exchange import shard_range
+    assert shard_range(1024, 8, 3) == (384, 512)
+    with pytest.raises(ValueError):
+        shard_range(10, 4, 0)
+
+
+def test_variable_store_flat_layout_cpu():
+    """Host logic of the store: reference names, creation order, 16-byte aligned offsets,
+    gradient views, state_dict round trip (runs on CPU tensors)."""
+    from cloudaae_amd.utils.variables import VariableStore
+    st = VariableStore(device="cpu", seed=1)
+    with st.variable_scope("dgcnn1"):
+        w = st.get_variable("weights", [1, 1, 48, 64], VariableStore.xavier_uniform(48, 64))
+        b = st.get_variable("biases", [64], VariableStore.constant(0.0))
+        with st.variable_scope("bn"):
+            st.get_variable("beta", [3], VariableStore.constant(0.0))
+            st.get_variable("moments/Squeeze/ExponentialMovingAverage", [3], VariableStore.constant(0.0),
+                            trainable=False)
+    assert list(st.vars) == ["dgcnn1/weights", "dgcnn1/biases", "dgcnn1/bn/beta",
+                             "dgcnn1/bn/moments/Squeeze/ExponentialMovingAverage"]
+    lim = (6.0 / (48 + 64)) ** 0.5
+    assert float(w.data.abs().max()) <= lim and float(w.data.abs().max()) > 0.8 * lim
+    with st.variable_scope("dgcnn1"):
+        assert st.get_variable("weights", [1, 1, 48, 64], None) is w          # AUTO_REUSE
+        with pytest.raises(ValueError):
+            st.get_variable("weights", [1, 1, 48, 32], None)
+    before = st.state_dict()
+    st.flatten()
+    assert st.num_params == 48 * 64 + 64 + 3
+    assert all(o % 4 == 0 for o in st.offsets.values())                        # 16-byte aligned
+    assert st.offsets["dgcnn1/bn/beta"] == 48 * 64 + 64
+    for n, t in st.state_dict().items():
+        assert torch.equal(t, before[n])
+    assert w.data.data_ptr() == st.flat_params.data_ptr() and w.grad.data_ptr() == st.flat_grads.data_ptr()
+    assert w.data.requires_grad and w.data.grad is w.grad
+    st.flat_params.add_(1.0)                                                    # an optimiser update is visible
+    assert torch.equal(st.vars["dgcnn1/biases"].data.detach(), torch.ones(64))
+    with pytest.raises(RuntimeError):
+        st.get_variable("late", [1], VariableStore.constant(0.0))
+    sd = st.state_dict()
+    sd["dgcnn1/biases"] = torch.full((64,), 3.0)
+    st.load_state_dict(sd)
+    assert float(st.flat_params[48 * 64]) == 3.0
