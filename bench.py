@@ -114,6 +114,12 @@ def main():
         M, Nn, K = B * N, 1024, 320
         flops = 2.0 * M * Nn * K                      # algorithmic flops of one dgcnn_agg forward launch
         achieved = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_roofline_traffic.json")
+        if os.path.exists(tpath) and B == 32 and N == 1024:
+            # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2
+            # corrected + WRITE_SIZE; collected separately, see profiles/ and DESIGN.md section 5)
+            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
         line = {
             "metric": "point-clouds/sec (train step, N=%d)" % N,
             "value": round(B * world * args.steps / elapsed, 2),
@@ -134,7 +140,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,2,2> dgcnn_agg forward "
                                                      "[%d x 320] x [320 x 1024]" % M,
                          "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launch_ms": round(k_ms, 4), "launches_timed": len(ms)},
         }
         if world == 1 and args.cpu_batch > 0:

@@ -92,10 +92,12 @@ class TrainGraph(object):
         require(self.OPTIMIZER in ('adam', 'gd'), "optimizer must be adam or gd")
         self.device = torch.device(device if device is not None else 'cuda:%d' % int(general_opts.get('gpu', 0)))
         self.k = int(k_neighbor)
-        self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (process_group is not None or
-                                                           (dist.is_available() and dist.is_initialized())) else 1
-        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        # process_group: None = the default group when torch.distributed is initialised;
+        # False = single-process even then; or an explicit group
+        solo = process_group is False or not (dist.is_available() and dist.is_initialized())
+        self.pg = None if solo else process_group
+        self.world = 1 if solo else dist.get_world_size(self.pg)
+        self.rank = 0 if solo else dist.get_rank(self.pg)
         require(self.BATCH_SIZE % self.world == 0, "global batch must divide by the number of ranks")
         self.local_batch = self.BATCH_SIZE // self.world
         # MODEL = importlib.import_module(general_opts['model'])   (:147) -- the plugin seam
@@ -131,7 +133,7 @@ class TrainGraph(object):
             if v is not None:
                 o = self.store.offsets[name]
                 early = (o, o + v.data.numel())
-        self.exchange = GradExchange(self.store.flat_grads, early, self.pg)
+        self.exchange = GradExchange(self.store.flat_grads, early, self.pg, world=self.world)
         self.exchange.broadcast_params(self.store.flat_params)     # identical initial weights on every rank
         if early is not None and self.world > 1:
             for name in ('dgcnn_output/weights', 'pn_output/weights'):

@@ -22,10 +22,12 @@ def shard_range(global_batch, world, rank):
 
 
 class GradExchange(object):
-    def __init__(self, flat_grads, early=None, group=None):
+    def __init__(self, flat_grads, early=None, group=None, world=None):
         self.g = flat_grads
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.world = world
         n = flat_grads.numel()
         if early is not None:
             lo, hi = early

@@ -1,0 +1,66 @@
+"""GPU: the data-parallel train step end to end with two ranks (sharing the one GPU of the
+test box, gloo backend -- RCCL refuses two ranks on one device; the code path is identical:
+early all-reduce of the decoder-output gradient from inside backward, remainder at the end,
+1/world folded into Adam)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cloudaae_amd import train_cloudAAE_ycbv as T
+        B, N = 4, 128                       # global batch 4 -> 2 clouds per rank
+        el = T.synthetic_element(B // world, N, torch.device("cuda:0"), seed=11, rank=rank)
+        el["noise"] = torch.zeros((B // world, N, 3), device="cuda")
+        # (a) every rank alone: its local gradient
+        solo = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B // world}, process_group=False, seed=5)
+        solo.store.begin_step()
+        solo.forward(el)["total_loss"].backward()
+        g_local = solo.store.flat_grads.clone()
+        p_init = solo.store.flat_params.clone()
+        gathered = [torch.empty_like(g_local) for _ in range(world)]
+        dist.all_gather(gathered, g_local)
+        g_sum = sum(gathered)
+        # (b) the data-parallel graph (same seed -> same initial weights, then broadcast)
+        dp = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, seed=5)
+        ok_world = dp.world == world and dp.local_batch == B // world and dp.exchange.early is not None
+        ok_init = torch.equal(dp.store.flat_params, p_init)
+        dp.train_step(el)
+        g_dp = dp.store.flat_grads
+        scale = float(g_sum.abs().max())
+        ok_grad = float((g_dp - g_sum).abs().max()) <= 2e-4 * scale          # fp32 atomics order
+        lo, hi = dp.exchange.early
+        ok_early = float((g_dp[lo:hi] - g_sum[lo:hi]).abs().max()) <= 2e-4 * scale
+        params = [torch.empty_like(dp.store.flat_params) for _ in range(world)]
+        dist.all_gather(params, dp.store.flat_params)
+        ok_same = all(torch.equal(params[0], p) for p in params)            # replicas stay bit-identical
+        ok_moved = not torch.equal(dp.store.flat_params, p_init)
+        out[rank] = [ok_world, ok_init, ok_grad, ok_early, ok_same, ok_moved]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks(hip):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert dict(out) == {0: [True] * 6, 1: [True] * 6}
