@@ -43,6 +43,33 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
+// ---- XCD-aware workgroup mapping ---------------------------------------------
+// MI355X: 8 XCDs, each with a private 4 MiB L2; workgroup b is observed to run on XCD
+// b % 8 (MI355X_MICROARCH.md).  These remaps only change WHICH workgroup does which
+// piece of work, so a different placement would change speed, never results.
+
+// bijective: linear id -> virtual id such that each XCD owns a contiguous virtual range
+__device__ __forceinline__ int xcd_contiguous(int lin, int total)
+{
+    const int q = total >> 3, r = total & 7, xcd = lin & 7, u = lin >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + u;
+}
+
+// grid (tiles, clouds): give every cloud's tiles to ONE XCD (cloud c -> XCD c % 8)
+__device__ __forceinline__ void xcd_cloud_tile(int &tile, int &cloud)
+{
+    const int gx = gridDim.x, B = gridDim.y;
+    if ((B & 7) == 0) {
+        const int lin = blockIdx.y * gx + blockIdx.x;
+        const int xcd = lin & 7, u = lin >> 3;
+        cloud = xcd + 8 * (u / gx);
+        tile = u % gx;
+    } else {
+        tile = blockIdx.x;
+        cloud = blockIdx.y;
+    }
+}
+
 // ---- wave64 helpers ------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 

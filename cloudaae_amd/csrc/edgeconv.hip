@@ -15,8 +15,10 @@
 // normalise+ReLU+pool pass both re-gather Q rows, which are L2-resident (a cloud's Q
 // is 256 KiB).  One wave owns one point; lanes own channels (coalesced 256/512 B row
 // reads); the k neighbour indices are loaded once per point and broadcast by
-// lane shuffles.  Backward mirrors it: dQ of neighbours accumulates with fp32
-// atomics, then four small GEMMs produce dX and dW.
+// lane shuffles.  Backward mirrors it without atomics: a counting sort in LDS builds
+// the reverse neighbour lists of each cloud, so dQ_m is GATHERED (sum over the points
+// that have m as a neighbour) by the wave that owns m; then four small GEMMs produce
+// dX and dW.
 // This is an algebraic refactoring of the reference arithmetic: results agree with
 // the edge-tensor formulation to fp32 round-off, not bitwise.
 #include "bn_common.h"
@@ -73,6 +75,26 @@ struct EcPoint {
     }
 };
 
+// Point -> wave assignment.  MI355X has 8 XCDs with private 4 MiB L2s and workgroup b runs
+// on XCD b % 8 (observed placement; used for speed only).  A cloud's P'/Q/dOut rows are
+// re-gathered ~k times, so all points of a cloud are given to workgroups of ONE XCD
+// (cloud c -> XCD c % 8): the gather working set of an XCD is B/8 clouds (< 4 MiB at
+// B=32) instead of the whole batch, and the re-reads hit L2 instead of the fabric.
+template <int NW, typename F>
+__device__ __forceinline__ void ec_for_each_point(const EcArgs &a, int wave, F &&body)
+{
+    const int B = a.P / a.N;
+    if (B >= 8 && (gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+        for (int cloud = xcd; cloud < B; cloud += 8)
+            for (int local = slot * NW + wave; local < a.N; local += nslot * NW)
+                body(cloud * a.N + local);
+    } else {
+        for (int pt = blockIdx.x * NW + wave; pt < a.P; pt += gridDim.x * NW)
+            body(pt);
+    }
+}
+
 template <int CPL>
 __device__ __forceinline__ void ec_block_reduce_store(double (&s)[CPL], double (&s2)[CPL], double *partial,
                                                       int cout, int lane, int wave)
@@ -107,7 +129,7 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_stats_kernel(EcArgs a, 
 #pragma unroll
     for (int e = 0; e < CPL; ++e)
         s[e] = s2[e] = 0.0;
-    for (int pt = blockIdx.x * EC_STAT_WAVES + wave; pt < a.P; pt += gridDim.x * EC_STAT_WAVES) {
+    ec_for_each_point<EC_STAT_WAVES>(a, wave, [&](int pt) {
         EcPoint<CPL, KCAP> p;
         p.load(a, pt, lane);
 #pragma unroll
@@ -119,12 +141,13 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_stats_kernel(EcArgs a, 
                     s2[e] += (double)p.y[j][e] * (double)p.y[j][e];
                 }
             }
-    }
+    });
     ec_block_reduce_store<CPL>(s, s2, partial, a.cout, lane, wave);
 }
 
 template <int CPL, int KCAP, int POOL>
-__global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float *__restrict__ out, int ldo)
+__global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float *__restrict__ out, int ldo,
+                                                                float *__restrict__ ties)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float sc[CPL], sh[CPL];
@@ -133,26 +156,36 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
         sc[e] = a.scale_shift[lane + 64 * e];
         sh[e] = a.scale_shift[a.cout + lane + 64 * e];
     }
-    for (int pt = blockIdx.x * EC_WAVES + wave; pt < a.P; pt += gridDim.x * EC_WAVES) {
+    ec_for_each_point<EC_WAVES>(a, wave, [&](int pt) {
         EcPoint<CPL, KCAP> p;
         p.load(a, pt, lane);
-        float acc[CPL];
+        float acc[CPL], cnt[CPL];
 #pragma unroll
-        for (int e = 0; e < CPL; ++e)
+        for (int e = 0; e < CPL; ++e) {
             acc[e] = POOL == 2 ? -__builtin_inff() : 0.0f;
+            cnt[e] = 0.0f;
+        }
 #pragma unroll
         for (int j = 0; j < KCAP; ++j)
             if (j < a.k) {
 #pragma unroll
                 for (int e = 0; e < CPL; ++e) {
                     const float z = fmaxf(p.y[j][e] * sc[e] + sh[e], 0.0f);
-                    acc[e] = POOL == 2 ? fmaxf(acc[e], z) : acc[e] + z;
+                    if (POOL == 2) {
+                        cnt[e] = z > acc[e] ? 1.0f : (z == acc[e] ? cnt[e] + 1.0f : cnt[e]);
+                        acc[e] = fmaxf(acc[e], z);
+                    } else {
+                        acc[e] = acc[e] + z;
+                    }
                 }
             }
 #pragma unroll
-        for (int e = 0; e < CPL; ++e)
+        for (int e = 0; e < CPL; ++e) {
             out[(size_t)pt * ldo + lane + 64 * e] = POOL == 2 ? acc[e] : acc[e] / (float)a.k;
-    }
+            if (POOL == 2 && ties != nullptr)
+                ties[(size_t)pt * a.cout + lane + 64 * e] = cnt[e];
+        }
+    });
 }
 
 // upstream gradient of z_ij for one point: mean -> dout/k; max -> dout shared among
@@ -214,7 +247,7 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_bwd_stats_kernel(EcArgs
         rstd[e] = bn_rsqrt(a.save_var[c] + BN_EPS);
         s[e] = s2[e] = 0.0;
     }
-    for (int pt = blockIdx.x * EC_STAT_WAVES + wave; pt < a.P; pt += gridDim.x * EC_STAT_WAVES) {
+    ec_for_each_point<EC_STAT_WAVES>(a, wave, [&](int pt) {
         EcPoint<CPL, KCAP> p;
         p.load(a, pt, lane);
         float dz[KCAP][CPL];
@@ -229,20 +262,79 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_bwd_stats_kernel(EcArgs
                     s2[e] += (double)dz[j][e] * (double)xh;
                 }
             }
-    }
+    });
     ec_block_reduce_store<CPL>(s, s2, partial, a.cout, lane, wave);
 }
 
-// dy_ij = gamma*rstd*((dz_ij - m1) - xhat_ij*m2);  S_i = sum_j dy_ij
-// dP'_i = S_i;  dQ_i -= S_i;  dQ_nbr(i,j) += dy_ij;  dbias += S_i
+// Reverse neighbour lists of one cloud (one workgroup per cloud): for every point m the
+// points i that have m among their k neighbours.  rev_off[N+1] (offsets into rev_src),
+// rev_src[N*k] (source point i, cloud-local).  Counting sort in LDS; the order inside a
+// list depends on LDS-atomic arrival order (so dQ sums are reproducible to fp32 round-off,
+// not bitwise, exactly like the atomic scatter it replaces).
+__global__ __launch_bounds__(512) void ec_revlist_kernel(int N, int k, const int *__restrict__ nn_idx,
+                                                         int *__restrict__ rev_off, int *__restrict__ rev_src)
+{
+    extern __shared__ int cnt[];
+    __shared__ int wsum[8];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int *idx = nn_idx + (size_t)blockIdx.x * N * k;
+    int *off = rev_off + (size_t)blockIdx.x * (N + 1);
+    int *src = rev_src + (size_t)blockIdx.x * N * k;
+    const int E = N * k;
+    for (int m = t; m < N; m += 512)
+        cnt[m] = 0;
+    __syncthreads();
+    for (int e = t; e < E; e += 512)
+        atomicAdd(&cnt[idx[e]], 1);
+    __syncthreads();
+    const int per = (N + 511) / 512;
+    const int lo = min(N, t * per), hi = min(N, lo + per);
+    int local = 0;
+    for (int m = lo; m < hi; ++m)
+        local += cnt[m];
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d)
+            incl += o;
+    }
+    if (lane == 63)
+        wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w)
+        base += wsum[w];
+    int run = base + incl - local;
+    for (int m = lo; m < hi; ++m) {
+        const int c = cnt[m];
+        cnt[m] = run;      // becomes the fill cursor
+        off[m] = run;
+        run += c;
+    }
+    if (t == 0)
+        off[N] = E;
+    __syncthreads();
+    for (int e = t; e < E; e += 512) {
+        const int pos = atomicAdd(&cnt[idx[e]], 1);
+        src[pos] = e / k;
+    }
+}
+
+// dy_ij = gamma*rstd*((dz_ij - m1) - xhat_ij*m2)
+//   dP'_m = S_m = sum_j dy_mj                     (own neighbours, forward direction)
+//   dQ_m  = T_m - S_m,  T_m = sum_{(i,j): nbr(i,j)=m} dy_ij   (reverse list, gathered)
+//   dbias += S_m
+// No atomics on the big tensors and no zero-fill: every dpq element is written once.
 template <int CPL, int KCAP, int POOL>
-__global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(EcArgs a, const float *__restrict__ m12,
-                                                                    float *__restrict__ dpq,
-                                                                    float *__restrict__ dbias)
+__global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
+    EcArgs a, const float *__restrict__ m12, const int *__restrict__ rev_off, const int *__restrict__ rev_src,
+    const float *__restrict__ fwd_out, int ldo, const float *__restrict__ ties, float *__restrict__ dpq,
+    float *__restrict__ dbias)
 {
     __shared__ float redb[EC_WAVES][64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float sc[CPL], sh[CPL], mean[CPL], rstd[CPL], gr[CPL], m1[CPL], m2[CPL], bsum[CPL];
+    float sc[CPL], sh[CPL], mean[CPL], rstd[CPL], gr[CPL], m1[CPL], m2[CPL], bsum[CPL], bias[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e) {
         const int c = lane + 64 * e;
@@ -253,37 +345,89 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(EcArgs a, c
         gr[e] = a.gamma[c] * rstd[e];
         m1[e] = m12[c];
         m2[e] = m12[a.cout + c];
+        bias[e] = a.bias[c];
         bsum[e] = 0.0f;
     }
-    for (int pt = blockIdx.x * EC_WAVES + wave; pt < a.P; pt += gridDim.x * EC_WAVES) {
-        EcPoint<CPL, KCAP> p;
-        p.load(a, pt, lane);
-        float dz[KCAP][CPL];
-        ec_upstream<CPL, KCAP, POOL>(a, p, pt, lane, sc, sh, dz);
-        float S[CPL];
+    const float invk = 1.0f;  // (mean pool divides by k exactly as the forward direction does, below)
+    (void)invk;
+    ec_for_each_point<EC_WAVES>(a, wave, [&](int pt) {
+        const int cloud = pt / a.N, m = pt - cloud * a.N;
+        float S[CPL], T[CPL], Qm[CPL];
+        {
+            EcPoint<CPL, KCAP> p;
+            p.load(a, pt, lane);
+            float dz[KCAP][CPL];
+            ec_upstream<CPL, KCAP, POOL>(a, p, pt, lane, sc, sh, dz);
 #pragma unroll
-        for (int e = 0; e < CPL; ++e)
-            S[e] = 0.0f;
+            for (int e = 0; e < CPL; ++e)
+                S[e] = 0.0f;
 #pragma unroll
-        for (int j = 0; j < KCAP; ++j)
-            if (j < a.k) {
-                float *tq = dpq + (size_t)p.nb[j] * a.ldpq + a.cout + lane;
+            for (int j = 0; j < KCAP; ++j)
+                if (j < a.k) {
 #pragma unroll
-                for (int e = 0; e < CPL; ++e) {
-                    const float xh = (p.y[j][e] - mean[e]) * rstd[e];
-                    const float dy = gr[e] * ((dz[j][e] - m1[e]) - xh * m2[e]);
-                    S[e] = S[e] + dy;
-                    atomicAdd(tq + 64 * e, dy);
+                    for (int e = 0; e < CPL; ++e) {
+                        const float xh = (p.y[j][e] - mean[e]) * rstd[e];
+                        const float dy = gr[e] * ((dz[j][e] - m1[e]) - xh * m2[e]);
+                        S[e] = S[e] + dy;
+                    }
                 }
-            }
-        float *mine = dpq + (size_t)pt * a.ldpq + lane;
+        }
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
-            mine[64 * e] = S[e];
-            atomicAdd(mine + a.cout + 64 * e, -S[e]);
+            T[e] = 0.0f;
+            Qm[e] = a.pq[(size_t)pt * a.ldpq + a.cout + lane + 64 * e];
+        }
+        const int *off = rev_off + (size_t)cloud * (a.N + 1);
+        const int *src = rev_src + (size_t)cloud * a.N * a.k;
+        const int beg = off[m], end = off[m + 1];
+        for (int s0 = beg; s0 < end; s0 += 64) {
+            const int cntc = min(64, end - s0);
+            const int mine = lane < cntc ? src[s0 + lane] : 0;
+            for (int q0 = 0; q0 < cntc; q0 += 4) {
+                float pi[4][CPL], qi[4][CPL], gi[4][CPL], oi[4][CPL], ti[4][CPL];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool on = q0 + u < cntc;
+                    const int i = cloud * a.N + __shfl(mine, on ? q0 + u : q0, 64);
+                    const float *row = a.pq + (size_t)i * a.ldpq + lane;
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e) {
+                        pi[u][e] = row[64 * e];
+                        qi[u][e] = row[a.cout + 64 * e];
+                        gi[u][e] = on ? a.dout[(size_t)i * a.lddo + lane + 64 * e] : 0.0f;
+                        if (POOL == 2) {
+                            oi[u][e] = fwd_out[(size_t)i * ldo + lane + 64 * e];
+                            ti[u][e] = ties[(size_t)i * a.cout + lane + 64 * e];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (q0 + u < cntc) {
+#pragma unroll
+                        for (int e = 0; e < CPL; ++e) {
+                            const float uu = (pi[u][e] - qi[u][e]) + bias[e];
+                            const float y = uu + Qm[e];
+                            const float z = fmaxf(y * sc[e] + sh[e], 0.0f);
+                            float d = POOL == 2 ? (z == oi[u][e] ? gi[u][e] / ti[u][e] : 0.0f)
+                                                : gi[u][e] / (float)a.k;
+                            if (!(z > 0.0f))
+                                d = 0.0f;
+                            const float xh = (y - mean[e]) * rstd[e];
+                            T[e] = T[e] + gr[e] * ((d - m1[e]) - xh * m2[e]);
+                        }
+                    }
+                }
+            }
+        }
+        float *mineo = dpq + (size_t)pt * a.ldpq + lane;
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) {
+            mineo[64 * e] = S[e];
+            mineo[a.cout + 64 * e] = T[e] - S[e];
             bsum[e] += S[e];
         }
-    }
+    });
 #pragma unroll
     for (int e = 0; e < CPL; ++e)
         redb[wave][lane + 64 * e] = bsum[e];
@@ -302,17 +446,17 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(EcArgs a, c
 
 static int ec_stat_grid(int P)
 {
-    int g = ceil_div(P, EC_STAT_WAVES * 2);
+    int g = ceil_div(ceil_div(P, EC_STAT_WAVES * 2), 8) * 8;   // multiple of 8: one share per XCD
     if (g > EC_MAX_PARTS)
         g = EC_MAX_PARTS;
-    return g < 1 ? 1 : g;
+    return g < 8 ? 8 : g;
 }
 static int ec_apply_grid(int P)
 {
-    int g = ceil_div(P, EC_WAVES * 2);   // >= 2 points per wave
+    int g = ceil_div(ceil_div(P, EC_WAVES * 2), 8) * 8;   // >= 2 points per wave, multiple of 8
     if (g > 4096)
         g = 4096;
-    return g < 1 ? 1 : g;
+    return g < 8 ? 8 : g;
 }
 
 // dispatch over (channels per lane, neighbour capacity, pool mode)
@@ -352,12 +496,14 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
                                            const float *gamma, const float *beta, int training,
                                            const float *decay, float *ema_mean, float *ema_var,
                                            int pool_mode, float *pq, float *save_mean, float *save_var,
-                                           float *out, int ldo, void *workspace, cloudaae_stream_t stream)
+                                           float *out, int ldo, float *tie_count, void *workspace,
+                                           cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_edgeconv_forward";
     if (int rc = ec_check(name, b, n, k, cin, cout, pool_mode))
         return rc;
     CLOUDAAE_REQUIRE(training || (ema_mean && ema_var), name, "inference needs the EMA statistics");
+    CLOUDAAE_REQUIRE(pool_mode != 2 || tie_count != nullptr, name, "max pool needs the tie_count output");
     hipStream_t s = (hipStream_t)stream;
     const int P = b * n;
     // P' = X W[0:cin], Q = X W[cin:2cin]   (two column blocks of pq)
@@ -384,11 +530,11 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
                        (double)P * (double)k, training, decay, ema_mean, ema_var, gamma, beta, save_mean,
                        save_var, scale_shift);
     if (pool_mode == 1) {
-#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo)
+#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count)
         EC_DISPATCH(EC_APPLY);
 #undef EC_APPLY
     } else {
-#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 2>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo)
+#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 2>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count)
         EC_DISPATCH(EC_APPLY);
 #undef EC_APPLY
     }
@@ -400,15 +546,18 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
                                             const int *nn_idx, const float *weights, const float *biases,
                                             const float *gamma, const float *beta, int training,
                                             int pool_mode, const float *pq, const float *save_mean,
-                                            const float *save_var, const float *dout, int lddo, float *dpq,
-                                            float *dx, int lddx, int accumulate_dx, float *dweights,
-                                            float *dbiases, float *dgamma, float *dbeta, void *workspace,
-                                            cloudaae_stream_t stream)
+                                            const float *save_var, const float *out, int ldo,
+                                            const float *tie_count, const float *dout, int lddo, float *dpq,
+                                            int *rev_scratch, float *dx, int lddx, int accumulate_dx,
+                                            float *dweights, float *dbiases, float *dgamma, float *dbeta,
+                                            void *workspace, cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_edgeconv_backward";
     if (int rc = ec_check(name, b, n, k, cin, cout, pool_mode))
         return rc;
-    CLOUDAAE_REQUIRE(dpq && dout && workspace, name, "null argument");
+    CLOUDAAE_REQUIRE(dpq && dout && workspace && rev_scratch, name, "null argument");
+    CLOUDAAE_REQUIRE(pool_mode != 2 || (out && tie_count), name, "max pool backward needs the forward output and tie count");
+    CLOUDAAE_REQUIRE((size_t)n * sizeof(int) <= 150 * 1024, name, "cloud too large for the LDS counting sort");
     hipStream_t s = (hipStream_t)stream;
     const int P = b * n;
     double *partial = (double *)workspace;
@@ -434,15 +583,22 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(cout, 64)), dim3(256), 0, s, cout, partial, grid,
                        (double)P * (double)k, training, dgamma, dbeta, 0, m12);
-    CLOUDAAE_CHECK_HIP(hipMemsetAsync(dpq, 0, sizeof(float) * (size_t)P * 2 * cout, s), name);
+    int *rev_off = rev_scratch, *rev_src = rev_scratch + (size_t)b * (n + 1);
+    {
+        const size_t lds = (size_t)n * sizeof(int);
+        if (lds > 48 * 1024)
+            CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)ec_revlist_kernel,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
+        hipLaunchKernelGGL(ec_revlist_kernel, dim3(b), dim3(512), lds, s, n, k, nn_idx, rev_off, rev_src);
+    }
     if (dbiases)
         CLOUDAAE_CHECK_HIP(hipMemsetAsync(dbiases, 0, sizeof(float) * (size_t)cout, s), name);
     if (pool_mode == 1) {
-#define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, dpq, dbiases)
+#define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src, out, ldo, tie_count, dpq, dbiases)
         EC_DISPATCH(EC_BA);
 #undef EC_BA
     } else {
-#define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 2>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, dpq, dbiases)
+#define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 2>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src, out, ldo, tie_count, dpq, dbiases)
         EC_DISPATCH(EC_BA);
 #undef EC_BA
     }

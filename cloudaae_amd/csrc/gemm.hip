@@ -134,7 +134,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups that share an A row-panel (same tile row) get
+    // consecutive virtual ids inside one XCD, so the panel is fetched from HBM once per XCD
+    // pass instead of once per column tile (PMC: 8x over-fetch of A without this)
+    const int tiles = gridDim.x * gridDim.y;
+    const int vid = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, tiles);
+    const int m0 = (vid / (int)gridDim.x) * BM, n0 = (vid % (int)gridDim.x) * BN;
     const int kbeg = blockIdx.z * kchunk;
     const int kend = min(K, kbeg + kchunk);
 

@@ -102,9 +102,10 @@ __global__ __launch_bounds__(KNN_THREADS) void knn3_kernel(int n, int ld, int k,
     int *mbuf_i = reinterpret_cast<int *>(smem) + (KNN_WAVES - 1) * K * 64;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cloud = blockIdx.y;
+    int tile, cloud;
+    xcd_cloud_tile(tile, cloud);   // a cloud's candidate rows stay in ONE XCD's L2
     const float *X = x + (size_t)cloud * n * ld;
-    const int i = blockIdx.x * 64 + lane;
+    const int i = tile * 64 + lane;
     const bool valid = i < n;
     const int ii = valid ? i : 0;
     const float qx = X[(size_t)ii * ld], qy = X[(size_t)ii * ld + 1], qz = X[(size_t)ii * ld + 2];
@@ -169,9 +170,10 @@ __global__ __launch_bounds__(KNN_THREADS) void knn64_kernel(int n, int ld, int k
     int *mbuf_i = reinterpret_cast<int *>(smem) + (KNN_WAVES - 1) * K * 64;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cloud = blockIdx.y;
+    int tile, cloud;
+    xcd_cloud_tile(tile, cloud);   // a cloud's candidate rows stay in ONE XCD's L2
     const float *X = x + (size_t)cloud * n * ld;
-    const int i = blockIdx.x * 64 + lane;
+    const int i = tile * 64 + lane;
     const bool valid = i < n;
     const int ii = valid ? i : 0;
 

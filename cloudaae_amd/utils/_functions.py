@@ -262,18 +262,20 @@ class EdgeConvFn(torch.autograd.Function):
         pq = torch.empty((B * N, 2 * cout), dtype=torch.float32, device=dev)
         save_mean = torch.empty(cout, dtype=torch.float32, device=dev)
         save_var = torch.empty(cout, dtype=torch.float32, device=dev)
+        ties = torch.empty((B * N, cout), dtype=torch.float32, device=dev) if pool_mode == 2 else None
         ws = _ws(L().cloudaae_edgeconv_workspace_bytes(cout), dev)
         _lib.check(L().cloudaae_edgeconv_forward(
             B, N, k, cin, cout, x.data_ptr(), ldx, ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
             int(training), ptr(decay), ptr(ema_mean), ptr(ema_var), int(pool_mode), ptr(pq), ptr(save_mean),
-            ptr(save_var), out.data_ptr(), ldo, ptr(ws), stream()), "cloudaae_edgeconv_forward")
-        ctx.save_for_backward(x, nn_idx, w, b, gamma, beta, pq, save_mean, save_var)
+            ptr(save_var), out.data_ptr(), ldo, ptr(ties), ptr(ws), stream()), "cloudaae_edgeconv_forward")
+        ctx.save_for_backward(x, nn_idx, w, b, gamma, beta, pq, save_mean, save_var, ties,
+                              out if pool_mode == 2 else None)
         ctx.cfg = (int(training), int(pool_mode))
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, nn_idx, w, b, gamma, beta, pq, save_mean, save_var = ctx.saved_tensors
+        x, nn_idx, w, b, gamma, beta, pq, save_mean, save_var, ties, fwd_out = ctx.saved_tensors
         training, pool_mode = ctx.cfg
         B, N, cin = x.shape
         cout = w.shape[1]
@@ -282,6 +284,7 @@ class EdgeConvFn(torch.autograd.Function):
         if not (dout.stride(2) == 1 and dout.stride(0) == N * dout.stride(1)):
             dout = dout.contiguous()
         dpq = torch.empty((B * N, 2 * cout), dtype=torch.float32, device=dev)
+        rev = torch.empty(B * (N + 1) + B * N * k, dtype=torch.int32, device=dev)
         dx = torch.empty((B, N, cin), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         gw = _ParamGrad(w, ctx.needs_input_grad[2])
         gb = _ParamGrad(b, ctx.needs_input_grad[3])
@@ -296,8 +299,10 @@ class EdgeConvFn(torch.autograd.Function):
         ws = _ws(L().cloudaae_edgeconv_workspace_bytes(cout), dev)
         _lib.check(L().cloudaae_edgeconv_backward(
             B, N, k, cin, cout, x.data_ptr(), x.stride(1), ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
-            training, pool_mode, ptr(pq), ptr(save_mean), ptr(save_var), dout.data_ptr(), dout.stride(1),
-            ptr(dpq), ptr(dx), cin, 0, ptr(gw.buf), ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), ptr(ws), stream()),
+            training, pool_mode, ptr(pq), ptr(save_mean), ptr(save_var),
+            fwd_out.data_ptr() if fwd_out is not None else None, fwd_out.stride(1) if fwd_out is not None else 0,
+            ptr(ties), dout.data_ptr(), dout.stride(1), ptr(dpq), ptr(rev), ptr(dx), cin, 0, ptr(gw.buf),
+            ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), ptr(ws), stream()),
             "cloudaae_edgeconv_backward")
         for g in shared:
             L().cloudaae_add_f32(g.buf.numel(), ptr(tmp[id(g)]), ptr(g.buf), ptr(tmp[id(g)]), stream())

@@ -132,19 +132,24 @@ int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, float *out, int a
  * (utils/tf_util.py:635-669,111-179; models/pointnet_ycb_23_decoder_4.py:337-350):
  * x[b*n, cin] (row stride ldx), nn_idx[b,n,k], weights[2*cin, cout] (the TF kernel
  * [1,1,2cin,cout]), pool_mode 1 mean / 2 max -> out[b*n, cout] (row stride ldo).
- * pq[b*n, 2*cout] is scratch that the backward pass reads again.  cout in {64,128}. */
+ * pq[b*n, 2*cout] is scratch that the backward pass reads again.  cout in {64,128}.
+ * max pool: tie_count[b*n, cout] receives the number of equal maxima (tf.reduce_max shares
+ * the gradient among them); backward then also needs the forward output.
+ * backward scratch: dpq[b*n, 2*cout] floats, rev_scratch[b*(n+1) + b*n*k] ints (reverse
+ * neighbour lists, built by a counting sort in LDS: no atomics on the gradient tensors). */
 long long cloudaae_edgeconv_workspace_bytes(int cout);
 int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cout, const float *x, int ldx,
                               const int *nn_idx, const float *weights, const float *biases,
                               const float *gamma, const float *beta, int training, const float *decay,
                               float *ema_mean, float *ema_var, int pool_mode, float *pq, float *save_mean,
-                              float *save_var, float *out, int ldo, void *workspace,
+                              float *save_var, float *out, int ldo, float *tie_count, void *workspace,
                               cloudaae_stream_t stream);
 int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int cout, const float *x, int ldx,
                                const int *nn_idx, const float *weights, const float *biases,
                                const float *gamma, const float *beta, int training, int pool_mode,
                                const float *pq, const float *save_mean, const float *save_var,
-                               const float *dout, int lddo, float *dpq, float *dx, int lddx,
+                               const float *out, int ldo, const float *tie_count, const float *dout,
+                               int lddo, float *dpq, int *rev_scratch, float *dx, int lddx,
                                int accumulate_dx, float *dweights, float *dbiases, float *dgamma,
                                float *dbeta, void *workspace, cloudaae_stream_t stream);
 
