@@ -56,6 +56,33 @@ def cpu_baseline(num_point, sample_batch, steps=1):
                       % (steps, sample_batch, num_point, dt)}
 
 
+def chamfer_kernel_rate(batch, n, m, iters=20):
+    """The second half of BASELINE's metric: Chamfer nn_distance forward kernel rate.
+    Algorithmic bytes = B*(n+m)*20 (12 B read + 4 B dist + 4 B idx per point, SURVEY 8d);
+    the kernel is fp32-VALU-bound (~1640 flop/B), so pairs/s against the VALU ceiling is
+    the meaningful fraction: 4.75 VALU lane-ops per pair (3 v_pk_add + 3 v_pk_mul +
+    2 v_pk_add per 2 pairs, v_min3_u32 per 2, tile bookkeeping) on 256 CU x 4 SIMD x 32
+    lanes x 2.4 GHz = 78.6 T lane-ops/s -> 16.6 T pairs/s."""
+    from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
+    g = torch.Generator(device="cuda").manual_seed(100)       # tf_nndistance.py:45-46 seeds
+    a = torch.randn((batch, n, 3), generator=g, device="cuda")
+    c = torch.randn((batch, m, 3), generator=g, device="cuda")
+    for _ in range(3):
+        tf_nndistance.nn_distance(a, c)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        tf_nndistance.nn_distance(a, c)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    pairs = 2.0 * batch * n * m
+    ceiling = 78.6e12 / 4.75
+    return {"shape": "[%d,%d,3]x[%d,%d,3]" % (batch, n, batch, m), "us_per_launch": round(sec * 1e6, 2),
+            "GB/s": round(batch * (n + m) * 20 / sec / 1e9, 3), "Tpairs/s": round(pairs / sec / 1e12, 3),
+            "clouds/s": round(batch / sec, 1), "frac_of_valu_ceiling": round(pairs / sec / ceiling, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +170,10 @@ def main():
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launch_ms": round(k_ms, 4), "launches_timed": len(ms)},
         }
+        if world == 1:
+            # "Chamfer kernel GB/s": the train shape (n = m = 4N) and the reference's own
+            # micro-benchmark shape (tf_nndistance.py:48-49)
+            line["chamfer_kernel"] = [chamfer_kernel_rate(B, 4 * N, 4 * N), chamfer_kernel_rate(32, 16384, 1024)]
         if world == 1 and args.cpu_batch > 0:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_batch)
         print(json.dumps(line))

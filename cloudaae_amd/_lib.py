@@ -38,6 +38,11 @@ _SIGNATURES = {
     "cloudaae_add_rowvec": [_I, _I, _I, _P, _P, _P, _P],
     "cloudaae_add_f32": [_L, _P, _P, _P, _P],
     "cloudaae_fill_scaled": [_L, _P, _F, _P, _P, _P],
+    "cloudaae_mul_add_f32": [_L, _P, _P, _P, _P, _P],
+    "cloudaae_edge_feature": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P],
+    "cloudaae_edge_feature_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "cloudaae_pool_rows": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "cloudaae_pool_rows_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cloudaae_mean_f32": [_L, _P, _P, _P, _P],
     "cloudaae_trans_error": [_I, _P, _P, _P, _P],
     "cloudaae_trans_error_grad": [_I, _P, _P, _P, _P, _P, _P],

@@ -94,6 +94,106 @@ __global__ void add_kernel(long long n, const float *__restrict__ a, const float
         out[i] = a[i] + b[i];
 }
 
+// out = a + b*c (a may be NULL): VAE reparameterisation z_mean + z_std * eps
+// (models/pointnet_ycb_23_decoder_4.py:953) and its gradient d(z_std) = g * eps
+__global__ void mul_add_kernel(long long n, const float *__restrict__ a, const float *__restrict__ b,
+                               const float *__restrict__ c, float *__restrict__ out)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float p = b[i] * c[i];
+        out[i] = a ? a[i] + p : p;
+    }
+}
+
+// ---- unfused graph pieces kept for API completeness -----------------------------------
+// get_edge_feature (utils/tf_util.py:635-669): out[b,i,j,:] = [x_i, x_nbr(i,j) - x_i];
+// wo_center variant (:672-706): only the second half.  One wave per (point, neighbour).
+__global__ __launch_bounds__(256) void edge_feature_kernel(int P, int N, int k, int C, int with_center,
+                                                          const float *__restrict__ x, int ldx,
+                                                          const int *__restrict__ nn_idx, float *__restrict__ out)
+{
+    const int W = with_center ? 2 * C : C;
+    const long long total = (long long)P * k * C;
+    for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += 256LL * gridDim.x) {
+        const int c = (int)(t % C);
+        const long long e = t / C;                 // edge id = pt*k + j
+        const int pt = (int)(e / k);
+        const int nb = (pt / N) * N + nn_idx[e];
+        const float ci = x[(size_t)pt * ldx + c];
+        float *row = out + (size_t)e * W;
+        if (with_center) {
+            row[c] = ci;
+            row[C + c] = x[(size_t)nb * ldx + c] - ci;
+        } else {
+            row[c] = x[(size_t)nb * ldx + c] - ci;
+        }
+    }
+}
+// gradient: dx_i += sum_j (g_center[i,j] - g_diff[i,j]); dx_nbr(i,j) += g_diff[i,j]  (dx zero-filled)
+__global__ __launch_bounds__(256) void edge_feature_grad_kernel(int P, int N, int k, int C, int with_center,
+                                                               const float *__restrict__ g,
+                                                               const int *__restrict__ nn_idx, float *__restrict__ dx)
+{
+    const int W = with_center ? 2 * C : C;
+    const long long total = (long long)P * k * C;
+    for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += 256LL * gridDim.x) {
+        const int c = (int)(t % C);
+        const long long e = t / C;
+        const int pt = (int)(e / k);
+        const int nb = (pt / N) * N + nn_idx[e];
+        const float *row = g + (size_t)e * W;
+        const float gd = with_center ? row[C + c] : row[c];
+        const float gc = with_center ? row[c] : 0.0f;
+        atomicAdd(dx + (size_t)pt * C + c, gc - gd);
+        atomicAdd(dx + (size_t)nb * C + c, gd);
+    }
+}
+
+// tf.reduce_mean / tf.reduce_max over groups of R consecutive rows of x[G*R, C]
+// (axis=-2 of [B,N,k,C], or axis=1 of [B,N,1,C]); max also returns the tie count.
+__global__ __launch_bounds__(256) void pool_rows_kernel(int G, int R, int C, int mode, const float *__restrict__ x,
+                                                       float *__restrict__ out, float *__restrict__ ties)
+{
+    const long long total = (long long)G * C;
+    for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += 256LL * gridDim.x) {
+        const int c = (int)(t % C);
+        const long long gidx = t / C;
+        const float *p = x + (size_t)gidx * R * C + c;
+        if (mode == 1) {
+            float s = 0.0f;
+            for (int r = 0; r < R; ++r)
+                s = s + p[(size_t)r * C];
+            out[t] = s / (float)R;
+        } else {
+            float m = -__builtin_inff(), n = 0.0f;
+            for (int r = 0; r < R; ++r) {
+                const float v = p[(size_t)r * C];
+                n = v > m ? 1.0f : (v == m ? n + 1.0f : n);
+                m = fmaxf(m, v);
+            }
+            out[t] = m;
+            if (ties)
+                ties[t] = n;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void pool_rows_grad_kernel(int G, int R, int C, int mode, const float *__restrict__ x,
+                                                            const float *__restrict__ out, const float *__restrict__ ties,
+                                                            const float *__restrict__ g, float *__restrict__ dx)
+{
+    const long long total = (long long)G * R * C;
+    for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += 256LL * gridDim.x) {
+        const int c = (int)(t % C);
+        const long long gidx = t / ((long long)R * C);
+        const size_t o = (size_t)gidx * C + c;
+        if (mode == 1)
+            dx[t] = g[o] / (float)R;
+        else
+            dx[t] = x[t] == out[o] ? g[o] / ties[o] : 0.0f;   // tf.reduce_max shares among equal maxima
+    }
+}
+
 // out[i] = scalar[0] * scale  (+ add[i])   -- gradient of a mean, broadcast
 __global__ void fill_scaled_kernel(long long n, const float *__restrict__ scalar, float scale,
                                    const float *__restrict__ add, float *__restrict__ out)
@@ -423,6 +523,71 @@ CLOUDAAE_API int cloudaae_add_f32(long long n, const float *a, const float *b, f
         return 0;
     hipLaunchKernelGGL(add_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, n, a, b, out);
     CLOUDAAE_CHECK_LAUNCH("cloudaae_add_f32");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_mul_add_f32(long long n, const float *a, const float *b, const float *c, float *out,
+                                      cloudaae_stream_t stream)
+{
+    if (n == 0)
+        return 0;
+    hipLaunchKernelGGL(mul_add_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, n, a, b, c, out);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_mul_add_f32");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_edge_feature(int b, int n, int k, int c, int with_center, const float *x, int ldx,
+                                       const int *nn_idx, float *out, cloudaae_stream_t stream)
+{
+    const long long total = (long long)b * n * k * c;
+    if (total == 0)
+        return 0;
+    hipLaunchKernelGGL(edge_feature_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, b * n, n,
+                       k, c, with_center, x, ldx, nn_idx, out);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_edge_feature");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_edge_feature_grad(int b, int n, int k, int c, int with_center, const float *g,
+                                            const int *nn_idx, float *dx, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_edge_feature_grad";
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)b * n * k * c;
+    if ((size_t)b * n * c)
+        CLOUDAAE_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)b * n * c, s), name);
+    if (total == 0)
+        return 0;
+    hipLaunchKernelGGL(edge_feature_grad_kernel, dim3(stream_grid(total)), dim3(256), 0, s, b * n, n, k, c,
+                       with_center, g, nn_idx, dx);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_pool_rows(int groups, int rows, int c, int mode, const float *x, float *out, float *ties,
+                                    cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_pool_rows";
+    CLOUDAAE_REQUIRE(rows > 0 && (mode == 1 || mode == 2), name, "rows > 0 and mode 1 (mean) / 2 (max)");
+    CLOUDAAE_REQUIRE(mode == 1 || ties != nullptr, name, "max pooling needs the tie_count output");
+    const long long total = (long long)groups * c;
+    if (total == 0)
+        return 0;
+    hipLaunchKernelGGL(pool_rows_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, groups, rows, c,
+                       mode, x, out, ties);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_pool_rows_grad(int groups, int rows, int c, int mode, const float *x, const float *out,
+                                         const float *ties, const float *g, float *dx, cloudaae_stream_t stream)
+{
+    const long long total = (long long)groups * rows * c;
+    if (total == 0)
+        return 0;
+    hipLaunchKernelGGL(pool_rows_grad_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, groups,
+                       rows, c, mode, x, out, ties, g, dx);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_pool_rows_grad");
     return 0;
 }
 

@@ -7,62 +7,79 @@ k-fold edge tensor, agg conv + BN + ReLU + pool in one pass) instead of the
 reference's op-by-op graph; the arithmetic definition is the reference's
 (SURVEY.md Appendix A/B).
 
-  get_model_dgcnn_mean_6d   models/...:327-455   (the variant both reference scripts call)
-  get_model_dgcnn_max_6d    models/...:592-723   (reduce_max instead of reduce_mean)
-  get_model_pn              models/...:23-89     (PointNet encoder)
+  get_model_pn                 models/...:23-89     (PointNet encoder)
+  get_model_dgcnn              models/...:93-207    (max pooling, reconstruction only)
+  get_model_dgcnn_mean         models/...:210-324
+  get_model_dgcnn_mean_6d      models/...:327-455   (the variant both reference scripts call)
+  get_model_dgcnn_mean_6d_hand models/...:458-589   (N x 5 decoder output)
+  get_model_dgcnn_max_6d       models/...:592-723   (reduce_max instead of reduce_mean)
+  get_model_dgcnn_mean_6d_2    models/...:726-856   (variables under 'model2/')
+  get_model_dgcnn_mean_vae     models/...:859-984
 """
 import torch
 
 from ..utils import tf_util
 
 
-def _dgcnn_6d(point_cloud, is_training_pl_encoder, is_training, k_neighbor, bn_decay, pool):
+def _dgcnn_encoder(point_cloud, is_training_pl_encoder, k, bn_decay, pool, prefix=''):
+    """The shared DGCNN encoder (models/...:337-426 and its copies): 4 x { kNN -> edge conv ->
+    pool over k }, concat, conv 320->1024, pool over the points.  Returns (embedding [B,1024],
+    lazy [B,N,1,1024] activation)."""
     batch_size, num_point = point_cloud.shape[0], point_cloud.shape[1]
-    end_points = {}
-    k = k_neighbor
-
     # net1..net4 are written as adjacent channel slices of ONE [B,N,320] buffer: that is the
     # tf.concat([net1, net2, net3, net4], axis=-1) of :410 without a copy
     widths = (64, 64, 64, 128)
     concat = torch.empty((batch_size, num_point, sum(widths)), dtype=torch.float32, device=point_cloud.device)
-
-    net = point_cloud                      # [B,N,3+classes]; kNN metric = xyz slice (tf_util.py:608)
+    net = point_cloud                      # [B,N,C]; kNN metric = xyz slice (tf_util.py:608)
     nets, off = [], 0
     for i, width in enumerate(widths):
         adj_matrix = tf_util.pairwise_xyz_distance(net)
         nn_idx = tf_util.knn(adj_matrix, k=k)
-        net = tf_util.edge_conv(net, nn_idx, width, scope='dgcnn%d' % (i + 1), pool=pool,
+        net = tf_util.edge_conv(net, nn_idx, width, scope='%sdgcnn%d' % (prefix, i + 1), pool=pool,
                                 bn_decay=bn_decay, is_training=is_training_pl_encoder,
                                 out_slot=(concat, off))      # [B,N,1,width]
         nets.append(net)
         off += width
+    return tf_util.conv2d_concat(nets, 1024, scope=prefix + 'dgcnn_agg', bn_decay=bn_decay,
+                                 is_training=is_training_pl_encoder, pool=pool)
 
-    embedding, before = tf_util.conv2d_concat(nets, 1024, scope='dgcnn_agg', bn_decay=bn_decay,
-                                              is_training=is_training_pl_encoder, pool=pool)
+
+def _decoder(net, out_units, is_training, bn_decay, prefix=''):
+    net, _, _ = tf_util.fully_connected(net, 1024, bn=True, is_training=is_training,
+                                        scope=prefix + 'dgcnn_fc1', bn_decay=bn_decay)
+    net, _, _ = tf_util.fully_connected(net, 1024, bn=True, is_training=is_training,
+                                        scope=prefix + 'dgcnn_fc2', bn_decay=bn_decay)
+    net, out_weight, out_biases = tf_util.fully_connected(net, out_units, activation_fn=None,
+                                                          scope=prefix + 'dgcnn_output')
+    return net
+
+
+def _pose_heads(embedding, is_training, bn_decay, prefix=''):
+    net_rot, _, _ = tf_util.fully_connected(embedding, 512, bn=True, is_training=is_training,
+                                            scope=prefix + 'dgcnn_rot_fc1', bn_decay=bn_decay)
+    net_rot, _, _ = tf_util.fully_connected(net_rot, 256, bn=True, is_training=is_training,
+                                            scope=prefix + 'dgcnn_rot_fc2', bn_decay=bn_decay)
+    net_rot, _, _ = tf_util.fully_connected(net_rot, 3, activation_fn=None, scope=prefix + 'dgcnn_output_rot')
+    net_trans, _, _ = tf_util.fully_connected(embedding, 512, bn=True, is_training=is_training,
+                                              scope=prefix + 'dgcnn_trans_fc1', bn_decay=bn_decay)
+    net_trans, _, _ = tf_util.fully_connected(net_trans, 256, bn=True, is_training=is_training,
+                                              scope=prefix + 'dgcnn_trans_fc2', bn_decay=bn_decay)
+    net_trans, _, _ = tf_util.fully_connected(net_trans, 3, activation_fn=None,
+                                              scope=prefix + 'dgcnn_output_trans')
+    return net_rot, net_trans
+
+
+def _dgcnn_6d(point_cloud, is_training_pl_encoder, is_training, k_neighbor, bn_decay, pool, prefix='',
+              point_out=(4, 3)):
+    batch_size, num_point = point_cloud.shape[0], point_cloud.shape[1]
+    end_points = {}
+    embedding, before = _dgcnn_encoder(point_cloud, is_training_pl_encoder, k_neighbor, bn_decay, pool, prefix)
     end_points['layer_before_embedding'] = before          # lazy [B,N,1,1024] (see LazyActivation)
     end_points['embedding'] = embedding                    # [B,1024]
-
-    net, _, _ = tf_util.fully_connected(embedding, 1024, bn=True, is_training=is_training,
-                                        scope='dgcnn_fc1', bn_decay=bn_decay)
-    net, _, _ = tf_util.fully_connected(net, 1024, bn=True, is_training=is_training,
-                                        scope='dgcnn_fc2', bn_decay=bn_decay)
-    net, out_weight, out_biases = tf_util.fully_connected(net, num_point * 3 * 4, activation_fn=None,
-                                                          scope='dgcnn_output')
-    net_recon = net.reshape(batch_size, num_point * 4, 3)
-
-    # 6d pose
-    net_rot, _, _ = tf_util.fully_connected(embedding, 512, bn=True, is_training=is_training,
-                                            scope='dgcnn_rot_fc1', bn_decay=bn_decay)
-    net_rot, _, _ = tf_util.fully_connected(net_rot, 256, bn=True, is_training=is_training,
-                                            scope='dgcnn_rot_fc2', bn_decay=bn_decay)
-    net_rot, _, _ = tf_util.fully_connected(net_rot, 3, activation_fn=None, scope='dgcnn_output_rot')
-
-    net_trans, _, _ = tf_util.fully_connected(embedding, 512, bn=True, is_training=is_training,
-                                              scope='dgcnn_trans_fc1', bn_decay=bn_decay)
-    net_trans, _, _ = tf_util.fully_connected(net_trans, 256, bn=True, is_training=is_training,
-                                              scope='dgcnn_trans_fc2', bn_decay=bn_decay)
-    net_trans, _, _ = tf_util.fully_connected(net_trans, 3, activation_fn=None, scope='dgcnn_output_trans')
-
+    mult, dim = point_out
+    net = _decoder(embedding, num_point * mult * dim, is_training, bn_decay, prefix)
+    net_recon = net.reshape(batch_size, num_point * mult, dim)
+    net_rot, net_trans = _pose_heads(embedding, is_training, bn_decay, prefix)
     return net_recon, net_rot, net_trans, end_points
 
 
@@ -76,6 +93,56 @@ def get_model_dgcnn_mean_6d(point_cloud, is_training_pl_encoder, is_training, k_
 def get_model_dgcnn_max_6d(point_cloud, is_training_pl_encoder, is_training, k_neighbor, bn_decay=None):
     """Same with reduce_max in place of every reduce_mean (models/...:592-723)."""
     return _dgcnn_6d(point_cloud, is_training_pl_encoder, is_training, k_neighbor, bn_decay, 'max')
+
+
+def get_model_dgcnn_mean_6d_hand(point_cloud, is_training_pl_encoder, is_training, k_neighbor, bn_decay=None):
+    """models/...:458-589: as mean_6d, but the decoder emits num_point x (3+2) values."""
+    return _dgcnn_6d(point_cloud, is_training_pl_encoder, is_training, k_neighbor, bn_decay, 'mean',
+                     point_out=(1, 5))
+
+
+def get_model_dgcnn_mean_6d_2(point_cloud, is_training_pl_encoder, is_training, k_neighbor, bn_decay=None):
+    """models/...:726-856: a second copy of mean_6d whose variables live under 'model2/'."""
+    return _dgcnn_6d(point_cloud, is_training_pl_encoder, is_training, k_neighbor, bn_decay, 'mean',
+                     prefix='model2/')
+
+
+def get_model_dgcnn(point_cloud, is_training, bn_decay=None):
+    """models/...:93-207: max-pooling DGCNN auto-encoder, k = 10, reconstruction only:
+    returns (net [B,4N,3], end_points)."""
+    batch_size, num_point = point_cloud.shape[0], point_cloud.shape[1]
+    end_points = {}
+    embedding, _ = _dgcnn_encoder(point_cloud, is_training, 10, bn_decay, 'max')
+    net = _decoder(embedding, num_point * 3 * 4, is_training, bn_decay)
+    return net.reshape(batch_size, num_point * 4, 3), end_points
+
+
+def get_model_dgcnn_mean(point_cloud, is_training, bn_decay=None):
+    """models/...:210-324: the same with mean pooling."""
+    batch_size, num_point = point_cloud.shape[0], point_cloud.shape[1]
+    end_points = {}
+    embedding, _ = _dgcnn_encoder(point_cloud, is_training, 10, bn_decay, 'mean')
+    net = _decoder(embedding, num_point * 3 * 4, is_training, bn_decay)
+    return net.reshape(batch_size, num_point * 4, 3), end_points
+
+
+def get_model_dgcnn_mean_vae(point_cloud, is_training, bn_decay=None, noise=None):
+    """models/...:859-984: mean-pooling encoder, z = z_mean + z_std * N(0,1) (:953), FC decoder.
+    Returns (net [B,4N,3], z_mean, z_std, end_points).  `noise` ([B,1024]) may be passed for
+    reproducibility; otherwise it is drawn on the device like tf.random_normal."""
+    batch_size, num_point = point_cloud.shape[0], point_cloud.shape[1]
+    end_points = {}
+    pooled, _ = _dgcnn_encoder(point_cloud, is_training, 10, bn_decay, 'mean')
+    z_mean, _, _ = tf_util.fully_connected(pooled, 1024, bn=True, is_training=is_training,
+                                           scope='dgcnn_z_mean', bn_decay=bn_decay)
+    z_std, _, _ = tf_util.fully_connected(pooled, 1024, bn=True, is_training=is_training,
+                                          scope='dgcnn_z_std', bn_decay=bn_decay)
+    if noise is None:
+        noise = torch.randn(z_mean.shape, dtype=torch.float32, device=z_mean.device)
+    net = tf_util.mul_add(z_mean, z_std, noise)
+    end_points['embedding'] = net
+    net = _decoder(net, num_point * 3 * 4, is_training, bn_decay)
+    return net.reshape(batch_size, num_point * 4, 3), z_mean, z_std, end_points
 
 
 def get_model_pn(point_cloud, is_training, bn_decay=None):

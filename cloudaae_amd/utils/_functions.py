@@ -433,3 +433,74 @@ class LossMixFn(torch.autograd.Function):
         _lib.check(L().cloudaae_loss_mix_grad(ptr(g.contiguous()), ctx.w[0], ctx.w[1], ctx.w[2], ptr(ga), ptr(gb),
                                               ptr(gc), stream()), "cloudaae_loss_mix_grad")
         return ga, gb, gc, None, None, None
+
+
+class EdgeFeatureFn(torch.autograd.Function):
+    """Unfused get_edge_feature / get_edge_feature_wo_center (utils/tf_util.py:635-706)."""
+
+    @staticmethod
+    def forward(ctx, x, nn_idx, with_center):
+        B, N, C = x.shape
+        require(x.stride(2) == 1 and (B == 1 or x.stride(0) == N * x.stride(1)), "EdgeFeatureFn: x rows must be contiguous")
+        nn_idx = nn_idx.contiguous()
+        k = nn_idx.shape[2]
+        out = torch.empty((B, N, k, (2 if with_center else 1) * C), dtype=torch.float32, device=x.device)
+        _lib.check(L().cloudaae_edge_feature(B, N, k, C, int(with_center), x.data_ptr(), x.stride(1), ptr(nn_idx),
+                                             ptr(out), stream()), "cloudaae_edge_feature")
+        ctx.save_for_backward(nn_idx)
+        ctx.cfg = (B, N, k, C, int(with_center))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (nn_idx,) = ctx.saved_tensors
+        B, N, k, C, wc = ctx.cfg
+        dx = torch.empty((B, N, C), dtype=torch.float32, device=g.device)
+        _lib.check(L().cloudaae_edge_feature_grad(B, N, k, C, wc, ptr(g.contiguous()), ptr(nn_idx), ptr(dx), stream()),
+                   "cloudaae_edge_feature_grad")
+        return dx, None, None
+
+
+class PoolRowsFn(torch.autograd.Function):
+    """tf.reduce_mean / tf.reduce_max over `rows` consecutive rows of x[groups*rows, C]."""
+
+    @staticmethod
+    def forward(ctx, x, rows, mode):
+        x = x.contiguous()
+        M, C = x.shape
+        G = M // rows
+        out = torch.empty((G, C), dtype=torch.float32, device=x.device)
+        ties = torch.empty_like(out) if mode == 2 else None
+        _lib.check(L().cloudaae_pool_rows(G, rows, C, mode, ptr(x), ptr(out), ptr(ties), stream()), "cloudaae_pool_rows")
+        ctx.save_for_backward(x, out, ties)
+        ctx.cfg = (G, rows, C, mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, out, ties = ctx.saved_tensors
+        G, rows, C, mode = ctx.cfg
+        dx = torch.empty_like(x)
+        _lib.check(L().cloudaae_pool_rows_grad(G, rows, C, mode, ptr(x), ptr(out), ptr(ties), ptr(g.contiguous()),
+                                               ptr(dx), stream()), "cloudaae_pool_rows_grad")
+        return dx, None, None
+
+
+class MulAddFn(torch.autograd.Function):
+    """out = a + b * c with c a constant (noise): z_mean + z_std * eps, models/...:953."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
+        out = torch.empty_like(a)
+        _lib.check(L().cloudaae_mul_add_f32(a.numel(), ptr(a), ptr(b), ptr(c), ptr(out), stream()), "cloudaae_mul_add_f32")
+        ctx.save_for_backward(c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (c,) = ctx.saved_tensors
+        g = g.contiguous()
+        db = torch.empty_like(g)
+        _lib.check(L().cloudaae_mul_add_f32(g.numel(), None, ptr(g), ptr(c), ptr(db), stream()), "cloudaae_mul_add_f32")
+        return g, db, None

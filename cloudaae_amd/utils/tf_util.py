@@ -366,8 +366,59 @@ class LazyActivation(object):
         return out.reshape(self.shape)
 
 
+def _points3(point_cloud):
+    x = point_cloud[:, :, 0, :] if point_cloud.dim() == 4 else point_cloud      # tf.squeeze, :645
+    B, N, _ = x.shape
+    if not (x.stride(2) == 1 and (B == 1 or x.stride(0) == N * x.stride(1))):
+        x = x.contiguous()
+    return x
+
+
 def get_edge_feature(point_cloud, nn_idx, k):
-    """Construct edge feature for each point (tf_util.py:635-669): [c_i, n_ij - c_i].
-    Unfused form, kept for API completeness; the model builders use `edge_conv`.
-    TODO(next round): dedicated gather kernel; until then it fails loudly."""
-    raise NotImplementedError("get_edge_feature (unfused) is not built yet; use tf_util.edge_conv")
+    """Construct edge feature for each point (tf_util.py:635-669)
+    Args:
+      point_cloud: (batch_size, num_points, num_dims)  [or (batch_size, num_points, 1, num_dims)]
+      nn_idx: (batch_size, num_points, k)
+      k: int
+    Returns:
+      edge features: (batch_size, num_points, k, 2*num_dims) = concat(central, neighbours - central)
+    Unfused form (materialises the k-fold tensor); the model builders use `edge_conv`."""
+    require(nn_idx.shape[2] == k, "get_edge_feature: nn_idx last dim != k")
+    return F.EdgeFeatureFn.apply(_points3(point_cloud), nn_idx, True)
+
+
+def get_edge_feature_wo_center(point_cloud, nn_idx, k):
+    """tf_util.py:672-706: (batch_size, num_points, k, num_dims) = neighbours - central."""
+    require(nn_idx.shape[2] == k, "get_edge_feature_wo_center: nn_idx last dim != k")
+    return F.EdgeFeatureFn.apply(_points3(point_cloud), nn_idx, False)
+
+
+def mul_add(a, b, c):
+    """a + b * c with `c` a constant tensor (VAE reparameterisation, models/...:953)."""
+    return F.MulAddFn.apply(a, b, c)
+
+
+def _reduce(x, axis, keep_dims, mode):
+    nd = x.dim()
+    axis = axis % nd
+    require(all(x.shape[d] == 1 for d in range(axis + 1, nd - 1)),
+            "reduce: only an axis whose trailing axes (before the channels) have size 1 is supported")
+    C = x.shape[-1]
+    rows = x.shape[axis]
+    out = F.PoolRowsFn.apply(x.reshape(-1, C), rows, mode)
+    shape = list(x.shape)
+    if keep_dims:
+        shape[axis] = 1
+    else:
+        del shape[axis]
+    return out.reshape(shape)
+
+
+def reduce_mean(x, axis, keep_dims=False):
+    """tf.reduce_mean over one axis (models/...:350, :419)."""
+    return _reduce(x, axis, keep_dims, 1)
+
+
+def reduce_max(x, axis, keep_dims=False):
+    """tf.reduce_max over one axis (models/...:615, :684); the gradient is shared among equal maxima."""
+    return _reduce(x, axis, keep_dims, 2)

@@ -164,6 +164,22 @@ int cloudaae_input_assemble(int b, int p, int n, int num_class, const float *vis
 int cloudaae_add_rowvec(int b, int r, int d, const float *x, const float *v, float *out,
                         cloudaae_stream_t stream);
 int cloudaae_add_f32(long long n, const float *a, const float *b, float *out, cloudaae_stream_t stream);
+/* out = a + b*c elementwise (a may be NULL): the VAE reparameterisation, models/...:953 */
+int cloudaae_mul_add_f32(long long n, const float *a, const float *b, const float *c, float *out,
+                         cloudaae_stream_t stream);
+/* get_edge_feature (utils/tf_util.py:635-669; with_center = 0: _wo_center, :672-706), unfused:
+ * x[b*n, c] (row stride ldx), nn_idx[b,n,k] -> out[b,n,k,(1+with_center)*c]; and its gradient
+ * (dx[b*n, c] is zero-filled here). */
+int cloudaae_edge_feature(int b, int n, int k, int c, int with_center, const float *x, int ldx,
+                          const int *nn_idx, float *out, cloudaae_stream_t stream);
+int cloudaae_edge_feature_grad(int b, int n, int k, int c, int with_center, const float *g, const int *nn_idx,
+                               float *dx, cloudaae_stream_t stream);
+/* tf.reduce_mean (mode 1) / tf.reduce_max (mode 2) over groups of `rows` consecutive rows of
+ * x[groups*rows, c] -> out[groups, c] (+ tie count for max), and the gradient. */
+int cloudaae_pool_rows(int groups, int rows, int c, int mode, const float *x, float *out, float *ties,
+                       cloudaae_stream_t stream);
+int cloudaae_pool_rows_grad(int groups, int rows, int c, int mode, const float *x, const float *out,
+                            const float *ties, const float *g, float *dx, cloudaae_stream_t stream);
 /* out[i] = scalar[0] * scale (+ add[i]) : gradient of a mean */
 int cloudaae_fill_scaled(long long n, const float *scalar, float scale, const float *add, float *out,
                          cloudaae_stream_t stream);

@@ -146,12 +146,15 @@ def get_edge_feature(point_cloud, nn_idx, k):
 # --------------------------------------------------------------------------------------
 # models/pointnet_ycb_23_decoder_4.py
 # --------------------------------------------------------------------------------------
-def _decoder_and_heads(embedding, num_point, V, is_training, bn_decay, prefix, fc_suffix=""):
+def _decoder_and_heads(embedding, num_point, V, is_training, bn_decay, prefix, fc_suffix="", point_out=(4, 3),
+                       heads=True):
     B = embedding.shape[0]
     net = fully_connected(embedding, 1024, prefix + "_fc1" + fc_suffix, V, True, is_training, bn_decay)
     net = fully_connected(net, 1024, prefix + "_fc2" + fc_suffix, V, True, is_training, bn_decay)
-    net = fully_connected(net, num_point * 3 * 4, prefix + "_output", V, relu=False)
-    recon = net.reshape(B, num_point * 4, 3)
+    net = fully_connected(net, num_point * point_out[0] * point_out[1], prefix + "_output", V, relu=False)
+    recon = net.reshape(B, num_point * point_out[0], point_out[1])
+    if not heads:
+        return recon, None, None
     rot = fully_connected(embedding, 512, prefix + "_rot_fc1", V, True, is_training, bn_decay)
     rot = fully_connected(rot, 256, prefix + "_rot_fc2", V, True, is_training, bn_decay)
     rot = fully_connected(rot, 3, prefix + "_output_rot", V, relu=False)
@@ -162,8 +165,10 @@ def _decoder_and_heads(embedding, num_point, V, is_training, bn_decay, prefix, f
 
 
 def get_model_dgcnn_6d(point_cloud, is_training_pl_encoder, is_training, k_neighbor, V, bn_decay=None,
-                       pool="mean"):
-    """get_model_dgcnn_mean_6d (models/...:327-455) / get_model_dgcnn_max_6d (:592-723)."""
+                       pool="mean", prefix="", point_out=(4, 3), heads=True, vae_noise=None):
+    """get_model_dgcnn_mean_6d (models/...:327-455) / _max_6d (:592-723) / _mean_6d_hand (:458-589,
+    point_out=(1,5)) / _mean_6d_2 (:726-856, prefix='model2/') / get_model_dgcnn[_mean] (:93-324,
+    heads=False) / _mean_vae (:859-984, vae_noise given)."""
     B, N, _ = point_cloud.shape
     k = k_neighbor
     red = (lambda t, d: t.mean(d, keepdim=True)) if pool == "mean" else (lambda t, d: t.max(d, keepdim=True)[0])
@@ -173,17 +178,24 @@ def get_model_dgcnn_6d(point_cloud, is_training_pl_encoder, is_training, k_neigh
     for i, cout in enumerate((64, 64, 64, 128)):
         nn_idx = knn_indices(net, k)
         edge = get_edge_feature(net, nn_idx, k)
-        net = conv2d_1x1(edge, cout, "dgcnn%d" % (i + 1), V, True, is_training_pl_encoder, bn_decay)
+        net = conv2d_1x1(edge, cout, "%sdgcnn%d" % (prefix, i + 1), V, True, is_training_pl_encoder, bn_decay)
         net = red(net, -2)                                  # [B,N,1,cout]
         nets.append(net)
         end_points["nn_idx%d" % (i + 1)] = nn_idx
-    net = conv2d_1x1(torch.cat(nets, dim=-1), 1024, "dgcnn_agg", V, True, is_training_pl_encoder, bn_decay)
+    net = conv2d_1x1(torch.cat(nets, dim=-1), 1024, prefix + "dgcnn_agg", V, True, is_training_pl_encoder,
+                     bn_decay)
     end_points["layer_before_embedding"] = net
     net = red(net, 1)
     embedding = net.reshape(B, -1)
-    end_points["embedding"] = embedding
     end_points["nets"] = nets
-    recon, rot, tr = _decoder_and_heads(embedding, N, V, is_training, bn_decay, "dgcnn")
+    if vae_noise is not None:       # :945-953
+        z_mean = fully_connected(embedding, 1024, "dgcnn_z_mean", V, True, is_training, bn_decay)
+        z_std = fully_connected(embedding, 1024, "dgcnn_z_std", V, True, is_training, bn_decay)
+        embedding = z_mean + z_std * vae_noise
+        end_points["z_mean"], end_points["z_std"] = z_mean, z_std
+    end_points["embedding"] = embedding
+    recon, rot, tr = _decoder_and_heads(embedding, N, V, is_training, bn_decay, prefix + "dgcnn",
+                                        point_out=point_out, heads=heads)
     return recon, rot, tr, end_points
 
 

@@ -1,0 +1,154 @@
+"""GPU: the remaining model builders and the unfused tf_util graph pieces vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(got, want):
+    got = got.detach().cpu().double().numpy()
+    want = want.detach().cpu().double().numpy()
+    return np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
+
+
+def _fresh_store():
+    from cloudaae_amd.utils import tf_util
+    return tf_util.reset_default_store(device="cuda")
+
+
+VARIANTS = [
+    # product builder, oracle kwargs, product kwargs
+    ("get_model_dgcnn_mean_6d_hand", dict(pool="mean", point_out=(1, 5)), {}),
+    ("get_model_dgcnn_mean_6d_2", dict(pool="mean", prefix="model2/"), {}),
+    ("get_model_dgcnn", dict(pool="max", heads=False), {}),
+    ("get_model_dgcnn_mean", dict(pool="mean", heads=False), {}),
+    ("get_model_dgcnn_mean_vae", dict(pool="mean", heads=False), {}),
+]
+
+
+@pytest.mark.parametrize("name,okw,pkw", VARIANTS)
+def test_model_variant_vs_oracle(hip, name, okw, pkw):
+    from cloudaae_amd.models import pointnet_ycb_23_decoder_4 as M
+    from oracle import model_oracle as MO
+    B, N = 4, 128
+    g = torch.Generator().manual_seed(17)
+    pc = torch.zeros(B, N, 24)
+    pc[:, :, :3] = torch.randn(B, N, 3, generator=g) * 0.05
+    pc[:, :, 3 + 4] = 1.0
+    noise = torch.randn(B, 1024, generator=g)
+    is_vae = name.endswith("vae")
+    six_d = "6d" in name
+    V = MO.Vars(seed=2)
+    okw = dict(okw)
+    if is_vae:
+        okw["vae_noise"] = noise
+    want = MO.get_model_dgcnn_6d(pc, True, True, 10, V, 0.5, **okw)
+    w = torch.randn(want[0].shape, generator=g)
+    loss = (want[0] * w).sum()
+    if six_d:
+        loss = loss + want[1].sum() + 2 * want[2].sum()
+    loss.backward()
+
+    store = _fresh_store()
+    fn = getattr(M, name)
+    pcd = pc.cuda()
+
+    def call(training):
+        if six_d:
+            return fn(pcd, training, training, 10, bn_decay=0.5)
+        if is_vae:
+            return fn(pcd, training, bn_decay=0.5, noise=noise.cuda())
+        return fn(pcd, training, bn_decay=0.5)
+
+    with torch.no_grad():
+        call(False)                               # build the variables
+    sd = {k: v.detach() for k, v in V.p.items()}
+    sd.update({k: torch.zeros_like(v) for k, v in V.s.items()})   # shadows as before the oracle's step
+    store.load_state_dict(sd)
+    assert list(store.vars) == list(sd) or set(store.vars) == set(sd)
+    store.flatten()
+    store.begin_step()
+    got = call(True)
+    gl = (got[0] * w.cuda()).sum()
+    if six_d:
+        gl = F_sum(gl, got[1], got[2])
+    gl.backward()
+    assert _rel(got[0], want[0]) < 2e-4
+    if six_d:
+        assert _rel(got[1], want[1]) < 2e-4 and _rel(got[2], want[2]) < 2e-4
+    if is_vae:
+        assert _rel(got[1], want[3]["z_mean"]) < 2e-4 and _rel(got[2], want[3]["z_std"]) < 2e-4
+    # gradients that are analytically zero (conv/fc biases in front of a BN; with max pooling also
+    # dgcnn_agg's beta, a per-channel shift that the next layer's batch norm removes) are round-off
+    # on both sides: errors are measured against the larger of the tensor's own scale and 1e-3 of
+    # the largest gradient in the model
+    gmax = max(float(p.grad.abs().max()) for p in V.p.values() if p.grad is not None)
+    for n, p in V.p.items():
+        if p.grad is None:
+            continue
+        got = store.vars[n].grad.cpu()
+        err = float((got - p.grad).abs().max()) / max(float(p.grad.abs().max()), 1e-3 * gmax)
+        assert err < 2e-2, (n, err)
+
+
+def F_sum(a, rot, trans):
+    # sum of device scalars via the product's own ops
+    from cloudaae_amd.utils import _functions as F
+    r = F.MeanFn.apply(rot) * rot.numel()
+    t = F.MeanFn.apply(trans) * trans.numel()
+    return a + r + 2 * t
+
+
+@pytest.mark.parametrize("pool", ["mean", "max"])
+def test_unfused_graph_equals_fused_block(hip, oracle, pool):
+    """get_edge_feature -> conv2d(bn) -> reduce_mean/max (the reference's op sequence,
+    models/...:337-350) against tf_util.edge_conv with the same variables."""
+    from cloudaae_amd.utils import tf_util
+    store = _fresh_store()
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(2, 96, 24, generator=g) * 0.3).cuda()
+    nn_idx = tf_util.knn(tf_util.pairwise_xyz_distance(x), k=10)
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    fused = tf_util.edge_conv(xa, nn_idx, 64, scope="dgcnn1", pool=pool, bn_decay=0.5, is_training=True)
+    edge = tf_util.get_edge_feature(xb, nn_idx=nn_idx, k=10)
+    assert edge.shape == (2, 96, 10, 48)
+    # oracle check of the gather itself
+    from oracle import model_oracle as MO
+    assert torch.equal(edge.detach().cpu(), MO.get_edge_feature(x.cpu(), nn_idx.cpu().long(), 10))
+    net = tf_util.conv2d(edge, 64, [1, 1], padding='VALID', stride=[1, 1], bn=True, is_training=True,
+                         scope='dgcnn1', bn_decay=0.5)
+    red = tf_util.reduce_mean if pool == "mean" else tf_util.reduce_max
+    unfused = red(net, axis=-2, keep_dims=True)
+    assert unfused.shape == fused.shape == (2, 96, 1, 64)
+    assert _rel(fused, unfused) < 3e-5
+    w = torch.randn(fused.shape, generator=g).cuda()
+    ga = torch.autograd.grad((fused * w).sum(), xa)[0]
+    gb = torch.autograd.grad((unfused * w).sum(), xb)[0]
+    assert _rel(ga, gb) < (2e-2 if pool == "max" else 1e-3)
+    wo = tf_util.get_edge_feature_wo_center(x, nn_idx=nn_idx, k=10)
+    assert torch.equal(wo, edge.detach()[..., 24:])
+
+
+def test_pool_rows_and_mul_add(hip):
+    from cloudaae_amd.utils import tf_util
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 50, 7, 33, generator=g)
+    x[:, :, 2] = x[:, :, 5]                       # ties for the max
+    for red, ref in ((tf_util.reduce_mean, lambda t: t.mean(2, keepdim=True)),
+                     (tf_util.reduce_max, lambda t: t.amax(2, keepdim=True))):
+        a = x.clone().requires_grad_(True)
+        d = x.cuda().requires_grad_(True)
+        want = ref(a)
+        got = red(d, axis=-2, keep_dims=True)
+        w = torch.randn(want.shape, generator=g)
+        (want * w).sum().backward()
+        (got * w.cuda()).sum().backward()
+        assert _rel(got, want) < 1e-6 and _rel(d.grad, a.grad) < 1e-6
+    a, b, c = (torch.randn(5, 100, generator=g) for _ in range(3))
+    ad, bd = a.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    out = tf_util.mul_add(ad, bd, c.cuda())
+    assert torch.allclose(out.cpu(), a + b * c, atol=1e-6)
+    out.sum().backward()
+    assert torch.equal(ad.grad.cpu(), torch.ones(5, 100)) and torch.allclose(bd.grad.cpu(), c)
