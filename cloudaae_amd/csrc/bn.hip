@@ -204,6 +204,139 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(int C, const doubl
     out[c] = (accumulate ? out[c] : 0.0f) + (float)s;
 }
 
+// ---- small batches (the FC layers: M = batch per GPU) -----------------------------------------
+// With M <= 128 rows a 64-channel column block fits in the registers of one workgroup
+// (64 channels x 4 row lanes, <= 32 rows per thread), so moments, EMA update, normalise(+ReLU)
+// are ONE launch instead of three, and the backward ONE instead of four.  At B=32 that is
+// 6 layers x 5 launches of ~6 us each per step.  Same arithmetic as the large-M path (fp64
+// sums, then the fp32 formulas), so results are identical up to the summation order.
+constexpr int BN_SMALL_M = 128;
+constexpr int BN_SMALL_R = BN_SMALL_M / 4;
+
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(int M, int C, const float *__restrict__ y, int ldy,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, int training,
+                                                          const float *__restrict__ decay,
+                                                          float *__restrict__ ema_mean, float *__restrict__ ema_var,
+                                                          float *__restrict__ save_mean, float *__restrict__ save_var,
+                                                          int relu, float *__restrict__ out, int ldo)
+{
+    __shared__ double red[2][4][64];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool ok = c < C;
+    float v[BN_SMALL_R];
+    double s = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < BN_SMALL_R; ++i) {
+        const int r = rl + 4 * i;
+        v[i] = (ok && r < M) ? y[(size_t)r * ldy + c] : 0.0f;
+        s += (double)v[i];
+        s2 += (double)v[i] * (double)v[i];
+    }
+    float mean, var;
+    if (training) {
+        red[0][rl][lane] = s;
+        red[1][rl][lane] = s2;
+        __syncthreads();
+        const double ts = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        const double ts2 = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+        const double mu = ts / (double)M;
+        double vv = ts2 / (double)M - mu * mu;
+        vv = vv > 0.0 ? vv : 0.0;
+        mean = (float)mu;
+        var = (float)vv;
+        if (ok && rl == 0 && ema_mean != nullptr) {
+            const float om = 1.0f - decay[0];
+            ema_mean[c] = ema_mean[c] - (ema_mean[c] - mean) * om;
+            ema_var[c] = ema_var[c] - (ema_var[c] - var) * om;
+        }
+    } else {
+        mean = ok ? ema_mean[c] : 0.0f;
+        var = ok ? ema_var[c] : 1.0f;
+    }
+    if (!ok)
+        return;
+    if (rl == 0) {
+        save_mean[c] = mean;
+        save_var[c] = var;
+    }
+    const float inv = gamma[c] * bn_rsqrt(var + BN_EPS);
+    const float sh = beta[c] - mean * inv;
+#pragma unroll
+    for (int i = 0; i < BN_SMALL_R; ++i) {
+        const int r = rl + 4 * i;
+        if (r < M) {
+            float z = v[i] * inv + sh;
+            if (relu)
+                z = fmaxf(z, 0.0f);
+            out[(size_t)r * ldo + c] = z;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(int M, int C, const float *__restrict__ y, int ldy,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta,
+                                                          const float *__restrict__ save_mean,
+                                                          const float *__restrict__ save_var, int training, int relu,
+                                                          const float *__restrict__ dout, int lddo,
+                                                          float *__restrict__ dy, int lddy,
+                                                          float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                          int accumulate)
+{
+    __shared__ double red[2][4][64];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool ok = c < C;
+    const float mean = ok ? save_mean[c] : 0.0f, var = ok ? save_var[c] : 1.0f;
+    const float g = ok ? gamma[c] : 0.0f, b = ok ? beta[c] : 0.0f;
+    const float rstd = bn_rsqrt(var + BN_EPS);
+    const float inv = g * rstd, sh = b - mean * inv;
+    float xh[BN_SMALL_R], dz[BN_SMALL_R];
+    double s = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < BN_SMALL_R; ++i) {
+        const int r = rl + 4 * i;
+        const bool in = ok && r < M;
+        const float v = in ? y[(size_t)r * ldy + c] : 0.0f;
+        float z = v * inv + sh;
+        if (relu)
+            z = fmaxf(z, 0.0f);
+        float d = in ? dout[(size_t)r * lddo + c] : 0.0f;
+        if (relu && !(z > 0.0f))
+            d = 0.0f;
+        dz[i] = d;
+        xh[i] = (v - mean) * rstd;
+        if (in) {
+            s += (double)d;
+            s2 += (double)d * (double)xh[i];
+        }
+    }
+    red[0][rl][lane] = s;
+    red[1][rl][lane] = s2;
+    __syncthreads();
+    if (!ok)
+        return;
+    const double ts = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+    const double ts2 = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    if (rl == 0) {
+        if (dbeta != nullptr)
+            dbeta[c] = (accumulate ? dbeta[c] : 0.0f) + (float)ts;
+        if (dgamma != nullptr)
+            dgamma[c] = (accumulate ? dgamma[c] : 0.0f) + (float)ts2;
+    }
+    const float m1 = training ? (float)(ts / (double)M) : 0.0f;
+    const float m2 = training ? (float)(ts2 / (double)M) : 0.0f;
+    const float gr = g * rstd;
+#pragma unroll
+    for (int i = 0; i < BN_SMALL_R; ++i) {
+        const int r = rl + 4 * i;
+        if (r < M)
+            dy[(size_t)r * lddy + c] = gr * ((dz[i] - m1) - xh[i] * m2);
+    }
+}
+
 static int bn_parts(int M)
 {
     int p = M / 64;
@@ -237,6 +370,12 @@ CLOUDAAE_API int cloudaae_bn_forward(int M, int C, const float *y, int ldy, cons
                      "pooling needs pool_rows | M and an output");
     CLOUDAAE_REQUIRE(pool_mode != 0 || out != nullptr, name, "no output requested");
     hipStream_t s = (hipStream_t)stream;
+    if (pool_mode == 0 && M <= BN_SMALL_M) {   // FC layers: one fused launch
+        hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, M, C, y, ldy, gamma, beta,
+                           training, decay, ema_mean, ema_var, save_mean, save_var, relu, out, ldo);
+        CLOUDAAE_CHECK_LAUNCH(name);
+        return 0;
+    }
     double *partial = (double *)workspace;
     float *scale_shift = (float *)(partial + (size_t)BN_MAX_PARTS * 2 * C);
     const int parts = bn_parts(M);
@@ -280,6 +419,13 @@ CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, con
     CLOUDAAE_REQUIRE(pool_mode != 2 || (pooled && tie_count), name, "max pool backward needs max and tie count");
     CLOUDAAE_REQUIRE(dout != nullptr || pool_mode != 0, name, "no upstream gradient");
     hipStream_t s = (hipStream_t)stream;
+    if (pool_mode == 0 && M <= BN_SMALL_M) {
+        hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, M, C, y, ldy, gamma, beta,
+                           save_mean, save_var, training, relu, dout, lddo, dy, lddy, dgamma, dbeta,
+                           accumulate_param_grads);
+        CLOUDAAE_CHECK_LAUNCH(name);
+        return 0;
+    }
     double *partial = (double *)workspace;
     float *scratch = (float *)(partial + (size_t)BN_MAX_PARTS * 2 * C);
     float *scale_shift = scratch, *m12 = scratch + 2 * (size_t)C;

@@ -266,7 +266,10 @@ CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K
     int splits = 1;
     const long long tiles = (long long)tm * tn;
     if (tiles < 256 && K >= 128) {
-        splits = (int)((512 + tiles - 1) / tiles);
+        // tiles * splits <= 512 = two resident workgroups per CU, i.e. one wave of workgroups
+        // (528 = 24 x 22 spilled into a second, nearly empty wave); outputs of <= 4 tiles get at
+        // most 256 slices: every slice adds to the SAME few thousand addresses with atomics
+        splits = (int)((tiles <= 4 ? 256 : 512) / tiles);
         const int max_splits = K / 64 > 0 ? K / 64 : 1;
         if (splits > max_splits)
             splits = max_splits;

@@ -297,6 +297,171 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_generic_kernel(int n, int c, 
         nn_idx[((size_t)cloud * n + i) * k + p] = top.i[p];
 }
 
+// ---- C = 64 on the matrix cores -----------------------------------------------------------
+// The inner products of a 32-candidate x 32-query tile are ONE chain of 32
+// v_mfma_f32_32x32x2_f32 (channels (2s, 2s+1) in step s): bitwise the channel-ordered fma
+// chain of the oracle, at the matrix-pipe rate and with almost no LDS traffic (the VALU
+// kernel above is LDS-bound: 16 broadcast ds_read_b128 per candidate per wave).  A
+// workgroup = 4 waves = the SAME 32 queries; wave w scans candidate quarter w.  In the
+// accumulator layout a lane holds query column (lane & 31) and 16 candidate rows, so lanes l
+// and l+32 keep separate sorted k-lists for the same query over disjoint candidates; the
+// 8 lists of a query (4 waves x 2 half-waves) are merged lexicographically by
+// (distance, index) at the end, which is exactly "ascending distance, ties -> lower index".
+// The selection (VALU) of one wave overlaps the MFMA chain of the others.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int KM_TILE = 32;
+constexpr int KM_LD = 65;   // LDS row stride of a staged candidate tile (odd: conflict-free column reads)
+
+template <int K>
+__global__ __launch_bounds__(KNN_THREADS) void knn64_mfma_kernel(int n, int ld, int k,
+                                                                 const float *__restrict__ x,
+                                                                 int *__restrict__ nn_idx)
+{
+    constexpr int TILE_FLOATS = KM_TILE * KM_LD + KM_TILE;            // rows + their |.|^2
+    constexpr int SCAN_BYTES = KNN_WAVES * TILE_FLOATS * 4;
+    constexpr int MERGE_BYTES = 2 * KNN_WAVES * K * 32 * 8;           // 8 lists x K x 32 queries x (d, idx)
+    __shared__ __attribute__((aligned(16))) char smem[SCAN_BYTES > MERGE_BYTES ? SCAN_BYTES : MERGE_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *tile = reinterpret_cast<float *>(smem) + wave * TILE_FLOATS;
+    float *csq = tile + KM_TILE * KM_LD;
+
+    int qtile, cloud;
+    xcd_cloud_tile(qtile, cloud);
+    const float *X = x + (size_t)cloud * n * ld;
+    const int col = lane & 31, half = lane >> 5;
+    const int qi = qtile * KM_TILE + col;               // this lane's query
+    const bool qvalid = qi < n;
+    const int qs = qvalid ? qi : 0;
+
+    // B operand: query channels of parity `half`, one register per MFMA step; and |x_q|^2
+    float bq[32];
+    float sqi = 0.0f;
+    {
+        const float *row = X + (size_t)qs * ld;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float4v v = *reinterpret_cast<const float4v *>(row + 4 * g);
+            const float a = v.x * v.x, b = v.y * v.y, c = v.z * v.z, d = v.w * v.w;
+            sqi = sqi + a;
+            sqi = sqi + b;
+            sqi = sqi + c;
+            sqi = sqi + d;
+            bq[2 * g] = half ? v.y : v.x;               // channels 4g + half, 4g + 2 + half
+            bq[2 * g + 1] = half ? v.w : v.z;
+        }
+    }
+    TopK<K> top;
+    top.init();
+
+    const int per = ((n + KNN_WAVES - 1) / KNN_WAVES + KM_TILE - 1) / KM_TILE * KM_TILE;
+    const int j_begin = min(wave * per, n), j_end = min(j_begin + per, n);
+    const int rounds = per / KM_TILE;                    // identical for all waves
+    const int srow = lane >> 1, shalf = lane & 1;        // two lanes stage one candidate row
+    for (int r = 0; r < rounds; ++r) {
+        const int c0 = j_begin + r * KM_TILE;
+        const int cnt = max(0, min(KM_TILE, j_end - c0));
+        __syncthreads();
+        {
+            const bool ok = srow < cnt;
+            const float *row = X + (size_t)(ok ? c0 + srow : 0) * ld + 32 * shalf;
+            float4v v[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                v[g] = ok ? *reinterpret_cast<const float4v *>(row + 4 * g) : float4v{0, 0, 0, 0};
+            float lo = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float a = v[g].x * v[g].x, b = v[g].y * v[g].y, c = v[g].z * v[g].z, d = v[g].w * v[g].w;
+                lo = lo + a;
+                lo = lo + b;
+                lo = lo + c;
+                lo = lo + d;
+            }
+            float part = __shfl(lo, lane & ~1, 64);      // the odd lane continues the even lane's sum
+            if (shalf) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const float a = v[g].x * v[g].x, b = v[g].y * v[g].y, c = v[g].z * v[g].z,
+                                d = v[g].w * v[g].w;
+                    part = part + a;
+                    part = part + b;
+                    part = part + c;
+                    part = part + d;
+                }
+                csq[srow] = part;
+            }
+            float *dst = tile + srow * KM_LD + 32 * shalf;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                dst[4 * g + 0] = v[g].x;
+                dst[4 * g + 1] = v[g].y;
+                dst[4 * g + 2] = v[g].z;
+                dst[4 * g + 3] = v[g].w;
+            }
+        }
+        __syncthreads();
+        if (cnt > 0) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                acc[e] = 0.0f;
+            const float *arow = tile + col * KM_LD + half;   // A operand: candidate row `col`, parity `half`
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                // step s covers channels 2s (lanes 0-31) and 2s+1 (lanes 32-63); bq[] is stored in
+                // the same order: bq[s] = channel 2s + half
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * s], bq[s], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = (e & 3) + 8 * (e >> 2) + 4 * half;    // candidate row of acc[e]
+                if (rr < cnt) {
+                    const float m2 = -2.0f * acc[e];
+                    const float t = sqi + m2;
+                    top.insert(t + csq[rr], c0 + rr);
+                }
+            }
+        }
+    }
+
+    // merge the 8 sorted lists of every query: [list][p][query]
+    __syncthreads();
+    float *md = reinterpret_cast<float *>(smem);
+    int *mi = reinterpret_cast<int *>(smem) + 2 * KNN_WAVES * K * 32;
+    const int list = wave * 2 + half;
+#pragma unroll
+    for (int p = 0; p < K; ++p) {
+        md[(list * K + p) * 32 + col] = top.d[p];
+        mi[(list * K + p) * 32 + col] = top.i[p];
+    }
+    __syncthreads();
+    if (wave == 0 && half == 0 && qvalid) {
+        int head[2 * KNN_WAVES];
+#pragma unroll
+        for (int l = 0; l < 2 * KNN_WAVES; ++l)
+            head[l] = 0;
+        int *dst = nn_idx + ((size_t)cloud * n + qi) * k;
+        for (int p = 0; p < k; ++p) {
+            float bd = __builtin_inff();
+            int bi = 0x7fffffff, bl = 0;
+#pragma unroll
+            for (int l = 0; l < 2 * KNN_WAVES; ++l) {
+                const int h = head[l];
+                const float d = h < K ? md[(l * K + h) * 32 + col] : __builtin_inff();
+                const int i = h < K ? mi[(l * K + h) * 32 + col] : 0x7fffffff;
+                const bool better = d < bd || (d == bd && i < bi);
+                bd = better ? d : bd;
+                bi = better ? i : bi;
+                bl = better ? l : bl;
+            }
+#pragma unroll
+            for (int l = 0; l < 2 * KNN_WAVES; ++l)
+                head[l] += (l == bl) ? 1 : 0;
+            dst[p] = bi == 0x7fffffff ? 0 : bi;
+        }
+    }
+}
+
 template <int K>
 static void launch_knn(int b, int n, int c, int ld, int k, const float *x, int *nn_idx,
                        hipStream_t s)
@@ -304,6 +469,9 @@ static void launch_knn(int b, int n, int c, int ld, int k, const float *x, int *
     if (c == 3)
         hipLaunchKernelGGL(knn3_kernel<K>, dim3(ceil_div(n, 64), b), dim3(KNN_THREADS), 0, s, n, ld,
                            k, x, nn_idx);
+    else if (c == 64 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && K <= 20)
+        hipLaunchKernelGGL(knn64_mfma_kernel<K>, dim3(ceil_div(n, KM_TILE), b), dim3(KNN_THREADS), 0, s, n,
+                           ld, k, x, nn_idx);
     else if (c == 64 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0)
         hipLaunchKernelGGL(knn64_kernel<K>, dim3(ceil_div(n, 64), b), dim3(KNN_THREADS), 0, s, n,
                            ld, k, x, nn_idx);
