@@ -21,6 +21,8 @@
 
 namespace cloudaae {
 
+constexpr int BN_U = 8;   // independent row loads in flight per thread in the streaming passes
+
 // ---- forward: column sums ------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_colsum_kernel(int M, int C, const float *__restrict__ y,
                                                        int ldy, double *__restrict__ partial, int parts)
@@ -30,10 +32,21 @@ __global__ __launch_bounds__(256) void bn_colsum_kernel(int M, int C, const floa
     const int c = blockIdx.x * 64 + lane;
     double s = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int r = blockIdx.y * 4 + rl; r < M; r += 4 * parts) {
-            const float v = y[(size_t)r * ldy + c];
-            s += (double)v;
-            s2 += (double)v * (double)v;
+        // BN_U loads in flight per thread: these passes are pure HBM streaming and a single
+        // dependent load per iteration leaves them latency-bound (1.6 TB/s measured)
+        const int step = 4 * parts;
+        for (int r = blockIdx.y * 4 + rl; r < M; r += step * BN_U) {
+            float v[BN_U];
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                const int rr = r + u * step;
+                v[u] = rr < M ? y[(size_t)rr * ldy + c] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                s += (double)v[u];
+                s2 += (double)v[u] * (double)v[u];
+            }
         }
     }
     red[0][rl][lane] = s;
@@ -65,20 +78,32 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(int M, int C, const float
     float cnt = 0.0f;
     if (c < C) {
         const float sc = scale_shift[c], sh = scale_shift[C + c];
-        for (int r = r0 + rl; r < r1; r += 4) {
-            float z = y[(size_t)r * ldy + c] * sc + sh;
-            if (relu)
-                z = fmaxf(z, 0.0f);
-            if (out != nullptr)
-                out[(size_t)r * ldo + c] = z;
-            if (POOL == 1)
-                acc = acc + z;
-            if (POOL == 2) {
-                if (z > acc) {
-                    acc = z;
-                    cnt = 1.0f;
-                } else if (z == acc) {
-                    cnt += 1.0f;
+        for (int rb = r0 + rl; rb < r1; rb += 4 * BN_U) {
+            float v[BN_U];
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                const int r = rb + 4 * u;
+                v[u] = r < r1 ? y[(size_t)r * ldy + c] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                const int r = rb + 4 * u;
+                if (r < r1) {
+                    float z = v[u] * sc + sh;
+                    if (relu)
+                        z = fmaxf(z, 0.0f);
+                    if (out != nullptr)
+                        out[(size_t)r * ldo + c] = z;
+                    if (POOL == 1)
+                        acc = acc + z;
+                    if (POOL == 2) {
+                        if (z > acc) {
+                            acc = z;
+                            cnt = 1.0f;
+                        } else if (z == acc) {
+                            cnt += 1.0f;
+                        }
+                    }
                 }
             }
         }
@@ -149,15 +174,27 @@ __global__ __launch_bounds__(256) void bn_bwd_colsum_kernel(BnBwdArgs a, double 
     if (c < a.C) {
         const float sc = a.scale_shift[c], sh = a.scale_shift[a.C + c];
         const float mean = a.save_mean[c], rstd = bn_rsqrt(a.save_var[c] + BN_EPS);
-        for (int r = blockIdx.y * 4 + rl; r < a.M; r += 4 * parts) {
-            const float v = a.y[(size_t)r * a.ldy + c];
-            float z = v * sc + sh;
-            if (a.relu)
-                z = fmaxf(z, 0.0f);
-            const float dz = bn_upstream(a, r, c, z);
-            const float xh = (v - mean) * rstd;
-            s += (double)dz;
-            s2 += (double)dz * (double)xh;
+        const int step = 4 * parts;
+        for (int rb = blockIdx.y * 4 + rl; rb < a.M; rb += step * BN_U) {
+            float v[BN_U];
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                const int r = rb + u * step;
+                v[u] = r < a.M ? a.y[(size_t)r * a.ldy + c] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) {
+                const int r = rb + u * step;
+                if (r < a.M) {
+                    float z = v[u] * sc + sh;
+                    if (a.relu)
+                        z = fmaxf(z, 0.0f);
+                    const float dz = bn_upstream(a, r, c, z);
+                    const float xh = (v[u] - mean) * rstd;
+                    s += (double)dz;
+                    s2 += (double)dz * (double)xh;
+                }
+            }
         }
     }
     red[0][rl][lane] = s;
@@ -181,19 +218,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
     const float m1 = m12[c], m2 = m12[a.C + c];
     const float gr = a.gamma[c] * rstd;
     const int r0 = blockIdx.y * slab, r1 = min(a.M, r0 + slab);
-    for (int r = r0 + rl; r < r1; r += 4) {
-        const float v = a.y[(size_t)r * a.ldy + c];
-        float z = v * sc + sh;
-        if (a.relu)
-            z = fmaxf(z, 0.0f);
-        const float dz = bn_upstream(a, r, c, z);
-        const float xh = (v - mean) * rstd;
-        dy[(size_t)r * lddy + c] = gr * ((dz - m1) - xh * m2);
+    for (int rb = r0 + rl; rb < r1; rb += 4 * BN_U) {
+        float v[BN_U];
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            const int r = rb + 4 * u;
+            v[u] = r < r1 ? a.y[(size_t)r * a.ldy + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            const int r = rb + 4 * u;
+            if (r < r1) {
+                float z = v[u] * sc + sh;
+                if (a.relu)
+                    z = fmaxf(z, 0.0f);
+                const float dz = bn_upstream(a, r, c, z);
+                const float xh = (v[u] - mean) * rstd;
+                dy[(size_t)r * lddy + c] = gr * ((dz - m1) - xh * m2);
+            }
+        }
     }
 }
 
 // plain column sums (bias gradients): out[c] (+)= sum_r x[r][c]; grid = ceil(C/64) x 256
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(int C, const double *__restrict__ partial,
+__global__ __launch_bounds__(BN_FIN_THREADS) void colsum_finalize_kernel(int C, const double *__restrict__ partial,
                                                              int parts, float *__restrict__ out, int accumulate)
 {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
@@ -382,7 +430,7 @@ CLOUDAAE_API int cloudaae_bn_forward(int M, int C, const float *y, int ldy, cons
     const int cb = ceil_div(C, 64);
     if (training)
         hipLaunchKernelGGL(bn_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, M, C, y, ldy, partial, parts);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, C, partial, parts,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts,
                        (double)M, training, decay, ema_mean, ema_var, gamma, beta, save_mean, save_var,
                        scale_shift);
     if (pool_mode == 0) {
@@ -439,7 +487,7 @@ CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, con
     const int parts = bn_parts(M);
     const int cb = ceil_div(C, 64);
     hipLaunchKernelGGL(bn_bwd_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, a, partial, parts);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, C, partial, parts,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts,
                        (double)M, training, dgamma, dbeta, accumulate_param_grads, m12);
     const int slab = 64;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cb, ceil_div(M, slab)), dim3(256), 0, s, a, m12, dy, lddy,
@@ -458,7 +506,7 @@ CLOUDAAE_API int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, floa
     const int parts = bn_parts(M);
     hipLaunchKernelGGL(bn_colsum_kernel, dim3(ceil_div(C, 64), parts), dim3(256), 0, s, M, C, x, ldx, partial,
                        parts);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, C, partial, parts, out,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 64)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts, out,
                        accumulate);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;

@@ -14,39 +14,49 @@ __host__ __device__ inline size_t bn_ws_doubles(int C) { return (size_t)BN_MAX_P
 
 __device__ __forceinline__ float bn_rsqrt(float v) { return 1.0f / sqrtf(v); }
 
-// Sum the [parts][2][C] partial sums of one 64-channel group: 256 threads = 64 channels x
-// 4 part-lanes, each lane 2x2 independent accumulators (the partial loads are what costs;
-// a single thread walking `parts` dependent loads took ~250 us at 1024 parts).
+// Sum the [parts][2][C] partial sums of one 64-channel group.  The finalise kernels run
+// BN_FIN_THREADS = 1024 threads = 64 channels x 16 part-lanes, each lane with independent
+// accumulators: the partial loads are what costs (a single thread walking 1024 dependent
+// loads took ~250 us; 4 part-lanes still ~20 us at 256 parts).  Fixed-shape tree, so the
+// result does not depend on scheduling.
+constexpr int BN_FIN_LANES = 16;
+constexpr int BN_FIN_THREADS = 64 * BN_FIN_LANES;
 __device__ __forceinline__ void bn_reduce_partials(const double *__restrict__ partial, int parts, int C, int c,
                                                    int pl, double &s, double &s2)
 {
-    __shared__ double red[2][4][64];
+    __shared__ double red[2][BN_FIN_LANES][64];
     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
     if (c < C) {
         int p = pl;
-        for (; p + 4 < parts; p += 8) {
+        for (; p + BN_FIN_LANES < parts; p += 2 * BN_FIN_LANES) {
             a0 += partial[((size_t)p * 2 + 0) * C + c];
             b0 += partial[((size_t)p * 2 + 1) * C + c];
-            a1 += partial[((size_t)(p + 4) * 2 + 0) * C + c];
-            b1 += partial[((size_t)(p + 4) * 2 + 1) * C + c];
+            a1 += partial[((size_t)(p + BN_FIN_LANES) * 2 + 0) * C + c];
+            b1 += partial[((size_t)(p + BN_FIN_LANES) * 2 + 1) * C + c];
         }
-        for (; p < parts; p += 4) {
+        for (; p < parts; p += BN_FIN_LANES) {
             a0 += partial[((size_t)p * 2 + 0) * C + c];
             b0 += partial[((size_t)p * 2 + 1) * C + c];
         }
     }
-    red[0][pl][threadIdx.x & 63] = a0 + a1;
-    red[1][pl][threadIdx.x & 63] = b0 + b1;
-    __syncthreads();
     const int l = threadIdx.x & 63;
-    s = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
-    s2 = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    red[0][pl][l] = a0 + a1;
+    red[1][pl][l] = b0 + b1;
+    __syncthreads();
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < BN_FIN_LANES; q += 4) {
+        t0 += (red[0][q][l] + red[0][q + 1][l]) + (red[0][q + 2][l] + red[0][q + 3][l]);
+        t1 += (red[1][q][l] + red[1][q + 1][l]) + (red[1][q + 2][l] + red[1][q + 3][l]);
+    }
+    s = t0;
+    s2 = t1;
 }
 
-// per-channel finalise (grid = ceil(C/64) blocks of 256 threads).  training: moments from
+// per-channel finalise (grid = ceil(C/64) blocks of BN_FIN_THREADS threads).  training: moments from
 // the partial sums + EMA update; inference: moments = EMA shadows.  Also derives inv/shift
 // for the apply pass.
-static __global__ __launch_bounds__(256) void bn_finalize_kernel(
+static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_kernel(
     int C, const double *__restrict__ partial, int parts, double count, int training,
     const float *__restrict__ decay, float *__restrict__ ema_mean, float *__restrict__ ema_var,
     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ save_mean,
@@ -95,8 +105,8 @@ static __global__ void bn_scale_shift_kernel(int C, const float *__restrict__ ga
 }
 
 // dbeta = sum dz, dgamma = sum dz*xhat; m1/m2 = their means (0 in inference mode,
-// where the statistics do not depend on the batch).  grid = ceil(C/64) x 256 threads.
-static __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+// where the statistics do not depend on the batch).  grid = ceil(C/64) x BN_FIN_THREADS threads.
+static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_bwd_finalize_kernel(
     int C, const double *__restrict__ partial, int parts, double count, int training,
     float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate, float *__restrict__ m12)
 {

@@ -30,7 +30,8 @@ constexpr int EC_MAX_PARTS = 256;   // partial-sum rows of the statistics passes
 constexpr int EC_WAVES = 4;         // apply passes: 4 waves per workgroup, grid sized by the work
 constexpr int EC_STAT_WAVES = 16;   // statistics passes: 16 waves per workgroup (<= 256 workgroups)
 
-__host__ __device__ inline size_t ec_ws_doubles(int C) { return (size_t)EC_MAX_PARTS * 2 * C + 2 * (size_t)C; }
+// [parts][2][C] partial sums + a second [parts][2][C] block (third sum) + 4*C floats of scratch
+__host__ __device__ inline size_t ec_ws_doubles(int C) { return (size_t)EC_MAX_PARTS * 4 * C + 2 * (size_t)C; }
 
 struct EcArgs {
     int P;        // total points B*N
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_bwd_stats_kernel(EcArgs
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float sc[CPL], sh[CPL], mean[CPL], rstd[CPL];
-    double s[CPL], s2[CPL];
+    double s[CPL], s2[CPL], s3[CPL], zero[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e) {
         const int c = lane + 64 * e;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_bwd_stats_kernel(EcArgs
         sh[e] = a.scale_shift[a.cout + c];
         mean[e] = a.save_mean[c];
         rstd[e] = bn_rsqrt(a.save_var[c] + BN_EPS);
-        s[e] = s2[e] = 0.0;
+        s[e] = s2[e] = s3[e] = zero[e] = 0.0;
     }
     ec_for_each_point<EC_STAT_WAVES>(a, wave, [&](int pt) {
         EcPoint<CPL, KCAP> p;
@@ -260,10 +261,45 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_bwd_stats_kernel(EcArgs
                     const float xh = (p.y[j][e] - mean[e]) * rstd[e];
                     s[e] += (double)dz[j][e];
                     s2[e] += (double)dz[j][e] * (double)xh;
+                    s3[e] += (double)xh;
                 }
             }
     });
     ec_block_reduce_store<CPL>(s, s2, partial, a.cout, lane, wave);
+    __syncthreads();
+    // third sum (sum of x_hat, ~0): needed for the conv-bias gradient, see ec_bwd_finalize_kernel
+    ec_block_reduce_store<CPL>(s3, zero, partial + (size_t)EC_MAX_PARTS * 2 * a.cout, a.cout, lane, wave);
+}
+
+// dgamma = sum dz*xhat, dbeta = sum dz, m1/m2 = their means, and the conv-bias gradient
+//   dbias = sum_ij dy_ij = gamma*rstd*((sum dz - cnt*m1) - m2 * sum xhat)
+// which is analytically zero (a bias in front of a batch norm) and numerically round-off,
+// exactly like the reference's autodiff value; computing it from the column sums avoids
+// funnelling every workgroup through atomics on the same 64-128 addresses (that was 100 us).
+static __global__ __launch_bounds__(BN_FIN_THREADS) void ec_bwd_finalize_kernel(
+    int C, const double *__restrict__ partial, const double *__restrict__ partial3, int parts, double count,
+    int training, const float *__restrict__ gamma, const float *__restrict__ save_var,
+    float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dbias, float *__restrict__ m12)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    double s, s2, s3, unused;
+    bn_reduce_partials(partial, parts, C, c, pl, s, s2);
+    __syncthreads();
+    bn_reduce_partials(partial3, parts, C, c, pl, s3, unused);
+    if (c >= C || pl != 0)
+        return;
+    if (dbeta != nullptr)
+        dbeta[c] = (float)s;
+    if (dgamma != nullptr)
+        dgamma[c] = (float)s2;
+    const float m1 = training ? (float)(s / count) : 0.0f;
+    const float m2 = training ? (float)(s2 / count) : 0.0f;
+    m12[c] = m1;
+    m12[C + c] = m2;
+    if (dbias != nullptr) {
+        const double gr = (double)gamma[c] * (double)bn_rsqrt(save_var[c] + BN_EPS);
+        dbias[c] = (float)(gr * ((s - count * (double)m1) - (double)m2 * s3));
+    }
 }
 
 // Reverse neighbour lists of one cloud (one workgroup per cloud): for every point m the
@@ -330,11 +366,10 @@ template <int CPL, int KCAP, int POOL>
 __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
     EcArgs a, const float *__restrict__ m12, const int *__restrict__ rev_off, const int *__restrict__ rev_src,
     const float *__restrict__ fwd_out, int ldo, const float *__restrict__ ties, float *__restrict__ dpq,
-    float *__restrict__ dbias)
+    float *__restrict__ /*unused*/)
 {
-    __shared__ float redb[EC_WAVES][64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float sc[CPL], sh[CPL], mean[CPL], rstd[CPL], gr[CPL], m1[CPL], m2[CPL], bsum[CPL], bias[CPL];
+    float sc[CPL], sh[CPL], mean[CPL], rstd[CPL], gr[CPL], m1[CPL], m2[CPL], bias[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e) {
         const int c = lane + 64 * e;
@@ -346,12 +381,18 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
         m1[e] = m12[c];
         m2[e] = m12[a.cout + c];
         bias[e] = a.bias[c];
-        bsum[e] = 0.0f;
     }
     const float invk = 1.0f;  // (mean pool divides by k exactly as the forward direction does, below)
     (void)invk;
     ec_for_each_point<EC_WAVES>(a, wave, [&](int pt) {
         const int cloud = pt / a.N, m = pt - cloud * a.N;
+        // the reverse list's bounds and first 64 sources are fetched up front so that they are
+        // in flight together with the forward-direction gathers (dependent stages cost ~20 us
+        // each across the grid)
+        const int *off = rev_off + (size_t)cloud * (a.N + 1);
+        const int *src = rev_src + (size_t)cloud * a.N * a.k;
+        const int beg = off[m], end = off[m + 1];
+        int mine = (beg + lane < end) ? src[beg + lane] : 0;
         float S[CPL], T[CPL], Qm[CPL];
         {
             EcPoint<CPL, KCAP> p;
@@ -377,16 +418,15 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
             T[e] = 0.0f;
             Qm[e] = a.pq[(size_t)pt * a.ldpq + a.cout + lane + 64 * e];
         }
-        const int *off = rev_off + (size_t)cloud * (a.N + 1);
-        const int *src = rev_src + (size_t)cloud * a.N * a.k;
-        const int beg = off[m], end = off[m + 1];
+        constexpr int RU = CPL == 1 ? 8 : 4;   // sources gathered per batch
         for (int s0 = beg; s0 < end; s0 += 64) {
             const int cntc = min(64, end - s0);
-            const int mine = lane < cntc ? src[s0 + lane] : 0;
-            for (int q0 = 0; q0 < cntc; q0 += 4) {
-                float pi[4][CPL], qi[4][CPL], gi[4][CPL], oi[4][CPL], ti[4][CPL];
+            if (s0 != beg)
+                mine = lane < cntc ? src[s0 + lane] : 0;
+            for (int q0 = 0; q0 < cntc; q0 += RU) {
+                float pi[RU][CPL], qi[RU][CPL], gi[RU][CPL], oi[RU][CPL], ti[RU][CPL];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < RU; ++u) {
                     const bool on = q0 + u < cntc;
                     const int i = cloud * a.N + __shfl(mine, on ? q0 + u : q0, 64);
                     const float *row = a.pq + (size_t)i * a.ldpq + lane;
@@ -402,7 +442,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < RU; ++u) {
                     if (q0 + u < cntc) {
 #pragma unroll
                         for (int e = 0; e < CPL; ++e) {
@@ -425,23 +465,8 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
         for (int e = 0; e < CPL; ++e) {
             mineo[64 * e] = S[e];
             mineo[a.cout + 64 * e] = T[e] - S[e];
-            bsum[e] += S[e];
         }
     });
-#pragma unroll
-    for (int e = 0; e < CPL; ++e)
-        redb[wave][lane + 64 * e] = bsum[e];
-    __syncthreads();
-    if (wave == 0 && dbias != nullptr) {
-#pragma unroll
-        for (int e = 0; e < CPL; ++e) {
-            const int c = lane + 64 * e;
-            float t = redb[0][c];
-            for (int w = 1; w < EC_WAVES; ++w)
-                t += redb[w][c];
-            atomicAdd(dbias + c, t);
-        }
-    }
 }
 
 static int ec_stat_grid(int P)
@@ -515,7 +540,7 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
     if (rc)
         return rc;
     double *partial = (double *)workspace;
-    float *scale_shift = (float *)(partial + (size_t)EC_MAX_PARTS * 2 * cout);
+    float *scale_shift = (float *)(partial + (size_t)EC_MAX_PARTS * 4 * cout);
     EcArgs a = {};
     a.P = P; a.N = n; a.k = k; a.cout = cout; a.ldpq = 2 * cout;
     a.pq = pq; a.bias = biases; a.nn_idx = nn_idx; a.scale_shift = scale_shift;
@@ -526,7 +551,7 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
         EC_DISPATCH(EC_STATS);
 #undef EC_STATS
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(cout, 64)), dim3(256), 0, s, cout, partial, grid,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(cout, 64)), dim3(BN_FIN_THREADS), 0, s, cout, partial, grid,
                        (double)P * (double)k, training, decay, ema_mean, ema_var, gamma, beta, save_mean,
                        save_var, scale_shift);
     if (pool_mode == 1) {
@@ -561,7 +586,7 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
     hipStream_t s = (hipStream_t)stream;
     const int P = b * n;
     double *partial = (double *)workspace;
-    float *scratch = (float *)(partial + (size_t)EC_MAX_PARTS * 2 * cout);
+    float *scratch = (float *)(partial + (size_t)EC_MAX_PARTS * 4 * cout);
     float *scale_shift = scratch, *m12 = scratch + 2 * (size_t)cout;
     hipLaunchKernelGGL(bn_scale_shift_kernel, dim3(ceil_div(cout, 256)), dim3(256), 0, s, cout, gamma, beta,
                        save_mean, save_var, scale_shift);
@@ -581,8 +606,9 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
         EC_DISPATCH(EC_BS);
 #undef EC_BS
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(cout, 64)), dim3(256), 0, s, cout, partial, grid,
-                       (double)P * (double)k, training, dgamma, dbeta, 0, m12);
+    hipLaunchKernelGGL(ec_bwd_finalize_kernel, dim3(ceil_div(cout, 64)), dim3(BN_FIN_THREADS), 0, s, cout, partial,
+                       partial + (size_t)EC_MAX_PARTS * 2 * cout, grid, (double)P * (double)k, training, gamma,
+                       save_var, dgamma, dbeta, dbiases, m12);
     int *rev_off = rev_scratch, *rev_src = rev_scratch + (size_t)b * (n + 1);
     {
         const size_t lds = (size_t)n * sizeof(int);
@@ -591,8 +617,6 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
         hipLaunchKernelGGL(ec_revlist_kernel, dim3(b), dim3(512), lds, s, n, k, nn_idx, rev_off, rev_src);
     }
-    if (dbiases)
-        CLOUDAAE_CHECK_HIP(hipMemsetAsync(dbiases, 0, sizeof(float) * (size_t)cout, s), name);
     if (pool_mode == 1) {
 #define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src, out, ldo, tie_count, dpq, dbiases)
         EC_DISPATCH(EC_BA);

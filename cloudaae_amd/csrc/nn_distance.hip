@@ -23,6 +23,7 @@
 // Build flags matter: -ffp-contract=off keeps mul/add un-fused (bit-parity with
 // the CPU reference).
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/cloudaae_hip.h"
 
 namespace cloudaae {
@@ -198,7 +199,12 @@ CLOUDAAE_API int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, co
     // queries per lane: enough workgroups to fill 256 CUs first, then amortise
     // LDS reads over more queries
     const long long total = (long long)b * ((long long)n + m);
-    const int Q = total >= 4LL * 256 * 1024 ? 4 : (total >= 256LL * 1024 ? 2 : 1);
+    int Q = total >= 4LL * 256 * 1024 ? 4 : (total >= 256LL * 1024 ? 2 : 1);
+    if (const char *env = getenv("CLOUDAAE_NN_Q")) {   // tuning knob (queries per lane)
+        const int q = atoi(env);
+        if (q == 1 || q == 2 || q == 4)
+            Q = q;
+    }
     const int t1 = ceil_div(n, NN_THREADS * Q), t2 = ceil_div(m, NN_THREADS * Q);
     dim3 grid(t1 + t2, b), block(NN_THREADS);
     if (Q == 4)
