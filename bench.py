@@ -102,7 +102,8 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run (WORLD_SIZE is unset)" % args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
-    if world > 1:
+    force = os.environ.get("CLOUDAAE_FORCE_COLLECTIVES") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or force:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from cloudaae_amd import train_cloudAAE_ycbv as T
@@ -179,7 +180,7 @@ def main():
         if world == 1 and args.cpu_batch > 0:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_batch)
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -10,7 +10,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcloudaae_hip.so")
+LIB_PATH = os.environ.get("CLOUDAAE_HIP_LIB", os.path.join(_HERE, "libcloudaae_hip.so"))   # env: kernel A/B builds
 CSRC = os.path.join(_HERE, "csrc")
 
 _lib = None

@@ -135,7 +135,7 @@ class TrainGraph(object):
                 early = (o, o + v.data.numel())
         self.exchange = GradExchange(self.store.flat_grads, early, self.pg, world=self.world)
         self.exchange.broadcast_params(self.store.flat_params)     # identical initial weights on every rank
-        if early is not None and self.world > 1:
+        if early is not None and self.exchange.active:
             for name in ('dgcnn_output/weights', 'pn_output/weights'):
                 if name in self.store.vars:
                     self.store.vars[name].on_ready = self.exchange.early_ready

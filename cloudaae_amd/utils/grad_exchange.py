@@ -10,6 +10,8 @@ launches its all-reduce asynchronously so it overlaps the rest of backward.  `fi
 launches the remaining pieces and waits for everything.  Averaging (1/world) is folded
 into the optimiser kernel (`scale`), not applied here.
 """
+import os
+
 import torch.distributed as dist
 
 
@@ -28,6 +30,9 @@ class GradExchange(object):
         if world is None:
             world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.world = world
+        # CLOUDAAE_FORCE_COLLECTIVES=1: issue the collectives even with one rank (exercises the
+        # RCCL code path on a single-GPU box)
+        self.active = world > 1 or (dist.is_initialized() and os.environ.get("CLOUDAAE_FORCE_COLLECTIVES") == "1")
         n = flat_grads.numel()
         if early is not None:
             lo, hi = early
@@ -43,7 +48,7 @@ class GradExchange(object):
 
     def early_ready(self):
         """Call right after the kernel writing the early range was enqueued."""
-        if self.world == 1 or self.early is None or self._early_sent:
+        if not self.active or self.early is None or self._early_sent:
             return
         lo, hi = self.early
         self._pending.append(dist.all_reduce(self.g[lo:hi], group=self.group, async_op=True))
@@ -51,7 +56,7 @@ class GradExchange(object):
 
     def finish(self):
         """Reduce whatever has not been sent yet and wait for all pieces."""
-        if self.world == 1:
+        if not self.active:
             return
         n = self.g.numel()
         if self.early is None:
@@ -70,5 +75,5 @@ class GradExchange(object):
         self._early_sent = False
 
     def broadcast_params(self, flat_params, src=0):
-        if self.world > 1:
+        if self.active:
             dist.broadcast(flat_params, src=src, group=self.group)

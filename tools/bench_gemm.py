@@ -1,0 +1,24 @@
+"""Times the GEMM shapes of the B=32, N=1024 train step (dev tool)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cloudaae_amd import _lib
+L = _lib.lib()
+def run(ta, tb, M, N, K, iters=20):
+    A = torch.randn((K, M) if ta else (M, K), device="cuda"); B = torch.randn((N, K) if tb else (K, N), device="cuda")
+    C = torch.empty((M, N), device="cuda")
+    def go():
+        _lib.check(L.cloudaae_gemm_f32(ta, tb, M, N, K, A.data_ptr(), A.shape[1], B.data_ptr(), B.shape[1], C.data_ptr(), N, None, 0, _lib.stream()), "g")
+    for _ in range(3): go()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): go()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    return us, 2.0 * M * N * K / us / 1e6
+if __name__ == "__main__":
+  for name, args in [("agg fwd", (0, 0, 32768, 1024, 320)), ("agg dX", (0, 1, 32768, 320, 1024)), ("agg dW", (1, 0, 320, 1024, 32768)),
+                     ("edge fwd", (0, 0, 32768, 64, 64)), ("edge dX", (0, 1, 32768, 64, 64)), ("edge dW", (1, 0, 64, 64, 32768)),
+                     ("fc fwd", (0, 0, 32, 1024, 1024)), ("out fwd", (0, 0, 32, 12288, 1024)), ("out dW", (1, 0, 1024, 12288, 32)),
+                     ("big sq", (0, 0, 8192, 8192, 8192))]:
+      us, tf = run(*args)
+      print("%-9s %-28s %9.1f us %7.1f TF" % (name, args, us, tf))
