@@ -16,6 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 _lib = None
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
+_U = ctypes.c_ulonglong
 # argument types of every entry point of include/cloudaae_hip.h (stream last)
 _SIGNATURES = {
     "cloudaae_nn_distance": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P],
@@ -55,6 +56,10 @@ _SIGNATURES = {
     "cloudaae_sgd": [_L, _P, _P, _F, _F, _P],
     "cloudaae_bn_decay_schedule": [_P, _F, _F, _F, _F, _F, _P, _P],
     "cloudaae_increment": [_P, _F, _P],
+    "cloudaae_transform_object_model": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "cloudaae_random_spherical_occluder": [_I, _I, _P, _F, _F, _F, _F, _U, _P, _P],
+    "cloudaae_spherical_flip": [_I, _I, _P, _I, _P, _P, _F, _P, _P, _P],
+    "cloudaae_hidden_point_removal": [_I, _I, _P, _P, _U, _P, _P, _P, _P, _P],
 }
 _LONGLONG_RESULTS = ["cloudaae_bn_workspace_bytes", "cloudaae_edgeconv_workspace_bytes",
                      "cloudaae_mean_workspace_bytes"]
@@ -90,6 +95,8 @@ def lib():
             f.restype = ctypes.c_int
         for fn in _LONGLONG_RESULTS:
             getattr(_lib, fn).restype = ctypes.c_longlong
+        _lib.cloudaae_hpr_workspace_bytes.restype = ctypes.c_longlong
+        _lib.cloudaae_hpr_workspace_bytes.argtypes = [_I, _I]
         _lib.cloudaae_bn_workspace_bytes.argtypes = [_I]
         _lib.cloudaae_edgeconv_workspace_bytes.argtypes = [_I]
     return _lib

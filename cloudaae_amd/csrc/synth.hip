@@ -1,0 +1,411 @@
+// synth.hip -- on-line data synthesis on the GPU (gfx950): rigid transform of the object
+// model, random spherical occluders, spherical flip and hidden-point removal (HPR).
+//
+// Replaces the tf.data pipeline of the reference (train_cloudAAE_ycbv.py:79-117):
+//   get_rotation_matrix / transform_object_model        train_cloudAAE_ycbv.py:79-93
+//   get_random_spherical_occluder                       utils/generate_occluder.py:38-81
+//   sphericalFlip[_org]                                 utils/hidden_point_removal.py:6-24, 51-68
+//   hidden_point_removal[_org] = convexHull             utils/hidden_point_removal.py:27-48
+// The reference runs HPR as scipy/qhull under the Python GIL, twice per sample (~5 ms per
+// 2449-point hull on a CPU core), which caps it at ~100 samples/s/core -- two orders of
+// magnitude below what the training step consumes here.
+//
+// HPR needs only the VERTEX SET of conv(flipped points + origin), not its facets.  A
+// point p is a vertex iff some direction d strictly separates it:  d.(q - p) < 0 for all
+// other q.  Normalising d by its largest component gives six charts d = (x, y, +-1) etc.
+// with (x, y) in [-1,1]^2, so "is p a vertex" is at most six 2-variable LP feasibility
+// problems with n constraints.  Each lane solves its own with Seidel's incremental
+// algorithm (expected O(n): a violated constraint triggers a 1-D re-solve over the
+// constraints seen so far, which happens ~2 ln n times), in fp64 on the fp32 inputs, with
+// the cloud in LDS.  The answer is algorithm-independent (it is the hull's vertex set), so
+// it equals qhull's except for points within ~1e-12 relative of a facet (tests compare with
+// scipy.spatial.ConvexHull on real object models: identical sets).
+#include "common.h"
+#include "../../include/cloudaae_hip.h"
+
+namespace cloudaae {
+
+// ---- Philox4x32-10 counter RNG + Box-Muller (occluder sampling, padding choice) -----------
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1)
+{
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+    c[0] = n0;
+    c[1] = (unsigned)p1;
+    c[2] = n2;
+    c[3] = (unsigned)p0;
+}
+__device__ __forceinline__ void philox4x32(unsigned long long seed, unsigned long long ctr, unsigned stream,
+                                           unsigned (&out)[4])
+{
+    unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), stream, 0x9E3779B9u};
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0];
+    out[1] = c[1];
+    out[2] = c[2];
+    out[3] = c[3];
+}
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ void normal2(unsigned a, unsigned b, float &n0, float &n1)
+{
+    const float r = sqrtf(-2.0f * logf(u01(a))), t = 6.283185307179586f * u01(b);
+    n0 = r * cosf(t);
+    n1 = r * sinf(t);
+}
+
+// ---- transform_object_model: out[b,j,:] = model[class[b],j,0:3] R_b^T + t_b -----------------
+// R = float32(exponential_map(float64 axis-angle)) (train...:80-83); the 3-term dot product is
+// evaluated left to right, un-fused (Eigen's order is not pinned by the reference).
+__global__ void transform_model_kernel(int b, int npts, int nmodels, const float *__restrict__ models,
+                                       const long long *__restrict__ class_id, const double *__restrict__ rot,
+                                       const float *__restrict__ trans, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b * npts)
+        return;
+    const int cloud = i / npts, j = i - cloud * npts;
+    long long cls = class_id[cloud];
+    cls = cls < 0 ? 0 : (cls >= nmodels ? nmodels - 1 : cls);
+    const float *p = models + ((size_t)cls * npts + j) * 6;
+    const double *R = rot + (size_t)cloud * 9;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float r0 = (float)R[3 * r], r1 = (float)R[3 * r + 1], r2 = (float)R[3 * r + 2];
+        const float a = p[0] * r0, bb = p[1] * r1, c = p[2] * r2;
+        out[(size_t)i * 3 + r] = ((a + bb) + c) + trans[cloud * 3 + r];
+    }
+}
+
+// ---- get_random_spherical_occluder (generate_occluder.py:38-81) ---------------------------
+// two Gaussian blobs of `per` points, sigma 0.01, centres ~ N(0, Wnear/10), N(0, Hnear/10),
+// N((near+z)/2, (z-near)/6); rows interleave the two blobs exactly as the reference's
+// concat([x1,y1,z1,x2,y2,z2], axis=1).reshape(-1,3) does.
+__global__ void occluder_kernel(int b, int per, const float *__restrict__ trans, float wnear, float hnear,
+                                float near_d, float sigma, unsigned long long seed, float *__restrict__ occ)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (cloud, pair of points)
+    if (i >= b * per)
+        return;
+    const int cloud = i / per, j = i - cloud * per;
+    const float z = trans[cloud * 3 + 2];
+    unsigned r[4];
+    float c[2][3], n0, n1;
+    philox4x32(seed, (unsigned long long)cloud, 1u, r);         // blob centres: shared by the cloud
+    normal2(r[0], r[1], n0, n1);
+    c[0][0] = n0 * (wnear / 10.0f);
+    c[1][0] = n1 * (wnear / 10.0f);
+    normal2(r[2], r[3], n0, n1);
+    c[0][1] = n0 * (hnear / 10.0f);
+    c[1][1] = n1 * (hnear / 10.0f);
+    philox4x32(seed, (unsigned long long)cloud, 2u, r);
+    normal2(r[0], r[1], n0, n1);
+    c[0][2] = (near_d + z) / 2.0f + n0 * ((z - near_d) / 6.0f);
+    c[1][2] = (near_d + z) / 2.0f + n1 * ((z - near_d) / 6.0f);
+    float g[6];
+    philox4x32(seed, ((unsigned long long)cloud << 32) | (unsigned)j, 3u, r);
+    normal2(r[0], r[1], g[0], g[1]);
+    normal2(r[2], r[3], g[2], g[3]);
+    philox4x32(seed, ((unsigned long long)cloud << 32) | (unsigned)j, 4u, r);
+    normal2(r[0], r[1], g[4], g[5]);
+    float *o = occ + ((size_t)cloud * 2 * per + 2 * j) * 3;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        o[a] = c[0][a] + sigma * g[a];
+        o[3 + a] = c[1][a] + sigma * g[3 + a];
+    }
+}
+
+// ---- sphericalFlip (hidden_point_removal.py:6-24): one workgroup per cloud -------------------
+// points = concat(a, b) - center; f = 2 (R - |p|) p / |p| + p with R = max|p| * 10^param;
+// a zero row (the viewpoint) is appended to both outputs.
+__global__ __launch_bounds__(256) void spherical_flip_kernel(int na, int nb, const float *__restrict__ a,
+                                                            const float *__restrict__ bpts,
+                                                            const float *__restrict__ center, float pow10param,
+                                                            float *__restrict__ flipped, float *__restrict__ org)
+{
+    __shared__ float red[4];
+    const int cloud = blockIdx.x, t = threadIdx.x, n = na + nb;
+    const float cx = center ? center[cloud * 3] : 0.f, cy = center ? center[cloud * 3 + 1] : 0.f,
+                cz = center ? center[cloud * 3 + 2] : 0.f;
+    float mx = 0.0f;
+    for (int j = t; j < n; j += 256) {
+        const float *p = j < na ? a + ((size_t)cloud * na + j) * 3 : bpts + ((size_t)cloud * nb + (j - na)) * 3;
+        const float x = p[0] - cx, y = p[1] - cy, z = p[2] - cz;
+        mx = fmaxf(mx, sqrtf((x * x + y * y) + z * z));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((t & 63) == 0)
+        red[t >> 6] = mx;
+    __syncthreads();
+    const float R = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * pow10param;
+    float *F = flipped + (size_t)cloud * (n + 1) * 3, *O = org + (size_t)cloud * (n + 1) * 3;
+    for (int j = t; j <= n; j += 256) {
+        if (j == n) {
+            F[3 * j] = F[3 * j + 1] = F[3 * j + 2] = 0.0f;
+            O[3 * j] = O[3 * j + 1] = O[3 * j + 2] = 0.0f;
+            continue;
+        }
+        const float *p = j < na ? a + ((size_t)cloud * na + j) * 3 : bpts + ((size_t)cloud * nb + (j - na)) * 3;
+        const float x = p[0] - cx, y = p[1] - cy, z = p[2] - cz;
+        const float nrm = sqrtf((x * x + y * y) + z * z);
+        const float s = 2.0f * (R - nrm);
+        F[3 * j] = (s * x) / nrm + x;
+        F[3 * j + 1] = (s * y) / nrm + y;
+        F[3 * j + 2] = (s * z) / nrm + z;
+        O[3 * j] = x;
+        O[3 * j + 1] = y;
+        O[3 * j + 2] = z;
+    }
+}
+
+// ---- hull vertex test ---------------------------------------------------------------------
+constexpr double HPR_EPS = 1e-12;   // relative separation margin (qhull-like coplanarity tolerance)
+
+struct Cons {
+    double a, b, c;
+};
+
+// constraint of point q against p in chart (axis, sign): d = (x, y) on the other two axes, d_axis = sign
+//   d.g <= -eps |g|,  g = q - p
+__device__ __forceinline__ Cons hpr_constraint(const float *__restrict__ pts, int q, double px, double py,
+                                               double pz, int axis, double sgn)
+{
+    const double gx = (double)pts[3 * q] - px, gy = (double)pts[3 * q + 1] - py, gz = (double)pts[3 * q + 2] - pz;
+    const double nrm = sqrt((gx * gx + gy * gy) + gz * gz);
+    Cons k;
+    if (axis == 2) {
+        k.a = gx; k.b = gy; k.c = -sgn * gz;
+    } else if (axis == 0) {
+        k.a = gy; k.b = gz; k.c = -sgn * gx;
+    } else {
+        k.a = gx; k.b = gz; k.c = -sgn * gy;
+    }
+    k.c -= HPR_EPS * nrm;
+    return k;
+}
+
+// Seidel's incremental 2-variable LP on [-1,1]^2, objective x + y/2; returns feasibility.
+// Constraints are visited in the order q = (start + i*stride) mod n1 (a fixed pseudo-random
+// permutation: stride is coprime with n1); q == self is skipped.
+__device__ bool hpr_lp2d(const float *__restrict__ pts, int n1, int self, int stride, int start, int axis,
+                         double sgn)
+{
+    const double px = pts[3 * self], py = pts[3 * self + 1], pz = pts[3 * self + 2];
+    double vx = 1.0, vy = 1.0;
+    int q = start;
+    for (int i = 0; i < n1; ++i, q = (q + stride >= n1 ? q + stride - n1 : q + stride)) {
+        if (q == self)
+            continue;
+        const Cons k = hpr_constraint(pts, q, px, py, pz, axis, sgn);
+        if (k.a * vx + k.b * vy <= k.c)
+            continue;
+        const double nn = k.a * k.a + k.b * k.b;
+        if (nn == 0.0)
+            return false;
+        const double p0x = k.a * k.c / nn, p0y = k.b * k.c / nn, ux = -k.b, uy = k.a;
+        double lo = -1e300, hi = 1e300;
+        // the box
+        {
+            const double bx[4] = {1.0, -1.0, 0.0, 0.0}, by[4] = {0.0, 0.0, 1.0, -1.0};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double den = bx[e] * ux + by[e] * uy, num = 1.0 - (bx[e] * p0x + by[e] * p0y);
+                if (den > 0.0)
+                    hi = fmin(hi, num / den);
+                else if (den < 0.0)
+                    lo = fmax(lo, num / den);
+                else if (num < 0.0)
+                    return false;
+            }
+        }
+        int r = start;
+        for (int j = 0; j < i; ++j, r = (r + stride >= n1 ? r + stride - n1 : r + stride)) {
+            if (r == self)
+                continue;
+            const Cons m = hpr_constraint(pts, r, px, py, pz, axis, sgn);
+            const double den = m.a * ux + m.b * uy, num = m.c - (m.a * p0x + m.b * p0y);
+            if (den > 0.0)
+                hi = fmin(hi, num / den);
+            else if (den < 0.0)
+                lo = fmax(lo, num / den);
+            else if (num < 0.0)
+                return false;
+            if (lo > hi)
+                return false;
+        }
+        if (lo > hi)
+            return false;
+        const double tt = (ux + 0.5 * uy) > 0.0 ? hi : lo;
+        vx = p0x + tt * ux;
+        vy = p0y + tt * uy;
+    }
+    return true;
+}
+
+// flags[h][j] = 1 iff point j of cloud h (n1 points, the last one is the viewpoint) is a
+// vertex of the convex hull.  grid (ceil(n1/256), hulls); the cloud sits in dynamic LDS.
+__global__ __launch_bounds__(256) void hull_vertex_kernel(int n1, const float *__restrict__ points,
+                                                         int stride, unsigned char *__restrict__ flags)
+{
+    extern __shared__ float pts[];
+    const float *P = points + (size_t)blockIdx.y * n1 * 3;
+    for (int f = threadIdx.x; f < n1 * 3; f += 256)
+        pts[f] = P[f];
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n1)
+        return;
+    const int start = (int)(((long long)j * 7919 + 13) % n1);
+    bool vertex = false;
+    // most visible points have a separating direction with a dominant +z or -z component
+    const int axes[3] = {2, 0, 1};
+#pragma unroll 1
+    for (int c = 0; c < 6 && !vertex; ++c)
+        vertex = hpr_lp2d(pts, n1, j, stride, start, axes[c >> 1], (c & 1) ? -1.0 : 1.0);
+    flags[(size_t)blockIdx.y * n1 + j] = vertex ? 1 : 0;
+}
+
+// convexHull() of hidden_point_removal.py:27-43, given the vertex flags: V = sorted vertex ids;
+// drop the largest (`hull.vertices[:-1]`, the viewpoint) and the next largest (`visibleId[:-1]`);
+// rows [0, num_vis) = org[visibleId], the remaining rows = org[random choice of visibleId].
+__global__ __launch_bounds__(512) void hpr_gather_kernel(int n1, const unsigned char *__restrict__ flags,
+                                                        const float *__restrict__ org, unsigned long long seed,
+                                                        float *__restrict__ visible, long long *__restrict__ num_vis,
+                                                        int *__restrict__ visible_id)
+{
+    extern __shared__ int ids[];          // n1 ints: compacted vertex ids
+    __shared__ int wsum[8];
+    __shared__ int total_s;
+    const int h = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned char *F = flags + (size_t)h * n1;
+    const int per = (n1 + 511) / 512;
+    const int lo = min(n1, t * per), hi = min(n1, lo + per);
+    int local = 0;
+    for (int j = lo; j < hi; ++j)
+        local += F[j];
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d)
+            incl += o;
+    }
+    if (lane == 63)
+        wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w)
+        base += wsum[w];
+    int pos = base + incl - local;
+    for (int j = lo; j < hi; ++j)
+        if (F[j])
+            ids[pos++] = j;
+    if (t == 511)
+        total_s = base + incl;
+    __syncthreads();
+    const int nv = max(0, total_s - 2);
+    if (t == 0)
+        num_vis[h] = nv;
+    const float *O = org + (size_t)h * n1 * 3;
+    float *V = visible + (size_t)h * n1 * 3;
+    for (int r = t; r < n1; r += 512) {
+        int src = -1;
+        if (r < nv) {
+            src = ids[r];
+        } else if (nv > 0) {
+            unsigned rnd[4];
+            philox4x32(seed, ((unsigned long long)h << 32) | (unsigned)r, 7u, rnd);
+            src = ids[rnd[0] % (unsigned)nv];        // np.random.choice(visibleId, ...)
+        }
+        if (visible_id)
+            visible_id[(size_t)h * n1 + r] = r < nv ? src : -1;
+        V[3 * r] = src >= 0 ? O[3 * src] : 0.0f;
+        V[3 * r + 1] = src >= 0 ? O[3 * src + 1] : 0.0f;
+        V[3 * r + 2] = src >= 0 ? O[3 * src + 2] : 0.0f;
+    }
+}
+
+static int coprime_stride(int n)
+{
+    const int primes[] = {1021, 769, 523, 257, 131, 67, 31, 17, 7, 5, 3};
+    for (int p : primes)
+        if (p < n && n % p != 0)
+            return p;
+    return 1;
+}
+
+} // namespace cloudaae
+
+using namespace cloudaae;
+
+CLOUDAAE_API int cloudaae_transform_object_model(int b, int npts, int nmodels, const float *models,
+                                                 const long long *class_id, const double *rot, const float *trans,
+                                                 float *out, cloudaae_stream_t stream)
+{
+    if (b * npts == 0)
+        return 0;
+    hipLaunchKernelGGL(transform_model_kernel, dim3(ceil_div(b * npts, 256)), dim3(256), 0, (hipStream_t)stream, b,
+                       npts, nmodels, models, class_id, rot, trans, out);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_transform_object_model");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_random_spherical_occluder(int b, int per_blob, const float *trans, float wnear,
+                                                    float hnear, float near_dist, float sigma,
+                                                    unsigned long long seed, float *occluder,
+                                                    cloudaae_stream_t stream)
+{
+    if (b * per_blob == 0)
+        return 0;
+    hipLaunchKernelGGL(occluder_kernel, dim3(ceil_div(b * per_blob, 256)), dim3(256), 0, (hipStream_t)stream, b,
+                       per_blob, trans, wnear, hnear, near_dist, sigma, seed, occluder);
+    CLOUDAAE_CHECK_LAUNCH("cloudaae_random_spherical_occluder");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_spherical_flip(int b, int na, const float *a, int nb, const float *bpts,
+                                         const float *center, float param, float *flipped, float *org,
+                                         cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_spherical_flip";
+    CLOUDAAE_REQUIRE(b >= 0 && na >= 0 && nb >= 0 && na + nb > 0 && b <= 65535, name, "bad size");
+    if (b == 0)
+        return 0;
+    hipLaunchKernelGGL(spherical_flip_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, na, nb, a, bpts, center,
+                       powf(10.0f, param), flipped, org);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API long long cloudaae_hpr_workspace_bytes(int b, int n1) { return (long long)b * n1; }
+
+CLOUDAAE_API int cloudaae_hidden_point_removal(int b, int n1, const float *flipped, const float *org,
+                                               unsigned long long seed, float *visible, long long *num_vis,
+                                               int *visible_id, void *workspace, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_hidden_point_removal";
+    CLOUDAAE_REQUIRE(b >= 0 && n1 >= 5 && b <= 65535 && workspace, name, "bad size (need >= 4 points + viewpoint)");
+    CLOUDAAE_REQUIRE((size_t)n1 * 12 <= 150 * 1024, name, "cloud too large for the LDS-resident hull test");
+    if (b == 0)
+        return 0;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char *flags = (unsigned char *)workspace;
+    const size_t lds = (size_t)n1 * 3 * sizeof(float);
+    if (lds > 48 * 1024)
+        CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)hull_vertex_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
+    hipLaunchKernelGGL(hull_vertex_kernel, dim3(ceil_div(n1, 256), b), dim3(256), lds, s, n1, flipped,
+                       coprime_stride(n1), flags);
+    hipLaunchKernelGGL(hpr_gather_kernel, dim3(b), dim3(512), (size_t)n1 * sizeof(int), s, n1, flags, org, seed,
+                       visible, num_vis, visible_id);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}

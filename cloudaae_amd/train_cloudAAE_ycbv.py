@@ -217,6 +217,54 @@ class TrainGraph(object):
             return self.forward(element, is_training=False)
 
 
+# ---- the data pipeline of train_cloudAAE_ycbv.py:42-117, batched on the GPU --------------------
+def get_object_model(x, obj_models):
+    """:68-76  x['obj_batch'] = obj_models[class_id]  (obj_models [21,2048,6] device tensor); the
+    gather itself happens inside transform_object_model."""
+    x['obj_model'] = obj_models
+    return x
+
+
+def get_rotation_matrix(x):
+    """:79-85  rot_mat = float32(exponential_map(float64(axisangle)))."""
+    x['axisangle'] = x['axisangle'].to(torch.float64)
+    x['rot_mat64'] = angular_distance_taylor.exponential_map(x['axisangle'])
+    x['rot_mat'] = x['rot_mat64'].to(torch.float32)
+    return x
+
+
+def transform_object_model(x):
+    """:88-93  model_xyz_rot_trans = obj_batch[:, :, 0:3] R^T + translation."""
+    models = x['obj_model'].to(torch.float32).contiguous()
+    nmodels, npts, _ = models.shape
+    t = x['translation'].to(torch.float32).contiguous()
+    B = t.shape[0]
+    out = torch.empty((B, npts, 3), dtype=torch.float32, device=t.device)
+    cls = x['class_id'].to(torch.int64).contiguous()
+    _lib.check(_lib.lib().cloudaae_transform_object_model(B, npts, nmodels, ptr(models), ptr(cls),
+                                                          ptr(x['rot_mat64'].contiguous()), ptr(t), ptr(out),
+                                                          stream()), "cloudaae_transform_object_model")
+    x['model_xyz_rot_trans'] = out
+    return x
+
+
+def get_small_data(records, obj_models, seed=0):
+    """:96-117 for one batch: records = dict of device tensors translation [B,3], axisangle [B,3],
+    class_id [B] (e.g. from tfrecord_io.PoseRecords.epoch); returns the reference's element dict:
+    visiblePoints [B,2449,3], visiblePoints_org [B,2049,3], occluder, model_xyz_rot_trans, ..."""
+    from .utils import generate_occluder, hidden_point_removal as hpr
+    x = dict(records)
+    x = get_object_model(x, obj_models)
+    x = get_rotation_matrix(x)
+    x = transform_object_model(x)
+    x = generate_occluder.get_random_spherical_occluder(x, 'ycbv', seed=seed)
+    x = hpr.sphericalFlip(x, None, 0.8 * math.pi)            # center = zeros_like(translation), :103
+    x = hpr.hidden_point_removal(x, seed=seed)
+    x = hpr.sphericalFlip_org(x, None, 0.8 * math.pi)
+    x = hpr.hidden_point_removal_org(x, seed=seed)
+    return x
+
+
 def synthetic_element(local_batch, num_point, device, seed=123456789, rank=0, single_class=None):
     """Synthetic `next_element` of SURVEY.md section 8d, generated on the device: object-scale
     points N(0, 0.05^2) + translation (t_xy ~ U(+-0.25), t_z ~ U(0.5,1.5)), class ids U{0..20},

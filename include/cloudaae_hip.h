@@ -214,6 +214,35 @@ int cloudaae_bn_decay_schedule(const float *step, float batch_size, float init, 
                                float rate, float clip, float *out, cloudaae_stream_t stream);
 int cloudaae_increment(float *x, float by, cloudaae_stream_t stream);
 
+/* ---- on-line synthesis (train_cloudAAE_ycbv.py:79-117) ------------------------------------ */
+
+/* transform_object_model (train...:88-93): out[b,j,:] = models[class_id[b], j, 0:3] R_b^T + t_b.
+ * models [nmodels,npts,6] (xyz|rgb, obj_models.tfrecords), rot [b,3,3] f64 (cloudaae_exponential_map). */
+int cloudaae_transform_object_model(int b, int npts, int nmodels, const float *models,
+                                    const long long *class_id, const double *rot, const float *trans,
+                                    float *out, cloudaae_stream_t stream);
+/* get_random_spherical_occluder (utils/generate_occluder.py:38-81): two Gaussian blobs of per_blob
+ * points (sigma), centres ~ N(0,wnear/10), N(0,hnear/10), N((near+z)/2,(z-near)/6), z = trans[:,2];
+ * occluder [b, 2*per_blob, 3], blobs interleaved row by row as in the reference.  Counter-based RNG
+ * (Philox4x32-10) keyed by `seed`: same distribution as tf.random.normal, not the same stream. */
+int cloudaae_random_spherical_occluder(int b, int per_blob, const float *trans, float wnear, float hnear,
+                                       float near_dist, float sigma, unsigned long long seed, float *occluder,
+                                       cloudaae_stream_t stream);
+/* sphericalFlip (utils/hidden_point_removal.py:6-24, 51-68): points = concat(a[b,na,3], bpts[b,nb,3])
+ * - center; flipped = 2 (R - |p|) p / |p| + p, R = max|p| * 10^param; both outputs are
+ * [b, na+nb+1, 3] with a zero last row (the viewpoint).  bpts may be NULL with nb = 0. */
+int cloudaae_spherical_flip(int b, int na, const float *a, int nb, const float *bpts, const float *center,
+                            float param, float *flipped, float *org, cloudaae_stream_t stream);
+/* convexHull / hidden_point_removal (utils/hidden_point_removal.py:27-48): visible points = vertices of
+ * conv(flipped[b,n1,3]) minus the two largest vertex indices (the reference's two `[:-1]`); visible
+ * [b,n1,3] = org rows of the visible ids (ascending), padded with random re-draws of visible ids;
+ * num_vis [b] int64; visible_id [b,n1] (optional; -1 in the padded rows).  qhull is replaced by an exact
+ * per-point vertex test (2-variable LPs in fp64); workspace: cloudaae_hpr_workspace_bytes(b, n1). */
+long long cloudaae_hpr_workspace_bytes(int b, int n1);
+int cloudaae_hidden_point_removal(int b, int n1, const float *flipped, const float *org,
+                                  unsigned long long seed, float *visible, long long *num_vis, int *visible_id,
+                                  void *workspace, cloudaae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

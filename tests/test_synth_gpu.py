@@ -1,0 +1,145 @@
+"""GPU: on-line synthesis (rigid transform, occluders, spherical flip, hidden point removal) vs the
+CPU restatement (oracle/synth_oracle.py: numpy + scipy/qhull) on the reference's own object model and
+pose records (tests/golden fixtures)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def data(golden_dir):
+    from cloudaae_amd import tfrecord_io as T
+    models, labels = T.read_and_decode_obj_model(os.path.join(golden_dir, "obj_model_first1.tfrecords"))
+    recs = T.PoseRecords([os.path.join(golden_dir, "pose_records_cls0_first4.tfrecords")])
+    return models, recs
+
+
+def _records(recs, device="cuda"):
+    return {"translation": torch.from_numpy(recs.translation).to(device),
+            "axisangle": torch.from_numpy(recs.axisangle).to(device),
+            "class_id": torch.from_numpy(recs.class_id).to(device)}
+
+
+def test_transform_and_flip_bit_exact(hip, data):
+    from cloudaae_amd import train_cloudAAE_ycbv as T
+    from cloudaae_amd.utils import hidden_point_removal as hpr
+    from oracle import synth_oracle as SO
+    models, recs = data
+    x = _records(recs)
+    x = T.get_object_model(x, torch.from_numpy(models).cuda())
+    x = T.transform_object_model(T.get_rotation_matrix(x))
+    got = x["model_xyz_rot_trans"].cpu().numpy()
+    for i in range(4):
+        want = SO.transform_object_model(models[0][:, :3], recs.axisangle[i], recs.translation[i])
+        assert np.array_equal(got[i], want)
+    rng = np.random.default_rng(0)
+    x["occluder"] = torch.from_numpy((rng.standard_normal((4, 400, 3)) * 0.01 + [0.0, 0.0, 0.6]).astype(np.float32)).cuda()
+    x = hpr.sphericalFlip(x, None, 0.8 * math.pi)
+    x = hpr.sphericalFlip_org(x, None, 0.8 * math.pi)
+    for i in range(4):
+        pts = np.concatenate([got[i], x["occluder"][i].cpu().numpy()], 0)
+        f, o = SO.spherical_flip(pts)
+        assert np.array_equal(x["orgPoints"][i].cpu().numpy(), o)
+        np.testing.assert_allclose(x["flippedPoints"][i].cpu().numpy(), f, rtol=2e-7, atol=0)
+        f2, o2 = SO.spherical_flip(got[i])
+        assert x["flippedPoints_org"].shape == (4, 2049, 3)
+        np.testing.assert_allclose(x["flippedPoints_org"][i].cpu().numpy(), f2, rtol=2e-7, atol=0)
+
+
+def test_hidden_point_removal_equals_qhull(hip, data):
+    """The visible-id sets must be IDENTICAL to scipy.spatial.ConvexHull's on the same flipped points
+    (real object model, real poses, with and without occluders)."""
+    from cloudaae_amd.utils import hidden_point_removal as hpr
+    from oracle import synth_oracle as SO
+    models, recs = data
+    rng = np.random.default_rng(1)
+    clouds = []
+    for i in range(4):
+        pts = SO.transform_object_model(models[0][:, :3], recs.axisangle[i], recs.translation[i])
+        z = recs.translation[i][2]
+        occ = (rng.standard_normal((400, 3)) * 0.01 + [0.01 * i, -0.01, (0.5 + z) / 2]).astype(np.float32)
+        clouds.append(np.concatenate([pts, occ], 0))
+    flipped, org = zip(*[SO.spherical_flip(c) for c in clouds])
+    F, O = torch.from_numpy(np.stack(flipped)).cuda(), torch.from_numpy(np.stack(org)).cuda()
+    vis, num, ids = hpr.convexHull(F, O, seed=3, return_ids=True)
+    assert vis.shape == (4, 2449, 3) and num.dtype == torch.int64
+    for i in range(4):
+        want, vertices = SO.convex_hull_visible(flipped[i])
+        assert vertices[-1] == 2448                       # the viewpoint is a hull vertex (what [:-1] assumes)
+        n = int(num[i])
+        assert n == len(want)
+        assert np.array_equal(ids[i, :n].cpu().numpy(), want)
+        assert (ids[i, n:] == -1).all()
+        v = vis[i].cpu().numpy()
+        assert np.array_equal(v[:n], org[i][want])
+        # padded rows are re-draws of visible points (np.random.choice(visibleId, ...))
+        visible_set = {tuple(r) for r in org[i][want]}
+        assert all(tuple(r) in visible_set for r in v[n:])
+        assert len({tuple(r) for r in v[n:]}) > 50        # and they are spread, not one repeated row
+    # without the occluder (the Chamfer target, 2048+1 points)
+    f2, o2 = zip(*[SO.spherical_flip(c[:2048]) for c in clouds])
+    vis2, num2, ids2 = hpr.convexHull(torch.from_numpy(np.stack(f2)).cuda(), torch.from_numpy(np.stack(o2)).cuda(),
+                                      return_ids=True)
+    for i in range(4):
+        want, _ = SO.convex_hull_visible(f2[i])
+        assert np.array_equal(ids2[i, :int(num2[i])].cpu().numpy(), want)
+
+
+def test_hull_vertices_random_clouds(hip):
+    """Generic clouds (not HPR-shaped): Gaussian blob, points on a sphere (all vertices), a cube
+    lattice (many coplanar/interior points)."""
+    from cloudaae_amd.utils import hidden_point_removal as hpr
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(5)
+    blob = rng.standard_normal((500, 3))
+    sph = rng.standard_normal((300, 3)); sph /= np.linalg.norm(sph, axis=1, keepdims=True)
+    for pts in (blob, sph * 3 + [0, 0, 10]):
+        P = np.concatenate([pts, np.zeros((1, 3))], 0).astype(np.float32)
+        hull = ConvexHull(P.astype(np.float64))
+        vis, num, ids = hpr.convexHull(torch.from_numpy(P[None]).cuda(), torch.from_numpy(P[None]).cuda(),
+                                       return_ids=True)
+        want = np.sort(hull.vertices)[:-2]
+        assert np.array_equal(ids[0, :int(num[0])].cpu().numpy(), want)
+
+
+def test_occluder_statistics_and_layout(hip):
+    from cloudaae_amd.utils import generate_occluder
+    from oracle import synth_oracle as SO
+    B = 512
+    t = torch.zeros((B, 3), device="cuda"); t[:, 2] = torch.linspace(0.6, 1.6, B, device="cuda")
+    x = generate_occluder.get_random_spherical_occluder({"translation": t}, "ycbv", seed=11)
+    occ = x["occluder"].cpu().numpy()
+    assert occ.shape == (B, 400, 3)
+    hnear, wnear = SO.get_frustum_near()
+    assert abs(hnear - 0.55785) < 1e-4 and abs(wnear - 0.71901) < 1e-4      # tan(22.5 rad) quirk
+    b1, b2 = occ[:, 0::2], occ[:, 1::2]                      # the two blobs interleave row by row
+    for blob in (b1, b2):
+        c = blob.mean(1)
+        assert abs(np.std(blob - c[:, None], axis=1).mean() - 0.01) < 5e-4          # sigma 0.01
+        assert abs(c[:, 0].std() - wnear / 10) < 0.012 and abs(c[:, 1].std() - hnear / 10) < 0.01
+        z = t[:, 2].cpu().numpy()
+        assert abs((c[:, 2] - (0.5 + z) / 2).mean()) < 0.02
+        assert abs((c[:, 2] - (0.5 + z) / 2).std() - ((z - 0.5) / 6).mean()) < 0.03
+    assert np.abs(b1.mean(1) - b2.mean(1)).mean() > 0.01                  # distinct centres
+    y = generate_occluder.get_random_spherical_occluder({"translation": t}, "ycbv", seed=11)
+    assert torch.equal(x["occluder"], y["occluder"])                      # counter-based: reproducible
+    z = generate_occluder.get_random_spherical_occluder({"translation": t}, "ycbv", seed=12)
+    assert not torch.equal(x["occluder"], z["occluder"])
+
+
+def test_pipeline_feeds_a_train_step(hip, data):
+    """tfrecord records -> get_small_data -> TrainGraph.train_step at the reference's default N=256."""
+    from cloudaae_amd import train_cloudAAE_ycbv as T
+    models, recs = data
+    obj = torch.from_numpy(np.repeat(models, 21, axis=0)).cuda()          # 21 classes (fixture has class 0)
+    el = T.get_small_data(_records(recs), obj, seed=5)
+    assert el["visiblePoints"].shape == (4, 2449, 3) and el["visiblePoints_org"].shape == (4, 2049, 3)
+    assert (el["num_vis_point"] > 300).all() and (el["num_vis_point_org"] >= el["num_vis_point"] - 400).all()
+    graph = T.TrainGraph({"num_point": 256, "gpu": 0}, {}, {"batch_size": 4})
+    out = graph.train_step(el)
+    assert math.isfinite(float(out["total_loss"])) and out["xyz_recon"].shape == (4, 1024, 3)
