@@ -179,7 +179,7 @@ __device__ __forceinline__ Cons hpr_constraint(const float *__restrict__ pts, in
                                                double pz, int axis, double sgn)
 {
     const double gx = (double)pts[3 * q] - px, gy = (double)pts[3 * q + 1] - py, gz = (double)pts[3 * q + 2] - pz;
-    const double nrm = sqrt((gx * gx + gy * gy) + gz * gz);
+    const double nrm = (fabs(gx) + fabs(gy)) + fabs(gz);   // L1 >= L2: the margin only has to be "tiny but positive"
     Cons k;
     if (axis == 2) {
         k.a = gx; k.b = gy; k.c = -sgn * gz;
@@ -193,84 +193,115 @@ __device__ __forceinline__ Cons hpr_constraint(const float *__restrict__ pts, in
 }
 
 // Seidel's incremental 2-variable LP on [-1,1]^2, objective x + y/2; returns feasibility.
-// Constraints are visited in the order q = (start + i*stride) mod n1 (a fixed pseudo-random
-// permutation: stride is coprime with n1); q == self is skipped.
-__device__ bool hpr_lp2d(const float *__restrict__ pts, int n1, int self, int stride, int start, int axis,
-                         double sgn)
+// ONE WAVE per point: the 64 lanes test 64 consecutive constraints against the current optimum
+// (ballot -> first violated one, which keeps Seidel's sequential semantics), and share the 1-D
+// re-solve over the constraints seen so far (per-lane lo/hi as FRACTIONS -- compared by cross
+// multiplication, so the loop has no fp64 division -- then a wave min/max).  A lane-per-point
+// version diverged: a wave executed the SUM of its lanes' re-solves (227 ms per batch of 32).
+// Constraint order = bit-reversal (van der Corput) sequence over [0, 2^bits) restricted to
+// [0, n1): Seidel's expected O(n) needs an order uncorrelated with the geometry, and object models
+// are stored in scan order.  q == self is skipped.
+struct Frac {
+    double num, den;   // den > 0
+};
+__device__ __forceinline__ bool frac_less(const Frac &x, const Frac &y) { return x.num * y.den < y.num * x.den; }
+
+__device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, int bits, int axis, double sgn,
+                              int lane)
 {
     const double px = pts[3 * self], py = pts[3 * self + 1], pz = pts[3 * self + 2];
     double vx = 1.0, vy = 1.0;
-    int q = start;
-    for (int i = 0; i < n1; ++i, q = (q + stride >= n1 ? q + stride - n1 : q + stride)) {
-        if (q == self)
+    const int span = 1 << bits;
+    int i = 0;
+    while (i < span) {
+        const int pos = i + lane;
+        const int q = pos < span ? (int)(__brev((unsigned)pos) >> (32 - bits)) : n1;
+        const bool valid = q < n1 && q != self;
+        Cons k = {0.0, 0.0, 0.0};
+        if (valid)
+            k = hpr_constraint(pts, q, px, py, pz, axis, sgn);
+        const bool viol = valid && (k.a * vx + k.b * vy > k.c);
+        const unsigned long long mask = __ballot(viol);
+        if (mask == 0ull) {
+            i += 64;
             continue;
-        const Cons k = hpr_constraint(pts, q, px, py, pz, axis, sgn);
-        if (k.a * vx + k.b * vy <= k.c)
-            continue;
-        const double nn = k.a * k.a + k.b * k.b;
+        }
+        const int first = __ffsll((long long)mask) - 1;
+        const double ka = __shfl(k.a, first, 64), kb = __shfl(k.b, first, 64), kc = __shfl(k.c, first, 64);
+        const double nn = ka * ka + kb * kb;
         if (nn == 0.0)
             return false;
-        const double p0x = k.a * k.c / nn, p0y = k.b * k.c / nn, ux = -k.b, uy = k.a;
-        double lo = -1e300, hi = 1e300;
-        // the box
-        {
-            const double bx[4] = {1.0, -1.0, 0.0, 0.0}, by[4] = {0.0, 0.0, 1.0, -1.0};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const double den = bx[e] * ux + by[e] * uy, num = 1.0 - (bx[e] * p0x + by[e] * p0y);
-                if (den > 0.0)
-                    hi = fmin(hi, num / den);
-                else if (den < 0.0)
-                    lo = fmax(lo, num / den);
-                else if (num < 0.0)
-                    return false;
+        const double p0x = ka * kc / nn, p0y = kb * kc / nn, ux = -kb, uy = ka;
+        // t in [lo, hi] with lo = max num/den over den<0 (stored with den > 0 after sign flip)
+        Frac lo = {-1e300, 1.0}, hi = {1e300, 1.0};
+        bool bad = false;
+        auto add = [&](double ca, double cb, double cc) {
+            const double den = ca * ux + cb * uy, num = cc - (ca * p0x + cb * p0y);
+            if (den > 0.0) {
+                const Frac f = {num, den};
+                if (frac_less(f, hi))
+                    hi = f;
+            } else if (den < 0.0) {
+                const Frac f = {-num, -den};
+                if (frac_less(lo, f))
+                    lo = f;
+            } else if (num < 0.0) {
+                bad = true;
             }
-        }
-        int r = start;
-        for (int j = 0; j < i; ++j, r = (r + stride >= n1 ? r + stride - n1 : r + stride)) {
-            if (r == self)
+        };
+        if (lane < 4)      // the box |x| <= 1, |y| <= 1
+            add(lane == 0 ? 1.0 : (lane == 1 ? -1.0 : 0.0), lane == 2 ? 1.0 : (lane == 3 ? -1.0 : 0.0), 1.0);
+        const int upto = i + first;            // sequence positions [0, upto) were already accepted
+        for (int jpos = lane; jpos < upto; jpos += 64) {
+            const int r = (int)(__brev((unsigned)jpos) >> (32 - bits));
+            if (r >= n1 || r == self)
                 continue;
             const Cons m = hpr_constraint(pts, r, px, py, pz, axis, sgn);
-            const double den = m.a * ux + m.b * uy, num = m.c - (m.a * p0x + m.b * p0y);
-            if (den > 0.0)
-                hi = fmin(hi, num / den);
-            else if (den < 0.0)
-                lo = fmax(lo, num / den);
-            else if (num < 0.0)
-                return false;
-            if (lo > hi)
-                return false;
+            add(m.a, m.b, m.c);
         }
-        if (lo > hi)
+        // wave reduction of lo (max) and hi (min) as fractions
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            Frac ol = {__shfl_xor(lo.num, off, 64), __shfl_xor(lo.den, off, 64)};
+            Frac oh = {__shfl_xor(hi.num, off, 64), __shfl_xor(hi.den, off, 64)};
+            if (frac_less(lo, ol))
+                lo = ol;
+            if (frac_less(oh, hi))
+                hi = oh;
+        }
+        if (__ballot(bad) != 0ull || frac_less(hi, lo))
             return false;
-        const double tt = (ux + 0.5 * uy) > 0.0 ? hi : lo;
+        const Frac pick = (ux + 0.5 * uy) > 0.0 ? hi : lo;
+        const double tt = pick.num / pick.den;
         vx = p0x + tt * ux;
         vy = p0y + tt * uy;
+        i = upto + 1;
     }
     return true;
 }
 
 // flags[h][j] = 1 iff point j of cloud h (n1 points, the last one is the viewpoint) is a
-// vertex of the convex hull.  grid (ceil(n1/256), hulls); the cloud sits in dynamic LDS.
-__global__ __launch_bounds__(256) void hull_vertex_kernel(int n1, const float *__restrict__ points,
-                                                         int stride, unsigned char *__restrict__ flags)
+// vertex of the convex hull.  One wave per point; a workgroup (8 waves) keeps the cloud in
+// dynamic LDS and walks points j = blockIdx.x*8 + wave, + 8*gridDim.x, ...
+constexpr int HPR_WAVES = 8;
+__global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, const float *__restrict__ points,
+                                                                    int bits, unsigned char *__restrict__ flags)
 {
     extern __shared__ float pts[];
     const float *P = points + (size_t)blockIdx.y * n1 * 3;
-    for (int f = threadIdx.x; f < n1 * 3; f += 256)
+    for (int f = threadIdx.x; f < n1 * 3; f += 64 * HPR_WAVES)
         pts[f] = P[f];
     __syncthreads();
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n1)
-        return;
-    const int start = (int)(((long long)j * 7919 + 13) % n1);
-    bool vertex = false;
-    // most visible points have a separating direction with a dominant +z or -z component
-    const int axes[3] = {2, 0, 1};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int axes[3] = {2, 0, 1};   // most visible points separate along +-z first
+    for (int j = blockIdx.x * HPR_WAVES + wave; j < n1; j += HPR_WAVES * gridDim.x) {
+        bool vertex = false;
 #pragma unroll 1
-    for (int c = 0; c < 6 && !vertex; ++c)
-        vertex = hpr_lp2d(pts, n1, j, stride, start, axes[c >> 1], (c & 1) ? -1.0 : 1.0);
-    flags[(size_t)blockIdx.y * n1 + j] = vertex ? 1 : 0;
+        for (int c = 0; c < 6 && !vertex; ++c)
+            vertex = hpr_lp2d_wave(pts, n1, j, bits, axes[c >> 1], (c & 1) ? -1.0 : 1.0, lane);
+        if (lane == 0)
+            flags[(size_t)blockIdx.y * n1 + j] = vertex ? 1 : 0;
+    }
 }
 
 // convexHull() of hidden_point_removal.py:27-43, given the vertex flags: V = sorted vertex ids;
@@ -333,13 +364,12 @@ __global__ __launch_bounds__(512) void hpr_gather_kernel(int n1, const unsigned 
     }
 }
 
-static int coprime_stride(int n)
+static int index_bits(int n)
 {
-    const int primes[] = {1021, 769, 523, 257, 131, 67, 31, 17, 7, 5, 3};
-    for (int p : primes)
-        if (p < n && n % p != 0)
-            return p;
-    return 1;
+    int b = 1;
+    while ((1 << b) < n)
+        ++b;
+    return b;
 }
 
 } // namespace cloudaae
@@ -402,8 +432,11 @@ CLOUDAAE_API int cloudaae_hidden_point_removal(int b, int n1, const float *flipp
     if (lds > 48 * 1024)
         CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)hull_vertex_kernel,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
-    hipLaunchKernelGGL(hull_vertex_kernel, dim3(ceil_div(n1, 256), b), dim3(256), lds, s, n1, flipped,
-                       coprime_stride(n1), flags);
+    // ~16 points per wave: enough workgroups to fill the chip at small batch, few enough that the
+    // cloud is not re-staged into LDS too often
+    int gx = ceil_div(n1, HPR_WAVES * 16);
+    hipLaunchKernelGGL(hull_vertex_kernel, dim3(gx, b), dim3(64 * HPR_WAVES), lds, s, n1, flipped,
+                       index_bits(n1), flags);
     hipLaunchKernelGGL(hpr_gather_kernel, dim3(b), dim3(512), (size_t)n1 * sizeof(int), s, n1, flags, org, seed,
                        visible, num_vis, visible_id);
     CLOUDAAE_CHECK_LAUNCH(name);
