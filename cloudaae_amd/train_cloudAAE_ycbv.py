@@ -29,7 +29,7 @@ from .losses import angular_distance_taylor, chamfer_loss, trans_distance
 from .utils import _functions as F
 from .utils import tf_util
 from .utils.grad_exchange import GradExchange
-from .utils.variables import reset_default_store
+from .utils.variables import reset_default_store, set_default_store
 
 NUM_CLASS = 21                      # train_cloudAAE_ycbv.py:29
 BN_INIT_DECAY = 0.5                 # :166-169
@@ -63,7 +63,12 @@ def get_training_argparser():
     extra = parser.add_argument_group('mi355x')
     extra.add_argument('--model_fn', default='get_model_dgcnn_mean_6d')
     extra.add_argument('--k', type=int, default=K_NEIGHBOR)
-    extra.add_argument('--steps', type=int, default=100, help='synthetic steps to run')
+    extra.add_argument('--steps', type=int, default=0,
+                       help='batches per epoch (0 = the whole epoch); synthetic steps without --data_dir (0 = 100)')
+    extra.add_argument('--data_dir', default='', help='directory holding object_model_tfrecord/ and '
+                       'ycb_video_data_tfRecords/train_syn/ (:31-39); empty = synthetic batches')
+    extra.add_argument('--restore', default='', help='checkpoint (.npz) to resume from')
+    extra.add_argument('--print_every', type=int, default=1, help='print the losses every n batches (each print syncs)')
     return parser
 
 
@@ -141,6 +146,7 @@ class TrainGraph(object):
                     self.store.vars[name].on_ready = self.exchange.early_ready
 
     def _call_model(self, pc, is_training):
+        set_default_store(self.store)      # several graphs may live in one process (cf. tf.Graph.as_default)
         if self.is_pn:
             return self.model_fn(pc, is_training, bn_decay=self.bn_decay)
         return self.model_fn(pc, is_training, is_training, self.k, bn_decay=self.bn_decay)
@@ -167,8 +173,8 @@ class TrainGraph(object):
                                                       ptr(cls), ptr(pc), ptr(element_mean), ptr(noisy), stream()),
                    "cloudaae_input_assemble")
         org = element['visiblePoints_org']
-        require(org.shape[1] >= 4 * N, "visiblePoints_org has fewer than 4*num_point rows "
-                                        "(the reference silently truncates here, train...:211-214)")
+        # :214 -- a slice, so fewer than 4N rows pass through here (and fail in chamfer_loss.py:12,
+        # whose sum needs n == m, exactly as in the reference)
         visiblePoints_org_final = org[:, 0:N * 4, :].contiguous()
 
         xyz_recon_res, rot_pred, trans_pred_res, endpoint = self._call_model(pc, is_training)
@@ -215,6 +221,50 @@ class TrainGraph(object):
     def eval_step(self, element):
         with torch.no_grad():
             return self.forward(element, is_training=False)
+
+    # -- tf.train.Saver (:276, :418-424): every variable under its TF name ---------------------
+    def checkpoint(self):
+        """name -> numpy array, with the names tf.train.Saver would write for this graph: the
+        model variables and BN moving averages (store names), the Adam slots `<var>/Adam`,
+        `<var>/Adam_1`, `beta1_power`, `beta2_power`, and the step counter `Variable` (:192)."""
+        ck = {n: t.cpu().numpy() for n, t in self.store.state_dict().items()}
+        for v in self.store.trainable_variables():
+            o = self.store.offsets[v.name]
+            n = v.data.numel()
+            ck[v.name + '/Adam'] = self.adam_m[o:o + n].view(v.shape).cpu().numpy()
+            ck[v.name + '/Adam_1'] = self.adam_v[o:o + n].view(v.shape).cpu().numpy()
+        ck['beta1_power'] = self.beta1_power.cpu().numpy().reshape(())
+        ck['beta2_power'] = self.beta2_power.cpu().numpy().reshape(())
+        ck['Variable'] = self.batch.cpu().numpy().reshape(())
+        return ck
+
+    def save(self, path):
+        """saver.save(sess, path) (:424).  Written as a NumPy archive (`path` + '.npz') by rank 0."""
+        import numpy as np
+        if self.rank == 0:
+            tmp = path + '.tmp.npz'
+            np.savez(tmp, **self.checkpoint())
+            os.replace(tmp, path + '.npz')
+        return path + '.npz'
+
+    def restore(self, path, strict=True):
+        """saver.restore(sess, path): accepts what save() wrote, or any name -> array archive with
+        the reference's variable names (e.g. a converted TF checkpoint; optimizer slots optional)."""
+        import numpy as np
+        with np.load(path if path.endswith('.npz') else path + '.npz') as z:
+            ck = {k: z[k] for k in z.files}
+        names = set(self.store.vars)
+        self.store.load_state_dict({k: v for k, v in ck.items() if k in names}, strict=strict)
+        with torch.no_grad():
+            for v in self.store.trainable_variables():
+                o = self.store.offsets[v.name]
+                n = v.data.numel()
+                for slot, flat in (('/Adam', self.adam_m), ('/Adam_1', self.adam_v)):
+                    if v.name + slot in ck:
+                        flat[o:o + n].copy_(torch.as_tensor(ck[v.name + slot], dtype=torch.float32).reshape(-1))
+            for key, t in (('beta1_power', self.beta1_power), ('beta2_power', self.beta2_power), ('Variable', self.batch)):
+                if key in ck:
+                    t.fill_(float(ck[key]))
 
 
 # ---- the data pipeline of train_cloudAAE_ycbv.py:42-117, batched on the GPU --------------------
@@ -287,6 +337,85 @@ def synthetic_element(local_batch, num_point, device, seed=123456789, rank=0, si
                 axisangle=axis * angle[:, None])
 
 
+class ClassLossLog(object):
+    """The per-class running averages of :318-321 / :397-414 (what the reference sends to
+    TensorBoard every 1000 batches), accumulated on the device so the loop never syncs."""
+
+    def __init__(self, device):
+        self.sums = torch.zeros((3, NUM_CLASS), dtype=torch.float64, device=device)
+        self.count = torch.zeros((NUM_CLASS,), dtype=torch.float64, device=device)
+        self.total = torch.zeros((NUM_CLASS,), dtype=torch.int64, device=device)
+
+    def add(self, out):
+        cls = out['class_id']
+        B = cls.shape[0]       # xyz_loss_per_sample is per point [B,4N] (chamfer_loss.py:12); np.average(:399) flattens it
+        per = torch.stack([out[k].detach().double().reshape(B, -1).mean(1)
+                           for k in ('xyz_loss_per_sample', 'axag_loss_perSample', 'trans_loss_perSample')])
+        self.sums.index_add_(1, cls, per)
+        self.count.index_add_(0, cls, torch.ones_like(cls, dtype=torch.float64))
+
+    def flush(self):
+        """-> list of (class, n_total, xyz, axag, trans) for classes seen since the last flush."""
+        self.total += self.count.long()
+        sums, count, total = self.sums.cpu(), self.count.cpu(), self.total.cpu()
+        rows = [(c, int(total[c]), float(sums[0, c] / count[c]), float(sums[1, c] / count[c]),
+                 float(sums[2, c] / count[c])) for c in range(NUM_CLASS) if count[c] > 0]
+        self.sums.zero_()
+        self.count.zero_()
+        return rows
+
+
+def train_graph(graph, records, obj_models, epoch, class_log=None, log=None, logdir=None, seed=None,
+                max_batches=None, print_every=1, summary_every=1000):
+    """One epoch of the reference's train_graph (:332-437): draw shuffled batches of pose records,
+    synthesise the element on the GPU (get_small_data), train_step, per-class loss bookkeeping
+    every `summary_every` batches, checkpoint at the end of the epoch (:418-424).
+    `records` is this rank's tfrecord_io.PoseRecords shard; obj_models the [21,2048,6] device tensor."""
+    start = time.time()
+    dev = graph.device
+    batch_idx = 0
+    out = None
+    for rec in records.epoch(graph.local_batch, seed=seed):
+        if max_batches is not None and batch_idx >= max_batches:
+            break
+        element = get_small_data({k: torch.as_tensor(v).to(dev, non_blocking=True) for k, v in rec.items()},
+                                 obj_models, seed=(epoch << 32) + batch_idx * graph.world + graph.rank)
+        out = graph.train_step(element)
+        if class_log is not None:
+            class_log.add(out)
+        if log is not None and print_every and batch_idx % print_every == 0:
+            log("epoch %d batch %d xyz_loss %f trans_loss %f axag_loss %f"
+                % (epoch, batch_idx, float(out['xyz_loss'].detach()), float(out['trans_loss'].detach()),
+                   float(out['axag_loss'].detach())))
+        if class_log is not None and log is not None and batch_idx != 0 and batch_idx % summary_every == 0:
+            for c, n, xyz, axag, trans in class_log.flush():
+                log("  class %2d samples %8d xyz_loss %f axag_loss %f trans_loss %f" % (c, n, xyz, axag, trans))
+        batch_idx += 1
+    torch.cuda.synchronize(dev)
+    if log is not None:
+        log('End of data!')
+    if logdir is not None:
+        name = "model_%d.ckpt" % epoch if (epoch + 1) % 50 == 0 else "model.ckpt"       # :419-422
+        path = graph.save(os.path.join(logdir, name))
+        if log is not None and graph.rank == 0:
+            log("Model saved in file: %s" % path)
+    if log is not None:
+        log('Current epoch Time elapsed %.1f s (%d batches)' % (time.time() - start, batch_idx))
+    return batch_idx, out
+
+
+def load_dataset(data_dir, device, rank=0, world=1, classes=None):
+    """The files of :31-39 under `data_dir`: object models -> device tensor [21,2048,6];
+    pose records of the chosen classes -> this rank's shard."""
+    from . import tfrecord_io
+    models, _ = tfrecord_io.read_and_decode_obj_model(os.path.join(data_dir, "object_model_tfrecord", "obj_models.tfrecords"))
+    obj_models = torch.as_tensor(models).to(device)
+    classes = range(NUM_CLASS) if classes is None else classes
+    files = [os.path.join(data_dir, "ycb_video_data_tfRecords", "train_syn", "%d_syn.tfrecords" % c) for c in classes]
+    records = tfrecord_io.PoseRecords(files)
+    return obj_models, (records.shard(rank, world) if world > 1 else records)
+
+
 def main(argv=None):
     parser = get_training_argparser()
     groups = parse_arg_groups(parser, argv)
@@ -298,16 +427,41 @@ def main(argv=None):
         dist.init_process_group('nccl')
         general['gpu'] = local
     graph = TrainGraph(general, topts, hyper, model_fn=extra['model_fn'], k_neighbor=extra['k'])
+    if extra['restore']:
+        graph.restore(extra['restore'])
+    if extra['data_dir']:
+        # the reference's run: LOG_DIR/<NUM_CLASS>/6d/<timestamp>/log_train.txt (:150-157)
+        logdir = os.path.join(general['log_dir'], str(NUM_CLASS), "6d", time.strftime("%Y%m%d-%H%M%S"))
+        fout = None
+        if graph.rank == 0:
+            os.makedirs(logdir, exist_ok=True)
+            fout = open(os.path.join(logdir, 'log_train.txt'), 'w')
+            for d in (general, topts, hyper):
+                fout.write(str(d) + '\n')
+
+        def log(msg):
+            if graph.rank == 0:
+                fout.write(msg + '\n')
+                fout.flush()
+                print(msg)
+        obj_models, records = load_dataset(extra['data_dir'], graph.device, graph.rank, graph.world)
+        log("%d pose records on rank 0, %d batches per epoch" % (len(records), len(records) // graph.local_batch))
+        class_log = ClassLossLog(graph.device)
+        for epoch in range(int(topts['max_epoch'])):
+            log('**** EPOCH %03d ****' % epoch)
+            train_graph(graph, records, obj_models, epoch, class_log, log, logdir, seed=123456789 + epoch,
+                        max_batches=extra['steps'] or None, print_every=extra['print_every'])
+        return
     el = synthetic_element(graph.local_batch, graph.NUM_POINT, graph.device, rank=graph.rank)
     t0 = time.time()
-    for i in range(extra['steps']):
+    for i in range(extra['steps'] or 100):
         out = graph.train_step(el)
         if i % 10 == 0 and graph.rank == 0:
             print("step %d xyz_loss %f trans_loss %f axag_loss %f" %
                   (i, float(out['xyz_loss']), float(out['trans_loss']), float(out['axag_loss'])))
     torch.cuda.synchronize()
     if graph.rank == 0:
-        print("%.1f clouds/s" % (extra['steps'] * graph.BATCH_SIZE / (time.time() - t0)))
+        print("%.1f clouds/s" % ((extra['steps'] or 100) * graph.BATCH_SIZE / (time.time() - t0)))
 
 
 if __name__ == "__main__":
