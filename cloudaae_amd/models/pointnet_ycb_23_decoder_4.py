@@ -21,7 +21,7 @@ import torch
 from ..utils import tf_util
 
 
-def _dgcnn_encoder(point_cloud, is_training_pl_encoder, k, bn_decay, pool, prefix=''):
+def _dgcnn_encoder(point_cloud, is_training_pl_encoder, k, bn_decay, pool, prefix='', nn_out=None):
     """The shared DGCNN encoder (models/...:337-426 and its copies): 4 x { kNN -> edge conv ->
     pool over k }, concat, conv 320->1024, pool over the points.  Returns (embedding [B,1024],
     lazy [B,N,1,1024] activation)."""
@@ -35,6 +35,8 @@ def _dgcnn_encoder(point_cloud, is_training_pl_encoder, k, bn_decay, pool, prefi
     for i, width in enumerate(widths):
         adj_matrix = tf_util.pairwise_xyz_distance(net)
         nn_idx = tf_util.knn(adj_matrix, k=k)
+        if nn_out is not None:
+            nn_out.append(nn_idx)
         net = tf_util.edge_conv(net, nn_idx, width, scope='%sdgcnn%d' % (prefix, i + 1), pool=pool,
                                 bn_decay=bn_decay, is_training=is_training_pl_encoder,
                                 out_slot=(concat, off))      # [B,N,1,width]
@@ -73,7 +75,10 @@ def _dgcnn_6d(point_cloud, is_training_pl_encoder, is_training, k_neighbor, bn_d
               point_out=(4, 3)):
     batch_size, num_point = point_cloud.shape[0], point_cloud.shape[1]
     end_points = {}
-    embedding, before = _dgcnn_encoder(point_cloud, is_training_pl_encoder, k_neighbor, bn_decay, pool, prefix)
+    nn = []
+    embedding, before = _dgcnn_encoder(point_cloud, is_training_pl_encoder, k_neighbor, bn_decay, pool, prefix, nn)
+    for i, idx in enumerate(nn):
+        end_points['nn_idx%d' % (i + 1)] = idx              # [B,N,k] int32 grouping indices (extra key)
     end_points['layer_before_embedding'] = before          # lazy [B,N,1,1024] (see LazyActivation)
     end_points['embedding'] = embedding                    # [B,1024]
     mult, dim = point_out

@@ -328,6 +328,55 @@ def test_train_step_vs_oracle(hip, B, N, model_fn):
         assert _rel(graph.store.vars[name].data, s) < 1e-4, name
 
 
+@pytest.mark.parametrize("B,N,k", [(4, 256, 20), (4, 4096, 20)])
+def test_train_step_k20_vs_oracle(hip, B, N, k):
+    """BASELINE config 4's shape: DGCNN with k=20 edge-conv, up to N=4096 points (LDS-tiled kNN
+    stress), one full step vs the CPU restatement.
+
+    The kNN op itself is bit-exact on identical inputs (test_ops_gpu.py).  Inside the network the
+    grouping inputs of the two implementations agree to ~1e-7 relative only (layer 1: the centroid
+    subtracted at train...:226 is a sum over N points; layers 2-4: features), so a k-th/(k+1)-th
+    near-tie can pick a different neighbour (measured: 0.05-0.7 % of the entries at k=20), and every
+    such swap moves losses and gradients by far more than round-off.  So: (1) free-running, the
+    neighbour sets must agree on > 95 % of the points; (2) with the oracle grouping on the GPU's
+    indices, the north-star tolerances apply unchanged."""
+    from cloudaae_amd import train_cloudAAE_ycbv as T
+    from oracle import model_oracle as MO
+    graph = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, k_neighbor=k)
+    V = MO.Vars(seed=13)
+    batch = MO.synthetic_batch(B, N, seed=17)
+    with torch.no_grad():
+        MO.forward_losses(batch, V, N, is_training=False, k=k)
+    graph.store.load_state_dict(V.state_dict())
+    out = graph.train_step({kk: v.cuda() for kk, v in batch.items()})
+    gpu_idx = [out["end_points"]["nn_idx%d" % i].cpu() for i in (1, 2, 3, 4)]
+    if N <= 256:
+        with torch.no_grad():
+            free = MO.forward_losses(batch, V, N, True, MO.bn_decay_schedule(0, B), k)
+        for i in range(4):
+            a = gpu_idx[i].long().sort(-1).values
+            b = free["end_points"]["nn_idx%d" % (i + 1)].long().sort(-1).values
+            assert float((a != b).any(-1).float().mean()) < 0.05, i
+    ref, grads = MO.train_step(batch, V, MO.AdamTF(), 0, N, B, k=k, nn_override=gpu_idx)
+    for key in ("xyz_loss", "trans_loss", "axag_loss"):
+        assert abs(float(out[key].detach()) - float(ref[key])) <= 1e-5 * max(1.0, abs(float(ref[key]))), key
+    assert _rel(out["xyz_recon"], ref["xyz_recon"]) < 1e-4
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    for name, g in grads.items():
+        got = graph.store.vars[name].grad.cpu()
+        if name.endswith("/biases") and (name.rsplit("/", 1)[0] + "/bn/beta") in grads:
+            assert float(got.abs().max()) < 1e-3 * gmax + 1e-4, name
+            continue
+        if N > 1024 and name.startswith("dgcnn_output"):
+            # 16384 x 16384 Chamfer pairs: a handful of nearest-neighbour assignments sit on 1e-7
+            # near-ties and flip, which moves one point's whole gradient to another column of this
+            # layer -- a discrete change for those columns, invisible in the norm
+            err = float((got - g).norm() / g.norm())
+            assert err < 1e-2, (name, err)
+            continue
+        assert _rel(got, g) < (5e-3 if "dgcnn" in name else 1e-3), (name, _rel(got, g))
+
+
 def test_eval_path_fps_gather(hip):
     """evaluate_cloudAAE_ycbv.py:442-452: eval-mode forward, FPS 4N->N on the reconstruction,
     gather, Chamfer against the first N target points."""
