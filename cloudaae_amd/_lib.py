@@ -77,6 +77,86 @@ def build(verbose=False):
     return LIB_PATH
 
 
+class StepPlan(object):
+    """A recorded step: the C-ABI calls (and host callbacks) of one pass through the hot path, in
+    issue order, with their arguments frozen -- device pointers included.  `replay()` re-issues them
+    on the same stream without going back through Python layers or autograd: the MI355X-native
+    stand-in for a captured graph (a hipGraph of the same ~330 kernel nodes replays SLOWER than
+    eager launches on ROCm 7.2: 5.3 ms vs 4.0 ms per step, tools/try_graph.py).
+
+    Pointers stay valid because every buffer the step allocates while recording comes from the
+    plan's arena (`empty()` below) and the arena lives as long as the plan."""
+
+    CHUNK = 256 << 20
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.entries = []          # (callable, args tuple, name or None)
+        self.chunks = []           # arena: uint8 tensors
+        self.offset = 0
+        self.bytes = 0
+        self.stream = None
+        self.foreign_ops = []      # aten kernels seen while recording (must stay empty)
+
+    # -- arena ------------------------------------------------------------------------------
+    def alloc(self, shape, dtype, device):
+        if device is not None and torch.device(device) != self.device:
+            raise HipLibraryError("plan arena is on %s, allocation asked for %s" % (self.device, device))
+        shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
+        n = 1
+        for x in shape:
+            n *= x
+        item = torch.empty((), dtype=dtype).element_size()
+        need = max(n * item, item)
+        padded = (need + 255) // 256 * 256
+        if not self.chunks or self.offset + padded > self.chunks[-1].numel():
+            self.chunks.append(torch.empty(max(padded, self.CHUNK), dtype=torch.uint8, device=self.device))
+            self.offset = 0
+        view = self.chunks[-1][self.offset:self.offset + max(n, 1) * item].view(dtype)
+        self.offset += padded
+        self.bytes += padded
+        return view[:n].view(shape) if n else view[:0].view(shape)
+
+    # -- replay -----------------------------------------------------------------------------
+    def replay(self):
+        if stream() != self.stream:
+            raise HipLibraryError("a recorded step must be replayed on the stream it was recorded on")
+        for fn, args, name in self.entries:
+            rc = fn(*args)
+            if name is not None and rc != 0:
+                check(rc, name)
+
+
+_recording = None       # the StepPlan being recorded (module-global: the autograd thread sees it too)
+
+
+class _Entry(object):
+    """One launching entry point: calls through, and appends itself to the plan being recorded."""
+    __slots__ = ("fn", "name")
+
+    def __init__(self, fn, name):
+        self.fn, self.name = fn, name
+
+    def __call__(self, *args):
+        rc = self.fn(*args)
+        if _recording is not None:
+            _recording.entries.append((self.fn, args, self.name))
+        return rc
+
+
+class _Library(object):
+    """What lib() returns: attribute access gives the ctypes function (non-launching queries) or
+    its recording wrapper (everything in _SIGNATURES)."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        for fn in _SIGNATURES:
+            setattr(self, fn, _Entry(getattr(cdll, fn), fn))
+
+    def __getattr__(self, name):          # only reached for names not set above
+        return getattr(self._cdll, name)
+
+
 def lib():
     """The loaded library.  torch is imported first so that the HIP runtime torch
     ships (SONAME libamdhip64.so.7) is the one the library binds to -- one runtime
@@ -87,19 +167,92 @@ def lib():
             raise HipLibraryError(
                 "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C cloudaae_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
-        _lib = ctypes.CDLL(LIB_PATH)
-        _lib.cloudaae_last_error.restype = ctypes.c_char_p
+        cdll = ctypes.CDLL(LIB_PATH)
+        cdll.cloudaae_last_error.restype = ctypes.c_char_p
         for fn, sig in _SIGNATURES.items():
-            f = getattr(_lib, fn)
+            f = getattr(cdll, fn)
             f.argtypes = sig
             f.restype = ctypes.c_int
         for fn in _LONGLONG_RESULTS:
-            getattr(_lib, fn).restype = ctypes.c_longlong
-        _lib.cloudaae_hpr_workspace_bytes.restype = ctypes.c_longlong
-        _lib.cloudaae_hpr_workspace_bytes.argtypes = [_I, _I]
-        _lib.cloudaae_bn_workspace_bytes.argtypes = [_I]
-        _lib.cloudaae_edgeconv_workspace_bytes.argtypes = [_I]
+            getattr(cdll, fn).restype = ctypes.c_longlong
+        cdll.cloudaae_hpr_workspace_bytes.restype = ctypes.c_longlong
+        cdll.cloudaae_hpr_workspace_bytes.argtypes = [_I, _I]
+        cdll.cloudaae_bn_workspace_bytes.argtypes = [_I]
+        cdll.cloudaae_edgeconv_workspace_bytes.argtypes = [_I]
+        _lib = _Library(cdll)
     return _lib
+
+
+class record(object):
+    """`with record(plan): step()` -- every launching C-ABI call and host() callback of the block
+    goes into `plan`, every empty() comes from its arena, and any OTHER GPU kernel torch launches
+    in the block (on this thread or the autograd thread) is noted in plan.foreign_ops: such a step
+    cannot be replayed faithfully, and the caller refuses it."""
+
+    def __init__(self, plan):
+        self.plan = plan
+        self.mode = None
+
+    def __enter__(self):
+        global _recording
+        if _recording is not None:
+            raise HipLibraryError("nested step recording")
+        self.plan.stream = stream()
+        _recording = self.plan
+        self.mode = _ForeignOps(self.plan)
+        self.mode.__enter__()
+        return self.plan
+
+    def __exit__(self, *exc):
+        global _recording
+        self.mode.__exit__(*exc)
+        _recording = None
+        return False
+
+
+def recording():
+    return _recording
+
+
+def host(fn, *args):
+    """Run a host-side callback now and, while recording, at the same position of every replay
+    (event records of bench.py, the early gradient all-reduce)."""
+    fn(*args)
+    if _recording is not None:
+        _recording.entries.append((fn, args, None))
+
+
+def empty(shape, dtype=torch.float32, device=None):
+    """torch.empty, or a slice of the recording plan's arena (stable address across replays)."""
+    if _recording is None:
+        return torch.empty(shape, dtype=dtype, device=device)
+    return _recording.alloc(shape, dtype, device)
+
+
+def empty_like(t):
+    return empty(t.shape, t.dtype, t.device)
+
+
+from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
+
+# aten ops that touch no device memory (views, metadata) or only allocate
+_HARMLESS = ("aten.view", "aten._unsafe_view", "aten.reshape", "aten.detach", "aten.alias", "aten.slice",
+             "aten.select", "aten.squeeze", "aten.unsqueeze", "aten.expand", "aten.transpose", "aten.t.",
+             "aten.permute", "aten.as_strided", "aten.empty", "aten.new_empty", "aten.empty_like",
+             "aten.empty_strided", "aten.lift_fresh", "aten.sym_", "aten.is_", "aten.unbind", "aten.split",
+             "aten.narrow", "aten._reshape_alias", "aten.view_as")
+
+
+class _ForeignOps(TorchDispatchMode):
+    def __init__(self, plan):
+        super().__init__()
+        self.plan = plan
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not name.startswith(_HARMLESS) and any(isinstance(a, torch.Tensor) and a.is_cuda for a in args):
+            self.plan.foreign_ops.append(name)      # a kernel (or a sync) the plan would not replay
+        return func(*args, **(kwargs or {}))
 
 
 def check(rc, what):
@@ -109,7 +262,8 @@ def check(rc, what):
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t of torch's current stream on the current device."""
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def ptr(t):

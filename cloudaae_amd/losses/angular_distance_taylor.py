@@ -31,6 +31,6 @@ def exponential_map(axag, EPS=1e-2):
     require(EPS == 1e-2, "exponential_map: the kernel implements the reference's EPS = 1e-2")
     a = axag.detach().to(torch.float64).contiguous()
     B = a.shape[0]
-    R = torch.empty((B, 3, 3), dtype=torch.float64, device=a.device)
+    R = _lib.empty((B, 3, 3), dtype=torch.float64, device=a.device)
     _lib.check(_lib.lib().cloudaae_exponential_map(B, ptr(a), ptr(R), stream()), "cloudaae_exponential_map")
     return R

@@ -18,6 +18,8 @@ reference's op-by-op graph; the arithmetic definition is the reference's
 """
 import torch
 
+from .. import _lib
+from ..utils import _functions as F
 from ..utils import tf_util
 
 
@@ -29,7 +31,8 @@ def _dgcnn_encoder(point_cloud, is_training_pl_encoder, k, bn_decay, pool, prefi
     # net1..net4 are written as adjacent channel slices of ONE [B,N,320] buffer: that is the
     # tf.concat([net1, net2, net3, net4], axis=-1) of :410 without a copy
     widths = (64, 64, 64, 128)
-    concat = torch.empty((batch_size, num_point, sum(widths)), dtype=torch.float32, device=point_cloud.device)
+    slot = F.ConcatSlot(_lib.empty((batch_size, num_point, sum(widths)), dtype=torch.float32,
+                                   device=point_cloud.device))
     net = point_cloud                      # [B,N,C]; kNN metric = xyz slice (tf_util.py:608)
     nets, off = [], 0
     for i, width in enumerate(widths):
@@ -39,11 +42,12 @@ def _dgcnn_encoder(point_cloud, is_training_pl_encoder, k, bn_decay, pool, prefi
             nn_out.append(nn_idx)
         net = tf_util.edge_conv(net, nn_idx, width, scope='%sdgcnn%d' % (prefix, i + 1), pool=pool,
                                 bn_decay=bn_decay, is_training=is_training_pl_encoder,
-                                out_slot=(concat, off))      # [B,N,1,width]
+                                out_slot=(slot, off),         # [B,N,1,width]
+                                in_slot=(slot, off - widths[i - 1]) if i > 0 else None)
         nets.append(net)
         off += width
     return tf_util.conv2d_concat(nets, 1024, scope=prefix + 'dgcnn_agg', bn_decay=bn_decay,
-                                 is_training=is_training_pl_encoder, pool=pool)
+                                 is_training=is_training_pl_encoder, pool=pool, slot=slot)
 
 
 def _decoder(net, out_units, is_training, bn_decay, prefix=''):
@@ -57,12 +61,14 @@ def _decoder(net, out_units, is_training, bn_decay, prefix=''):
 
 
 def _pose_heads(embedding, is_training, bn_decay, prefix=''):
+    # two consumers: the sum of their input gradients is made by our add kernel (F.FanOutFn)
+    embedding, emb_trans = F.FanOutFn.apply(embedding, 2)
     net_rot, _, _ = tf_util.fully_connected(embedding, 512, bn=True, is_training=is_training,
                                             scope=prefix + 'dgcnn_rot_fc1', bn_decay=bn_decay)
     net_rot, _, _ = tf_util.fully_connected(net_rot, 256, bn=True, is_training=is_training,
                                             scope=prefix + 'dgcnn_rot_fc2', bn_decay=bn_decay)
     net_rot, _, _ = tf_util.fully_connected(net_rot, 3, activation_fn=None, scope=prefix + 'dgcnn_output_rot')
-    net_trans, _, _ = tf_util.fully_connected(embedding, 512, bn=True, is_training=is_training,
+    net_trans, _, _ = tf_util.fully_connected(emb_trans, 512, bn=True, is_training=is_training,
                                               scope=prefix + 'dgcnn_trans_fc1', bn_decay=bn_decay)
     net_trans, _, _ = tf_util.fully_connected(net_trans, 256, bn=True, is_training=is_training,
                                               scope=prefix + 'dgcnn_trans_fc2', bn_decay=bn_decay)
@@ -82,9 +88,10 @@ def _dgcnn_6d(point_cloud, is_training_pl_encoder, is_training, k_neighbor, bn_d
     end_points['layer_before_embedding'] = before          # lazy [B,N,1,1024] (see LazyActivation)
     end_points['embedding'] = embedding                    # [B,1024]
     mult, dim = point_out
-    net = _decoder(embedding, num_point * mult * dim, is_training, bn_decay, prefix)
+    emb_dec, emb_pose = F.FanOutFn.apply(embedding, 2)
+    net = _decoder(emb_dec, num_point * mult * dim, is_training, bn_decay, prefix)
     net_recon = net.reshape(batch_size, num_point * mult, dim)
-    net_rot, net_trans = _pose_heads(embedding, is_training, bn_decay, prefix)
+    net_rot, net_trans = _pose_heads(emb_pose, is_training, bn_decay, prefix)
     return net_recon, net_rot, net_trans, end_points
 
 
@@ -176,8 +183,9 @@ def get_model_pn(point_cloud, is_training, bn_decay=None):
                                          is_training=is_training, pool='max')
     end_points['embedding'] = embedding
 
+    emb_dec, emb_rot, emb_trans = F.FanOutFn.apply(embedding, 3)     # three consumers, one summed gradient
     # FC Decoder
-    net, _, _ = tf_util.fully_connected(embedding, 1024, bn=True, is_training=is_training,
+    net, _, _ = tf_util.fully_connected(emb_dec, 1024, bn=True, is_training=is_training,
                                         scope='pn_fc1_decoder', bn_decay=bn_decay)
     net, _, _ = tf_util.fully_connected(net, 1024, bn=True, is_training=is_training,
                                         scope='pn_fc2_decoder', bn_decay=bn_decay)
@@ -186,13 +194,13 @@ def get_model_pn(point_cloud, is_training, bn_decay=None):
     net_recon = net.reshape(batch_size, num_point * 4, 3)
 
     # 6d pose
-    net_rot, _, _ = tf_util.fully_connected(embedding, 512, bn=True, is_training=is_training,
+    net_rot, _, _ = tf_util.fully_connected(emb_rot, 512, bn=True, is_training=is_training,
                                             scope='pn_rot_fc1', bn_decay=bn_decay)
     net_rot, _, _ = tf_util.fully_connected(net_rot, 256, bn=True, is_training=is_training,
                                             scope='pn_rot_fc2', bn_decay=bn_decay)
     net_rot, _, _ = tf_util.fully_connected(net_rot, 3, activation_fn=None, scope='pn_output_rot')
 
-    net_trans, _, _ = tf_util.fully_connected(embedding, 512, bn=True, is_training=is_training,
+    net_trans, _, _ = tf_util.fully_connected(emb_trans, 512, bn=True, is_training=is_training,
                                               scope='pn_trans_fc1', bn_decay=bn_decay)
     net_trans, _, _ = tf_util.fully_connected(net_trans, 256, bn=True, is_training=is_training,
                                               scope='pn_trans_fc2', bn_decay=bn_decay)

@@ -27,10 +27,10 @@ class _NnDistance(torch.autograd.Function):
         xyz2 = xyz2.contiguous()
         b, n, _ = xyz1.shape
         m = xyz2.shape[1]
-        dist1 = torch.empty((b, n), dtype=torch.float32, device=xyz1.device)
-        idx1 = torch.empty((b, n), dtype=torch.int32, device=xyz1.device)
-        dist2 = torch.empty((b, m), dtype=torch.float32, device=xyz1.device)
-        idx2 = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+        dist1 = _lib.empty((b, n), dtype=torch.float32, device=xyz1.device)
+        idx1 = _lib.empty((b, n), dtype=torch.int32, device=xyz1.device)
+        dist2 = _lib.empty((b, m), dtype=torch.float32, device=xyz1.device)
+        idx2 = _lib.empty((b, m), dtype=torch.int32, device=xyz1.device)
         _lib.check(_lib.lib().cloudaae_nn_distance(b, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1),
                                                    ptr(idx1), ptr(dist2), ptr(idx2), stream()),
                    "cloudaae_nn_distance")
@@ -49,8 +49,8 @@ class _NnDistance(torch.autograd.Function):
             grad_dist1 = torch.zeros((b, n), dtype=torch.float32, device=xyz1.device)
         if grad_dist2 is None:
             grad_dist2 = torch.zeros((b, m), dtype=torch.float32, device=xyz1.device)
-        g1 = torch.empty_like(xyz1) if need1 else None
-        g2 = torch.empty_like(xyz2) if need2 else None
+        g1 = _lib.empty_like(xyz1) if need1 else None
+        g2 = _lib.empty_like(xyz2) if need2 else None
         _lib.check(_lib.lib().cloudaae_nn_distance_grad(
             b, n, ptr(xyz1), m, ptr(xyz2), ptr(grad_dist1.contiguous()), ptr(idx1),
             ptr(grad_dist2.contiguous()), ptr(idx2), ptr(g1), ptr(g2), stream()),
@@ -84,8 +84,8 @@ def nn_distance_grad(xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2):
     require(tuple(idx2.shape) == (b, m), "NnDistanceGrad requires idx2 be of shape(batch,#points)")
     require(idx1.dtype == torch.int32 and idx2.dtype == torch.int32, "idx must be int32")
     xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
-    g1 = torch.empty_like(xyz1)
-    g2 = torch.empty_like(xyz2)
+    g1 = _lib.empty_like(xyz1)
+    g2 = _lib.empty_like(xyz2)
     _lib.check(_lib.lib().cloudaae_nn_distance_grad(
         b, n, ptr(xyz1), m, ptr(xyz2), ptr(grad_dist1.contiguous()), ptr(idx1.contiguous()),
         ptr(grad_dist2.contiguous()), ptr(idx2.contiguous()), ptr(g1), ptr(g2), stream()),

@@ -14,7 +14,7 @@ L = _lib.lib
 
 
 def _ws(nbytes, device):
-    return torch.empty((int(nbytes) + 7) // 8, dtype=torch.float64, device=device)
+    return _lib.empty((int(nbytes) + 7) // 8, dtype=torch.float64, device=device)
 
 
 def _var(t):
@@ -34,34 +34,38 @@ class _ParamGrad(object):
             self.buf = self.var.grad
             self.accumulate = 0 if self.var.fresh else 1
         else:
-            self.own = torch.empty(param.shape, dtype=torch.float32, device=param.device)
+            self.own = _lib.empty(param.shape, dtype=torch.float32, device=param.device)
             self.buf, self.accumulate = self.own, 0
 
     def done(self):
         if self.var is not None and self.var.grad is not None:
             self.var.fresh = False
             if self.var.on_ready is not None:
-                self.var.on_ready()
+                _lib.host(self.var.on_ready)
             return None
         return self.own
 
 
-# bench.py times individual launches: TIMED_SITES[name] = [] switches a site on; each launch
-# of that site then appends a (start, end) HIP event pair recorded on the launch stream.
+# bench.py times individual launches: TIMED_SITES[name] = [] switches a site on; each launch of
+# that site then appends a start and an end HIP event (recorded on the launch stream) to the list
+# -- also on every replay of a recorded step, where the two records are host callbacks of the plan.
 TIMED_SITES = {}
+
+
+def _mark(rec):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    rec.append(e)
 
 
 def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, accumulate=0, site=None):
     rec = TIMED_SITES.get(site) if site is not None else None
     if rec is not None:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+        _lib.host(_mark, rec)
     _lib.check(L().cloudaae_gemm_f32(int(ta), int(tb), M, N, K, A, lda, B, ldb, C, ldc, bias, int(accumulate),
                                      stream()), "cloudaae_gemm_f32")
     if rec is not None:
-        e1.record()
-        rec.append((e0, e1))
+        _lib.host(_mark, rec)
 
 
 class LinearFn(torch.autograd.Function):
@@ -73,7 +77,7 @@ class LinearFn(torch.autograd.Function):
         xp, ldx = rows_ptr(x)
         M, K = x.shape
         N = w.shape[1]
-        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        y = _lib.empty((M, N), dtype=torch.float32, device=x.device)
         gemm(0, 0, M, N, K, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None)
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
@@ -90,7 +94,7 @@ class LinearFn(torch.autograd.Function):
         xp, ldx = rows_ptr(x)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
+            dx = _lib.empty((M, K), dtype=torch.float32, device=x.device)
             gemm(0, 1, M, K, N, dyp, lddy, ptr(w), N, ptr(dx), K)
         gw = _ParamGrad(w, ctx.needs_input_grad[1])
         if gw.needed:
@@ -105,6 +109,18 @@ class LinearFn(torch.autograd.Function):
         return dx, gw.done(), gb_ret
 
 
+class ConcatSlot(object):
+    """The one [B,N,Ctot] buffer the encoder's layer outputs are written into as column slices
+    (the tf.concat of models/...:410 without a copy) and, in backward, its gradient twin: the agg
+    GEMM deposits d(concat) here, and each edge-conv layer whose INPUT is a slice accumulates its dx
+    straight into that slice -- the sum autograd would otherwise make with an extra add kernel per
+    layer (and which a recorded step could not replay)."""
+
+    def __init__(self, buf):
+        self.buf = buf
+        self.dcat = None
+
+
 class ConcatLinearFn(torch.autograd.Function):
     """Linear over the channel-concatenation of several [M,Ci] inputs
     (models/pointnet_ycb_23_decoder_4.py:410: conv2d(tf.concat([net1..net4], -1))).
@@ -113,8 +129,9 @@ class ConcatLinearFn(torch.autograd.Function):
     column slices of one [M, sum Ci] buffer."""
 
     @staticmethod
-    def forward(ctx, w, b, *nets):
+    def forward(ctx, slot, w, b, *nets):
         M = nets[0].shape[0]
+        ctx.slot = slot
         widths = [t.shape[1] for t in nets]
         Ktot = sum(widths)
         require(w.shape[0] == Ktot, "ConcatLinearFn: weight rows != total input channels")
@@ -133,7 +150,7 @@ class ConcatLinearFn(torch.autograd.Function):
             xp, ldx = cat.data_ptr(), Ktot
             ctx.cat = cat
         N = w.shape[1]
-        y = torch.empty((M, N), dtype=torch.float32, device=w.device)
+        y = _lib.empty((M, N), dtype=torch.float32, device=w.device)
         gemm(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, site="agg_fwd")
         ctx.save_for_backward(w, *nets)
         ctx.widths, ctx.xp, ctx.bvar = widths, xp, b
@@ -148,14 +165,16 @@ class ConcatLinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         xp = ctx.cat.data_ptr() if ctx.cat is not None else ctx.xp
         dcat = None
-        if any(ctx.needs_input_grad[2:]):
-            dcat = torch.empty((M, Ktot), dtype=torch.float32, device=w.device)
+        if any(ctx.needs_input_grad[3:]):
+            dcat = _lib.empty((M, Ktot), dtype=torch.float32, device=w.device)
             gemm(0, 1, M, Ktot, N, ptr(dy), N, ptr(w), N, ptr(dcat), Ktot)
-        gw = _ParamGrad(w, ctx.needs_input_grad[0])
+            if ctx.slot is not None and ctx.cat is None:
+                ctx.slot.dcat = dcat
+        gw = _ParamGrad(w, ctx.needs_input_grad[1])
         if gw.needed:
             gemm(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.accumulate)
         gb_ret = None
-        if ctx.bvar is not None and ctx.needs_input_grad[1]:
+        if ctx.bvar is not None and ctx.needs_input_grad[2]:
             gb = _ParamGrad(ctx.bvar, True)
             ws = _ws(L().cloudaae_bn_workspace_bytes(N), w.device)
             _lib.check(L().cloudaae_colsum_f32(M, N, ptr(dy), N, ptr(gb.buf), gb.accumulate, ptr(ws), stream()),
@@ -163,9 +182,9 @@ class ConcatLinearFn(torch.autograd.Function):
             gb_ret = gb.done()
         grads, off = [], 0
         for i, wd in enumerate(ctx.widths):
-            grads.append(dcat[:, off:off + wd] if (dcat is not None and ctx.needs_input_grad[2 + i]) else None)
+            grads.append(dcat[:, off:off + wd] if (dcat is not None and ctx.needs_input_grad[3 + i]) else None)
             off += wd
-        return (gw.done(), gb_ret) + tuple(grads)
+        return (None, gw.done(), gb_ret) + tuple(grads)
 
 
 class BatchNormFn(torch.autograd.Function):
@@ -179,14 +198,14 @@ class BatchNormFn(torch.autograd.Function):
         yp, ldy = rows_ptr(y)
         M, C = y.shape
         dev = y.device
-        save_mean = torch.empty(C, dtype=torch.float32, device=dev)
-        save_var = torch.empty(C, dtype=torch.float32, device=dev)
-        out = torch.empty((M, C), dtype=torch.float32, device=dev) if (want_activation or pool_mode == 0) else None
+        save_mean = _lib.empty(C, dtype=torch.float32, device=dev)
+        save_var = _lib.empty(C, dtype=torch.float32, device=dev)
+        out = _lib.empty((M, C), dtype=torch.float32, device=dev) if (want_activation or pool_mode == 0) else None
         pooled = ties = None
         if pool_mode != 0:
-            pooled = torch.empty((M // pool_rows, C), dtype=torch.float32, device=dev)
+            pooled = _lib.empty((M // pool_rows, C), dtype=torch.float32, device=dev)
             if pool_mode == 2:
-                ties = torch.empty_like(pooled)
+                ties = _lib.empty_like(pooled)
         ws = _ws(L().cloudaae_bn_workspace_bytes(C), dev)
         _lib.check(L().cloudaae_bn_forward(
             M, C, yp, ldy, ptr(gamma), ptr(beta), int(training), ptr(decay), ptr(ema_mean), ptr(ema_var),
@@ -219,7 +238,7 @@ class BatchNormFn(torch.autograd.Function):
             dpooled = torch.zeros_like(pooled) if dpooled is None else dpooled.contiguous()
         if dout is None and pool_mode == 0:
             return (None,) * 11
-        dy = torch.empty((M, C), dtype=torch.float32, device=y.device)
+        dy = _lib.empty((M, C), dtype=torch.float32, device=y.device)
         gg = _ParamGrad(gamma, ctx.needs_input_grad[1])
         gb = _ParamGrad(beta, ctx.needs_input_grad[2])
         acc = 1 if (gg.accumulate or gb.accumulate) else 0
@@ -237,7 +256,8 @@ class EdgeConvFn(torch.autograd.Function):
     """Fused get_edge_feature + conv2d(1x1)+bias + batch norm + ReLU + pool over k."""
 
     @staticmethod
-    def forward(ctx, x, nn_idx, w, b, gamma, beta, ema_mean, ema_var, decay, training, pool_mode, out_slot):
+    def forward(ctx, x, nn_idx, w, b, gamma, beta, ema_mean, ema_var, decay, training, pool_mode, out_slot,
+                in_slot=None):
         # x: [B, N, Cin] whose rows are contiguous (row stride may exceed Cin)
         B, N, cin = x.shape
         require(x.stride(2) == 1 and x.stride(0) == N * x.stride(1), "EdgeConvFn: x rows must be contiguous")
@@ -249,20 +269,22 @@ class EdgeConvFn(torch.autograd.Function):
         dev = x.device
         nn_idx = nn_idx.contiguous()
         if out_slot is None:
-            out = torch.empty((B, N, cout), dtype=torch.float32, device=dev)
+            out = _lib.empty((B, N, cout), dtype=torch.float32, device=dev)
         else:
             # (buffer [B,N,Ctot], channel offset): the output is written in place as a
             # column slice of a wider row-major buffer (saves the later concat copy).
             # The view is created HERE so autograd sees a fresh output, not an input.
             buf, off = out_slot
+            if isinstance(buf, ConcatSlot):
+                buf = buf.buf
             out = buf[:, :, off:off + cout]
             require(tuple(out.shape) == (B, N, cout) and out.stride(2) == 1 and
                     out.stride(0) == N * out.stride(1), "EdgeConvFn: bad output slot")
         ldo = out.stride(1)
-        pq = torch.empty((B * N, 2 * cout), dtype=torch.float32, device=dev)
-        save_mean = torch.empty(cout, dtype=torch.float32, device=dev)
-        save_var = torch.empty(cout, dtype=torch.float32, device=dev)
-        ties = torch.empty((B * N, cout), dtype=torch.float32, device=dev) if pool_mode == 2 else None
+        pq = _lib.empty((B * N, 2 * cout), dtype=torch.float32, device=dev)
+        save_mean = _lib.empty(cout, dtype=torch.float32, device=dev)
+        save_var = _lib.empty(cout, dtype=torch.float32, device=dev)
+        ties = _lib.empty((B * N, cout), dtype=torch.float32, device=dev) if pool_mode == 2 else None
         ws = _ws(L().cloudaae_edgeconv_workspace_bytes(cout), dev)
         _lib.check(L().cloudaae_edgeconv_forward(
             B, N, k, cin, cout, x.data_ptr(), ldx, ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
@@ -271,6 +293,12 @@ class EdgeConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, nn_idx, w, b, gamma, beta, pq, save_mean, save_var, ties,
                               out if pool_mode == 2 else None)
         ctx.cfg = (int(training), int(pool_mode))
+        # x is a column slice of a ConcatSlot buffer: backward may add dx into the slot's gradient twin
+        ctx.in_slot = None
+        if in_slot is not None and isinstance(in_slot[0], ConcatSlot):
+            slot, ioff = in_slot
+            if x.data_ptr() == slot.buf.data_ptr() + 4 * ioff and ldx == slot.buf.shape[2]:
+                ctx.in_slot = (slot, int(ioff))
         return out
 
     @staticmethod
@@ -283,9 +311,18 @@ class EdgeConvFn(torch.autograd.Function):
         dev = x.device
         if not (dout.stride(2) == 1 and dout.stride(0) == N * dout.stride(1)):
             dout = dout.contiguous()
-        dpq = torch.empty((B * N, 2 * cout), dtype=torch.float32, device=dev)
-        rev = torch.empty(B * (N + 1) + B * N * k, dtype=torch.int32, device=dev)
-        dx = torch.empty((B, N, cin), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dpq = _lib.empty((B * N, 2 * cout), dtype=torch.float32, device=dev)
+        rev = _lib.empty(B * (N + 1) + B * N * k, dtype=torch.int32, device=dev)
+        dx, dx_ptr, lddx, acc_dx = None, None, cin, 0
+        if ctx.needs_input_grad[0]:
+            slot = ctx.in_slot[0] if ctx.in_slot is not None else None
+            if slot is not None and slot.dcat is not None:
+                # the agg GEMM's d(concat) already holds this slice's other gradient: add ours in place
+                lddx = slot.dcat.shape[1]
+                dx_ptr, acc_dx = slot.dcat.data_ptr() + 4 * ctx.in_slot[1], 1
+            else:
+                dx = _lib.empty((B, N, cin), dtype=torch.float32, device=dev)
+                dx_ptr = dx.data_ptr()
         gw = _ParamGrad(w, ctx.needs_input_grad[2])
         gb = _ParamGrad(b, ctx.needs_input_grad[3])
         gg = _ParamGrad(gamma, ctx.needs_input_grad[4])
@@ -295,19 +332,40 @@ class EdgeConvFn(torch.autograd.Function):
         tmp = {}
         for g in shared:
             tmp[id(g)] = g.buf
-            g.buf = torch.empty_like(g.buf)
+            g.buf = _lib.empty_like(g.buf)
         ws = _ws(L().cloudaae_edgeconv_workspace_bytes(cout), dev)
         _lib.check(L().cloudaae_edgeconv_backward(
             B, N, k, cin, cout, x.data_ptr(), x.stride(1), ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
             training, pool_mode, ptr(pq), ptr(save_mean), ptr(save_var),
             fwd_out.data_ptr() if fwd_out is not None else None, fwd_out.stride(1) if fwd_out is not None else 0,
-            ptr(ties), dout.data_ptr(), dout.stride(1), ptr(dpq), ptr(rev), ptr(dx), cin, 0, ptr(gw.buf),
+            ptr(ties), dout.data_ptr(), dout.stride(1), ptr(dpq), ptr(rev), dx_ptr, lddx, acc_dx, ptr(gw.buf),
             ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), ptr(ws), stream()),
             "cloudaae_edgeconv_backward")
         for g in shared:
             L().cloudaae_add_f32(g.buf.numel(), ptr(tmp[id(g)]), ptr(g.buf), ptr(tmp[id(g)]), stream())
             g.buf = tmp[id(g)]
-        return (dx, None, gw.done(), gb.done(), gg.done(), gbe.done()) + (None,) * 6
+        return (dx, None, gw.done(), gb.done(), gg.done(), gbe.done()) + (None,) * 7
+
+
+class FanOutFn(torch.autograd.Function):
+    """n aliases of one tensor for n consumers; the gradients are summed HERE by our add kernel.
+    (Autograd would sum them with its own kernel, which a recorded step cannot replay.)"""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g if g.is_contiguous() else g.contiguous() for g in grads if g is not None]
+        if not gs:
+            return None, None
+        acc = gs[0]
+        for g in gs[1:]:
+            out = _lib.empty_like(acc)
+            _lib.check(L().cloudaae_add_f32(acc.numel(), ptr(acc), ptr(g), ptr(out), stream()), "cloudaae_add_f32")
+            acc = out
+        return acc, None
 
 
 class AddRowVecFn(torch.autograd.Function):
@@ -319,7 +377,7 @@ class AddRowVecFn(torch.autograd.Function):
         x = x.contiguous()
         v = v.contiguous()
         B, R, D = x.shape
-        out = torch.empty_like(x)
+        out = _lib.empty_like(x)
         _lib.check(L().cloudaae_add_rowvec(B, R, D, ptr(x), ptr(v), ptr(out), stream()), "cloudaae_add_rowvec")
         return out
 
@@ -333,7 +391,7 @@ class AddFn(torch.autograd.Function):
     def forward(ctx, a, b):
         a, b = a.contiguous(), b.contiguous()
         require(a.shape == b.shape, "AddFn: shapes differ (chamfer_loss.py:12 needs n == m)")
-        out = torch.empty_like(a)
+        out = _lib.empty_like(a)
         _lib.check(L().cloudaae_add_f32(a.numel(), ptr(a), ptr(b), ptr(out), stream()), "cloudaae_add_f32")
         return out
 
@@ -348,7 +406,7 @@ class MeanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         x = x.contiguous()
-        out = torch.empty((), dtype=torch.float32, device=x.device)
+        out = _lib.empty((), dtype=torch.float32, device=x.device)
         ws = _ws(L().cloudaae_mean_workspace_bytes(), x.device)
         _lib.check(L().cloudaae_mean_f32(x.numel(), ptr(x), ptr(out), ptr(ws), stream()), "cloudaae_mean_f32")
         ctx.shape = x.shape
@@ -359,7 +417,7 @@ class MeanFn(torch.autograd.Function):
         n = 1
         for s in ctx.shape:
             n *= s
-        out = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        out = _lib.empty(ctx.shape, dtype=torch.float32, device=g.device)
         _lib.check(L().cloudaae_fill_scaled(n, ptr(g.contiguous()), 1.0 / n, None, ptr(out), stream()),
                    "cloudaae_fill_scaled")
         return out
@@ -370,7 +428,7 @@ class TransErrorFn(torch.autograd.Function):
     def forward(ctx, pred, label):
         pred, label = pred.contiguous(), label.contiguous()
         B = pred.shape[0]
-        per = torch.empty(B, dtype=torch.float32, device=pred.device)
+        per = _lib.empty(B, dtype=torch.float32, device=pred.device)
         _lib.check(L().cloudaae_trans_error(B, ptr(pred), ptr(label), ptr(per), stream()), "cloudaae_trans_error")
         ctx.save_for_backward(pred, label, per)
         return per
@@ -378,7 +436,7 @@ class TransErrorFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gper):
         pred, label, per = ctx.saved_tensors
-        d = torch.empty_like(pred)
+        d = _lib.empty_like(pred)
         _lib.check(L().cloudaae_trans_error_grad(pred.shape[0], ptr(pred), ptr(label), ptr(per),
                                                  ptr(gper.contiguous()), ptr(d), stream()),
                    "cloudaae_trans_error_grad")
@@ -395,9 +453,9 @@ class RotationErrorFn(torch.autograd.Function):
         pred = pred.contiguous()
         label = label.to(torch.float64).contiguous()
         B = pred.shape[0]
-        per = torch.empty(B, dtype=torch.float64, device=pred.device)
-        jac = torch.empty((B, 3), dtype=torch.float64, device=pred.device)
-        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        per = _lib.empty(B, dtype=torch.float64, device=pred.device)
+        jac = _lib.empty((B, 3), dtype=torch.float64, device=pred.device)
+        loss = _lib.empty((), dtype=torch.float32, device=pred.device)
         _lib.check(L().cloudaae_rotation_error(B, ptr(pred), ptr(label), ptr(per), ptr(jac), ptr(loss), stream()),
                    "cloudaae_rotation_error")
         ctx.save_for_backward(jac)
@@ -410,7 +468,7 @@ class RotationErrorFn(torch.autograd.Function):
         if gloss is None:
             return None, None
         B = jac.shape[0]
-        d = torch.empty((B, 3), dtype=torch.float32, device=jac.device)
+        d = _lib.empty((B, 3), dtype=torch.float32, device=jac.device)
         _lib.check(L().cloudaae_rotation_error_grad(B, ptr(jac), ptr(gloss.contiguous()), ptr(d), stream()),
                    "cloudaae_rotation_error_grad")
         return d, None
@@ -421,7 +479,7 @@ class LossMixFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b, c, w0, w1, w2):
-        out = torch.empty((), dtype=torch.float32, device=a.device)
+        out = _lib.empty((), dtype=torch.float32, device=a.device)
         _lib.check(L().cloudaae_loss_mix(ptr(a), ptr(b), ptr(c), w0, w1, w2, ptr(out), stream()),
                    "cloudaae_loss_mix")
         ctx.w = (w0, w1, w2)
@@ -429,7 +487,7 @@ class LossMixFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        ga, gb, gc = (torch.empty((), dtype=torch.float32, device=g.device) for _ in range(3))
+        ga, gb, gc = (_lib.empty((), dtype=torch.float32, device=g.device) for _ in range(3))
         _lib.check(L().cloudaae_loss_mix_grad(ptr(g.contiguous()), ctx.w[0], ctx.w[1], ctx.w[2], ptr(ga), ptr(gb),
                                               ptr(gc), stream()), "cloudaae_loss_mix_grad")
         return ga, gb, gc, None, None, None
@@ -444,7 +502,7 @@ class EdgeFeatureFn(torch.autograd.Function):
         require(x.stride(2) == 1 and (B == 1 or x.stride(0) == N * x.stride(1)), "EdgeFeatureFn: x rows must be contiguous")
         nn_idx = nn_idx.contiguous()
         k = nn_idx.shape[2]
-        out = torch.empty((B, N, k, (2 if with_center else 1) * C), dtype=torch.float32, device=x.device)
+        out = _lib.empty((B, N, k, (2 if with_center else 1) * C), dtype=torch.float32, device=x.device)
         _lib.check(L().cloudaae_edge_feature(B, N, k, C, int(with_center), x.data_ptr(), x.stride(1), ptr(nn_idx),
                                              ptr(out), stream()), "cloudaae_edge_feature")
         ctx.save_for_backward(nn_idx)
@@ -455,7 +513,7 @@ class EdgeFeatureFn(torch.autograd.Function):
     def backward(ctx, g):
         (nn_idx,) = ctx.saved_tensors
         B, N, k, C, wc = ctx.cfg
-        dx = torch.empty((B, N, C), dtype=torch.float32, device=g.device)
+        dx = _lib.empty((B, N, C), dtype=torch.float32, device=g.device)
         _lib.check(L().cloudaae_edge_feature_grad(B, N, k, C, wc, ptr(g.contiguous()), ptr(nn_idx), ptr(dx), stream()),
                    "cloudaae_edge_feature_grad")
         return dx, None, None
@@ -469,8 +527,8 @@ class PoolRowsFn(torch.autograd.Function):
         x = x.contiguous()
         M, C = x.shape
         G = M // rows
-        out = torch.empty((G, C), dtype=torch.float32, device=x.device)
-        ties = torch.empty_like(out) if mode == 2 else None
+        out = _lib.empty((G, C), dtype=torch.float32, device=x.device)
+        ties = _lib.empty_like(out) if mode == 2 else None
         _lib.check(L().cloudaae_pool_rows(G, rows, C, mode, ptr(x), ptr(out), ptr(ties), stream()), "cloudaae_pool_rows")
         ctx.save_for_backward(x, out, ties)
         ctx.cfg = (G, rows, C, mode)
@@ -480,7 +538,7 @@ class PoolRowsFn(torch.autograd.Function):
     def backward(ctx, g):
         x, out, ties = ctx.saved_tensors
         G, rows, C, mode = ctx.cfg
-        dx = torch.empty_like(x)
+        dx = _lib.empty_like(x)
         _lib.check(L().cloudaae_pool_rows_grad(G, rows, C, mode, ptr(x), ptr(out), ptr(ties), ptr(g.contiguous()),
                                                ptr(dx), stream()), "cloudaae_pool_rows_grad")
         return dx, None, None
@@ -492,7 +550,7 @@ class MulAddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, c):
         a, b, c = a.contiguous(), b.contiguous(), c.contiguous()
-        out = torch.empty_like(a)
+        out = _lib.empty_like(a)
         _lib.check(L().cloudaae_mul_add_f32(a.numel(), ptr(a), ptr(b), ptr(c), ptr(out), stream()), "cloudaae_mul_add_f32")
         ctx.save_for_backward(c)
         return out
@@ -501,6 +559,6 @@ class MulAddFn(torch.autograd.Function):
     def backward(ctx, g):
         (c,) = ctx.saved_tensors
         g = g.contiguous()
-        db = torch.empty_like(g)
+        db = _lib.empty_like(g)
         _lib.check(L().cloudaae_mul_add_f32(g.numel(), None, ptr(g), ptr(c), ptr(db), stream()), "cloudaae_mul_add_f32")
         return g, db, None

@@ -282,14 +282,14 @@ def knn(adj_matrix, k=9):
     x = adj_matrix.points
     b, n, _ = x.shape
     ld = x.stride(1)
-    nn_idx = torch.empty((b, n, int(k)), dtype=torch.int32, device=x.device)
+    nn_idx = _lib.empty((b, n, int(k)), dtype=torch.int32, device=x.device)
     _lib.check(_lib.lib().cloudaae_knn(b, n, adj_matrix.channels, ld, int(k), x.data_ptr(), ptr(nn_idx),
                                        stream()), "cloudaae_knn")
     return nn_idx
 
 
 def edge_conv(point_cloud, nn_idx, num_output_channels, scope, pool='mean', bn_decay=None, is_training=None,
-              out_slot=None):
+              out_slot=None, in_slot=None):
     """Fused  get_edge_feature(point_cloud, nn_idx, k)            (tf_util.py:635-669)
               -> conv2d(., num_output_channels, [1,1], bn=True)   (tf_util.py:111-179)
               -> tf.reduce_mean / tf.reduce_max(axis=-2, keep_dims=True)
@@ -301,7 +301,8 @@ def edge_conv(point_cloud, nn_idx, num_output_channels, scope, pool='mean', bn_d
       point_cloud: (batch_size, num_points, num_dims) or (batch_size, num_points, 1, num_dims)
       nn_idx: (batch_size, num_points, k) int32
       pool: 'mean' or 'max'
-      out_slot: optional (buffer [B,N,Ctot], channel offset) to write the result into
+      out_slot: optional (buffer [B,N,Ctot] or ConcatSlot, channel offset) to write the result into
+      in_slot: optional (ConcatSlot, channel offset) saying point_cloud IS that slice of the slot
     Returns:
       (batch_size, num_points, 1, num_output_channels)
     """
@@ -319,11 +320,12 @@ def edge_conv(point_cloud, nn_idx, num_output_channels, scope, pool='mean', bn_d
     w2 = kernel.data.reshape(2 * C, num_output_channels)
     w2._cloudaae_var = kernel
     out = F.EdgeConvFn.apply(x, nn_idx, w2, biases.data, gamma.data, beta.data, ema_mean.data, ema_var.data,
-                             _decay_tensor(bn_decay), bool(is_training), 1 if pool == 'mean' else 2, out_slot)
+                             _decay_tensor(bn_decay), bool(is_training), 1 if pool == 'mean' else 2, out_slot,
+                             in_slot)
     return out.unsqueeze(2)
 
 
-def conv2d_concat(inputs_list, num_output_channels, scope, bn_decay=None, is_training=None, pool=None):
+def conv2d_concat(inputs_list, num_output_channels, scope, bn_decay=None, is_training=None, pool=None, slot=None):
     """conv2d(tf.concat(inputs_list, axis=-1), C, [1,1], bn=True) followed, when `pool` is
     'mean'/'max', by the reduction over the point axis (models/...:410-419 / :675-684) --
     without the concat copy when the inputs are adjacent slices of one buffer, and without
@@ -340,7 +342,7 @@ def conv2d_concat(inputs_list, num_output_channels, scope, bn_decay=None, is_tra
             beta, gamma, ema_mean, ema_var = _bn_variables(num_output_channels)
     w2 = kernel.data.reshape(cin, num_output_channels)
     w2._cloudaae_var = kernel
-    y = F.ConcatLinearFn.apply(w2, biases.data, *rows)
+    y = F.ConcatLinearFn.apply(slot, w2, biases.data, *rows)
     mode = {None: 0, 'mean': 1, 'max': 2}[pool]
     if mode == 0:
         act, mean, var = F.BatchNormFn.apply(y, gamma.data, beta.data, ema_mean.data, ema_var.data,

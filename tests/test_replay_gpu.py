@@ -1,0 +1,89 @@
+"""GPU: the recorded step (TrainGraph(replay=True): _lib.StepPlan) against the ordinary one --
+same weights and inputs in, same losses and weights out, step after step, with inputs that change
+between steps; and the recording must not contain a single kernel that is not ours."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(B, N, model_fn="get_model_dgcnn_mean_6d"):
+    from cloudaae_amd import train_cloudAAE_ycbv as T
+    mk = lambda r: T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, model_fn=model_fn, replay=r)
+    a, b = mk(False), mk(True)
+    assert torch.equal(a.store.flat_params, b.store.flat_params)
+    return T, a, b
+
+
+@pytest.mark.parametrize("B,N,model_fn", [(4, 256, "get_model_dgcnn_mean_6d"), (8, 128, "get_model_dgcnn_max_6d"),
+                                          (4, 128, "get_model_pn")])
+def test_replay_equals_eager(hip, B, N, model_fn):
+    T, eager, planned = _pair(B, N, model_fn)
+    for step in range(6):
+        # Two runs of the SAME path drift apart step by step (fp32 atomics in split-K GEMMs and the
+        # Chamfer gradient; Adam turns round-off-sized gradients into +-lr moves), so every step
+        # starts from the eager graph's exact state and is compared on its own.
+        with torch.no_grad():
+            for dst, src in ((planned.store.flat_params, eager.store.flat_params),
+                             (planned.store.flat_state, eager.store.flat_state),
+                             (planned.adam_m, eager.adam_m), (planned.adam_v, eager.adam_v),
+                             (planned.batch, eager.batch), (planned.beta1_power, eager.beta1_power),
+                             (planned.beta2_power, eager.beta2_power)):
+                dst.copy_(src)
+        el = T.synthetic_element(B, N, eager.device, seed=100 + step)      # new inputs every step
+        el["noise"] = torch.randn((B, N, 3), device="cuda") * 0.001
+        o1 = eager.train_step(el)
+        o2 = planned.train_step(el)
+        assert planned.replay, "the step was not replayable"
+        for k in ("xyz_loss", "trans_loss", "axag_loss", "total_loss"):
+            a, b = float(o1[k].detach()), float(o2[k])
+            assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (step, k, a, b)
+        assert torch.allclose(o1["xyz_recon"].detach(), o2["xyz_recon"], rtol=1e-4, atol=1e-5)   # split-K atomics
+        # gradients of the step (what the plan's backward half wrote into the flat buffer)
+        g1, g2 = eager.store.flat_grads, planned.store.flat_grads
+        # (max pooling routes a whole gradient through the arg-max: a round-off near-tie flips it)
+        gtol = 2e-3 if "mean" in model_fn else 2e-2
+        assert float((g1 - g2).abs().max()) <= gtol * float(g1.abs().max()), step
+        diff = (eager.store.flat_params - planned.store.flat_params).abs()
+        assert float(diff.max()) <= 2.1 * 0.0008
+        assert float((diff > 1e-5).float().mean()) < 0.01
+        assert torch.allclose(eager.store.flat_state, planned.store.flat_state, rtol=1e-4, atol=1e-6)
+    assert planned._plan is not None and not planned._plan.foreign_ops
+    assert float(planned.batch) == 6.0 and float(eager.batch) == 6.0
+
+
+def test_replay_draws_fresh_noise_and_rerecords_on_new_shape(hip):
+    from cloudaae_amd import train_cloudAAE_ycbv as T
+    g = T.TrainGraph({"num_point": 128, "gpu": 0}, {}, {"batch_size": 4}, replay=True)
+    el = T.synthetic_element(4, 128, g.device, seed=1)
+    o = g.train_step(el)
+    n1 = o["visiblePoints_final"].clone()
+    o = g.train_step(el)
+    n2 = o["visiblePoints_final"].clone()
+    assert not torch.equal(n1, n2)                      # tf.random.normal of :217 differs per step
+    assert float((n1 - n2).abs().max()) < 0.05
+    plan = g._plan
+    el8 = T.synthetic_element(4, 128, g.device, seed=2)
+    el8["visiblePoints"] = torch.cat([el8["visiblePoints"], el8["visiblePoints"]], 1)   # [4,256,3]: new shape
+    o = g.train_step(el8)
+    assert g._plan is not plan and np.isfinite(float(o["total_loss"]))
+
+
+def test_replay_timed_site_and_eval(hip):
+    from cloudaae_amd import train_cloudAAE_ycbv as T
+    from cloudaae_amd.utils import _functions as F
+    F.TIMED_SITES["agg_fwd"] = []
+    try:
+        g = T.TrainGraph({"num_point": 128, "gpu": 0}, {}, {"batch_size": 4}, replay=True)
+        el = T.synthetic_element(4, 128, g.device, seed=1)
+        F.TIMED_SITES["agg_fwd"].clear()                 # (building the graph ran the model once)
+        for _ in range(3):
+            g.train_step(el)
+        torch.cuda.synchronize()
+        ev = F.TIMED_SITES["agg_fwd"]
+        assert len(ev) == 6 and all(ev[i].elapsed_time(ev[i + 1]) > 0 for i in (0, 2, 4))
+    finally:
+        F.TIMED_SITES.pop("agg_fwd", None)
+    e = g.eval_step(el)                                  # the ordinary path still works next to a plan
+    assert np.isfinite(float(e["xyz_loss"]))
