@@ -31,6 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GEMM_BK = 16;
 constexpr int GEMM_THREADS = 256;
+#define GEMM_ATTR
 
 enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_ATOMIC = 2 };
 
@@ -45,7 +46,10 @@ struct Panel {
 
     float4v reg[PER_THREAD];
 
-    // global -> registers for the slab starting at k0; outer0 = first outer index
+    // global -> registers for the slab starting at k0; outer0 = first outer index.
+    // FAST: the whole slab is inside the matrix and 16-byte aligned (checked once at launch):
+    // straight global_load_dwordx4, no per-element predicates in the loop.
+    template <bool FAST>
     __device__ __forceinline__ void load(const float *__restrict__ P, int ld, int outer0, int nouter,
                                          int k0, int kend, bool vec_ok)
     {
@@ -53,7 +57,14 @@ struct Panel {
         for (int it = 0; it < PER_THREAD; ++it) {
             const int v = it * GEMM_THREADS + (int)threadIdx.x;
             float4v r = {0.f, 0.f, 0.f, 0.f};
-            if (VECS % GEMM_THREADS == 0 || v < VECS) {
+            if (FAST) {
+                if (VECS % GEMM_THREADS != 0 && v >= VECS)
+                    break;
+                const size_t off = KC ? (size_t)(outer0 + v / (GEMM_BK / 4)) * ld + k0 + (v % (GEMM_BK / 4)) * 4
+                                      : (size_t)(k0 + v / (ROWS / 4)) * ld + outer0 + (v % (ROWS / 4)) * 4;
+                reg[it] = *reinterpret_cast<const float4v *>(P + off);
+                continue;
+            } else if (VECS % GEMM_THREADS == 0 || v < VECS) {
                 if (KC) {
                     const int o = v / (GEMM_BK / 4), kq = v % (GEMM_BK / 4);
                     const int go = outer0 + o, gk = k0 + kq * 4;
@@ -119,8 +130,8 @@ struct Panel {
 
 // C[M,N] (+)= op(A)[M,K] * op(B)[K,N] (+ bias[N])
 // TA: A is stored [K][M] (lda >= M); else [M][K].  TB: B is stored [N][K]; else [K][N].
-template <int BM, int BN, int WM, int WN, bool TA, bool TB>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool FAST>
+__global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
     int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
     float *__restrict__ C, int ldc, const float *__restrict__ bias, int epilogue, int kchunk,
     int vecA, int vecB)
@@ -154,8 +165,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 
     PA pa;
     PB pb;
-    pa.load(A, lda, m0, M, kbeg, kend, vecA != 0);
-    pb.load(B, ldb, n0, N, kbeg, kend, vecB != 0);
+    pa.template load<FAST>(A, lda, m0, M, kbeg, kend, vecA != 0);
+    pb.template load<FAST>(B, ldb, n0, N, kbeg, kend, vecB != 0);
 
     const int fr = lane & 31, fk = lane >> 5;
     for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
@@ -164,23 +175,37 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
         pb.stage(ldsB);
         __syncthreads();
         if (k0 + GEMM_BK < kend) {  // prefetch the next slab behind the MFMAs
-            pa.load(A, lda, m0, M, k0 + GEMM_BK, kend, vecA != 0);
-            pb.load(B, ldb, n0, N, k0 + GEMM_BK, kend, vecB != 0);
+            pa.template load<FAST>(A, lda, m0, M, k0 + GEMM_BK, kend, vecA != 0);
+            pb.template load<FAST>(B, ldb, n0, N, k0 + GEMM_BK, kend, vecB != 0);
         }
+        // operand fragments are read one k-step ahead of the MFMAs that consume them
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            a[0][i] = PA::frag(ldsA, (wm * TM + i) * 32 + fr, fk);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            b[0][j] = PB::frag(ldsB, (wn * TN + j) * 32 + fr, fk);
 #pragma unroll
         for (int s = 0; s < GEMM_BK / 2; ++s) {
-            float a[TM], b[TN];
+            const int c = s & 1, n = c ^ 1;
+            if (s + 1 < GEMM_BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = PA::frag(ldsA, (wm * TM + i) * 32 + fr, 2 * s + fk);
+                for (int i = 0; i < TM; ++i)
+                    a[n][i] = PA::frag(ldsA, (wm * TM + i) * 32 + fr, 2 * (s + 1) + fk);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = PB::frag(ldsB, (wn * TN + j) * 32 + fr, 2 * s + fk);
+                for (int j = 0; j < TN; ++j)
+                    b[n][j] = PB::frag(ldsB, (wn * TN + j) * 32 + fr, 2 * (s + 1) + fk);
+            }
+            // keep the ds_reads of step s+1 AHEAD of the MFMAs of step s (the scheduler otherwise
+            // sinks them next to their use and every fourth MFMA waits a full LDS round trip)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -189,7 +214,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wn * TN + j) * 32 + fr;
-        if (col >= N)
+        if (!FAST && col >= N)
             continue;
         const float bv = add_bias ? bias[col] : 0.0f;
 #pragma unroll
@@ -197,7 +222,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                if (row < M) {
+                if (FAST || row < M) {
                     float *dst = C + (size_t)row * ldc + col;
                     const float v = acc[i][j][r] + bv;
                     if (epilogue == EPI_STORE)
@@ -212,24 +237,39 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_kernel(
     }
 }
 
+template <int BM, int BN, int WM, int WN, bool FAST>
+static void launch_fast(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A,
+                        int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int epi,
+                        int kchunk, int vecA, int vecB)
+{
+    dim3 block(GEMM_THREADS);
+    if (!ta && !tb)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false, FAST>), grid, block, 0, s, M, N, K,
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+    else if (!ta && tb)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true, FAST>), grid, block, 0, s, M, N, K,
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+    else if (ta && !tb)
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false, FAST>), grid, block, 0, s, M, N, K,
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, FAST>), grid, block, 0, s, M, N, K,
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A,
                        int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int epi,
                        int kchunk, int vecA, int vecB)
 {
-    dim3 block(GEMM_THREADS);
-    if (!ta && !tb)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
-    else if (!ta && tb)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
-    else if (ta && !tb)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+    // every tile and every K-slab whole, both operands float4-loadable: the predicate-free kernel
+    const bool fast = M % BM == 0 && N % BN == 0 && K % kchunk == 0 && kchunk % GEMM_BK == 0 && vecA && vecB;
+    if (fast)
+        launch_fast<BM, BN, WM, WN, true>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
+                                          vecA, vecB);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+        launch_fast<BM, BN, WM, WN, false>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
+                                           vecA, vecB);
 }
 
 } // namespace cloudaae
@@ -248,14 +288,19 @@ CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K
     CLOUDAAE_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, name,
                      "leading dimension too small");
 
-    // tile shape: small-batch FC rows -> 32-row tiles; narrow outputs -> 64 columns
+    // tile shape: small-batch FC rows -> 32-row tiles; narrow outputs -> 64 columns; a dimension
+    // that is a multiple of 64 but not of 128 (the 320 concat channels of dgcnn_agg: dX has N = 320,
+    // dW has M = 320) takes 64-wide tiles on that side instead of a half-empty 128 one
     int BM, BN;
     if (M <= 32) {
         BM = 32;
         BN = 128;
-    } else if (N <= 64) {
+    } else if (N <= 64 || (N % 128 != 0 && N % 64 == 0)) {
         BM = 128;
         BN = 64;
+    } else if (M % 128 != 0 && M % 64 == 0) {
+        BM = 64;
+        BN = 128;
     } else {
         BM = 128;
         BN = 128;
@@ -297,6 +342,9 @@ CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K
                                   vecA, vecB);
     else if (BN == 64)
         launch_cfg<128, 64, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
+                                  vecA, vecB);
+    else if (BM == 64)
+        launch_cfg<64, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
                                   vecA, vecB);
     else
         launch_cfg<128, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
