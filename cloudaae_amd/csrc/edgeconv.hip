@@ -574,8 +574,8 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
                                             const float *save_var, const float *out, int ldo,
                                             const float *tie_count, const float *dout, int lddo, float *dpq,
                                             int *rev_scratch, float *dx, int lddx, int accumulate_dx,
-                                            float *dweights, float *dbiases, float *dgamma, float *dbeta,
-                                            void *workspace, cloudaae_stream_t stream)
+                                            float *dweights, int dweights_zeroed, float *dbiases, float *dgamma,
+                                            float *dbeta, void *workspace, cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_edgeconv_backward";
     if (int rc = ec_check(name, b, n, k, cin, cout, pool_mode))
@@ -640,11 +640,12 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
             return rc;
     }
     if (dweights != nullptr) {
-        rc = cloudaae_gemm_f32(1, 0, cin, cout, P, x, ldx, dpq, 2 * cout, dweights, cout, nullptr, 0, stream);
+        const int wacc = dweights_zeroed ? 2 : 0;     // 2: the caller cleared dweights already
+        rc = cloudaae_gemm_f32(1, 0, cin, cout, P, x, ldx, dpq, 2 * cout, dweights, cout, nullptr, wacc, stream);
         if (rc)
             return rc;
         rc = cloudaae_gemm_f32(1, 0, cin, cout, P, x, ldx, dpq + cout, 2 * cout, dweights + (size_t)cin * cout,
-                               cout, nullptr, 0, stream);
+                               cout, nullptr, wacc, stream);
         if (rc)
             return rc;
     }

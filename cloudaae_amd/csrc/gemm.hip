@@ -325,7 +325,10 @@ CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K
     }
     int kchunk = K > 0 ? ceil_div(ceil_div(K, splits), GEMM_BK) * GEMM_BK : GEMM_BK;
     splits = K > 0 ? ceil_div(K, kchunk) : 1;
-    int epi = accumulate ? EPI_ACCUM : EPI_STORE;
+    // accumulate: 0 = overwrite C, 1 = add to C, 2 = C is known to hold zeros (the caller cleared
+    // a whole gradient buffer once): plain stores when K is not split, atomics WITHOUT the clear
+    // pass when it is
+    int epi = accumulate == 1 ? EPI_ACCUM : EPI_STORE;
     if (splits > 1) {
         epi = EPI_ATOMIC;
         if (!accumulate)  // slices add into a zeroed output

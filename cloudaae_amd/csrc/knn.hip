@@ -15,6 +15,7 @@
 // A workgroup is 4 waves x 64 queries; wave w scans candidate quarter w in
 // ascending j, then wave 0 merges the four sorted lists in wave order with the
 // same stable insertion, which preserves the tie rule.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/cloudaae_hip.h"
 
@@ -462,6 +463,241 @@ __global__ __launch_bounds__(KNN_THREADS) void knn64_mfma_kernel(int n, int ld, 
     }
 }
 
+// ---- C = 64, second generation: one wave per 32-query tile scans the WHOLE cloud -------------
+// The kernel above gives every query eight short lists (4 candidate quarters x 2 lane halves); each
+// list sees only n/8 candidates, so nearly every candidate still passes its threshold and the
+// 40-instruction sorted insert runs for all 64 lanes almost every time -- the selection network,
+// not the MFMAs, is what that kernel spends its time on (MFMA utilisation 17 %).
+// Here a workgroup owns QW consecutive 32-query tiles of one cloud (one wave each) and walks ALL
+// candidates in 32-row tiles that the waves stage cooperatively (each row is fetched once per
+// workgroup instead of once per wave) into a double-buffered LDS tile, prefetched one tile ahead
+// through registers.  A lane keeps ONE list per (query, lane half), so thresholds tighten fast, and
+// the selection is split in two:
+//   filter : d < (current k-th best of this lane)?  -> push (d, j) on the lane's LDS queue
+//            (three instructions; runs for every candidate)
+//   drain  : when some lane's queue could overflow next round, every lane pops its queue through
+//            the sorted insert; the wave pays max-over-lanes pops instead of one insert per
+//            candidate for which ANY lane passes.
+// |x_j|^2 of the whole cloud is computed once per workgroup (sequential un-fused sum, as the oracle
+// defines it) and kept in LDS.  Arithmetic and tie rule are those of the kernels above, so the
+// indices stay bit-identical to oracle_knn.
+constexpr int KS_QCAP = 32;          // queue slots per lane; a round pushes at most 16
+
+template <int K, int QW>
+__global__ __launch_bounds__(64 * QW) void knn64_scan_kernel(int n, int ld, int k,
+                                                             const float *__restrict__ x,
+                                                             int *__restrict__ nn_idx)
+{
+    constexpr int THREADS = 64 * QW;
+    constexpr int TILE_FLOATS = KM_TILE * KM_LD;
+    extern __shared__ __attribute__((aligned(16))) char ks_smem[];
+    // layout: tile[2][TILE_FLOATS] | queue d[QW][QCAP][64] | queue i[QW][QCAP][64] | sq[n]
+    float *tiles = reinterpret_cast<float *>(ks_smem);
+    float *qd_all = tiles + 2 * TILE_FLOATS;
+    int *qi_all = reinterpret_cast<int *>(qd_all + QW * KS_QCAP * 64);
+    float *sq = reinterpret_cast<float *>(qi_all + QW * KS_QCAP * 64);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int qgroup, cloud;
+    xcd_cloud_tile(qgroup, cloud);
+    const float *X = x + (size_t)cloud * n * ld;
+    float *qd = qd_all + wave * KS_QCAP * 64;
+    int *qi = qi_all + wave * KS_QCAP * 64;
+
+    // |x_j|^2 for every point of the cloud
+    for (int j = tid; j < n; j += THREADS) {
+        const float *row = X + (size_t)j * ld;
+        float acc = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float4v v = *reinterpret_cast<const float4v *>(row + 4 * g);
+            const float a = v.x * v.x, b = v.y * v.y, c = v.z * v.z, d = v.w * v.w;
+            acc = acc + a;
+            acc = acc + b;
+            acc = acc + c;
+            acc = acc + d;
+        }
+        sq[j] = acc;
+    }
+
+    const int col = lane & 31, half = lane >> 5;
+    const int qi0 = (qgroup * QW + wave) * KM_TILE + col;     // this lane's query
+    const bool qvalid = qi0 < n;
+    const int qs = qvalid ? qi0 : 0;
+    // B operand: query channels of parity `half`, one register per MFMA step
+    float bq[32];
+    {
+        const float *row = X + (size_t)qs * ld;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float4v v = *reinterpret_cast<const float4v *>(row + 4 * g);
+            bq[2 * g] = half ? v.y : v.x;               // channels 4g + half, 4g + 2 + half
+            bq[2 * g + 1] = half ? v.w : v.z;
+        }
+    }
+
+    // staging map: 32 rows x 16 float4 per tile, spread over the workgroup
+    constexpr int VECS = KM_TILE * 16, PER = (VECS + THREADS - 1) / THREADS;
+    float4v stage[PER];
+    auto fetch = [&](int t) {
+        const int c0 = t * KM_TILE;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int v = u * THREADS + tid;
+            const int row = v >> 4, q4 = v & 15;
+            stage[u] = (c0 + row < n) ? *reinterpret_cast<const float4v *>(X + (size_t)(c0 + row) * ld + 4 * q4)
+                                      : float4v{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&](float *buf) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int v = u * THREADS + tid;
+            const int row = v >> 4, q4 = v & 15;
+            float *dst = buf + row * KM_LD + 4 * q4;
+            dst[0] = stage[u].x;
+            dst[1] = stage[u].y;
+            dst[2] = stage[u].z;
+            dst[3] = stage[u].w;
+        }
+    };
+
+    TopK<K> top;
+    top.init();
+    float thr = __builtin_inff();
+    int cnt = 0;
+    auto drain = [&]() {
+        // the queue entry of the NEXT pop is read while the current one goes through the insert
+        float nd = cnt > 0 ? qd[lane] : 0.0f;
+        int ni = cnt > 0 ? qi[lane] : 0;
+        for (int t = 0; __any(t < cnt); ++t) {
+            const float cd = nd;
+            const int ci = ni;
+            if (t + 1 < cnt) {
+                nd = qd[(t + 1) * 64 + lane];
+                ni = qi[(t + 1) * 64 + lane];
+            }
+            if (t < cnt)
+                top.insert(cd, ci);
+        }
+        cnt = 0;
+        thr = top.d[K - 1];
+    };
+
+    const int ntiles = (n + KM_TILE - 1) / KM_TILE;
+    fetch(0);
+    commit(tiles);
+    __syncthreads();                                      // tile 0 and sq[] visible
+    const float sqi = sq[qs];
+    // filter of one finished tile: acc[e] = <x_q, x_{c0 + row(e)}>, csq[e] = |x_{c0 + row(e)}|^2 (read
+    // from LDS ahead of time: the queue lives in the same LDS array, so the compiler cannot move
+    // those reads across the queue writes by itself)
+    auto filter = [&](const f32x16 &acc, const float (&csq)[16], int c0) {
+        const int cnt_rows = min(KM_TILE, n - c0);
+        if (__any(cnt > KS_QCAP - 17))
+            drain();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rr = (e & 3) + 8 * (e >> 2) + 4 * half;    // candidate row of acc[e]
+            const float m2 = -2.0f * acc[e];
+            const float tt = sqi + m2;
+            const float d = tt + csq[e];
+            // branch-free push: the slot is always written, the count moves only for a pass
+            qd[cnt * 64 + lane] = d;
+            qi[cnt * 64 + lane] = c0 + rr;
+            cnt += (rr < cnt_rows && d < thr) ? 1 : 0;
+        }
+    };
+    auto load_csq = [&](float (&csq)[16], int c0) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            csq[e] = sq[min(c0 + (e & 3) + 8 * (e >> 2) + 4 * half, n - 1)];
+    };
+    f32x16 prev;
+    float pcsq[16];
+    for (int t = 0; t < ntiles; ++t) {
+        const float *cur = tiles + (t & 1) * TILE_FLOATS;
+        const float *arow = cur + col * KM_LD + half;     // A operand: candidate row `col`, parity `half`
+        float aop[32], ccsq[16];
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+            aop[s] = arow[2 * s];                         // all LDS reads of the tile in flight at once
+        load_csq(ccsq, t * KM_TILE);
+        if (t + 1 < ntiles)
+            fetch(t + 1);                                 // global -> registers behind the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        if (t > 0)
+            filter(prev, pcsq, (t - 1) * KM_TILE);        // VALU work of the previous tile hides the LDS latency
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            acc[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[s], bq[s], acc, 0, 0, 0);
+        prev = acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            pcsq[e] = ccsq[e];
+        if (t + 1 < ntiles)
+            commit(tiles + ((t + 1) & 1) * TILE_FLOATS);  // last read of that buffer: one barrier ago
+        __syncthreads();
+    }
+    filter(prev, pcsq, (ntiles - 1) * KM_TILE);
+    drain();
+
+    // merge the two half-lists of every query lexicographically by (d, j): each is already sorted
+    // that way (candidates arrive in ascending j, the insert is stable)
+    if (half) {
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            qd[p * 64 + col] = top.d[p];
+            qi[p * 64 + col] = top.i[p];
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (!half && qvalid) {
+        int *dst = nn_idx + ((size_t)cloud * n + qi0) * k;
+        int pa = 0, pb = 0;
+        for (int p = 0; p < k; ++p) {
+            float da = __builtin_inff(), db = __builtin_inff();
+            int ia = 0x7fffffff, ib = 0x7fffffff;
+#pragma unroll
+            for (int u = 0; u < K; ++u) {                 // register file has no dynamic index: select
+                da = (u == pa) ? top.d[u] : da;
+                ia = (u == pa) ? top.i[u] : ia;
+            }
+            if (pb < K) {
+                db = qd[pb * 64 + col];
+                ib = qi[pb * 64 + col];
+            }
+            const bool take_b = db < da || (db == da && ib < ia);
+            dst[p] = take_b ? ib : ia;
+            pa += take_b ? 0 : 1;
+            pb += take_b ? 1 : 0;
+        }
+    }
+}
+
+template <int K, int QW>
+static hipError_t launch_knn_scan(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
+{
+    const size_t lds = sizeof(float) * (2 * KM_TILE * KM_LD + 2 * QW * KS_QCAP * 64 + (size_t)n);
+    static bool raised = false;       // >64 KiB of dynamic LDS needs the attribute once per kernel
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn64_scan_kernel<K, QW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess)
+            return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL((knn64_scan_kernel<K, QW>), dim3(ceil_div(n, KM_TILE * QW), b), dim3(64 * QW), lds, s, n, ld,
+                       k, x, nn_idx);
+    return hipSuccess;
+}
+
 template <int K>
 static void launch_knn(int b, int n, int c, int ld, int k, const float *x, int *nn_idx,
                        hipStream_t s)
@@ -469,7 +705,21 @@ static void launch_knn(int b, int n, int c, int ld, int k, const float *x, int *
     if (c == 3)
         hipLaunchKernelGGL(knn3_kernel<K>, dim3(ceil_div(n, 64), b), dim3(KNN_THREADS), 0, s, n, ld,
                            k, x, nn_idx);
-    else if (c == 64 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && K <= 20)
+    else if (c == 64 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && K <= 20 && n <= 16384 &&
+             getenv("CLOUDAAE_KNN_SCAN")) {
+        // EXPERIMENTAL (opt-in): measured 143 us vs 138 us for knn64_mfma_kernel at B=32, N=1024.
+        // It issues 5x fewer VALU instructions per SIMD (18 k vs ~90 k), but with one wave per SIMD
+        // nothing overlaps the MFMAs (65 k cycles), the VALU work (73 k), LDS/queue waits (94 k)
+        // and the per-tile workgroup barrier; two waves per query tile is the next thing to try.
+        // query tiles per workgroup: as many as still leave one workgroup per CU
+        const long long tiles = (long long)ceil_div(n, KM_TILE) * b;
+        if (tiles >= 4 * 256)
+            (void)launch_knn_scan<K, 4>(b, n, ld, k, x, nn_idx, s);
+        else if (tiles >= 2 * 256)
+            (void)launch_knn_scan<K, 2>(b, n, ld, k, x, nn_idx, s);
+        else
+            (void)launch_knn_scan<K, 1>(b, n, ld, k, x, nn_idx, s);
+    } else if (c == 64 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && K <= 20)
         hipLaunchKernelGGL(knn64_mfma_kernel<K>, dim3(ceil_div(n, KM_TILE), b), dim3(KNN_THREADS), 0, s, n,
                            ld, k, x, nn_idx);
     else if (c == 64 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0)

@@ -210,7 +210,7 @@ class TrainGraph(object):
     def _step(self, element):
         L = _lib.lib()
         s = stream()
-        self.store.begin_step()
+        self.store.begin_step(zero_grads=True)
         # bn_decay = min(0.99, 1 - 0.5 * 0.5^floor(batch*BATCH_SIZE/40)), :194-202
         _lib.check(L.cloudaae_bn_decay_schedule(ptr(self.batch), float(self.BATCH_SIZE), BN_INIT_DECAY,
                                                 BN_DECAY_DECAY_STEP, BN_DECAY_DECAY_RATE, BN_DECAY_CLIP,

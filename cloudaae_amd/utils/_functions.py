@@ -37,6 +37,14 @@ class _ParamGrad(object):
             self.own = _lib.empty(param.shape, dtype=torch.float32, device=param.device)
             self.buf, self.accumulate = self.own, 0
 
+    @property
+    def gemm_acc(self):
+        """accumulate flag for cloudaae_gemm_f32: 2 = first write of this step into a gradient buffer
+        that begin_step() cleared as a whole (no per-product clear pass for split-K)."""
+        if self.var is not None and self.var.grad is not None and self.var.fresh and self.var.zeroed:
+            return 2
+        return self.accumulate
+
     def done(self):
         if self.var is not None and self.var.grad is not None:
             self.var.fresh = False
@@ -98,7 +106,7 @@ class LinearFn(torch.autograd.Function):
             gemm(0, 1, M, K, N, dyp, lddy, ptr(w), N, ptr(dx), K)
         gw = _ParamGrad(w, ctx.needs_input_grad[1])
         if gw.needed:
-            gemm(1, 0, K, N, M, xp, ldx, dyp, lddy, ptr(gw.buf), N, None, gw.accumulate)
+            gemm(1, 0, K, N, M, xp, ldx, dyp, lddy, ptr(gw.buf), N, None, gw.gemm_acc)
         gb_ret = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _ParamGrad(ctx.bvar, True)
@@ -172,7 +180,7 @@ class ConcatLinearFn(torch.autograd.Function):
                 ctx.slot.dcat = dcat
         gw = _ParamGrad(w, ctx.needs_input_grad[1])
         if gw.needed:
-            gemm(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.accumulate)
+            gemm(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.gemm_acc)
         gb_ret = None
         if ctx.bvar is not None and ctx.needs_input_grad[2]:
             gb = _ParamGrad(ctx.bvar, True)
@@ -339,7 +347,7 @@ class EdgeConvFn(torch.autograd.Function):
             training, pool_mode, ptr(pq), ptr(save_mean), ptr(save_var),
             fwd_out.data_ptr() if fwd_out is not None else None, fwd_out.stride(1) if fwd_out is not None else 0,
             ptr(ties), dout.data_ptr(), dout.stride(1), ptr(dpq), ptr(rev), dx_ptr, lddx, acc_dx, ptr(gw.buf),
-            ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), ptr(ws), stream()),
+            1 if (gw.needed and gw.gemm_acc == 2) else 0, ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), ptr(ws), stream()),
             "cloudaae_edgeconv_backward")
         for g in shared:
             L().cloudaae_add_f32(g.buf.numel(), ptr(tmp[id(g)]), ptr(g.buf), ptr(tmp[id(g)]), stream())

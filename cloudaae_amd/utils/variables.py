@@ -22,7 +22,7 @@ import torch
 
 
 class Variable(object):
-    __slots__ = ("name", "shape", "trainable", "data", "grad", "fresh", "on_ready")
+    __slots__ = ("name", "shape", "trainable", "data", "grad", "fresh", "zeroed", "on_ready")
 
     def __init__(self, name, data, trainable):
         self.name = name
@@ -31,6 +31,7 @@ class Variable(object):
         self.data = data      # leaf tensor (requires_grad for trainables)
         self.grad = None      # view into the flat gradient buffer (trainables)
         self.fresh = True     # first gradient write of a backward pass stores, later ones add
+        self.zeroed = False   # begin_step(zero_grads=True) cleared the gradient slot as part of one big fill
         self.on_ready = None  # called right after the gradient kernel is enqueued (comm overlap)
 
 
@@ -141,15 +142,26 @@ class VariableStore(object):
         tv = self.trainable_variables()
         self.flat_params, offs = pack(tv, True)
         self.flat_grads = torch.zeros_like(self.flat_params)
+        self._zero = torch.zeros(1, dtype=torch.float32, device=self.device)
         for v, o in zip(tv, offs):
             v.grad = self.flat_grads[o:o + v.data.numel()].view(v.shape)
             v.data.grad = v.grad          # `.grad` is visible in the usual place
         self.flat_state, _ = pack(self.state_variables(), False)
         self.offsets = OrderedDict((v.name, o) for v, o in zip(tv, offs))
 
-    def begin_step(self):
+    def begin_step(self, zero_grads=False):
+        """Marks every gradient slot unwritten.  zero_grads: clear the flat gradient buffer with ONE
+        fill, so that the split-K weight-gradient products of the step can add into it directly
+        instead of each clearing its own output first (a dozen tiny fills per step)."""
+        zeroed = bool(zero_grads) and self.flat_grads is not None
+        if zeroed:
+            from .. import _lib
+            _lib.check(_lib.lib().cloudaae_fill_scaled(self.flat_grads.numel(), _lib.ptr(self._zero), 1.0, None,
+                                                       _lib.ptr(self.flat_grads), _lib.stream()),
+                       "cloudaae_fill_scaled")
         for v in self.vars.values():
             v.fresh = True
+            v.zeroed = zeroed
 
     # ---- checkpoint-style access with the reference's variable names -------------------
     def state_dict(self):

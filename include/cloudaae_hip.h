@@ -92,7 +92,8 @@ int cloudaae_knn(int b, int n, int c, int ld, int k, const float *x, int *nn_idx
 
 /* C[M,N] (+)= op(A)[M,K] op(B)[K,N] (+ bias[N]); fp32 in / fp32 accumulate on the
  * matrix cores (v_mfma_f32_32x32x2_f32 = k-ordered fmaf chain).  Row-major.
- * trans_a: A is stored [K][M]; trans_b: B is stored [N][K].  accumulate: add to C.
+ * trans_a: A is stored [K][M]; trans_b: B is stored [N][K].  accumulate: 0 overwrite C, 1 add to C,
+ * 2 C already holds zeros (skips the clear pass of a split-K product).
  * Replaces tf.nn.conv2d 1x1 + bias_add (utils/tf_util.py:161-166) and tf.matmul +
  * bias_add (utils/tf_util.py:349-352) and their two gradient products. */
 int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
@@ -150,8 +151,8 @@ int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int cout, const flo
                                const float *pq, const float *save_mean, const float *save_var,
                                const float *out, int ldo, const float *tie_count, const float *dout,
                                int lddo, float *dpq, int *rev_scratch, float *dx, int lddx,
-                               int accumulate_dx, float *dweights, float *dbiases, float *dgamma,
-                               float *dbeta, void *workspace, cloudaae_stream_t stream);
+                               int accumulate_dx, float *dweights, int dweights_zeroed, float *dbiases,
+                               float *dgamma, float *dbeta, void *workspace, cloudaae_stream_t stream);
 
 /* ---- train_cloudAAE_ycbv.py:194-273: the step around the network --------- */
 

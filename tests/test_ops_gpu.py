@@ -173,3 +173,19 @@ def test_knn_vs_oracle(hip, oracle, b, n, c, ld, k):
     got = torch.empty((b, n, k), dtype=torch.int32, device="cuda")
     _lib.check(_lib.lib().cloudaae_knn(b, n, c, ld, k, _lib.ptr(xd), _lib.ptr(got), _lib.stream()), "knn")
     assert np.array_equal(want, got.cpu().numpy())
+
+
+@pytest.mark.parametrize("b,n,k", [(2, 333, 10), (40, 1024, 10), (3, 1500, 20)])
+def test_knn_scan_kernel_vs_oracle(hip, oracle, monkeypatch, b, n, k):
+    """The opt-in whole-cloud scan kernel (CLOUDAAE_KNN_SCAN=1, knn.hip) keeps the same bit-exact
+    contract, ties included, with 1, 2 and 4 query tiles per workgroup."""
+    from cloudaae_amd import _lib
+    monkeypatch.setenv("CLOUDAAE_KNN_SCAN", "1")
+    rng = np.random.default_rng(n + k)
+    x = np.maximum(rng.standard_normal((b, n, 64)), -0.5).astype(np.float32) * 0.1
+    x[:, n // 2:n // 2 + 30] = x[:, :30]
+    want = oracle.knn(x, k, channels=64, threads=8)
+    xd = _dev(x)
+    got = torch.empty((b, n, k), dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().cloudaae_knn(b, n, 64, 64, k, _lib.ptr(xd), _lib.ptr(got), _lib.stream()), "knn")
+    assert np.array_equal(want, got.cpu().numpy())

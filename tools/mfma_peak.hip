@@ -51,6 +51,9 @@ int main()
     run<4>(256, 200000, "long ");
     run<4>(512, 100000, "long ");
     run<4>(768, 60000, "long ");
+    run<1>(256, 100000, "dep1w");
+    run<2>(256, 100000, "dep1w");
+    run<1>(512, 100000, "dep2w");
     run<1>(1024, 100000, "dep  ");
     run<2>(1024, 100000, "dep2 ");
     return 0;
