@@ -22,6 +22,7 @@
 // MFMAs (register prefetch).  K can be split across workgroups (grid.z) when the
 // output has too few tiles to fill 256 CUs (dW products, tiny-batch FC layers);
 // slices then combine with hardware fp32 atomics.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/cloudaae_hip.h"
 
@@ -307,14 +308,17 @@ CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K
     }
     const int tm = ceil_div(M, BM), tn = ceil_div(N, BN);
     CLOUDAAE_REQUIRE(tm <= 65535, name, "M too large");
-    // split K until ~2 workgroups per CU exist, keeping >= 64 k per slice
+    // split K until one full wave of workgroups exists (tiles * splits ~ the workgroups the chip
+    // holds at once for this tile shape: registers allow 3 per CU for 128x128, 5 for 64x128, 6 for
+    // 128x64), keeping >= 64 k per slice; outputs of <= 4 tiles get at most 256
+    // slices: every slice adds to the SAME few thousand addresses with atomics.
+    // Measured on dgcnn_agg dW (40 tiles of 64x128, K = 32768): 12 slices 247 us, 32 slices 196 us,
+    // 64 slices 203 us, 128 slices 219 us.
     int splits = 1;
     const long long tiles = (long long)tm * tn;
+    const int resident = 256 * (BM == 32 ? 2 : BN == 64 ? 6 : BM == 64 ? 5 : 3);   // (32-row tiles: 2 measured best)
     if (tiles < 256 && K >= 128) {
-        // tiles * splits <= 512 = two resident workgroups per CU, i.e. one wave of workgroups
-        // (528 = 24 x 22 spilled into a second, nearly empty wave); outputs of <= 4 tiles get at
-        // most 256 slices: every slice adds to the SAME few thousand addresses with atomics
-        splits = (int)((tiles <= 4 ? 256 : 512) / tiles);
+        splits = (int)((tiles <= 4 ? 256 : resident) / tiles);
         const int max_splits = K / 64 > 0 ? K / 64 : 1;
         if (splits > max_splits)
             splits = max_splits;
@@ -322,6 +326,8 @@ CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K
             splits = 1024;
         if (splits < 1)
             splits = 1;
+        if (const char *e = getenv("CLOUDAAE_GEMM_SPLITS"))
+            splits = atoi(e);
     }
     int kchunk = K > 0 ? ceil_div(ceil_div(K, splits), GEMM_BK) * GEMM_BK : GEMM_BK;
     splits = K > 0 ? ceil_div(K, kchunk) : 1;
