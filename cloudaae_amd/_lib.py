@@ -97,6 +97,11 @@ class StepPlan(object):
         self.bytes = 0
         self.stream = None
         self.foreign_ops = []      # aten kernels seen while recording (must stay empty)
+        # zero zone: buffers that must hold zeros when the step reaches them (outputs of split-K
+        # products) sit together, so ONE fill at the start of a replay clears them all instead of
+        # one ~4 us clear pass per product
+        self.zchunks = []          # [tensor, used bytes]
+        self.internal = False      # allocator-internal torch calls are not "foreign"
 
     # -- arena ------------------------------------------------------------------------------
     def alloc(self, shape, dtype, device):
@@ -117,10 +122,38 @@ class StepPlan(object):
         self.bytes += padded
         return view[:n].view(shape) if n else view[:0].view(shape)
 
+    ZCHUNK = 32 << 20
+
+    def alloc_zero(self, shape, dtype, device):
+        """A buffer that holds zeros now and again at the start of every replay."""
+        shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
+        n = 1
+        for x in shape:
+            n *= x
+        item = torch.empty((), dtype=dtype).element_size()
+        padded = (max(n, 1) * item + 255) // 256 * 256
+        if not self.zchunks or self.zchunks[-1][1] + padded > self.zchunks[-1][0].numel():
+            self.internal = True
+            try:
+                self.zchunks.append([torch.zeros(max(padded, self.ZCHUNK), dtype=torch.uint8, device=self.device), 0])
+            finally:
+                self.internal = False
+        chunk, used = self.zchunks[-1]
+        view = chunk[used:used + max(n, 1) * item].view(dtype)
+        self.zchunks[-1][1] = used + padded
+        return view[:n].view(shape)
+
     # -- replay -----------------------------------------------------------------------------
     def replay(self):
         if stream() != self.stream:
             raise HipLibraryError("a recorded step must be replayed on the stream it was recorded on")
+        if self.zchunks:
+            fill = lib()._cdll.cloudaae_fill_scaled
+            if getattr(self, "_zero", None) is None:
+                self._zero = torch.zeros(1, dtype=torch.float32, device=self.device)
+            for chunk, used in self.zchunks:
+                check(fill(used // 4, self._zero.data_ptr(), 1.0, None, chunk.data_ptr(), self.stream),
+                      "cloudaae_fill_scaled")
         for fn, args, name in self.entries:
             rc = fn(*args)
             if name is not None and rc != 0:
@@ -177,6 +210,8 @@ def lib():
             getattr(cdll, fn).restype = ctypes.c_longlong
         cdll.cloudaae_hpr_workspace_bytes.restype = ctypes.c_longlong
         cdll.cloudaae_hpr_workspace_bytes.argtypes = [_I, _I]
+        cdll.cloudaae_gemm_f32_splits.argtypes = [_I, _I, _I]
+        cdll.cloudaae_gemm_f32_splits.restype = ctypes.c_int
         cdll.cloudaae_bn_workspace_bytes.argtypes = [_I]
         cdll.cloudaae_edgeconv_workspace_bytes.argtypes = [_I]
         _lib = _Library(cdll)
@@ -233,6 +268,18 @@ def empty_like(t):
     return empty(t.shape, t.dtype, t.device)
 
 
+def zeros(shape, dtype=torch.float32, device=None):
+    """torch.zeros, or a slice of the recording plan's zero zone (cleared once per replay)."""
+    if _recording is None:
+        return torch.zeros(shape, dtype=dtype, device=device)
+    return _recording.alloc_zero(shape, dtype, device)
+
+
+def gemm_splits(M, N, K):
+    """K slices cloudaae_gemm_f32 uses for this shape; > 1 means the output is built with atomics."""
+    return int(lib().cloudaae_gemm_f32_splits(int(M), int(N), int(K)))
+
+
 from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
 
 # aten ops that touch no device memory (views, metadata) or only allocate
@@ -250,7 +297,7 @@ class _ForeignOps(TorchDispatchMode):
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
-        if not name.startswith(_HARMLESS) and any(isinstance(a, torch.Tensor) and a.is_cuda for a in args):
+        if not self.plan.internal and not name.startswith(_HARMLESS) and any(isinstance(a, torch.Tensor) and a.is_cuda for a in args):
             self.plan.foreign_ops.append(name)      # a kernel (or a sync) the plan would not replay
         return func(*args, **(kwargs or {}))
 

@@ -25,26 +25,18 @@ __device__ __forceinline__ void bn_reduce_partials(const double *__restrict__ pa
                                                    int pl, double &s, double &s2)
 {
     __shared__ double red[2][BN_FIN_LANES][64];
-    // all loads of a 256-part chunk are issued before the first add (16 x 2 independent loads per
-    // lane): the chain of dependent global loads, not the arithmetic, is what this kernel waits for
     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
     if (c < C) {
-        for (int base = 0; base < parts; base += 16 * BN_FIN_LANES) {
-            double va[16], vb[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int p = base + pl + q * BN_FIN_LANES;
-                const bool ok = p < parts;
-                va[q] = ok ? partial[((size_t)p * 2 + 0) * C + c] : 0.0;
-                vb[q] = ok ? partial[((size_t)p * 2 + 1) * C + c] : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < 16; q += 2) {
-                a0 += va[q];
-                a1 += va[q + 1];
-                b0 += vb[q];
-                b1 += vb[q + 1];
-            }
+        int p = pl;
+        for (; p + BN_FIN_LANES < parts; p += 2 * BN_FIN_LANES) {
+            a0 += partial[((size_t)p * 2 + 0) * C + c];
+            b0 += partial[((size_t)p * 2 + 1) * C + c];
+            a1 += partial[((size_t)(p + BN_FIN_LANES) * 2 + 0) * C + c];
+            b1 += partial[((size_t)(p + BN_FIN_LANES) * 2 + 1) * C + c];
+        }
+        for (; p < parts; p += BN_FIN_LANES) {
+            a0 += partial[((size_t)p * 2 + 0) * C + c];
+            b0 += partial[((size_t)p * 2 + 1) * C + c];
         }
     }
     const int l = threadIdx.x & 63;

@@ -275,24 +275,14 @@ static void launch_cfg(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N,
 
 } // namespace cloudaae
 
-using namespace cloudaae;
+namespace cloudaae {
 
-CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A,
-                                   int lda, const float *B, int ldb, float *C, int ldc,
-                                   const float *bias, int accumulate, cloudaae_stream_t stream)
+// Tile shape and split-K slice count of a product (shared by the launcher and the query below).
+static void gemm_plan(int M, int N, int K, int &BM, int &BN, int &splits)
 {
-    const char *name = "cloudaae_gemm_f32";
-    CLOUDAAE_REQUIRE(M >= 0 && N >= 0 && K >= 0, name, "negative size");
-    if (M == 0 || N == 0)
-        return 0;
-    hipStream_t s = (hipStream_t)stream;
-    CLOUDAAE_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, name,
-                     "leading dimension too small");
-
     // tile shape: small-batch FC rows -> 32-row tiles; narrow outputs -> 64 columns; a dimension
     // that is a multiple of 64 but not of 128 (the 320 concat channels of dgcnn_agg: dX has N = 320,
     // dW has M = 320) takes 64-wide tiles on that side instead of a half-empty 128 one
-    int BM, BN;
     if (M <= 32) {
         BM = 32;
         BN = 128;
@@ -307,14 +297,13 @@ CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K
         BN = 128;
     }
     const int tm = ceil_div(M, BM), tn = ceil_div(N, BN);
-    CLOUDAAE_REQUIRE(tm <= 65535, name, "M too large");
     // split K until one full wave of workgroups exists (tiles * splits ~ the workgroups the chip
     // holds at once for this tile shape: registers allow 3 per CU for 128x128, 5 for 64x128, 6 for
     // 128x64), keeping >= 64 k per slice; outputs of <= 4 tiles get at most 256
     // slices: every slice adds to the SAME few thousand addresses with atomics.
     // Measured on dgcnn_agg dW (40 tiles of 64x128, K = 32768): 12 slices 247 us, 32 slices 196 us,
     // 64 slices 203 us, 128 slices 219 us.
-    int splits = 1;
+    splits = 1;
     const long long tiles = (long long)tm * tn;
     const int resident = 256 * (BM == 32 ? 2 : BN == 64 ? 6 : BM == 64 ? 5 : 3);   // (32-row tiles: 2 measured best)
     if (tiles < 256 && K >= 128) {
@@ -329,6 +318,38 @@ CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K
         if (const char *e = getenv("CLOUDAAE_GEMM_SPLITS"))
             splits = atoi(e);
     }
+}
+
+} // namespace cloudaae
+
+using namespace cloudaae;
+
+CLOUDAAE_API int cloudaae_gemm_f32_splits(int M, int N, int K)
+{
+    if (M <= 0 || N <= 0 || K <= 0)
+        return 1;
+    int BM, BN, splits;
+    gemm_plan(M, N, K, BM, BN, splits);
+    const int kchunk = ceil_div(ceil_div(K, splits), GEMM_BK) * GEMM_BK;
+    return ceil_div(K, kchunk);
+}
+
+CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A,
+                                   int lda, const float *B, int ldb, float *C, int ldc,
+                                   const float *bias, int accumulate, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_gemm_f32";
+    CLOUDAAE_REQUIRE(M >= 0 && N >= 0 && K >= 0, name, "negative size");
+    if (M == 0 || N == 0)
+        return 0;
+    hipStream_t s = (hipStream_t)stream;
+    CLOUDAAE_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, name,
+                     "leading dimension too small");
+
+    int BM, BN, splits;
+    gemm_plan(M, N, K, BM, BN, splits);
+    const int tm = ceil_div(M, BM), tn = ceil_div(N, BN);
+    CLOUDAAE_REQUIRE(tm <= 65535, name, "M too large");
     int kchunk = K > 0 ? ceil_div(ceil_div(K, splits), GEMM_BK) * GEMM_BK : GEMM_BK;
     splits = K > 0 ? ceil_div(K, kchunk) : 1;
     // accumulate: 0 = overwrite C, 1 = add to C, 2 = C is known to hold zeros (the caller cleared

@@ -76,6 +76,15 @@ def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, accumulate=0, site=
         _lib.host(_mark, rec)
 
 
+def _gemm_out(shape, K, device):
+    """Output buffer of a product and the accumulate flag to pass: when the product is split over K
+    while a step is being recorded, the buffer comes from the plan's zero zone (cleared by one fill
+    per replay) and the product skips its own clear pass."""
+    if _lib.recording() is not None and _lib.gemm_splits(shape[0], shape[1], K) > 1:
+        return _lib.zeros(shape, dtype=torch.float32, device=device), 2
+    return _lib.empty(shape, dtype=torch.float32, device=device), 0
+
+
 class LinearFn(torch.autograd.Function):
     """y[M,N] = x[M,K] W[K,N] + b  (tf.matmul/conv2d-1x1 + bias_add)."""
 
@@ -85,8 +94,8 @@ class LinearFn(torch.autograd.Function):
         xp, ldx = rows_ptr(x)
         M, K = x.shape
         N = w.shape[1]
-        y = _lib.empty((M, N), dtype=torch.float32, device=x.device)
-        gemm(0, 0, M, N, K, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None)
+        y, acc = _gemm_out((M, N), K, x.device)
+        gemm(0, 0, M, N, K, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, acc)
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.bvar = b
@@ -102,8 +111,8 @@ class LinearFn(torch.autograd.Function):
         xp, ldx = rows_ptr(x)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _lib.empty((M, K), dtype=torch.float32, device=x.device)
-            gemm(0, 1, M, K, N, dyp, lddy, ptr(w), N, ptr(dx), K)
+            dx, acc = _gemm_out((M, K), N, x.device)
+            gemm(0, 1, M, K, N, dyp, lddy, ptr(w), N, ptr(dx), K, None, acc)
         gw = _ParamGrad(w, ctx.needs_input_grad[1])
         if gw.needed:
             gemm(1, 0, K, N, M, xp, ldx, dyp, lddy, ptr(gw.buf), N, None, gw.gemm_acc)

@@ -99,6 +99,9 @@ int cloudaae_knn(int b, int n, int c, int ld, int k, const float *x, int *nn_idx
 int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                       const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
                       cloudaae_stream_t stream);
+/* K slices cloudaae_gemm_f32 will use for this shape (> 1: the output is combined with atomics and
+ * must hold zeros first -- the call clears it itself unless accumulate is 1 or 2). */
+int cloudaae_gemm_f32_splits(int M, int N, int K);
 
 /* batch_norm_template (utils/tf_util.py:473-511) on rows y[M,C] (+ ReLU), writing the
  * activation out[M,C] and/or its pool over groups of pool_rows consecutive rows
