@@ -29,7 +29,7 @@ _SIGNATURES = {
     "cloudaae_bn_forward": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P,
                             _P, _P],
     "cloudaae_bn_backward": [_I, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I,
-                             _P, _P, _I, _P, _P],
+                             _P, _P, _P, _I, _P, _P],
     "cloudaae_colsum_f32": [_I, _I, _P, _I, _P, _I, _P, _P],
     "cloudaae_edgeconv_forward": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P,
                                   _P, _P, _P, _I, _P, _P, _P],

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(int M, int C, const float
 //                                                 the gradient among equal maxima)
 // times the ReLU mask [z > 0].
 struct BnBwdArgs {
-    int M, C, ldy, lddo, rows, pool, relu, training;
+    int M, C, ldy, lddo, rows, pool, relu, training, want_xhat_sum;
     const float *y, *dout, *dpooled, *pooled, *ties;
     const float *gamma, *save_mean, *save_var, *scale_shift;
 };
@@ -167,10 +167,10 @@ __device__ __forceinline__ float bn_upstream(const BnBwdArgs &a, int r, int c, f
 __global__ __launch_bounds__(256) void bn_bwd_colsum_kernel(BnBwdArgs a, double *__restrict__ partial,
                                                            int parts)
 {
-    __shared__ double red[2][4][64];
+    __shared__ double red[3][4][64];
     const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    double s = 0.0, s2 = 0.0;
+    double s = 0.0, s2 = 0.0, s3 = 0.0;
     if (c < a.C) {
         const float sc = a.scale_shift[c], sh = a.scale_shift[a.C + c];
         const float mean = a.save_mean[c], rstd = bn_rsqrt(a.save_var[c] + BN_EPS);
@@ -193,16 +193,23 @@ __global__ __launch_bounds__(256) void bn_bwd_colsum_kernel(BnBwdArgs a, double 
                     const float xh = (v[u] - mean) * rstd;
                     s += (double)dz;
                     s2 += (double)dz * (double)xh;
+                    s3 += (double)xh;
                 }
             }
         }
     }
     red[0][rl][lane] = s;
     red[1][rl][lane] = s2;
+    red[2][rl][lane] = s3;
     __syncthreads();
     if (rl == 0 && c < a.C) {
         partial[((size_t)blockIdx.y * 2 + 0) * a.C + c] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
         partial[((size_t)blockIdx.y * 2 + 1) * a.C + c] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+        if (a.want_xhat_sum) {      // third sum (sum of x_hat, ~0) for the gradient of a bias in front of this BN
+            double *p3 = partial + (size_t)BN_MAX_PARTS * 2 * a.C;
+            p3[((size_t)blockIdx.y * 2 + 0) * a.C + c] = (red[2][0][lane] + red[2][1][lane]) + (red[2][2][lane] + red[2][3][lane]);
+            p3[((size_t)blockIdx.y * 2 + 1) * a.C + c] = 0.0;
+        }
     }
 }
 
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(int M, int C, const f
                                                           const float *__restrict__ dout, int lddo,
                                                           float *__restrict__ dy, int lddy,
                                                           float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                          int accumulate)
+                                                          float *__restrict__ dbias, int accumulate)
 {
     __shared__ double red[2][4][64];
     const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -377,11 +384,23 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(int M, int C, const f
     const float m1 = training ? (float)(ts / (double)M) : 0.0f;
     const float m2 = training ? (float)(ts2 / (double)M) : 0.0f;
     const float gr = g * rstd;
+    double sdy = 0.0;
 #pragma unroll
     for (int i = 0; i < BN_SMALL_R; ++i) {
         const int r = rl + 4 * i;
-        if (r < M)
-            dy[(size_t)r * lddy + c] = gr * ((dz[i] - m1) - xh[i] * m2);
+        if (r < M) {
+            const float v = gr * ((dz[i] - m1) - xh[i] * m2);
+            dy[(size_t)r * lddy + c] = v;
+            sdy += (double)v;
+        }
+    }
+    if (dbias != nullptr) {     // gradient of a bias added right in front of this BN: column sum of dy
+        __syncthreads();
+        red[0][rl][lane] = sdy;
+        __syncthreads();
+        if (rl == 0)
+            dbias[c] = (accumulate ? dbias[c] : 0.0f) +
+                       (float)((red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]));
     }
 }
 
@@ -425,7 +444,7 @@ CLOUDAAE_API int cloudaae_bn_forward(int M, int C, const float *y, int ldy, cons
         return 0;
     }
     double *partial = (double *)workspace;
-    float *scale_shift = (float *)(partial + (size_t)BN_MAX_PARTS * 2 * C);
+    float *scale_shift = (float *)(partial + (size_t)BN_MAX_PARTS * 4 * C);
     const int parts = bn_parts(M);
     const int cb = ceil_div(C, 64);
     if (training)
@@ -455,7 +474,7 @@ CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, con
                                       int training, int relu, const float *dout, int lddo, int pool_rows,
                                       int pool_mode, const float *dpooled, const float *pooled,
                                       const float *tie_count, float *dy, int lddy, float *dgamma,
-                                      float *dbeta, int accumulate_param_grads, void *workspace,
+                                      float *dbeta, float *dbias, int accumulate_param_grads, void *workspace,
                                       cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_bn_backward";
@@ -469,17 +488,18 @@ CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, con
     hipStream_t s = (hipStream_t)stream;
     if (pool_mode == 0 && M <= BN_SMALL_M) {
         hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, M, C, y, ldy, gamma, beta,
-                           save_mean, save_var, training, relu, dout, lddo, dy, lddy, dgamma, dbeta,
+                           save_mean, save_var, training, relu, dout, lddo, dy, lddy, dgamma, dbeta, dbias,
                            accumulate_param_grads);
         CLOUDAAE_CHECK_LAUNCH(name);
         return 0;
     }
     double *partial = (double *)workspace;
-    float *scratch = (float *)(partial + (size_t)BN_MAX_PARTS * 2 * C);
+    float *scratch = (float *)(partial + (size_t)BN_MAX_PARTS * 4 * C);
     float *scale_shift = scratch, *m12 = scratch + 2 * (size_t)C;
     hipLaunchKernelGGL(bn_scale_shift_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, C, gamma, beta,
                        save_mean, save_var, scale_shift);
     BnBwdArgs a;
+    a.want_xhat_sum = dbias != nullptr;
     a.M = M; a.C = C; a.ldy = ldy; a.lddo = lddo; a.rows = pool_rows > 0 ? pool_rows : 1;
     a.pool = pool_mode; a.relu = relu; a.training = training;
     a.y = y; a.dout = dout; a.dpooled = dpooled; a.pooled = pooled; a.ties = tie_count;
@@ -488,7 +508,7 @@ CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, con
     const int cb = ceil_div(C, 64);
     hipLaunchKernelGGL(bn_bwd_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, a, partial, parts);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts,
-                       (double)M, training, dgamma, dbeta, accumulate_param_grads, m12);
+                       (double)M, training, dgamma, dbeta, accumulate_param_grads, m12, dbias, gamma, save_var);
     const int slab = 64;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cb, ceil_div(M, slab)), dim3(256), 0, s, a, m12, dy, lddy,
                        slab);

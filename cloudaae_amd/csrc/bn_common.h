@@ -8,9 +8,10 @@ namespace cloudaae {
 constexpr float BN_EPS = 1e-3f;         // tf_util.py:510
 constexpr int BN_MAX_PARTS = 128;       // row-slices of the column reductions
 
-// workspace layout (doubles): [parts][2][C] partial sums, then 4*C floats of
+// workspace layout (doubles): [parts][2][C] partial sums, a second [parts][2][C] block (third sum of
+// the backward pass), then 4*C floats of
 // per-channel scratch (scale, shift | m1, m2) packed into 2*C doubles.
-__host__ __device__ inline size_t bn_ws_doubles(int C) { return (size_t)BN_MAX_PARTS * 2 * C + 2 * (size_t)C; }
+__host__ __device__ inline size_t bn_ws_doubles(int C) { return (size_t)BN_MAX_PARTS * 4 * C + 2 * (size_t)C; }
 
 __device__ __forceinline__ float bn_rsqrt(float v) { return 1.0f / sqrtf(v); }
 
@@ -108,19 +109,32 @@ static __global__ void bn_scale_shift_kernel(int C, const float *__restrict__ ga
 // where the statistics do not depend on the batch).  grid = ceil(C/64) x BN_FIN_THREADS threads.
 static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_bwd_finalize_kernel(
     int C, const double *__restrict__ partial, int parts, double count, int training,
-    float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate, float *__restrict__ m12)
+    float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate, float *__restrict__ m12,
+    float *__restrict__ dbias, const float *__restrict__ gamma, const float *__restrict__ save_var)
 {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-    double s, s2;
+    double s, s2, s3 = 0.0, unused;
     bn_reduce_partials(partial, parts, C, c, pl, s, s2);
+    if (dbias != nullptr) {
+        __syncthreads();
+        bn_reduce_partials(partial + (size_t)BN_MAX_PARTS * 2 * C, parts, C, c, pl, s3, unused);
+    }
     if (c >= C || pl != 0)
         return;
     if (dbeta != nullptr)
         dbeta[c] = (accumulate ? dbeta[c] : 0.0f) + (float)s;
     if (dgamma != nullptr)
         dgamma[c] = (accumulate ? dgamma[c] : 0.0f) + (float)s2;
-    m12[c] = training ? (float)(s / count) : 0.0f;
-    m12[C + c] = training ? (float)(s2 / count) : 0.0f;
+    const float m1 = training ? (float)(s / count) : 0.0f;
+    const float m2 = training ? (float)(s2 / count) : 0.0f;
+    m12[c] = m1;
+    m12[C + c] = m2;
+    if (dbias != nullptr) {
+        // gradient of a bias added right in front of this BN = sum_r dy = gamma*rstd*((sum dz - M*m1) -
+        // m2 * sum xhat): analytically zero, numerically the same round-off a column sum of dy gives
+        const double gr = (double)gamma[c] * (double)bn_rsqrt(save_var[c] + BN_EPS);
+        dbias[c] = (accumulate ? dbias[c] : 0.0f) + (float)(gr * ((s - count * (double)m1) - (double)m2 * s3));
+    }
 }
 
 } // namespace cloudaae

@@ -89,7 +89,9 @@ class LinearFn(torch.autograd.Function):
     """y[M,N] = x[M,K] W[K,N] + b  (tf.matmul/conv2d-1x1 + bias_add)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, bias_grad_by_bn=False):
+        # bias_grad_by_bn: a BatchNormFn consumes y directly and writes d(b) itself (column sums of
+        # its dy come out of its own reductions), so backward here skips the extra pass over dy
         require(x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[0], "LinearFn: shape mismatch")
         xp, ldx = rows_ptr(x)
         M, K = x.shape
@@ -97,7 +99,7 @@ class LinearFn(torch.autograd.Function):
         y, acc = _gemm_out((M, N), K, x.device)
         gemm(0, 0, M, N, K, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, acc)
         ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
+        ctx.has_bias = b is not None and not bias_grad_by_bn
         ctx.bvar = b
         return y
 
@@ -123,7 +125,7 @@ class LinearFn(torch.autograd.Function):
             _lib.check(L().cloudaae_colsum_f32(M, N, dyp, lddy, ptr(gb.buf), gb.accumulate, ptr(ws), stream()),
                        "cloudaae_colsum_f32")
             gb_ret = gb.done()
-        return dx, gw.done(), gb_ret
+        return dx, gw.done(), gb_ret, None
 
 
 class ConcatSlot(object):
@@ -146,9 +148,10 @@ class ConcatLinearFn(torch.autograd.Function):
     column slices of one [M, sum Ci] buffer."""
 
     @staticmethod
-    def forward(ctx, slot, w, b, *nets):
+    def forward(ctx, slot, w, b, bias_grad_by_bn, *nets):
         M = nets[0].shape[0]
         ctx.slot = slot
+        ctx.bias_here = b is not None and not bias_grad_by_bn
         widths = [t.shape[1] for t in nets]
         Ktot = sum(widths)
         require(w.shape[0] == Ktot, "ConcatLinearFn: weight rows != total input channels")
@@ -182,7 +185,7 @@ class ConcatLinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         xp = ctx.cat.data_ptr() if ctx.cat is not None else ctx.xp
         dcat = None
-        if any(ctx.needs_input_grad[3:]):
+        if any(ctx.needs_input_grad[4:]):
             dcat = _lib.empty((M, Ktot), dtype=torch.float32, device=w.device)
             gemm(0, 1, M, Ktot, N, ptr(dy), N, ptr(w), N, ptr(dcat), Ktot)
             if ctx.slot is not None and ctx.cat is None:
@@ -191,7 +194,7 @@ class ConcatLinearFn(torch.autograd.Function):
         if gw.needed:
             gemm(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.gemm_acc)
         gb_ret = None
-        if ctx.bvar is not None and ctx.needs_input_grad[2]:
+        if ctx.bias_here and ctx.needs_input_grad[2]:
             gb = _ParamGrad(ctx.bvar, True)
             ws = _ws(L().cloudaae_bn_workspace_bytes(N), w.device)
             _lib.check(L().cloudaae_colsum_f32(M, N, ptr(dy), N, ptr(gb.buf), gb.accumulate, ptr(ws), stream()),
@@ -199,9 +202,9 @@ class ConcatLinearFn(torch.autograd.Function):
             gb_ret = gb.done()
         grads, off = [], 0
         for i, wd in enumerate(ctx.widths):
-            grads.append(dcat[:, off:off + wd] if (dcat is not None and ctx.needs_input_grad[3 + i]) else None)
+            grads.append(dcat[:, off:off + wd] if (dcat is not None and ctx.needs_input_grad[4 + i]) else None)
             off += wd
-        return (None, gw.done(), gb_ret) + tuple(grads)
+        return (None, gw.done(), gb_ret, None) + tuple(grads)
 
 
 class BatchNormFn(torch.autograd.Function):
@@ -210,8 +213,11 @@ class BatchNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, ema_mean, ema_var, decay, training, relu, pool_rows, pool_mode,
-                want_activation):
+                want_activation, lin_bias=None):
+        # lin_bias: the bias the producing Linear added to y; its gradient (column sums of dy) is
+        # written by this function's backward (see LinearFn.forward: bias_grad_by_bn)
         ctx.set_materialize_grads(False)
+        ctx.lin_bias = lin_bias
         yp, ldy = rows_ptr(y)
         M, C = y.shape
         dev = y.device
@@ -254,19 +260,23 @@ class BatchNormFn(torch.autograd.Function):
         if pool_mode != 0:
             dpooled = torch.zeros_like(pooled) if dpooled is None else dpooled.contiguous()
         if dout is None and pool_mode == 0:
-            return (None,) * 11
+            return (None,) * 12
         dy = _lib.empty((M, C), dtype=torch.float32, device=y.device)
         gg = _ParamGrad(gamma, ctx.needs_input_grad[1])
         gb = _ParamGrad(beta, ctx.needs_input_grad[2])
-        acc = 1 if (gg.accumulate or gb.accumulate) else 0
-        if acc and not (gg.accumulate and gb.accumulate):   # mixed freshness: zero the fresh one
-            (gb if gg.accumulate else gg).buf.zero_()
+        glb = _ParamGrad(ctx.lin_bias, ctx.lin_bias is not None and ctx.needs_input_grad[11])
+        grads = [g for g in (gg, gb, glb) if g.needed]
+        acc = 1 if any(g.accumulate for g in grads) else 0
+        if acc:                                             # mixed freshness: zero the fresh ones
+            for g in grads:
+                if not g.accumulate:
+                    g.buf.zero_()
         ws = _ws(L().cloudaae_bn_workspace_bytes(C), y.device)
         _lib.check(L().cloudaae_bn_backward(
             M, C, yp, ldy, ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_var), training, relu, ptr(dout), C,
             pool_rows, pool_mode, ptr(dpooled), ptr(pooled), ptr(ties), ptr(dy), C, ptr(gg.buf), ptr(gb.buf),
-            acc, ptr(ws), stream()), "cloudaae_bn_backward")
-        return (dy, gg.done(), gb.done()) + (None,) * 8
+            ptr(glb.buf), acc, ptr(ws), stream()), "cloudaae_bn_backward")
+        return (dy, gg.done(), gb.done()) + (None,) * 8 + (glb.done() if glb.needed else None,)
 
 
 class EdgeConvFn(torch.autograd.Function):

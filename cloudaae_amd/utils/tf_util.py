@@ -160,12 +160,13 @@ def conv2d(inputs,
             out_shape = (B, H, 1, num_output_channels)
         w2 = kernel.data.reshape(-1, num_output_channels)
         w2._cloudaae_var = kernel
-        outputs = F.LinearFn.apply(rows, w2, biases.data)
+        outputs = F.LinearFn.apply(rows, w2, biases.data, bool(bn))
         if bn:
             with variable_scope('bn'):
                 beta, gamma, ema_mean, ema_var = _bn_variables(num_output_channels)
             outputs, _, _ = F.BatchNormFn.apply(outputs, gamma.data, beta.data, ema_mean.data, ema_var.data,
-                                                _decay_tensor(bn_decay), bool(is_training), act, 0, 0, True)
+                                                _decay_tensor(bn_decay), bool(is_training), act, 0, 0, True,
+                                                biases.data)
         elif act:
             outputs = _relu_rows(outputs)
     return outputs.reshape(out_shape)
@@ -199,12 +200,13 @@ def fully_connected(inputs,
                                               wd=weight_decay, use_xavier=use_xavier, trainable=trainable,
                                               fan=(num_input_units, num_outputs))
         biases = _variable_on_cpu('biases', [num_outputs], VariableStore.constant(0.0), trainable=trainable)
-        outputs = F.LinearFn.apply(inputs, weights.data, biases.data)
+        outputs = F.LinearFn.apply(inputs, weights.data, biases.data, bool(bn))
         if bn:
             with variable_scope('bn'):
                 beta, gamma, ema_mean, ema_var = _bn_variables(num_outputs)
             outputs, _, _ = F.BatchNormFn.apply(outputs, gamma.data, beta.data, ema_mean.data, ema_var.data,
-                                                _decay_tensor(bn_decay), bool(is_training), act, 0, 0, True)
+                                                _decay_tensor(bn_decay), bool(is_training), act, 0, 0, True,
+                                                biases.data)
         elif act:
             outputs = _relu_rows(outputs)
     return outputs, weights.data, biases.data
@@ -342,14 +344,16 @@ def conv2d_concat(inputs_list, num_output_channels, scope, bn_decay=None, is_tra
             beta, gamma, ema_mean, ema_var = _bn_variables(num_output_channels)
     w2 = kernel.data.reshape(cin, num_output_channels)
     w2._cloudaae_var = kernel
-    y = F.ConcatLinearFn.apply(slot, w2, biases.data, *rows)
+    y = F.ConcatLinearFn.apply(slot, w2, biases.data, True, *rows)
     mode = {None: 0, 'mean': 1, 'max': 2}[pool]
     if mode == 0:
         act, mean, var = F.BatchNormFn.apply(y, gamma.data, beta.data, ema_mean.data, ema_var.data,
-                                             _decay_tensor(bn_decay), bool(is_training), True, 0, 0, True)
+                                             _decay_tensor(bn_decay), bool(is_training), True, 0, 0, True,
+                                             biases.data)
         return None, act.reshape(B, N, 1, num_output_channels)
     pooled, mean, var = F.BatchNormFn.apply(y, gamma.data, beta.data, ema_mean.data, ema_var.data,
-                                            _decay_tensor(bn_decay), bool(is_training), True, N, mode, False)
+                                            _decay_tensor(bn_decay), bool(is_training), True, N, mode, False,
+                                            biases.data)
     return pooled, LazyActivation(y, mean, var, gamma.data, beta.data, (B, N, 1, num_output_channels))
 
 

@@ -119,12 +119,14 @@ int cloudaae_bn_forward(int M, int C, const float *y, int ldy, const float *gamm
                         cloudaae_stream_t stream);
 /* gradient of the above: upstream = dout[M,C] (may be NULL) and/or dpooled[M/pool_rows,C]
  * (mean: /pool_rows; max: shared among equal maxima, as tf.reduce_max does);
- * produces dy[M,C], dgamma[C], dbeta[C] (NULL = not wanted). */
+ * produces dy[M,C], dgamma[C], dbeta[C] (NULL = not wanted), and dbias[C] (NULL = not wanted): the
+ * gradient of a bias added to y right before the batch norm (tf_util.py:166 / :352 followed by
+ * :173 / :355), i.e. the column sums of dy, without another pass over dy. */
 int cloudaae_bn_backward(int M, int C, const float *y, int ldy, const float *gamma, const float *beta,
                          const float *save_mean, const float *save_var, int training, int relu,
                          const float *dout, int lddo, int pool_rows, int pool_mode, const float *dpooled,
                          const float *pooled, const float *tie_count, float *dy, int lddy, float *dgamma,
-                         float *dbeta, int accumulate_param_grads, void *workspace,
+                         float *dbeta, float *dbias, int accumulate_param_grads, void *workspace,
                          cloudaae_stream_t stream);
 /* out[c] (+)= sum_r x[r][c] (bias gradients); workspace as for bn (same C). */
 int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, float *out, int accumulate, void *workspace,
