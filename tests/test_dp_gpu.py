@@ -54,7 +54,30 @@ def _worker(rank, world, port, out):
         dist.all_gather(params, dp.store.flat_params)
         ok_same = all(torch.equal(params[0], p) for p in params)            # replicas stay bit-identical
         ok_moved = not torch.equal(dp.store.flat_params, p_init)
-        out[rank] = [ok_world, ok_init, ok_grad, ok_early, ok_same, ok_moved]
+        # (c) the same with the recorded step: step 1 records, steps 2-3 are replays whose
+        # all-reduces are host callbacks of the plan; replicas must stay bit-identical and the
+        # replayed gradient must be the all-reduced sum of what each rank computes alone
+        rp = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, seed=5, replay=True)
+        for _ in range(3):
+            rp.train_step(el)
+        ok_replayed = rp.replay and rp._plan is not None
+        params = [torch.empty_like(rp.store.flat_params) for _ in range(world)]
+        dist.all_gather(params, rp.store.flat_params)
+        ok_rsame = all(torch.equal(params[0], p) for p in params)
+        solo2 = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B // world}, process_group=False, seed=5)
+        solo2.store.load_state_dict(rp.store.state_dict())
+        snap = rp.store.flat_params.clone()
+        rp.train_step(el)                                   # 4th step (replay): its gradients ...
+        with torch.no_grad():
+            solo2.store.flat_params.copy_(snap)             # ... vs one rank alone on the same weights
+        solo2.bn_decay.copy_(rp.bn_decay)
+        solo2.store.begin_step()
+        solo2.forward(el)["total_loss"].backward()
+        g2 = [torch.empty_like(g_local) for _ in range(world)]
+        dist.all_gather(g2, solo2.store.flat_grads.clone())
+        g2sum = sum(g2)
+        ok_rgrad = float((rp.store.flat_grads - g2sum).abs().max()) <= 5e-4 * float(g2sum.abs().max())
+        out[rank] = [ok_world, ok_init, ok_grad, ok_early, ok_same, ok_moved, ok_replayed, ok_rsame, ok_rgrad]
     finally:
         dist.destroy_process_group()
 
@@ -63,4 +86,4 @@ def test_data_parallel_two_ranks(hip):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    assert dict(out) == {0: [True] * 6, 1: [True] * 6}
+    assert dict(out) == {0: [True] * 9, 1: [True] * 9}
