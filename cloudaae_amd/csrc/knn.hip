@@ -481,23 +481,25 @@ __global__ __launch_bounds__(KNN_THREADS) void knn64_mfma_kernel(int n, int ld, 
 // |x_j|^2 of the whole cloud is computed once per workgroup (sequential un-fused sum, as the oracle
 // defines it) and kept in LDS.  Arithmetic and tie rule are those of the kernels above, so the
 // indices stay bit-identical to oracle_knn.
-constexpr int KS_QCAP = 32;          // queue slots per lane; a round pushes at most 16
+constexpr int KS_QCAP = 24;          // queue slots per lane; a round pushes at most 16
 
-template <int K, int QW>
-__global__ __launch_bounds__(64 * QW) void knn64_scan_kernel(int n, int ld, int k,
-                                                             const float *__restrict__ x,
-                                                             int *__restrict__ nn_idx)
+// QW query tiles per workgroup, CS waves per query tile (wave cs scans the candidate tiles t = r*CS + cs)
+template <int K, int QW, int CS>
+__global__ __launch_bounds__(64 * QW * CS) void knn64_scan_kernel(int n, int ld, int k,
+                                                                  const float *__restrict__ x,
+                                                                  int *__restrict__ nn_idx)
 {
-    constexpr int THREADS = 64 * QW;
+    constexpr int WAVES = QW * CS, THREADS = 64 * WAVES;
     constexpr int TILE_FLOATS = KM_TILE * KM_LD;
     extern __shared__ __attribute__((aligned(16))) char ks_smem[];
-    // layout: tile[2][TILE_FLOATS] | queue d[QW][QCAP][64] | queue i[QW][QCAP][64] | sq[n]
+    // layout: tile[2][CS][TILE_FLOATS] | queue d[WAVES][QCAP][64] | queue i[WAVES][QCAP][64] | sq[n]
     float *tiles = reinterpret_cast<float *>(ks_smem);
-    float *qd_all = tiles + 2 * TILE_FLOATS;
-    int *qi_all = reinterpret_cast<int *>(qd_all + QW * KS_QCAP * 64);
-    float *sq = reinterpret_cast<float *>(qi_all + QW * KS_QCAP * 64);
+    float *qd_all = tiles + 2 * CS * TILE_FLOATS;
+    int *qi_all = reinterpret_cast<int *>(qd_all + WAVES * KS_QCAP * 64);
+    float *sq = reinterpret_cast<float *>(qi_all + WAVES * KS_QCAP * 64);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qt = wave / CS, cs = wave % CS;
     int qgroup, cloud;
     xcd_cloud_tile(qgroup, cloud);
     const float *X = x + (size_t)cloud * n * ld;
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(64 * QW) void knn64_scan_kernel(int n, int ld, int 
     }
 
     const int col = lane & 31, half = lane >> 5;
-    const int qi0 = (qgroup * QW + wave) * KM_TILE + col;     // this lane's query
+    const int qi0 = (qgroup * QW + qt) * KM_TILE + col;       // this lane's query
     const bool qvalid = qi0 < n;
     const int qs = qvalid ? qi0 : 0;
     // B operand: query channels of parity `half`, one register per MFMA step
@@ -536,29 +538,32 @@ __global__ __launch_bounds__(64 * QW) void knn64_scan_kernel(int n, int ld, int 
         }
     }
 
-    // staging map: 32 rows x 16 float4 per tile, spread over the workgroup
-    constexpr int VECS = KM_TILE * 16, PER = (VECS + THREADS - 1) / THREADS;
+    // staging map: a round = CS tiles of 32 rows x 16 float4, spread over the workgroup
+    constexpr int VECS = CS * KM_TILE * 16, PER = (VECS + THREADS - 1) / THREADS;
     float4v stage[PER];
-    auto fetch = [&](int t) {
-        const int c0 = t * KM_TILE;
+    auto fetch = [&](int r) {
+        const int c0 = r * CS * KM_TILE;
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int v = u * THREADS + tid;
             const int row = v >> 4, q4 = v & 15;
-            stage[u] = (c0 + row < n) ? *reinterpret_cast<const float4v *>(X + (size_t)(c0 + row) * ld + 4 * q4)
-                                      : float4v{0.f, 0.f, 0.f, 0.f};
+            stage[u] = (v < VECS && c0 + row < n)
+                           ? *reinterpret_cast<const float4v *>(X + (size_t)(c0 + row) * ld + 4 * q4)
+                           : float4v{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto commit = [&](float *buf) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int v = u * THREADS + tid;
-            const int row = v >> 4, q4 = v & 15;
-            float *dst = buf + row * KM_LD + 4 * q4;
-            dst[0] = stage[u].x;
-            dst[1] = stage[u].y;
-            dst[2] = stage[u].z;
-            dst[3] = stage[u].w;
+            if (VECS % THREADS == 0 || v < VECS) {
+                const int row = v >> 4, q4 = v & 15;      // row in [0, CS*32): tile row / 32, line row % 32
+                float *dst = buf + (row >> 5) * TILE_FLOATS + (row & 31) * KM_LD + 4 * q4;
+                dst[0] = stage[u].x;
+                dst[1] = stage[u].y;
+                dst[2] = stage[u].z;
+                dst[3] = stage[u].w;
+            }
         }
     };
 
@@ -585,15 +590,16 @@ __global__ __launch_bounds__(64 * QW) void knn64_scan_kernel(int n, int ld, int 
     };
 
     const int ntiles = (n + KM_TILE - 1) / KM_TILE;
+    const int rounds = (ntiles + CS - 1) / CS;
     fetch(0);
     commit(tiles);
-    __syncthreads();                                      // tile 0 and sq[] visible
+    __syncthreads();                                      // round 0 and sq[] visible
     const float sqi = sq[qs];
     // filter of one finished tile: acc[e] = <x_q, x_{c0 + row(e)}>, csq[e] = |x_{c0 + row(e)}|^2 (read
     // from LDS ahead of time: the queue lives in the same LDS array, so the compiler cannot move
     // those reads across the queue writes by itself)
     auto filter = [&](const f32x16 &acc, const float (&csq)[16], int c0) {
-        const int cnt_rows = min(KM_TILE, n - c0);
+        const int cnt_rows = min(KM_TILE, n - c0);        // <= 0 for a tile past the end
         if (__any(cnt > KS_QCAP - 17))
             drain();
 #pragma unroll
@@ -615,87 +621,121 @@ __global__ __launch_bounds__(64 * QW) void knn64_scan_kernel(int n, int ld, int 
     };
     f32x16 prev;
     float pcsq[16];
-    for (int t = 0; t < ntiles; ++t) {
-        const float *cur = tiles + (t & 1) * TILE_FLOATS;
+    for (int r = 0; r < rounds; ++r) {
+        const int c0 = (r * CS + cs) * KM_TILE;           // this wave's tile of the round
+        const float *cur = tiles + ((r & 1) * CS + cs) * TILE_FLOATS;
         const float *arow = cur + col * KM_LD + half;     // A operand: candidate row `col`, parity `half`
         float aop[32], ccsq[16];
 #pragma unroll
         for (int s = 0; s < 32; ++s)
             aop[s] = arow[2 * s];                         // all LDS reads of the tile in flight at once
-        load_csq(ccsq, t * KM_TILE);
-        if (t + 1 < ntiles)
-            fetch(t + 1);                                 // global -> registers behind the MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-        if (t > 0)
-            filter(prev, pcsq, (t - 1) * KM_TILE);        // VALU work of the previous tile hides the LDS latency
+        load_csq(ccsq, c0);
+        if (r + 1 < rounds)
+            fetch(r + 1);                                 // global -> registers behind the MFMAs
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e)
             acc[e] = 0.0f;
+        if (r > 0 && __any(cnt > KS_QCAP - 17))
+            drain();
+        // the filter of the PREVIOUS tile (VALU + LDS pushes, independent of acc) is issued between the
+        // MFMAs of this tile, two MFMAs per candidate row, so it runs in their shadow
 #pragma unroll
-        for (int s = 0; s < 32; ++s)
+        for (int s = 0; s < 32; ++s) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[s], bq[s], acc, 0, 0, 0);
+            if (r > 0 && (s & 1)) {
+                const int e = s >> 1;
+                const int pc0 = c0 - CS * KM_TILE;
+                const int rr = (e & 3) + 8 * (e >> 2) + 4 * half;
+                const float m2 = -2.0f * prev[e];
+                const float tt = sqi + m2;
+                const float d = tt + pcsq[e];
+                qd[cnt * 64 + lane] = d;
+                qi[cnt * 64 + lane] = pc0 + rr;
+                cnt += (rr < min(KM_TILE, n - pc0) && d < thr) ? 1 : 0;
+            }
+        }
         prev = acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e)
             pcsq[e] = ccsq[e];
-        if (t + 1 < ntiles)
-            commit(tiles + ((t + 1) & 1) * TILE_FLOATS);  // last read of that buffer: one barrier ago
+        if (r + 1 < rounds)
+            commit(tiles + ((r + 1) & 1) * CS * TILE_FLOATS);   // last read of that buffer: one barrier ago
         __syncthreads();
     }
-    filter(prev, pcsq, (ntiles - 1) * KM_TILE);
+    filter(prev, pcsq, ((rounds - 1) * CS + cs) * KM_TILE);
     drain();
 
-    // merge the two half-lists of every query lexicographically by (d, j): each is already sorted
-    // that way (candidates arrive in ascending j, the insert is stable)
-    if (half) {
+    // merge the 2*CS lists of every query lexicographically by (d, j): each is already sorted that
+    // way (its candidates arrive in ascending j, the insert is stable).  The lists go through the
+    // queue area of the query tile's first wave: [list][p][query].
+    __syncthreads();
+    float *md = qd_all + (qt * CS) * KS_QCAP * 64;
+    int *mi = qi_all + (qt * CS) * KS_QCAP * 64;
+    static_assert(2 * CS * K * 32 <= CS * KS_QCAP * 64, "merge lists must fit the queue area of one query tile");
+    const int list = cs * 2 + half;
 #pragma unroll
-        for (int p = 0; p < K; ++p) {
-            qd[p * 64 + col] = top.d[p];
-            qi[p * 64 + col] = top.i[p];
-        }
+    for (int p = 0; p < K; ++p) {
+        md[(list * K + p) * 32 + col] = top.d[p];
+        mi[(list * K + p) * 32 + col] = top.i[p];
     }
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    if (!half && qvalid) {
-        int *dst = nn_idx + ((size_t)cloud * n + qi0) * k;
-        int pa = 0, pb = 0;
-        for (int p = 0; p < k; ++p) {
-            float da = __builtin_inff(), db = __builtin_inff();
-            int ia = 0x7fffffff, ib = 0x7fffffff;
+    __syncthreads();
+    if (cs == 0 && half == 0 && qvalid) {
+        int head[2 * CS];
 #pragma unroll
-            for (int u = 0; u < K; ++u) {                 // register file has no dynamic index: select
-                da = (u == pa) ? top.d[u] : da;
-                ia = (u == pa) ? top.i[u] : ia;
+        for (int l = 0; l < 2 * CS; ++l)
+            head[l] = 0;
+        int *dst = nn_idx + ((size_t)cloud * n + qi0) * k;
+        for (int p = 0; p < k; ++p) {
+            float bd = __builtin_inff();
+            int bi = 0x7fffffff, bl = 0;
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l) {
+                const int h = head[l];
+                const float d = h < K ? md[(l * K + h) * 32 + col] : __builtin_inff();
+                const int i = h < K ? mi[(l * K + h) * 32 + col] : 0x7fffffff;
+                const bool better = d < bd || (d == bd && i < bi);
+                bd = better ? d : bd;
+                bi = better ? i : bi;
+                bl = better ? l : bl;
             }
-            if (pb < K) {
-                db = qd[pb * 64 + col];
-                ib = qi[pb * 64 + col];
-            }
-            const bool take_b = db < da || (db == da && ib < ia);
-            dst[p] = take_b ? ib : ia;
-            pa += take_b ? 0 : 1;
-            pb += take_b ? 1 : 0;
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l)
+                head[l] += (l == bl) ? 1 : 0;
+            dst[p] = bi == 0x7fffffff ? 0 : bi;
         }
     }
 }
 
-template <int K, int QW>
+template <int K, int QW, int CS>
 static hipError_t launch_knn_scan(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
-    const size_t lds = sizeof(float) * (2 * KM_TILE * KM_LD + 2 * QW * KS_QCAP * 64 + (size_t)n);
+    const size_t lds = sizeof(float) * (2 * CS * KM_TILE * KM_LD + 2 * QW * CS * KS_QCAP * 64 + (size_t)n);
     static bool raised = false;       // >64 KiB of dynamic LDS needs the attribute once per kernel
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn64_scan_kernel<K, QW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn64_scan_kernel<K, QW, CS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess)
             return e;
         raised = true;
     }
-    hipLaunchKernelGGL((knn64_scan_kernel<K, QW>), dim3(ceil_div(n, KM_TILE * QW), b), dim3(64 * QW), lds, s, n, ld,
-                       k, x, nn_idx);
+    hipLaunchKernelGGL((knn64_scan_kernel<K, QW, CS>), dim3(ceil_div(n, KM_TILE * QW), b), dim3(64 * QW * CS), lds, s,
+                       n, ld, k, x, nn_idx);
     return hipSuccess;
+}
+
+// Which C = 64 kernel for `tiles` 32-query tiles (measured, B x N = 1024 points, k = 10, us):
+//   tiles      knn64_mfma   scan, 1 wave/tile   scan, 2 waves/tile
+//    256 (B=8)      61            108                 82
+//   1024 (B=32)    138            134                113
+//   8192 (B=256)   808            645                833
+// 0 = knn64_mfma_kernel.  CLOUDAAE_KNN_SCAN=0/1/2 forces a choice (tests cover all three).
+static int knn_scan_waves(long long tiles)
+{
+    if (const char *e = getenv("CLOUDAAE_KNN_SCAN"))
+        return atoi(e);
+    return tiles >= 4096 ? 1 : tiles >= 1024 ? 2 : 0;
 }
 
 template <int K>
@@ -706,19 +746,14 @@ static void launch_knn(int b, int n, int c, int ld, int k, const float *x, int *
         hipLaunchKernelGGL(knn3_kernel<K>, dim3(ceil_div(n, 64), b), dim3(KNN_THREADS), 0, s, n, ld,
                            k, x, nn_idx);
     else if (c == 64 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && K <= 20 && n <= 16384 &&
-             getenv("CLOUDAAE_KNN_SCAN")) {
-        // EXPERIMENTAL (opt-in): measured 143 us vs 138 us for knn64_mfma_kernel at B=32, N=1024.
-        // It issues 5x fewer VALU instructions per SIMD (18 k vs ~90 k), but with one wave per SIMD
-        // nothing overlaps the MFMAs (65 k cycles), the VALU work (73 k), LDS/queue waits (94 k)
-        // and the per-tile workgroup barrier; two waves per query tile is the next thing to try.
-        // query tiles per workgroup: as many as still leave one workgroup per CU
-        const long long tiles = (long long)ceil_div(n, KM_TILE) * b;
-        if (tiles >= 4 * 256)
-            (void)launch_knn_scan<K, 4>(b, n, ld, k, x, nn_idx, s);
-        else if (tiles >= 2 * 256)
-            (void)launch_knn_scan<K, 2>(b, n, ld, k, x, nn_idx, s);
-        else
-            (void)launch_knn_scan<K, 1>(b, n, ld, k, x, nn_idx, s);
+             knn_scan_waves((long long)ceil_div(n, KM_TILE) * b) > 0) {
+        if constexpr (K <= 20) {
+            const long long tiles = (long long)ceil_div(n, KM_TILE) * b;
+            if (knn_scan_waves(tiles) == 2)
+                (void)launch_knn_scan<K, 4, 2>(b, n, ld, k, x, nn_idx, s);
+            else
+                (void)launch_knn_scan<K, 4, 1>(b, n, ld, k, x, nn_idx, s);
+        }
     } else if (c == 64 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && K <= 20)
         hipLaunchKernelGGL(knn64_mfma_kernel<K>, dim3(ceil_div(n, KM_TILE), b), dim3(KNN_THREADS), 0, s, n,
                            ld, k, x, nn_idx);

@@ -175,12 +175,16 @@ def test_knn_vs_oracle(hip, oracle, b, n, c, ld, k):
     assert np.array_equal(want, got.cpu().numpy())
 
 
-@pytest.mark.parametrize("b,n,k", [(2, 333, 10), (40, 1024, 10), (3, 1500, 20)])
-def test_knn_scan_kernel_vs_oracle(hip, oracle, monkeypatch, b, n, k):
-    """The opt-in whole-cloud scan kernel (CLOUDAAE_KNN_SCAN=1, knn.hip) keeps the same bit-exact
-    contract, ties included, with 1, 2 and 4 query tiles per workgroup."""
+@pytest.mark.parametrize("b,n,k,mode", [(2, 333, 10, 1), (40, 1024, 10, 1), (3, 1500, 20, 2), (33, 1024, 10, 2),
+                                          (2, 700, 20, 0), (140, 1024, 10, None)])
+def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, monkeypatch, b, n, k, mode):
+    """All three C = 64 kernels (CLOUDAAE_KNN_SCAN = 0: knn64_mfma, 1 / 2: whole-cloud scan with one /
+    two waves per query tile; None: the launcher's own choice) keep the same bit-exact contract."""
     from cloudaae_amd import _lib
-    monkeypatch.setenv("CLOUDAAE_KNN_SCAN", "1")
+    if mode is None:
+        monkeypatch.delenv("CLOUDAAE_KNN_SCAN", raising=False)
+    else:
+        monkeypatch.setenv("CLOUDAAE_KNN_SCAN", str(mode))
     rng = np.random.default_rng(n + k)
     x = np.maximum(rng.standard_normal((b, n, 64)), -0.5).astype(np.float32) * 0.1
     x[:, n // 2:n // 2 + 30] = x[:, :30]
