@@ -24,6 +24,7 @@ _SIGNATURES = {
     "cloudaae_farthest_point_sample": [_I, _I, _I, _P, _P, _P, _P],
     "cloudaae_gather_point": [_I, _I, _I, _P, _P, _P, _P],
     "cloudaae_gather_point_grad": [_I, _I, _I, _P, _P, _P, _P],
+    "cloudaae_prob_sample": [_I, _I, _I, _P, _P, _P, _P, _P],
     "cloudaae_knn": [_I, _I, _I, _I, _I, _P, _P, _P],
     "cloudaae_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "cloudaae_bn_forward": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P,

@@ -230,6 +230,91 @@ static int launch_fps_reg(int b, int n, int m, const float *inp, int *out, hipSt
     return 0;
 }
 
+// ---- ProbSample (tf_sampling_g.cu:7-104) ------------------------------------------------
+// Inclusive prefix sums of a row of category weights, then one search per uniform draw.  The
+// association order of the sums is part of the result (it decides which index a draw next to a
+// boundary gets), so it is the reference's, as restated in oracle_prob_sample: chunks of 8192
+// values; quads a, a+b, c+(a+b), (d+c)+(a+b); the quad totals scanned in place by an up-sweep /
+// down-sweep tree; a compensated carry between chunks.  One workgroup per row; the tree levels are
+// data-parallel (every level touches disjoint pairs), one barrier per level.
+constexpr int PS_CHUNK = 8192, PS_THREADS = 512;
+
+__global__ __launch_bounds__(PS_THREADS) void prob_cumsum_kernel(int n, const float *__restrict__ inp,
+                                                                float *__restrict__ cum)
+{
+    __shared__ float val[PS_CHUNK];
+    __shared__ float tot[PS_CHUNK / 4];
+    const float *p = inp + (size_t)blockIdx.x * n;
+    float *c = cum + (size_t)blockIdx.x * n;
+    const int t = threadIdx.x;
+    float carry = 0.0f, carry2 = 0.0f;      // identical in every thread
+    for (int j = 0; j < n; j += PS_CHUNK) {
+        const int len = min(n - j, PS_CHUNK);
+        const int padded = (len + 3) & ~3, quads = padded >> 2;
+        for (int g = t; g < quads; g += PS_THREADS) {
+            const int k = 4 * g;
+            if (k + 3 < len) {
+                const float a = p[j + k], b = p[j + k + 1], cc = p[j + k + 2], d = p[j + k + 3];
+                const float ab = b + a, dc = d + cc;
+                val[k] = a;
+                val[k + 1] = ab;
+                val[k + 2] = cc + ab;
+                val[k + 3] = dc + ab;
+                tot[g] = dc + ab;
+            } else {                          // ragged last quad: left to right, padded with its total
+                float v = 0.0f;
+                for (int e = k; e < len; ++e) {
+                    v = v + p[j + e];
+                    val[e] = v;
+                }
+                for (int e = len; e < padded; ++e)
+                    val[e] = v;
+                tot[g] = v;
+            }
+        }
+        int u = 0;
+        for (; (2 << u) <= quads; ++u) {      // up-sweep
+            __syncthreads();
+            for (int k = t; k < (quads >> (u + 1)); k += PS_THREADS)
+                tot[(((k << 1) + 2) << u) - 1] += tot[(((k << 1) + 1) << u) - 1];
+        }
+        for (--u; u >= 0; --u) {              // down-sweep
+            __syncthreads();
+            for (int k = t; k < ((quads - (1 << u)) >> (u + 1)); k += PS_THREADS)
+                tot[(((k << 1) + 3) << u) - 1] += tot[(((k << 1) + 2) << u) - 1];
+        }
+        __syncthreads();
+        for (int e = t; e < len; e += PS_THREADS) {
+            const int g = e >> 2;
+            const float v = g > 0 ? val[e] + tot[g - 1] : val[e];
+            c[j + e] = v + carry;
+        }
+        const float tt = tot[quads - 1] + carry2;
+        const float r2 = carry + tt;
+        carry2 = tt - (r2 - carry);
+        carry = r2;
+        __syncthreads();                      // val/tot are rewritten by the next chunk
+    }
+}
+
+__global__ __launch_bounds__(256) void prob_search_kernel(int n, int m, const float *__restrict__ cum,
+                                                         const float *__restrict__ draws, int *__restrict__ out)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= m)
+        return;
+    const float *c = cum + (size_t)blockIdx.y * n;
+    int base = 1;
+    while (base < n)
+        base <<= 1;
+    const float key = draws[(size_t)blockIdx.y * m + q] * c[n - 1];
+    int r = n - 1;
+    for (int k = base; k >= 1; k >>= 1)
+        if (r >= k && c[r - k] >= key)
+            r -= k;
+    out[(size_t)blockIdx.y * m + q] = r;
+}
+
 } // namespace cloudaae
 
 using namespace cloudaae;
@@ -292,6 +377,22 @@ CLOUDAAE_API int cloudaae_gather_point_grad(int b, int n, int m, const float *ou
         return 0;
     hipLaunchKernelGGL(scatter_add_point_kernel, dim3(ceil_div(m, 256), b), dim3(256), 0, s, n, m,
                        out_g, idx, inp_g);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp,
+                                      int *out, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_prob_sample";
+    CLOUDAAE_REQUIRE(b >= 0 && n >= 1 && m >= 0 && b <= 65535, name, "bad size");
+    if (b == 0)
+        return 0;
+    CLOUDAAE_REQUIRE(inp_p && temp && (m == 0 || (inp_r && out)), name, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(prob_cumsum_kernel, dim3(b), dim3(PS_THREADS), 0, s, n, inp_p, temp);
+    if (m > 0)
+        hipLaunchKernelGGL(prob_search_kernel, dim3(ceil_div(m, 256), b), dim3(256), 0, s, n, m, temp, inp_r, out);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }

@@ -1,11 +1,36 @@
 """Sampling ops -- mirror of the reference's tf_ops/sampling/tf_sampling.py:14-57,
-backed by cloudaae_farthest_point_sample / cloudaae_gather_point[_grad]
+backed by cloudaae_prob_sample / cloudaae_farthest_point_sample / cloudaae_gather_point[_grad]
 (include/cloudaae_hip.h).
 """
 import torch
 
 from ... import _lib
 from ..._lib import ptr, require, stream
+
+
+def prob_sample(inp, inpr):
+    """
+input:
+    batch_size * ncategory float32
+    batch_size * npoints   float32
+returns:
+    batch_size * npoints   int32
+    """
+    # tf_sampling.cpp:77-82: rank-2 inputs with equal batch; no gradient (tf_sampling.py:22)
+    require(inp.dim() == 2, "ProbSample expects (batch_size,num_choices) inp shape")
+    require(inpr.dim() == 2 and inpr.shape[0] == inp.shape[0],
+            "ProbSample expects (batch_size,num_points) inpr shape")
+    require(inp.dtype == torch.float32 and inpr.dtype == torch.float32, "ProbSample: float32 inputs")
+    require(inp.shape[1] >= 1, "ProbSample needs at least one category")
+    inp = inp.detach().contiguous()
+    inpr = inpr.detach().contiguous()
+    b, n = inp.shape
+    m = inpr.shape[1]
+    out = torch.empty((b, m), dtype=torch.int32, device=inp.device)
+    temp = torch.empty((b, n), dtype=torch.float32, device=inp.device)
+    _lib.check(_lib.lib().cloudaae_prob_sample(b, n, m, ptr(inp), ptr(inpr), ptr(temp), ptr(out), stream()),
+               "cloudaae_prob_sample")
+    return out
 
 
 def farthest_point_sample(npoint, inp):

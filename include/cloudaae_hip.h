@@ -76,6 +76,15 @@ int cloudaae_gather_point(int b, int n, int m, const float *inp, const int *idx,
 int cloudaae_gather_point_grad(int b, int n, int m, const float *out_g, const int *idx,
                                float *inp_g, cloudaae_stream_t stream);
 
+/* out[b,m] = for every draw inp_r[b,m] in [0,1) the smallest category whose inclusive prefix sum of
+ * inp_p[b,n] reaches inp_r * total; temp[b*n] receives the prefix sums (the reference's workspace).
+ * The prefix sums keep the reference's association order (quads, scan tree, compensated chunk
+ * carry), so the indices are those of its kernels.  No gradient (tf_sampling.py:22).
+ * Replaces: void probsampleLauncher(int b,int n,int m,const float* inp_p,const float* inp_r,
+ *   float* temp,int* out) (tf_sampling.cpp:65, tf_sampling_g.cu:7-104,198-201). */
+int cloudaae_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp,
+                         int *out, cloudaae_stream_t stream);
+
 /* ---- utils/tf_util.py: kNN grouping ------------------------------------- */
 
 /* pairwise_xyz_distance + knn fused (utils/tf_util.py:597-632): for every point

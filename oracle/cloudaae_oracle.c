@@ -210,6 +210,98 @@ ORACLE_API void oracle_gather_point_grad(int b, int n, int m, const float *out_g
 }
 
 /* ------------------------------------------------------------------------
+ * ProbSample = tf_sampling_g.cu:7-87 (cumsumKernel) + :89-104 (binarysearchKernel),
+ * launched by probsampleLauncher (:198-201): for every row, an inclusive prefix
+ * sum of the category weights, then for every uniform draw r the smallest index
+ * whose prefix sum is >= r * total.
+ * The prefix sum is NOT a left-to-right sum; its association order is part of
+ * the result (it decides which index an r near a boundary gets), so it is
+ * restated here exactly:
+ *   - the row is cut into chunks of 8192 values (:8, BlockSize*4);
+ *   - a chunk is cut into quads; quad prefix = a, a+b, c+(a+b), (d+c)+(a+b)
+ *     (:20-33); a ragged last quad is summed left to right and padded with its
+ *     total (:34-43);
+ *   - the quad totals G[0..n2) get an in-place inclusive scan: up-sweep
+ *     G[((2k+2)<<u)-1] += G[((2k+1)<<u)-1] for u = 0,1,.. while (2<<u) <= n2
+ *     (:46-56), then down-sweep G[((2k+3)<<u)-1] += G[((2k+2)<<u)-1] for u back
+ *     to 0 (:57-67);
+ *   - quad g >= 1 adds G[g-1] to its four prefixes (:69-77);
+ *   - the chunk adds the carry of the previous chunks, kept as a compensated
+ *     pair: t = G[n2-1] + c2; r = c1 + t; c2 = t - (r - c1); c1 = r (:81-84).
+ * Search (:89-104): q = r * cum[n-1]; idx = n-1; for k = pow2 >= n down to 1:
+ * if (idx >= k && cum[idx-k] >= q) idx -= k.
+ * `cum` (b*n floats) receives the prefix sums, as the reference's `temp`. */
+ORACLE_API void oracle_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r,
+                                   float *cum, int32_t *out)
+{
+    enum { CHUNK = 8192 };
+    float *G = (float *)malloc(sizeof(float) * (CHUNK / 4));
+    float *V = (float *)malloc(sizeof(float) * CHUNK);
+    for (int row = 0; row < b; ++row) {
+        const float *p = inp_p + (size_t)row * n;
+        float *c = cum + (size_t)row * n;
+        float carry = 0.0f, carry2 = 0.0f;
+        for (int j = 0; j < n; j += CHUNK) {
+            const int len = n - j < CHUNK ? n - j : CHUNK;
+            const int padded = (len + 3) & ~3, n2 = padded >> 2;
+            for (int g = 0; g < n2; ++g) {
+                const int k = 4 * g;
+                if (k + 3 < len) {
+                    const float v1 = p[j + k];
+                    float v2 = p[j + k + 1];
+                    v2 = v2 + v1;
+                    float v3 = p[j + k + 2];
+                    float v4 = p[j + k + 3];
+                    v4 = v4 + v3;
+                    v3 = v3 + v2;
+                    v4 = v4 + v2;
+                    V[k] = v1; V[k + 1] = v2; V[k + 2] = v3; V[k + 3] = v4;
+                    G[g] = v4;
+                } else {
+                    float v = 0.0f;
+                    for (int t = k; t < len; ++t) {
+                        v = v + p[j + t];
+                        V[t] = v;
+                    }
+                    for (int t = len; t < padded; ++t)
+                        V[t] = v;
+                    G[g] = v;
+                }
+            }
+            int u = 0;
+            for (; (2 << u) <= n2; ++u)
+                for (int k = 0; k < (n2 >> (u + 1)); ++k)
+                    G[(((k << 1) + 2) << u) - 1] += G[(((k << 1) + 1) << u) - 1];
+            for (--u; u >= 0; --u)
+                for (int k = 0; k < ((n2 - (1 << u)) >> (u + 1)); ++k)
+                    G[(((k << 1) + 3) << u) - 1] += G[(((k << 1) + 2) << u) - 1];
+            for (int g = 1; g < n2; ++g)
+                for (int t = 0; t < 4; ++t)
+                    V[4 * g + t] = V[4 * g + t] + G[g - 1];
+            for (int t = 0; t < len; ++t)
+                c[j + t] = V[t] + carry;
+            const float tt = G[n2 - 1] + carry2;
+            const float r2 = carry + tt;
+            carry2 = tt - (r2 - carry);
+            carry = r2;
+        }
+        int base = 1;
+        while (base < n)
+            base <<= 1;
+        for (int q = 0; q < m; ++q) {
+            const float key = inp_r[(size_t)row * m + q] * c[n - 1];
+            int r = n - 1;
+            for (int k = base; k >= 1; k >>= 1)
+                if (r >= k && c[r - k] >= key)
+                    r -= k;
+            out[(size_t)row * m + q] = r;
+        }
+    }
+    free(G);
+    free(V);
+}
+
+/* ------------------------------------------------------------------------
  * kNN grouping = utils/tf_util.py:597-618 (pairwise_xyz_distance) followed by
  * utils/tf_util.py:621-632 (knn = top_k of the negated matrix).
  *   D[i][j] = (sq[i] + (-2 * inner[i][j])) + sq[j]                  (:618)

@@ -32,6 +32,17 @@ def chamfer_case(name, xyz1, xyz2, seed):
                         grad_xyz2=gx2)
 
 
+def prob_sample_case():
+    """ProbSample (tf_sampling_g.cu:7-104): weights with zeros, a ragged quad tail, more than one
+    8192-value chunk; own generator, so adding it does not move the other fixtures."""
+    r = np.random.default_rng(7)
+    p = r.random((2, 8192 + 35)).astype(np.float32)
+    p[:, ::5] = 0.0
+    draws = r.random((2, 400)).astype(np.float32)
+    out, cum = O.prob_sample(p, draws, return_cumsum=True)
+    np.savez_compressed(os.path.join(OUT, "probsample_2x8227_400.npz"), inp=p, inpr=draws, out=out, cumsum=cum)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     # (1) the reference's seeded known-answer input, tf_nndistance_cpu.py:28-46
@@ -96,6 +107,7 @@ def main():
     f[:, 200] = f[:, 3]
     knn_case("knn_feat64_2x257_k10", f, 10, 64)
     knn_case("knn_feat64_2x257_k20", f, 20, 64)
+    prob_sample_case()
     print("wrote", sorted(os.listdir(OUT)))
 
 

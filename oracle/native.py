@@ -167,6 +167,18 @@ def gather_point_grad(inp_shape, idx, out_g):
     return inp_g
 
 
+def prob_sample(inp, inpr, return_cumsum=False):
+    """out [b, m] int32 -- tf_sampling_g.cu:7-104 (ProbSample): inp [b, n] weights, inpr [b, m] in [0,1)."""
+    inp, pp = _f(inp)
+    inpr, pr = _f(inpr)
+    b, n_ = inp.shape
+    m = inpr.shape[1]
+    cum = np.zeros((b, n_), np.float32)
+    out = np.zeros((b, m), np.int32)
+    lib().oracle_prob_sample(b, n_, m, pp, pr, cum.ctypes.data_as(_c_f), out.ctypes.data_as(_c_i))
+    return (out, cum) if return_cumsum else out
+
+
 def knn(x, k, channels=None, threads=1, return_dist=False):
     """nn_idx [b, n, k] int32 -- tf_util.py:597-632 on the first `channels` of x[b,n,ld]."""
     x, p = _f(x)

@@ -141,5 +141,27 @@ def test_gather_and_grad(oracle):
     assert np.array_equal(ig, want)
 
 
+def test_prob_sample_golden_and_semantics(oracle, golden_dir):
+    """tf_sampling_g.cu:7-104: fixture replay, prefix sums close to a float64 cumsum, every index the
+    first one whose prefix sum reaches draw * total."""
+    g = np.load(os.path.join(golden_dir, "probsample_2x8227_400.npz"))
+    out, cum = oracle.prob_sample(g["inp"], g["inpr"], return_cumsum=True)
+    assert np.array_equal(out, g["out"]) and np.array_equal(cum, g["cumsum"])
+    ref = np.cumsum(g["inp"].astype(np.float64), axis=1)
+    assert np.abs(cum - ref).max() <= 1e-6 * ref.max()
+    key = g["inpr"] * cum[:, -1:]
+    for b in range(out.shape[0]):
+        i = out[b]
+        assert (cum[b, i] >= key[b]).all()
+        prev = np.where(i > 0, cum[b, np.maximum(i - 1, 0)], -np.inf)
+        assert (prev < key[b]).all()
+    # quad order on a hand case: a, a+b, c+(a+b), (d+c)+(a+b)
+    p = np.array([[0.1, 0.2, 0.3, 0.4, 0.5]], np.float32)
+    _, c = oracle.prob_sample(p, np.zeros((1, 1), np.float32), return_cumsum=True)
+    a, b_, cc, d, e = (np.float32(v) for v in p[0])
+    q3 = (d + cc) + (b_ + a)
+    assert np.array_equal(c[0], np.array([a, b_ + a, cc + (b_ + a), q3, e + q3], np.float32))
+
+
 def test_golden_files_present(golden_dir):
     assert len(glob.glob(os.path.join(golden_dir, "*.npz"))) >= 10
