@@ -58,6 +58,25 @@ def cpu_baseline(num_point, sample_batch, steps=1):
                       % (steps, sample_batch, num_point, dt)}
 
 
+def chamfer_cpu_rate(n, m, clouds=4):
+    """The reference's CPU Chamfer next to the kernel: its own nnsearch loops (tf_nndistance.cpp:21-43,
+    compiled from the reference's lines into oracle/_ref, kind "reference") when that library
+    travelled with the snapshot, else the oracle's restatement (kind "port"); single-threaded, as
+    tf_nndistance.cpp:79-80 runs them, on a few clouds of the same shape and seed."""
+    import numpy as np
+    from oracle import native as O
+    rng = np.random.default_rng(100)
+    a = rng.standard_normal((clouds, n, 3)).astype(np.float32)
+    c = rng.standard_normal((clouds, m, 3)).astype(np.float32)
+    fn, kind = (O.ref_nn_distance, "reference") if O.have_ref() else (lambda x, y: O.nn_distance(x, y, threads=1), "port")
+    fn(a[:1], c[:1])
+    t0 = time.time()
+    fn(a, c)
+    dt = time.time() - t0
+    return {"clouds/s": round(clouds / dt, 2), "Gpairs/s": round(2.0 * clouds * n * m / dt / 1e9, 3), "cores": 1,
+            "kind": kind, "sample": "%d clouds of %dx%d, %.2f s" % (clouds, n, m, dt)}
+
+
 def chamfer_kernel_rate(batch, n, m, iters=20):
     """The second half of BASELINE's metric: Chamfer nn_distance forward kernel rate.
     Algorithmic bytes = B*(n+m)*20 (12 B read + 4 B dist + 4 B idx per point, SURVEY 8d);
@@ -186,6 +205,8 @@ def main():
             # "Chamfer kernel GB/s": the train shape (n = m = 4N) and the reference's own
             # micro-benchmark shape (tf_nndistance.py:48-49)
             line["chamfer_kernel"] = [chamfer_kernel_rate(B, 4 * N, 4 * N), chamfer_kernel_rate(32, 16384, 1024)]
+            if args.cpu_batch > 0:
+                line["chamfer_kernel"][0]["cpu"] = chamfer_cpu_rate(4 * N, 4 * N)
         if world == 1 and args.cpu_batch > 0:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_batch, args.cpu_steps)
         print(json.dumps(line))
