@@ -51,6 +51,8 @@ _SIGNATURES = {
     "cloudaae_rotation_error": [_I, _P, _P, _P, _P, _P, _P],
     "cloudaae_rotation_error_grad": [_I, _P, _P, _P, _P],
     "cloudaae_exponential_map": [_I, _P, _P, _P],
+    "cloudaae_pose_losses": [_I, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    "cloudaae_pose_losses_grad": [_I, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P],
     "cloudaae_loss_mix": [_P, _P, _P, _F, _F, _F, _P, _P],
     "cloudaae_loss_mix_grad": [_P, _F, _F, _F, _P, _P, _P, _P],
     "cloudaae_adam_tf": [_L, _P, _P, _P, _P, _F, _F, _F, _F, _P, _P, _F, _I, _P],

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(int M, int C, const float
 struct BnBwdArgs {
     int M, C, ldy, lddo, rows, pool, relu, training, want_xhat_sum;
     const float *y, *dout, *dpooled, *pooled, *ties;
-    const float *gamma, *save_mean, *save_var, *scale_shift;
+    const float *gamma, *beta, *save_mean, *save_var;
 };
 
 __device__ __forceinline__ float bn_upstream(const BnBwdArgs &a, int r, int c, float z)
@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void bn_bwd_colsum_kernel(BnBwdArgs a, double 
     const int c = blockIdx.x * 64 + lane;
     double s = 0.0, s2 = 0.0, s3 = 0.0;
     if (c < a.C) {
-        const float sc = a.scale_shift[c], sh = a.scale_shift[a.C + c];
+        float sc, sh;
+        bn_scale_shift_of(a.gamma, a.beta, a.save_mean, a.save_var, c, sc, sh);
         const float mean = a.save_mean[c], rstd = bn_rsqrt(a.save_var[c] + BN_EPS);
         const int step = 4 * parts;
         for (int rb = blockIdx.y * 4 + rl; rb < a.M; rb += step * BN_U) {
@@ -220,7 +221,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
     const int c = blockIdx.x * 64 + lane;
     if (c >= a.C)
         return;
-    const float sc = a.scale_shift[c], sh = a.scale_shift[a.C + c];
+    float sc, sh;
+    bn_scale_shift_of(a.gamma, a.beta, a.save_mean, a.save_var, c, sc, sh);
     const float mean = a.save_mean[c], rstd = bn_rsqrt(a.save_var[c] + BN_EPS);
     const float m1 = m12[c], m2 = m12[a.C + c];
     const float gr = a.gamma[c] * rstd;
@@ -495,15 +497,13 @@ CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, con
     }
     double *partial = (double *)workspace;
     float *scratch = (float *)(partial + (size_t)BN_MAX_PARTS * 4 * C);
-    float *scale_shift = scratch, *m12 = scratch + 2 * (size_t)C;
-    hipLaunchKernelGGL(bn_scale_shift_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, C, gamma, beta,
-                       save_mean, save_var, scale_shift);
+    float *m12 = scratch + 2 * (size_t)C;
     BnBwdArgs a;
     a.want_xhat_sum = dbias != nullptr;
     a.M = M; a.C = C; a.ldy = ldy; a.lddo = lddo; a.rows = pool_rows > 0 ? pool_rows : 1;
     a.pool = pool_mode; a.relu = relu; a.training = training;
     a.y = y; a.dout = dout; a.dpooled = dpooled; a.pooled = pooled; a.ties = tie_count;
-    a.gamma = gamma; a.save_mean = save_mean; a.save_var = save_var; a.scale_shift = scale_shift;
+    a.gamma = gamma; a.beta = beta; a.save_mean = save_mean; a.save_var = save_var;
     const int parts = bn_parts(M);
     const int cb = ceil_div(C, 64);
     hipLaunchKernelGGL(bn_bwd_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, a, partial, parts);

@@ -15,6 +15,17 @@ __host__ __device__ inline size_t bn_ws_doubles(int C) { return (size_t)BN_MAX_P
 
 __device__ __forceinline__ float bn_rsqrt(float v) { return 1.0f / sqrtf(v); }
 
+// scale and shift of the normalisation, z = y * sc + sh, exactly as the finalise kernels derive them
+// (the backward kernels recompute them per lane instead of spending a launch on a 2*C table)
+__device__ __forceinline__ void bn_scale_shift_of(const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                  const float *__restrict__ mean, const float *__restrict__ var,
+                                                  int c, float &sc, float &sh)
+{
+    const float inv = gamma[c] * bn_rsqrt(var[c] + BN_EPS);
+    sc = inv;
+    sh = beta[c] - mean[c] * inv;
+}
+
 // Sum the [parts][2][C] partial sums of one 64-channel group.  The finalise kernels run
 // BN_FIN_THREADS = 1024 threads = 64 channels x 16 part-lanes, each lane with independent
 // accumulators: the partial loads are what costs (a single thread walking 1024 dependent
@@ -90,19 +101,6 @@ static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_kernel(
     const float inv = gamma[c] * bn_rsqrt(var + BN_EPS);
     scale_shift[c] = inv;
     scale_shift[C + c] = beta[c] - mean * inv;
-}
-
-// inv / shift from saved moments (backward recomputes them: its workspace may differ)
-static __global__ void bn_scale_shift_kernel(int C, const float *__restrict__ gamma,
-                                      const float *__restrict__ beta, const float *__restrict__ mean,
-                                      const float *__restrict__ var, float *__restrict__ scale_shift)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C)
-        return;
-    const float inv = gamma[c] * bn_rsqrt(var[c] + BN_EPS);
-    scale_shift[c] = inv;
-    scale_shift[C + c] = beta[c] - mean[c] * inv;
 }
 
 // dbeta = sum dz, dgamma = sum dz*xhat; m1/m2 = their means (0 in inference mode,

@@ -40,7 +40,7 @@ struct EcArgs {
     const float *bias;     // [cout]
     const int *nn_idx;     // [P][k], indices within the cloud
     const float *scale_shift;  // [2*cout]
-    const float *gamma, *save_mean, *save_var;
+    const float *gamma, *beta, *save_mean, *save_var;
     const float *dout;     // [P][lddo]
     int lddo;
     int training;
@@ -242,8 +242,7 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_bwd_stats_kernel(EcArgs
 #pragma unroll
     for (int e = 0; e < CPL; ++e) {
         const int c = lane + 64 * e;
-        sc[e] = a.scale_shift[c];
-        sh[e] = a.scale_shift[a.cout + c];
+        bn_scale_shift_of(a.gamma, a.beta, a.save_mean, a.save_var, c, sc[e], sh[e]);
         mean[e] = a.save_mean[c];
         rstd[e] = bn_rsqrt(a.save_var[c] + BN_EPS);
         s[e] = s2[e] = s3[e] = zero[e] = 0.0;
@@ -373,8 +372,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
 #pragma unroll
     for (int e = 0; e < CPL; ++e) {
         const int c = lane + 64 * e;
-        sc[e] = a.scale_shift[c];
-        sh[e] = a.scale_shift[a.cout + c];
+        bn_scale_shift_of(a.gamma, a.beta, a.save_mean, a.save_var, c, sc[e], sh[e]);
         mean[e] = a.save_mean[c];
         rstd[e] = bn_rsqrt(a.save_var[c] + BN_EPS);
         gr[e] = a.gamma[c] * rstd[e];
@@ -587,13 +585,11 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
     const int P = b * n;
     double *partial = (double *)workspace;
     float *scratch = (float *)(partial + (size_t)EC_MAX_PARTS * 4 * cout);
-    float *scale_shift = scratch, *m12 = scratch + 2 * (size_t)cout;
-    hipLaunchKernelGGL(bn_scale_shift_kernel, dim3(ceil_div(cout, 256)), dim3(256), 0, s, cout, gamma, beta,
-                       save_mean, save_var, scale_shift);
+    float *m12 = scratch + 2 * (size_t)cout;
     EcArgs a = {};
     a.P = P; a.N = n; a.k = k; a.cout = cout; a.ldpq = 2 * cout;
-    a.pq = pq; a.bias = biases; a.nn_idx = nn_idx; a.scale_shift = scale_shift;
-    a.gamma = gamma; a.save_mean = save_mean; a.save_var = save_var; a.dout = dout; a.lddo = lddo;
+    a.pq = pq; a.bias = biases; a.nn_idx = nn_idx; a.scale_shift = nullptr;   // backward kernels derive it per lane
+    a.gamma = gamma; a.beta = beta; a.save_mean = save_mean; a.save_var = save_var; a.dout = dout; a.lddo = lddo;
     a.training = training;
     const int cpl = cout / 64, kcap = k <= 10 ? 10 : (k <= 20 ? 20 : 32);
     const int grid = ec_stat_grid(P), agrid = ec_apply_grid(P);

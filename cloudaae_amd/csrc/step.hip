@@ -413,6 +413,94 @@ __global__ void loss_mix_grad_kernel(const float *g, float w0, float w1, float w
     gc[0] = g[0] * w2;
 }
 
+// ---- the loss tail of the step in one launch (train...:241-268) ----------------------------
+// translation error per sample + mean, SO(3) error per sample (fp64) + Jacobian + mean, and the
+// weighted total; the backward twin turns d(total) into the three upstream gradients.  Same
+// arithmetic as the single-purpose kernels above (ten launches of ~4.5 us become two).
+__global__ __launch_bounds__(256) void pose_losses_kernel(int b, const float *__restrict__ tpred,
+                                                         const float *__restrict__ tlabel,
+                                                         const float *__restrict__ rpred,
+                                                         const double *__restrict__ rlabel,
+                                                         const float *__restrict__ xyz_loss, float w0, float w1,
+                                                         float w2, float *__restrict__ tper,
+                                                         float *__restrict__ tloss, double *__restrict__ rper,
+                                                         double *__restrict__ rjac, float *__restrict__ rloss,
+                                                         float *__restrict__ total)
+{
+    __shared__ double red[2][4];
+    double st = 0.0, sr = 0.0;
+    for (int i = threadIdx.x; i < b; i += 256) {
+        const float dx = tlabel[3 * i] - tpred[3 * i], dy = tlabel[3 * i + 1] - tpred[3 * i + 1],
+                    dz = tlabel[3 * i + 2] - tpred[3 * i + 2];
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        tper[i] = d;
+        st += (double)d;
+        Dual p[3], l[3];
+        for (int a = 0; a < 3; ++a) {
+            p[a] = dconst((double)rpred[3 * i + a]);
+            p[a].d[a] = 1.0;
+            l[a] = dconst(rlabel[3 * i + a]);
+        }
+        Dual Rp[3][3], Rl[3][3];
+        exp_map(p, Rp);
+        exp_map(l, Rl);
+        Dual tr = dconst(0.0);
+        for (int r = 0; r < 3; ++r) {
+            Dual e = dconst(0.0);
+            for (int k = 0; k < 3; ++k)
+                e = e + Rl[r][k] * Rp[r][k];
+            tr = tr + e;
+        }
+        Dual t = (tr - dconst(1.0)) / 2.0;
+        const double lim = 0.9999999;
+        if (t.v < -lim)
+            t = dconst(-lim);
+        else if (t.v > lim)
+            t = dconst(lim);
+        const double theta = acos(t.v);
+        const double k = -1.0 / sqrt(1.0 - t.v * t.v);
+        rper[i] = theta;
+        rjac[3 * i + 0] = k * t.d[0];
+        rjac[3 * i + 1] = k * t.d[1];
+        rjac[3 * i + 2] = k * t.d[2];
+        sr += theta;
+    }
+    st = wave_sum(st);
+    sr = wave_sum(sr);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = st;
+        red[1][threadIdx.x >> 6] = sr;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tl = (float)(((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (double)b);
+        const float rl = (float)(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (double)b);
+        tloss[0] = tl;
+        rloss[0] = rl;
+        total[0] = (w0 * xyz_loss[0] + w1 * tl) + w2 * rl;
+    }
+}
+
+__global__ void pose_losses_grad_kernel(int b, const float *__restrict__ tpred, const float *__restrict__ tlabel,
+                                        const float *__restrict__ tper, const double *__restrict__ rjac,
+                                        const float *__restrict__ g, float w0, float w1, float w2,
+                                        float *__restrict__ dxyz, float *__restrict__ dtpred,
+                                        float *__restrict__ drpred)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0)
+        dxyz[0] = g[0] * w0;
+    if (i >= b)
+        return;
+    const float gt = g[0] * w1, gr = g[0] * w2;
+    const float gp = (gt / (float)b) / tper[i];           // d mean / d per = 1/b, d per / d pred = -(l - p)/per
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        dtpred[3 * i + a] = -(gp * (tlabel[3 * i + a] - tpred[3 * i + a]));
+        drpred[3 * i + a] = (float)((double)gr / (double)b * rjac[3 * i + a]);
+    }
+}
+
 // ---- optimiser: tf.train.AdamOptimizer (train...:263-273), TF-1.x ApplyAdam form ----
 //   lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
 //   m += (g - m) * (1 - beta1);  v += (g*g - v) * (1 - beta2)
@@ -733,5 +821,38 @@ CLOUDAAE_API int cloudaae_increment(float *x, float by, cloudaae_stream_t stream
 {
     hipLaunchKernelGGL(increment_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, x, by);
     CLOUDAAE_CHECK_LAUNCH("cloudaae_increment");
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_pose_losses(int b, const float *trans_pred, const float *trans_label,
+                                      const float *rot_pred, const double *rot_label, const float *xyz_loss,
+                                      float w_xyz, float w_trans, float w_rot, float *trans_per,
+                                      float *trans_loss, double *rot_per, double *rot_jac, float *rot_loss,
+                                      float *total, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_pose_losses";
+    CLOUDAAE_REQUIRE(b > 0, name, "empty batch");
+    CLOUDAAE_REQUIRE(trans_pred && trans_label && rot_pred && rot_label && xyz_loss && trans_per && trans_loss &&
+                         rot_per && rot_jac && rot_loss && total, name, "null argument");
+    hipLaunchKernelGGL(pose_losses_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, trans_pred, trans_label,
+                       rot_pred, rot_label, xyz_loss, w_xyz, w_trans, w_rot, trans_per, trans_loss, rot_per, rot_jac,
+                       rot_loss, total);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_pose_losses_grad(int b, const float *trans_pred, const float *trans_label,
+                                           const float *trans_per, const double *rot_jac, const float *g_total,
+                                           float w_xyz, float w_trans, float w_rot, float *d_xyz_loss,
+                                           float *d_trans_pred, float *d_rot_pred, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_pose_losses_grad";
+    CLOUDAAE_REQUIRE(b > 0, name, "empty batch");
+    CLOUDAAE_REQUIRE(trans_pred && trans_label && trans_per && rot_jac && g_total && d_xyz_loss && d_trans_pred &&
+                         d_rot_pred, name, "null argument");
+    hipLaunchKernelGGL(pose_losses_grad_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, (hipStream_t)stream, b,
+                       trans_pred, trans_label, trans_per, rot_jac, g_total, w_xyz, w_trans, w_rot, d_xyz_loss,
+                       d_trans_pred, d_rot_pred);
+    CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }

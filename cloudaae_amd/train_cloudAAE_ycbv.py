@@ -189,11 +189,11 @@ class TrainGraph(object):
         xyz_recon = F.AddRowVecFn.apply(xyz_recon_res, element_mean)                          # :232
         trans_pred = F.AddRowVecFn.apply(trans_pred_res.unsqueeze(1), element_mean).squeeze(1)  # :233
         xyz_loss, xyz_loss_per_sample = chamfer_loss.get_loss(xyz_recon, visiblePoints_org_final)  # :236
-        trans_loss, trans_loss_perSample = trans_distance.get_translation_error(
-            trans_pred, element['translation'].to(torch.float32))                                # :241
-        axag_loss, axag_loss_perSample = angular_distance_taylor.get_rotation_error(
-            rot_pred, element['axisangle'])                                                      # :249-253
-        total_loss = F.LossMixFn.apply(xyz_loss, trans_loss, axag_loss, *LOSS_WEIGHTS)          # :268
+        # :241-268 -- translation error, SO(3) error (float64) and the weighted total in one launch
+        # (same arithmetic as trans_distance.get_translation_error / angular_distance_taylor.
+        # get_rotation_error / the sum of :268, which stay available on their own)
+        total_loss, trans_loss, trans_loss_perSample, axag_loss, axag_loss_perSample = F.PoseLossFn.apply(
+            xyz_loss, trans_pred, element['translation'], rot_pred, element['axisangle'], *LOSS_WEIGHTS)
         return dict(total_loss=total_loss, xyz_loss=xyz_loss, trans_loss=trans_loss, axag_loss=axag_loss,
                     xyz_recon=xyz_recon, xyz_loss_per_sample=xyz_loss_per_sample,
                     trans_loss_perSample=trans_loss_perSample, axag_loss_perSample=axag_loss_perSample,

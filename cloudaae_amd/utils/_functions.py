@@ -501,6 +501,51 @@ class RotationErrorFn(torch.autograd.Function):
         return d, None
 
 
+class PoseLossFn(torch.autograd.Function):
+    """The loss tail of the step in one launch each way (train_cloudAAE_ycbv.py:241-268):
+    (total, trans_loss, trans_per [B], axag_loss, axag_per [B] float64) from the Chamfer loss scalar
+    and the two pose predictions; only `total` carries a gradient (it is what the optimiser
+    minimises, :268-273)."""
+
+    @staticmethod
+    def forward(ctx, xyz_loss, trans_pred, trans_label, rot_pred, rot_label, w0, w1, w2):
+        ctx.set_materialize_grads(False)
+        B = trans_pred.shape[0]
+        dev = trans_pred.device
+        trans_pred = trans_pred.contiguous()
+        rot_pred = rot_pred.contiguous()
+        trans_label = trans_label.to(torch.float32).contiguous()
+        rot_label = rot_label.to(torch.float64).contiguous()
+        tper = _lib.empty(B, dtype=torch.float32, device=dev)
+        rper = _lib.empty(B, dtype=torch.float64, device=dev)
+        jac = _lib.empty((B, 3), dtype=torch.float64, device=dev)
+        tloss = _lib.empty((), dtype=torch.float32, device=dev)
+        rloss = _lib.empty((), dtype=torch.float32, device=dev)
+        total = _lib.empty((), dtype=torch.float32, device=dev)
+        _lib.check(L().cloudaae_pose_losses(B, ptr(trans_pred), ptr(trans_label), ptr(rot_pred), ptr(rot_label),
+                                            ptr(xyz_loss), w0, w1, w2, ptr(tper), ptr(tloss), ptr(rper), ptr(jac),
+                                            ptr(rloss), ptr(total), stream()), "cloudaae_pose_losses")
+        ctx.save_for_backward(trans_pred, trans_label, tper, jac)
+        ctx.w = (w0, w1, w2)
+        ctx.mark_non_differentiable(tloss, tper, rloss, rper)
+        return total, tloss, tper, rloss, rper
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        if g is None:
+            return (None,) * 8
+        trans_pred, trans_label, tper, jac = ctx.saved_tensors
+        B = trans_pred.shape[0]
+        dev = trans_pred.device
+        dxyz = _lib.empty((), dtype=torch.float32, device=dev)
+        dtp = _lib.empty((B, 3), dtype=torch.float32, device=dev)
+        drp = _lib.empty((B, 3), dtype=torch.float32, device=dev)
+        _lib.check(L().cloudaae_pose_losses_grad(B, ptr(trans_pred), ptr(trans_label), ptr(tper), ptr(jac),
+                                                 ptr(g.contiguous()), ctx.w[0], ctx.w[1], ctx.w[2], ptr(dxyz),
+                                                 ptr(dtp), ptr(drp), stream()), "cloudaae_pose_losses_grad")
+        return dxyz, dtp, None, drp, None, None, None, None
+
+
 class LossMixFn(torch.autograd.Function):
     """total = w0*a + w1*b + w2*c on device scalars (train_cloudAAE_ycbv.py:268)."""
 

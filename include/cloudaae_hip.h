@@ -212,6 +212,19 @@ int cloudaae_rotation_error(int b, const float *pred, const double *label, doubl
 int cloudaae_exponential_map(int b, const double *axag, double *rot, cloudaae_stream_t stream);
 int cloudaae_rotation_error_grad(int b, const double *jac, const float *gloss, float *dpred,
                                  cloudaae_stream_t stream);
+/* The whole loss tail of train_cloudAAE_ycbv.py:241-268 in one launch: translation error per sample
+ * (trans_per[b]) and its mean, SO(3) geodesic error per sample in float64 (rot_per[b], with the
+ * Jacobian rot_jac[b,3] w.r.t. rot_pred) and its mean, total = w_xyz*xyz_loss + w_trans*trans_loss +
+ * w_rot*rot_loss.  Same arithmetic as cloudaae_trans_error / cloudaae_rotation_error /
+ * cloudaae_loss_mix.  _grad: d(total) -> d(xyz_loss), d(trans_pred)[b,3], d(rot_pred)[b,3]. */
+int cloudaae_pose_losses(int b, const float *trans_pred, const float *trans_label, const float *rot_pred,
+                         const double *rot_label, const float *xyz_loss, float w_xyz, float w_trans, float w_rot,
+                         float *trans_per, float *trans_loss, double *rot_per, double *rot_jac, float *rot_loss,
+                         float *total, cloudaae_stream_t stream);
+int cloudaae_pose_losses_grad(int b, const float *trans_pred, const float *trans_label, const float *trans_per,
+                              const double *rot_jac, const float *g_total, float w_xyz, float w_trans,
+                              float w_rot, float *d_xyz_loss, float *d_trans_pred, float *d_rot_pred,
+                              cloudaae_stream_t stream);
 /* :268  total = w0*a + w1*b + w2*c on device scalars */
 int cloudaae_loss_mix(const float *a, const float *b, const float *c, float w0, float w1, float w2,
                       float *out, cloudaae_stream_t stream);
