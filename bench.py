@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--num-point", type=int, default=1024)
     ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="train steps of the CPU-baseline sample")
+    ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "bf16"], help="bf16: BASELINE config 3's "
+                    "arithmetic (dense-layer operands rounded to bf16, fp32 accumulate; everything else fp32)")
     ap.add_argument("--eager", action="store_true", help="step through Python/autograd every time instead of "
                     "replaying the recorded step (TrainGraph(replay=False))")
     args = ap.parse_args()
@@ -139,7 +141,8 @@ def main():
     # live in every step of the timed region (host callbacks of the recorded step)
     F.TIMED_SITES["agg_fwd"] = []
     graph = T.TrainGraph({"num_point": N, "gpu": local}, {"optimizer": "adam"},
-                         {"batch_size": B * world, "learning_rate": 0.0008}, replay=not args.eager)
+                         {"batch_size": B * world, "learning_rate": 0.0008}, replay=not args.eager,
+                         gemm_dtype=args.gemm_dtype)
     el = T.synthetic_element(B, N, graph.device, seed=123456789, rank=rank)
 
     for _ in range(args.warmup):
@@ -188,7 +191,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.gemm_dtype == "f32" else "bf16 dense-layer operands, f32 accumulate and everything else",
             "data": "synthetic",
             "config": {"workload": "CloudAAE train step: get_model_dgcnn_mean_6d, all 21 YCB classes, "
                                    "batch %d/GPU, N=%d points, k=10, 4N-point Chamfer target, TF-Adam" % (B, N),
@@ -201,6 +204,16 @@ def main():
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launch_ms": round(k_ms, 4), "launches_timed": len(ms)},
         }
+        if args.gemm_dtype == "bf16":
+            # with bf16 operands the same product leaves the matrix pipe (2.5 PFLOP/s dense) and is bound by
+            # HBM: fp32 activations in (M x 320), weights, fp32 output out (M x 1024)
+            nbytes = 4.0 * (M * K + K * Nn + Nn + M * Nn)
+            gbs = nbytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+            line["roofline"] = {"bound": "hbm", "kernel": "gemm_bf16_kernel<128,128,2,2> dgcnn_agg forward "
+                                                          "[%d x 320] x [320 x 1024]" % M,
+                                "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                                "frac": round(gbs / 8000.0, 4), "traffic": None, "launch_ms": round(k_ms, 4),
+                                "launches_timed": len(ms)}
         if world == 1:
             # "Chamfer kernel GB/s": the train shape (n = m = 4N) and the reference's own
             # micro-benchmark shape (tf_nndistance.py:48-49)

@@ -27,15 +27,16 @@ _SIGNATURES = {
     "cloudaae_prob_sample": [_I, _I, _I, _P, _P, _P, _P, _P],
     "cloudaae_knn": [_I, _I, _I, _I, _I, _P, _P, _P],
     "cloudaae_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
+    "cloudaae_gemm_bf16": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "cloudaae_bn_forward": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P,
                             _P, _P],
     "cloudaae_bn_backward": [_I, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I,
                              _P, _P, _P, _I, _P, _P],
     "cloudaae_colsum_f32": [_I, _I, _P, _I, _P, _I, _P, _P],
     "cloudaae_edgeconv_forward": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P,
-                                  _P, _P, _P, _I, _P, _P, _P],
+                                  _P, _P, _P, _I, _P, _I, _P, _P],
     "cloudaae_edgeconv_backward": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P,
-                                   _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P],
+                                   _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P],
     "cloudaae_input_assemble": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "cloudaae_add_rowvec": [_I, _I, _I, _P, _P, _P, _P],
     "cloudaae_add_f32": [_L, _P, _P, _P, _P],
@@ -215,6 +216,8 @@ def lib():
         cdll.cloudaae_hpr_workspace_bytes.argtypes = [_I, _I]
         cdll.cloudaae_gemm_f32_splits.argtypes = [_I, _I, _I]
         cdll.cloudaae_gemm_f32_splits.restype = ctypes.c_int
+        cdll.cloudaae_gemm_bf16_splits.argtypes = [_I, _I, _I]
+        cdll.cloudaae_gemm_bf16_splits.restype = ctypes.c_int
         cdll.cloudaae_bn_workspace_bytes.argtypes = [_I]
         cdll.cloudaae_edgeconv_workspace_bytes.argtypes = [_I]
         _lib = _Library(cdll)
@@ -278,9 +281,10 @@ def zeros(shape, dtype=torch.float32, device=None):
     return _recording.alloc_zero(shape, dtype, device)
 
 
-def gemm_splits(M, N, K):
-    """K slices cloudaae_gemm_f32 uses for this shape; > 1 means the output is built with atomics."""
-    return int(lib().cloudaae_gemm_f32_splits(int(M), int(N), int(K)))
+def gemm_splits(M, N, K, bf16=False):
+    """K slices cloudaae_gemm_f32 / _bf16 uses for this shape; > 1 means the output is built with atomics."""
+    fn = lib().cloudaae_gemm_bf16_splits if bf16 else lib().cloudaae_gemm_f32_splits
+    return int(fn(int(M), int(N), int(K)))
 
 
 from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402

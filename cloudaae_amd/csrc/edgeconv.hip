@@ -499,6 +499,15 @@ using namespace cloudaae;
 
 extern "C" int cloudaae_gemm_f32(int, int, int, int, int, const float *, int, const float *, int, float *, int,
                                  const float *, int, cloudaae_stream_t);
+extern "C" int cloudaae_gemm_bf16(int, int, int, int, int, const float *, int, const float *, int, float *, int,
+                                  const float *, int, cloudaae_stream_t);
+// the block's dense products: fp32 operands, or rounded to bf16 on the way to the matrix cores
+static int ec_gemm(int bf16, int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                   float *C, int ldc, int accumulate, cloudaae_stream_t stream)
+{
+    return bf16 ? cloudaae_gemm_bf16(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, nullptr, accumulate, stream)
+                : cloudaae_gemm_f32(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, nullptr, accumulate, stream);
+}
 
 CLOUDAAE_API long long cloudaae_edgeconv_workspace_bytes(int cout)
 {
@@ -519,8 +528,8 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
                                            const float *gamma, const float *beta, int training,
                                            const float *decay, float *ema_mean, float *ema_var,
                                            int pool_mode, float *pq, float *save_mean, float *save_var,
-                                           float *out, int ldo, float *tie_count, void *workspace,
-                                           cloudaae_stream_t stream)
+                                           float *out, int ldo, float *tie_count, int gemm_bf16,
+                                           void *workspace, cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_edgeconv_forward";
     if (int rc = ec_check(name, b, n, k, cin, cout, pool_mode))
@@ -530,11 +539,11 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
     hipStream_t s = (hipStream_t)stream;
     const int P = b * n;
     // P' = X W[0:cin], Q = X W[cin:2cin]   (two column blocks of pq)
-    int rc = cloudaae_gemm_f32(0, 0, P, cout, cin, x, ldx, weights, cout, pq, 2 * cout, nullptr, 0, stream);
+    int rc = ec_gemm(gemm_bf16, 0, 0, P, cout, cin, x, ldx, weights, cout, pq, 2 * cout, 0, stream);
     if (rc)
         return rc;
-    rc = cloudaae_gemm_f32(0, 0, P, cout, cin, x, ldx, weights + (size_t)cin * cout, cout, pq + cout, 2 * cout,
-                           nullptr, 0, stream);
+    rc = ec_gemm(gemm_bf16, 0, 0, P, cout, cin, x, ldx, weights + (size_t)cin * cout, cout, pq + cout, 2 * cout, 0,
+                 stream);
     if (rc)
         return rc;
     double *partial = (double *)workspace;
@@ -573,7 +582,8 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
                                             const float *tie_count, const float *dout, int lddo, float *dpq,
                                             int *rev_scratch, float *dx, int lddx, int accumulate_dx,
                                             float *dweights, int dweights_zeroed, float *dbiases, float *dgamma,
-                                            float *dbeta, void *workspace, cloudaae_stream_t stream)
+                                            float *dbeta, int gemm_bf16, void *workspace,
+                                            cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_edgeconv_backward";
     if (int rc = ec_check(name, b, n, k, cin, cout, pool_mode))
@@ -626,22 +636,21 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
     // dX = dP' W_c^T + dQ W_n^T ; dW_c = X^T dP' ; dW_n = X^T dQ
     int rc = 0;
     if (dx != nullptr) {
-        rc = cloudaae_gemm_f32(0, 1, P, cin, cout, dpq, 2 * cout, weights, cout, dx, lddx, nullptr,
-                               accumulate_dx, stream);
+        rc = ec_gemm(gemm_bf16, 0, 1, P, cin, cout, dpq, 2 * cout, weights, cout, dx, lddx, accumulate_dx, stream);
         if (rc)
             return rc;
-        rc = cloudaae_gemm_f32(0, 1, P, cin, cout, dpq + cout, 2 * cout, weights + (size_t)cin * cout, cout, dx,
-                               lddx, nullptr, 1, stream);
+        rc = ec_gemm(gemm_bf16, 0, 1, P, cin, cout, dpq + cout, 2 * cout, weights + (size_t)cin * cout, cout, dx,
+                     lddx, 1, stream);
         if (rc)
             return rc;
     }
     if (dweights != nullptr) {
         const int wacc = dweights_zeroed ? 2 : 0;     // 2: the caller cleared dweights already
-        rc = cloudaae_gemm_f32(1, 0, cin, cout, P, x, ldx, dpq, 2 * cout, dweights, cout, nullptr, wacc, stream);
+        rc = ec_gemm(gemm_bf16, 1, 0, cin, cout, P, x, ldx, dpq, 2 * cout, dweights, cout, wacc, stream);
         if (rc)
             return rc;
-        rc = cloudaae_gemm_f32(1, 0, cin, cout, P, x, ldx, dpq + cout, 2 * cout, dweights + (size_t)cin * cout,
-                               cout, nullptr, wacc, stream);
+        rc = ec_gemm(gemm_bf16, 1, 0, cin, cout, P, x, ldx, dpq + cout, 2 * cout, dweights + (size_t)cin * cout, cout,
+                     wacc, stream);
         if (rc)
             return rc;
     }

@@ -1,0 +1,306 @@
+// gemm_bf16.hip -- the dense layers with bf16 operands on the gfx950 matrix cores
+// (v_mfma_f32_32x32x16_bf16), fp32 accumulate, fp32 in and out.
+//
+// BASELINE config 3 ("bf16 MLPs + fp32 Chamfer"): every conv1x1 / fully connected product of the
+// CloudAAE path (reference utils/tf_util.py:161-166, :349-352) and both of its gradient products
+//     y  = x W + b,   dx = dy W^T,   dW = x^T dy
+// with the operands rounded to bfloat16 (round to nearest even, v_cvt_pk_bf16_f32) as they are
+// staged into LDS; tensors stay fp32 in HBM, so nothing else in the step changes.  The bf16 MFMA
+// runs at 16x the fp32 MFMA rate, which moves these products from the matrix pipe to HBM: the
+// dgcnn_agg forward product writes 134 MB of fp32 output.
+//
+// Same decomposition as gemm.hip: a workgroup of 4 waves owns a BM x BN tile as 32x32 accumulator
+// tiles, K walked in slabs of 32 (two MFMA k-steps), next slab prefetched through registers, K
+// split across grid.z with fp32 atomics when the output has too few tiles.  One MFMA consumes 8
+// bf16 per operand per lane (row/column = lane & 31, k-block = lane >> 5), so both operands are
+// staged k-contiguous, rows padded to 40 bf16 (80 B: conflict-free ds_read_b128); an operand whose
+// memory layout is [k][outer] is transposed on the way in by packing two k-rows per 32-bit store.
+#include <cstdlib>
+#include "common.h"
+#include "../../include/cloudaae_hip.h"
+
+namespace cloudaae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GB_BK = 32;            // k per slab
+constexpr int GB_LDK = 40;           // bf16 per staged row (32 + 8 pad)
+constexpr int GB_THREADS = 256;
+
+enum { GB_STORE = 0, GB_ACCUM = 1, GB_ATOMIC = 2 };
+
+// One operand slab: ROWS outer indices x 32 k.  KC: memory is [outer][k]; else [k][outer].
+template <int ROWS, bool KC>
+struct SlabB {
+    // KC : float4 = 4 consecutive k of one outer row      -> one 64-bit LDS store
+    // !KC: two float4 = 4 consecutive outer at k, k + 1   -> four 32-bit LDS stores
+    static constexpr int ITEMS = KC ? ROWS * (GB_BK / 4) : (GB_BK / 2) * (ROWS / 4);
+    static constexpr int PER = (ITEMS + GB_THREADS - 1) / GB_THREADS;
+    float4v r0[PER], r1[KC ? 1 : PER];
+
+    __device__ __forceinline__ float4v fetch4(const float *__restrict__ src, int avail, bool vec) const
+    {
+        float4v v = {0.f, 0.f, 0.f, 0.f};
+        if (avail >= 4 && vec) {
+            v = *reinterpret_cast<const float4v *>(src);
+        } else {
+            if (avail > 0) v.x = src[0];
+            if (avail > 1) v.y = src[1];
+            if (avail > 2) v.z = src[2];
+            if (avail > 3) v.w = src[3];
+        }
+        return v;
+    }
+
+    __device__ __forceinline__ void load(const float *__restrict__ P, int ld, int outer0, int nouter, int k0,
+                                         int kend, bool vec)
+    {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int it = u * GB_THREADS + (int)threadIdx.x;
+            float4v a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (ITEMS % GB_THREADS == 0 || it < ITEMS) {
+                if (KC) {
+                    const int o = it / (GB_BK / 4), kq = it % (GB_BK / 4);
+                    const int go = outer0 + o, gk = k0 + 4 * kq;
+                    if (go < nouter && gk < kend)
+                        a = fetch4(P + (size_t)go * ld + gk, kend - gk, vec);
+                } else {
+                    const int kp = it / (ROWS / 4), oq = it % (ROWS / 4);
+                    const int gk = k0 + 2 * kp, go = outer0 + 4 * oq;
+                    if (go < nouter) {
+                        if (gk < kend)
+                            a = fetch4(P + (size_t)gk * ld + go, nouter - go, vec);
+                        if (gk + 1 < kend)
+                            b = fetch4(P + (size_t)(gk + 1) * ld + go, nouter - go, vec);
+                    }
+                }
+            }
+            r0[u] = a;
+            if (!KC)
+                r1[u] = b;
+        }
+    }
+
+    __device__ __forceinline__ void stage(__bf16 *__restrict__ lds) const
+    {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int it = u * GB_THREADS + (int)threadIdx.x;
+            if (ITEMS % GB_THREADS == 0 || it < ITEMS) {
+                if (KC) {
+                    const int o = it / (GB_BK / 4), kq = it % (GB_BK / 4);
+                    bf16x4 p = {(__bf16)r0[u].x, (__bf16)r0[u].y, (__bf16)r0[u].z, (__bf16)r0[u].w};
+                    *reinterpret_cast<bf16x4 *>(lds + o * GB_LDK + 4 * kq) = p;
+                } else {
+                    const int kp = it / (ROWS / 4), oq = it % (ROWS / 4);
+                    __bf16 *dst = lds + (4 * oq) * GB_LDK + 2 * kp;
+                    const bf16x2 p0 = {(__bf16)r0[u].x, (__bf16)r1[u].x}, p1 = {(__bf16)r0[u].y, (__bf16)r1[u].y},
+                                 p2 = {(__bf16)r0[u].z, (__bf16)r1[u].z}, p3 = {(__bf16)r0[u].w, (__bf16)r1[u].w};
+                    *reinterpret_cast<bf16x2 *>(dst) = p0;
+                    *reinterpret_cast<bf16x2 *>(dst + GB_LDK) = p1;
+                    *reinterpret_cast<bf16x2 *>(dst + 2 * GB_LDK) = p2;
+                    *reinterpret_cast<bf16x2 *>(dst + 3 * GB_LDK) = p3;
+                }
+            }
+        }
+    }
+};
+
+// C[M,N] (+)= bf16(op(A))[M,K] * bf16(op(B))[K,N] (+ bias[N]), fp32 accumulate
+template <int BM, int BN, int WM, int WN, bool TA, bool TB>
+__global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int K, const float *__restrict__ A,
+                                                               int lda, const float *__restrict__ B, int ldb,
+                                                               float *__restrict__ C, int ldc,
+                                                               const float *__restrict__ bias, int epilogue,
+                                                               int kchunk, int vecA, int vecB)
+{
+    static_assert(WM * WN * 64 == GB_THREADS, "4 waves");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    typedef SlabB<BM, !TA> SA;
+    typedef SlabB<BN, TB> SB;
+    __shared__ __attribute__((aligned(16))) __bf16 ldsA[BM * GB_LDK];
+    __shared__ __attribute__((aligned(16))) __bf16 ldsB[BN * GB_LDK];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles = gridDim.x * gridDim.y;
+    const int vid = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, tiles);
+    const int m0 = (vid / (int)gridDim.x) * BM, n0 = (vid % (int)gridDim.x) * BN;
+    const int kbeg = blockIdx.z * kchunk;
+    const int kend = min(K, kbeg + kchunk);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0.0f;
+
+    SA sa;
+    SB sb;
+    sa.load(A, lda, m0, M, kbeg, kend, vecA != 0);
+    sb.load(B, ldb, n0, N, kbeg, kend, vecB != 0);
+
+    const int fr = lane & 31, fk = lane >> 5;
+    for (int k0 = kbeg; k0 < kend; k0 += GB_BK) {
+        __syncthreads();
+        sa.stage(ldsA);
+        sb.stage(ldsB);
+        __syncthreads();
+        if (k0 + GB_BK < kend) {
+            sa.load(A, lda, m0, M, k0 + GB_BK, kend, vecA != 0);
+            sb.load(B, ldb, n0, N, k0 + GB_BK, kend, vecB != 0);
+        }
+#pragma unroll
+        for (int s = 0; s < GB_BK / 16; ++s) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const bf16x8 *>(ldsA + ((wm * TM + i) * 32 + fr) * GB_LDK + 16 * s + 8 * fk);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const bf16x8 *>(ldsB + ((wn * TN + j) * 32 + fr) * GB_LDK + 16 * s + 8 * fk);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool add_bias = bias != nullptr && (epilogue != GB_ATOMIC || blockIdx.z == 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + fr;
+        if (col >= N)
+            continue;
+        const float bv = add_bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row < M) {
+                    float *dst = C + (size_t)row * ldc + col;
+                    const float v = acc[i][j][r] + bv;
+                    if (epilogue == GB_STORE)
+                        *dst = v;
+                    else if (epilogue == GB_ACCUM)
+                        *dst = *dst + v;
+                    else
+                        atomicAdd(dst, v);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_bf16(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A, int lda,
+                        const float *B, int ldb, float *C, int ldc, const float *bias, int epi, int kchunk,
+                        int vecA, int vecB)
+{
+    dim3 block(GB_THREADS);
+    if (!ta && !tb)
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, M, N, K, A, lda, B,
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+    else if (!ta && tb)
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, M, N, K, A, lda, B,
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+    else if (ta && !tb)
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, M, N, K, A, lda, B,
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+    else
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, M, N, K, A, lda, B,
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+}
+
+// tile shape and K slices (same policy as gemm.hip's gemm_plan, slabs of 32)
+static void gemm_bf16_plan(int M, int N, int K, int &BM, int &BN, int &splits)
+{
+    if (M <= 32) {
+        BM = 32;
+        BN = 128;
+    } else if (N <= 64 || (N % 128 != 0 && N % 64 == 0)) {
+        BM = 128;
+        BN = 64;
+    } else if (M % 128 != 0 && M % 64 == 0) {
+        BM = 64;
+        BN = 128;
+    } else {
+        BM = 128;
+        BN = 128;
+    }
+    const long long tiles = (long long)ceil_div(M, BM) * ceil_div(N, BN);
+    splits = 1;
+    const int resident = 256 * (BM == 32 ? 2 : 4);
+    if (tiles < 256 && K >= 256) {
+        splits = (int)((tiles <= 4 ? 256 : resident) / tiles);
+        const int max_splits = K / 128 > 0 ? K / 128 : 1;
+        if (splits > max_splits)
+            splits = max_splits;
+        if (splits < 1)
+            splits = 1;
+    }
+}
+
+} // namespace cloudaae
+
+using namespace cloudaae;
+
+CLOUDAAE_API int cloudaae_gemm_bf16_splits(int M, int N, int K)
+{
+    if (M <= 0 || N <= 0 || K <= 0)
+        return 1;
+    int BM, BN, splits;
+    gemm_bf16_plan(M, N, K, BM, BN, splits);
+    const int kchunk = ceil_div(ceil_div(K, splits), GB_BK) * GB_BK;
+    return ceil_div(K, kchunk);
+}
+
+CLOUDAAE_API int cloudaae_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                                    const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
+                                    cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_gemm_bf16";
+    CLOUDAAE_REQUIRE(M >= 0 && N >= 0 && K >= 0, name, "negative size");
+    if (M == 0 || N == 0)
+        return 0;
+    hipStream_t s = (hipStream_t)stream;
+    CLOUDAAE_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, name,
+                     "leading dimension too small");
+    int BM, BN, splits;
+    gemm_bf16_plan(M, N, K, BM, BN, splits);
+    const int tm = ceil_div(M, BM), tn = ceil_div(N, BN);
+    CLOUDAAE_REQUIRE(tm <= 65535, name, "M too large");
+    int kchunk = K > 0 ? ceil_div(ceil_div(K, splits), GB_BK) * GB_BK : GB_BK;
+    splits = K > 0 ? ceil_div(K, kchunk) : 1;
+    int epi = accumulate == 1 ? GB_ACCUM : GB_STORE;
+    if (splits > 1) {
+        epi = GB_ATOMIC;
+        if (!accumulate)
+            CLOUDAAE_CHECK_HIP(hipMemset2DAsync(C, sizeof(float) * (size_t)ldc, 0, sizeof(float) * (size_t)N,
+                                                (size_t)M, s), name);
+    }
+    const int vecA = (((uintptr_t)A & 15) == 0 && lda % 4 == 0) ? 1 : 0;
+    const int vecB = (((uintptr_t)B & 15) == 0 && ldb % 4 == 0) ? 1 : 0;
+    dim3 grid(tn, tm, splits);
+    const bool ta = trans_a != 0, tb = trans_b != 0;
+    if (BM == 32)
+        launch_bf16<32, 128, 1, 4>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+    else if (BN == 64)
+        launch_bf16<128, 64, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+    else if (BM == 64)
+        launch_bf16<64, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+    else
+        launch_bf16<128, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}

@@ -68,6 +68,7 @@ def get_training_argparser():
     extra.add_argument('--data_dir', default='', help='directory holding object_model_tfrecord/ and '
                        'ycb_video_data_tfRecords/train_syn/ (:31-39); empty = synthetic batches')
     extra.add_argument('--restore', default='', help='checkpoint (.npz) to resume from')
+    extra.add_argument('--gemm_dtype', default='f32', help="f32, or bf16 = bf16 operands for the dense layers")
     extra.add_argument('--print_every', type=int, default=1, help='print the losses every n batches (each print syncs)')
     return parser
 
@@ -87,7 +88,7 @@ class TrainGraph(object):
 
     def __init__(self, general_opts=None, train_opts=None, hyperparameters=None, device=None,
                  model_fn='get_model_dgcnn_mean_6d', k_neighbor=K_NEIGHBOR, process_group=None, seed=123456789,
-                 replay=False):
+                 replay=False, gemm_dtype='f32'):
         general_opts = dict(general_opts or {})
         train_opts = dict(train_opts or {})
         hyperparameters = dict(hyperparameters or {})
@@ -124,6 +125,11 @@ class TrainGraph(object):
         # C-ABI calls in issue order, buffers from the plan's arena) and later steps re-issue it
         # without Python layers or autograd in between -- the host cost of a step drops from ~3 ms
         # to the launches themselves, which is what keeps a batch-32 step GPU-bound.
+        # gemm_dtype='bf16': the per-point conv1x1 products (and their gradient products) round their operands
+        # to bfloat16 on the way to the matrix cores, fp32 accumulate; everything else -- tensors in
+        # HBM, batch norm, kNN, Chamfer, pose losses, Adam -- stays fp32 (BASELINE config 3)
+        require(gemm_dtype in ('f32', 'bf16'), "gemm_dtype must be 'f32' or 'bf16'")
+        self.gemm_dtype = gemm_dtype
         self.replay = bool(replay)
         self._plan = self._plan_key = self._plan_out = self._static = None
         self._build()
@@ -155,6 +161,7 @@ class TrainGraph(object):
 
     def _call_model(self, pc, is_training):
         set_default_store(self.store)      # several graphs may live in one process (cf. tf.Graph.as_default)
+        F.GEMM_DTYPE = self.gemm_dtype     # read by every dense layer's forward (its backward follows suit)
         if self.is_pn:
             return self.model_fn(pc, is_training, bn_decay=self.bn_decay)
         return self.model_fn(pc, is_training, is_training, self.k, bn_decay=self.bn_decay)
@@ -485,7 +492,8 @@ def main(argv=None):
         torch.cuda.set_device(local)
         dist.init_process_group('nccl')
         general['gpu'] = local
-    graph = TrainGraph(general, topts, hyper, model_fn=extra['model_fn'], k_neighbor=extra['k'])
+    graph = TrainGraph(general, topts, hyper, model_fn=extra['model_fn'], k_neighbor=extra['k'], replay=True,
+                       gemm_dtype=extra['gemm_dtype'])
     if extra['restore']:
         graph.restore(extra['restore'])
     if extra['data_dir']:

@@ -66,21 +66,35 @@ def _mark(rec):
     rec.append(e)
 
 
-def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, accumulate=0, site=None):
+# Operand type of the per-point dense layers (conv2d 1x1, the edge convolution, dgcnn_agg): "f32", or
+# "bf16" = operands rounded to bfloat16 on their way to the matrix cores, fp32 accumulate (BASELINE
+# config 3).  The fully connected stack (rows = batch size) stays fp32: it is bound by reading its
+# fp32 weights, not by the matrix pipe, and bf16 staging only adds work there (measured: 12.9 vs
+# 7.9 us per 32 x 1024 x 1024 product).  Read when a layer's FORWARD runs; its backward follows suit.
+GEMM_DTYPE = "f32"
+
+
+def gemm_is_bf16():
+    require(GEMM_DTYPE in ("f32", "bf16"), "GEMM_DTYPE must be 'f32' or 'bf16'")
+    return GEMM_DTYPE == "bf16"
+
+
+def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, accumulate=0, site=None, bf16=False):
     rec = TIMED_SITES.get(site) if site is not None else None
     if rec is not None:
         _lib.host(_mark, rec)
-    _lib.check(L().cloudaae_gemm_f32(int(ta), int(tb), M, N, K, A, lda, B, ldb, C, ldc, bias, int(accumulate),
-                                     stream()), "cloudaae_gemm_f32")
+    fn = L().cloudaae_gemm_bf16 if bf16 else L().cloudaae_gemm_f32
+    _lib.check(fn(int(ta), int(tb), M, N, K, A, lda, B, ldb, C, ldc, bias, int(accumulate), stream()),
+               "cloudaae_gemm_bf16" if bf16 else "cloudaae_gemm_f32")
     if rec is not None:
         _lib.host(_mark, rec)
 
 
-def _gemm_out(shape, K, device):
+def _gemm_out(shape, K, device, bf16=False):
     """Output buffer of a product and the accumulate flag to pass: when the product is split over K
     while a step is being recorded, the buffer comes from the plan's zero zone (cleared by one fill
     per replay) and the product skips its own clear pass."""
-    if _lib.recording() is not None and _lib.gemm_splits(shape[0], shape[1], K) > 1:
+    if _lib.recording() is not None and _lib.gemm_splits(shape[0], shape[1], K, bf16) > 1:
         return _lib.zeros(shape, dtype=torch.float32, device=device), 2
     return _lib.empty(shape, dtype=torch.float32, device=device), 0
 
@@ -89,15 +103,16 @@ class LinearFn(torch.autograd.Function):
     """y[M,N] = x[M,K] W[K,N] + b  (tf.matmul/conv2d-1x1 + bias_add)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, bias_grad_by_bn=False):
+    def forward(ctx, x, w, b, bias_grad_by_bn=False, allow_bf16=True):
         # bias_grad_by_bn: a BatchNormFn consumes y directly and writes d(b) itself (column sums of
         # its dy come out of its own reductions), so backward here skips the extra pass over dy
         require(x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[0], "LinearFn: shape mismatch")
         xp, ldx = rows_ptr(x)
         M, K = x.shape
         N = w.shape[1]
-        y, acc = _gemm_out((M, N), K, x.device)
-        gemm(0, 0, M, N, K, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, acc)
+        ctx.bf16 = gemm_is_bf16() and bool(allow_bf16)
+        y, acc = _gemm_out((M, N), K, x.device, ctx.bf16)
+        gemm(0, 0, M, N, K, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, acc, bf16=ctx.bf16)
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None and not bias_grad_by_bn
         ctx.bvar = b
@@ -113,11 +128,11 @@ class LinearFn(torch.autograd.Function):
         xp, ldx = rows_ptr(x)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx, acc = _gemm_out((M, K), N, x.device)
-            gemm(0, 1, M, K, N, dyp, lddy, ptr(w), N, ptr(dx), K, None, acc)
+            dx, acc = _gemm_out((M, K), N, x.device, ctx.bf16)
+            gemm(0, 1, M, K, N, dyp, lddy, ptr(w), N, ptr(dx), K, None, acc, bf16=ctx.bf16)
         gw = _ParamGrad(w, ctx.needs_input_grad[1])
         if gw.needed:
-            gemm(1, 0, K, N, M, xp, ldx, dyp, lddy, ptr(gw.buf), N, None, gw.gemm_acc)
+            gemm(1, 0, K, N, M, xp, ldx, dyp, lddy, ptr(gw.buf), N, None, gw.gemm_acc, bf16=ctx.bf16)
         gb_ret = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _ParamGrad(ctx.bvar, True)
@@ -125,7 +140,7 @@ class LinearFn(torch.autograd.Function):
             _lib.check(L().cloudaae_colsum_f32(M, N, dyp, lddy, ptr(gb.buf), gb.accumulate, ptr(ws), stream()),
                        "cloudaae_colsum_f32")
             gb_ret = gb.done()
-        return dx, gw.done(), gb_ret, None
+        return dx, gw.done(), gb_ret, None, None
 
 
 class ConcatSlot(object):
@@ -171,7 +186,9 @@ class ConcatLinearFn(torch.autograd.Function):
             ctx.cat = cat
         N = w.shape[1]
         y = _lib.empty((M, N), dtype=torch.float32, device=w.device)
-        gemm(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, site="agg_fwd")
+        ctx.bf16 = gemm_is_bf16()
+        gemm(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, site="agg_fwd",
+             bf16=ctx.bf16)
         ctx.save_for_backward(w, *nets)
         ctx.widths, ctx.xp, ctx.bvar = widths, xp, b
         return y
@@ -187,12 +204,12 @@ class ConcatLinearFn(torch.autograd.Function):
         dcat = None
         if any(ctx.needs_input_grad[4:]):
             dcat = _lib.empty((M, Ktot), dtype=torch.float32, device=w.device)
-            gemm(0, 1, M, Ktot, N, ptr(dy), N, ptr(w), N, ptr(dcat), Ktot)
+            gemm(0, 1, M, Ktot, N, ptr(dy), N, ptr(w), N, ptr(dcat), Ktot, bf16=ctx.bf16)
             if ctx.slot is not None and ctx.cat is None:
                 ctx.slot.dcat = dcat
         gw = _ParamGrad(w, ctx.needs_input_grad[1])
         if gw.needed:
-            gemm(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.gemm_acc)
+            gemm(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.gemm_acc, bf16=ctx.bf16)
         gb_ret = None
         if ctx.bias_here and ctx.needs_input_grad[2]:
             gb = _ParamGrad(ctx.bvar, True)
@@ -316,7 +333,9 @@ class EdgeConvFn(torch.autograd.Function):
         _lib.check(L().cloudaae_edgeconv_forward(
             B, N, k, cin, cout, x.data_ptr(), ldx, ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
             int(training), ptr(decay), ptr(ema_mean), ptr(ema_var), int(pool_mode), ptr(pq), ptr(save_mean),
-            ptr(save_var), out.data_ptr(), ldo, ptr(ties), ptr(ws), stream()), "cloudaae_edgeconv_forward")
+            ptr(save_var), out.data_ptr(), ldo, ptr(ties), int(gemm_is_bf16()), ptr(ws), stream()),
+            "cloudaae_edgeconv_forward")
+        ctx.bf16 = gemm_is_bf16()
         ctx.save_for_backward(x, nn_idx, w, b, gamma, beta, pq, save_mean, save_var, ties,
                               out if pool_mode == 2 else None)
         ctx.cfg = (int(training), int(pool_mode))
@@ -366,7 +385,8 @@ class EdgeConvFn(torch.autograd.Function):
             training, pool_mode, ptr(pq), ptr(save_mean), ptr(save_var),
             fwd_out.data_ptr() if fwd_out is not None else None, fwd_out.stride(1) if fwd_out is not None else 0,
             ptr(ties), dout.data_ptr(), dout.stride(1), ptr(dpq), ptr(rev), dx_ptr, lddx, acc_dx, ptr(gw.buf),
-            1 if (gw.needed and gw.gemm_acc == 2) else 0, ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), ptr(ws), stream()),
+            1 if (gw.needed and gw.gemm_acc == 2) else 0, ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), int(ctx.bf16),
+            ptr(ws), stream()),
             "cloudaae_edgeconv_backward")
         for g in shared:
             L().cloudaae_add_f32(g.buf.numel(), ptr(tmp[id(g)]), ptr(g.buf), ptr(tmp[id(g)]), stream())

@@ -200,7 +200,7 @@ def fully_connected(inputs,
                                               wd=weight_decay, use_xavier=use_xavier, trainable=trainable,
                                               fan=(num_input_units, num_outputs))
         biases = _variable_on_cpu('biases', [num_outputs], VariableStore.constant(0.0), trainable=trainable)
-        outputs = F.LinearFn.apply(inputs, weights.data, biases.data, bool(bn))
+        outputs = F.LinearFn.apply(inputs, weights.data, biases.data, bool(bn), False)   # FC stack: always fp32
         if bn:
             with variable_scope('bn'):
                 beta, gamma, ema_mean, ema_var = _bn_variables(num_outputs)

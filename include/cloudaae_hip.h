@@ -111,6 +111,13 @@ int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float
 /* K slices cloudaae_gemm_f32 will use for this shape (> 1: the output is combined with atomics and
  * must hold zeros first -- the call clears it itself unless accumulate is 1 or 2). */
 int cloudaae_gemm_f32_splits(int M, int N, int K);
+/* The same product with both operands rounded to bfloat16 (round to nearest even) on their way
+ * to the matrix cores (v_mfma_f32_32x32x16_bf16), fp32 accumulate; A, B, C, bias stay fp32 in
+ * memory, so the call is interchangeable with cloudaae_gemm_f32 (BASELINE config 3: bf16 MLPs). */
+int cloudaae_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                       const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
+                       cloudaae_stream_t stream);
+int cloudaae_gemm_bf16_splits(int M, int N, int K);
 
 /* batch_norm_template (utils/tf_util.py:473-511) on rows y[M,C] (+ ReLU), writing the
  * activation out[M,C] and/or its pool over groups of pool_rows consecutive rows
@@ -151,14 +158,16 @@ int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, float *out, int a
  * max pool: tie_count[b*n, cout] receives the number of equal maxima (tf.reduce_max shares
  * the gradient among them); backward then also needs the forward output.
  * backward scratch: dpq[b*n, 2*cout] floats, rev_scratch[b*(n+1) + b*n*k] ints (reverse
- * neighbour lists, built by a counting sort in LDS: no atomics on the gradient tensors). */
+ * neighbour lists, built by a counting sort in LDS: no atomics on the gradient tensors).
+ * gemm_bf16 != 0: the block's dense products round their operands to bfloat16 (cloudaae_gemm_bf16).
+ * dweights_zeroed != 0: the caller already cleared dweights (skips the clear pass of the split-K products). */
 long long cloudaae_edgeconv_workspace_bytes(int cout);
 int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cout, const float *x, int ldx,
                               const int *nn_idx, const float *weights, const float *biases,
                               const float *gamma, const float *beta, int training, const float *decay,
                               float *ema_mean, float *ema_var, int pool_mode, float *pq, float *save_mean,
-                              float *save_var, float *out, int ldo, float *tie_count, void *workspace,
-                              cloudaae_stream_t stream);
+                              float *save_var, float *out, int ldo, float *tie_count, int gemm_bf16,
+                              void *workspace, cloudaae_stream_t stream);
 int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int cout, const float *x, int ldx,
                                const int *nn_idx, const float *weights, const float *biases,
                                const float *gamma, const float *beta, int training, int pool_mode,
@@ -166,7 +175,8 @@ int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int cout, const flo
                                const float *out, int ldo, const float *tie_count, const float *dout,
                                int lddo, float *dpq, int *rev_scratch, float *dx, int lddx,
                                int accumulate_dx, float *dweights, int dweights_zeroed, float *dbiases,
-                               float *dgamma, float *dbeta, void *workspace, cloudaae_stream_t stream);
+                               float *dgamma, float *dbeta, int gemm_bf16, void *workspace,
+                               cloudaae_stream_t stream);
 
 /* ---- train_cloudAAE_ycbv.py:194-273: the step around the network --------- */
 

@@ -87,13 +87,61 @@ def batch_norm(x, scope, V, is_training, bn_decay):
     return x * inv + (beta - mean * inv)
 
 
+# ---- BASELINE config 3: dense layers with bf16 operands ------------------------------------------
+# GEMM_BF16 = True: every per-point product (conv2d 1x1, edge convolution, dgcnn_agg; NOT the fully
+# connected stack) rounds BOTH operands to bfloat16 (round to nearest
+# even) and accumulates in fp32, in the forward product AND in the two gradient products
+# (dx = bf16(dy) bf16(W)^T, dW = bf16(x)^T bf16(dy)); everything else stays fp32.  The reference has
+# no such mode (it is BASELINE.json's config 3), so this IS the definition; the edge convolution is
+# then evaluated in the split form y_ij = (x_i Wc - x_i Wn + b) + x_j Wn, because rounding x_j - x_i
+# is not rounding x_j and x_i.
+GEMM_BF16 = False
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _MatmulBf16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return _bf(x) @ _bf(w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dyb = _bf(dy)
+        x2 = _bf(x).reshape(-1, x.shape[-1])
+        return (dyb @ _bf(w).t()).reshape(x.shape), x2.t() @ dyb.reshape(-1, dy.shape[-1])
+
+
+def mm(x, w):
+    """x[..., cin] @ w[cin, cout] -- fp32, or with bf16 operands when GEMM_BF16 is set."""
+    return _MatmulBf16.apply(x, w) if GEMM_BF16 else x @ w
+
+
+def edge_conv_split(x, nn_idx, cout, scope, V, is_training, bn_decay):
+    """The DGCNN block in the algebraically equal split form (used when GEMM_BF16 is set):
+    conv([x_i, x_j - x_i]) = x_i Wc + (x_j - x_i) Wn + b = (x_i Wc - x_i Wn + b) + x_j Wn."""
+    B, N, C = x.shape
+    W = V.get(scope + "/weights", (1, 1, 2 * C, cout), "xavier", fan=(2 * C, cout)).reshape(2 * C, cout)
+    b = V.get(scope + "/biases", (cout,), "zeros")
+    P = mm(x, W[:C])
+    Q = mm(x, W[C:])
+    idx = nn_idx.long() + (torch.arange(B) * N).view(B, 1, 1)
+    y = ((P - Q) + b).unsqueeze(2) + Q.reshape(B * N, cout)[idx]          # [B,N,k,cout]
+    y = batch_norm(y, scope + "/bn", V, is_training, bn_decay)
+    return torch.relu(y)
+
+
 def conv2d_1x1(x, cout, scope, V, bn, is_training, bn_decay, relu=True):
     """conv2d with a [1,1] kernel, utils/tf_util.py:111-179: matmul over the last axis + bias
     (+BN, +ReLU)."""
     cin = x.shape[-1]
     W = V.get(scope + "/weights", (1, 1, cin, cout), "xavier", fan=(cin, cout))
     b = V.get(scope + "/biases", (cout,), "zeros")
-    y = x @ W.reshape(cin, cout) + b
+    y = mm(x, W.reshape(cin, cout)) + b
     if bn:
         y = batch_norm(y, scope + "/bn", V, is_training, bn_decay)
     return torch.relu(y) if relu else y
@@ -114,7 +162,7 @@ def fully_connected(x, cout, scope, V, bn=False, is_training=None, bn_decay=None
     cin = x.shape[-1]
     W = V.get(scope + "/weights", (cin, cout), "xavier", fan=(cin, cout))
     b = V.get(scope + "/biases", (cout,), "zeros")
-    y = x @ W + b
+    y = x @ W + b                      # the FC stack stays fp32 in the bf16 mode too
     if bn:
         y = batch_norm(y, scope + "/bn", V, is_training, bn_decay)
     return torch.relu(y) if relu else y
@@ -179,8 +227,12 @@ def get_model_dgcnn_6d(point_cloud, is_training_pl_encoder, is_training, k_neigh
         # nn_override: grouping indices given by the caller (tests feed the GPU's, so that a
         # round-off-level k-th/(k+1)-th near-tie cannot send the two networks down different paths)
         nn_idx = knn_indices(net, k) if nn_override is None else nn_override[i].long()
-        edge = get_edge_feature(net, nn_idx, k)
-        net = conv2d_1x1(edge, cout, "%sdgcnn%d" % (prefix, i + 1), V, True, is_training_pl_encoder, bn_decay)
+        if GEMM_BF16:
+            net = edge_conv_split(net.reshape(B, N, -1), nn_idx, cout, "%sdgcnn%d" % (prefix, i + 1), V,
+                                  is_training_pl_encoder, bn_decay)
+        else:
+            edge = get_edge_feature(net, nn_idx, k)
+            net = conv2d_1x1(edge, cout, "%sdgcnn%d" % (prefix, i + 1), V, True, is_training_pl_encoder, bn_decay)
         net = red(net, -2)                                  # [B,N,1,cout]
         nets.append(net)
         end_points["nn_idx%d" % (i + 1)] = nn_idx

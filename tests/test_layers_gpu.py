@@ -48,6 +48,37 @@ def test_gemm(hip, ta, tb, M, N, K):
     assert np.abs(C.cpu().numpy() - (2 * want - bias)).max() / scale < 4e-5
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (32, 1024, 1024), (2, 3, 256), (200, 130, 70), (4096, 64, 24),
+                                   (4096, 128, 64), (320, 1024, 8192), (64, 64, 20000), (129, 257, 33),
+                                   (2, 12288, 1024), (32768, 1024, 320)])
+def test_gemm_bf16(hip, ta, tb, M, N, K):
+    """bf16 operands (round to nearest even), fp32 accumulate: equals the float64 product of the
+    bf16-rounded operands up to fp32 accumulation round-off -- the rounding itself is exact."""
+    if M * N * K > 2 ** 31 and (ta or tb):
+        pytest.skip("largest shape once")
+    rng = np.random.default_rng(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = torch.from_numpy(rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32))
+    B = torch.from_numpy(rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32))
+    bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32))
+    Ar, Br = A.cuda().bfloat16().double(), B.cuda().bfloat16().double()      # torch rounds RNE too
+    want = ((Ar.T if ta else Ar) @ (Br.T if tb else Br) + bias.cuda().double())
+    dA, dB, dbias = A.cuda(), B.cuda(), bias.cuda()
+    C = torch.full((M, N), float("nan"), device="cuda")
+    L = hip.lib()
+    hip.check(L.cloudaae_gemm_bf16(ta, tb, M, N, K, hip.ptr(dA), A.shape[1], hip.ptr(dB), B.shape[1], hip.ptr(C), N,
+                                   hip.ptr(dbias), 0, hip.stream()), "gemm_bf16")
+    scale = np.sqrt(K) + 1
+    assert float((C.double() - want).abs().max()) / scale < 2e-5
+    hip.check(L.cloudaae_gemm_bf16(ta, tb, M, N, K, hip.ptr(dA), A.shape[1], hip.ptr(dB), B.shape[1], hip.ptr(C), N,
+                                   None, 1, hip.stream()), "gemm_bf16")
+    assert float((C.double() - (2 * want - bias.cuda().double())).abs().max()) / scale < 4e-5
+    # and it is a bf16 product, not an fp32 one
+    if K >= 256:
+        full = (A.cuda().double().T if ta else A.cuda().double()) @ (B.cuda().double().T if tb else B.cuda().double())
+        assert float((want - bias.cuda().double() - full).abs().max()) / scale > 1e-4
+
+
 def test_gemm_strided_views(hip):
     # column slices of wider buffers as A and C (what the fused encoder uses)
     rng = np.random.default_rng(0)
@@ -375,6 +406,49 @@ def test_train_step_k20_vs_oracle(hip, B, N, k):
             assert err < 1e-2, (name, err)
             continue
         assert _rel(got, g) < (5e-3 if "dgcnn" in name else 1e-3), (name, _rel(got, g))
+
+
+@pytest.mark.parametrize("B,N", [(8, 256), (4, 1024)])
+def test_train_step_bf16_gemms_vs_oracle(hip, B, N):
+    """BASELINE config 3's arithmetic: the per-point conv1x1 products and their gradient products with bf16
+    operands (round to nearest even) and fp32 accumulate, everything else fp32 -- against the
+    restatement with the same rounding (oracle/model_oracle.py: GEMM_BF16), grouped on the GPU's
+    neighbour indices.  A value on a bf16 rounding boundary rounds differently when the two
+    implementations differ by an fp32 ulp, so agreement is ~1e-4, not round-off; and the bf16 step
+    must differ from the fp32 step by far more than that."""
+    from cloudaae_amd import train_cloudAAE_ycbv as T
+    from oracle import model_oracle as MO
+    graph = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, gemm_dtype="bf16")
+    f32 = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B})
+    V = MO.Vars(seed=21)
+    batch = MO.synthetic_batch(B, N, seed=23)
+    with torch.no_grad():
+        MO.forward_losses(batch, V, N, is_training=False)
+    graph.store.load_state_dict(V.state_dict())
+    f32.store.load_state_dict(V.state_dict())
+    dev = {k: v.cuda() for k, v in batch.items()}
+    out = graph.train_step(dev)
+    ref32 = f32.train_step(dev)
+    gpu_idx = [out["end_points"]["nn_idx%d" % i].cpu() for i in (1, 2, 3, 4)]
+    MO.GEMM_BF16 = True
+    try:
+        ref, grads = MO.train_step(batch, V, MO.AdamTF(), 0, N, B, nn_override=gpu_idx)
+    finally:
+        MO.GEMM_BF16 = False
+    for key in ("xyz_loss", "trans_loss", "axag_loss"):
+        a, b = float(out[key].detach()), float(ref[key])
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (key, a, b)
+    assert _rel(out["xyz_recon"], ref["xyz_recon"]) < 5e-3
+    # it really is the bf16 arithmetic
+    assert abs(float(out["trans_loss"].detach()) - float(ref32["trans_loss"].detach())) > 1e-4
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    for name, g in grads.items():
+        got = graph.store.vars[name].grad.cpu()
+        if name.endswith("/biases") and (name.rsplit("/", 1)[0] + "/bn/beta") in grads:
+            assert float(got.abs().max()) < 1e-2 * gmax + 1e-3, name
+            continue
+        err = float((got - g).norm() / (g.norm() + 1e-12))
+        assert err < 1e-1, (name, err)
 
 
 def test_eval_path_fps_gather(hip):

@@ -3,11 +3,12 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cloudaae_amd import _lib
 L = _lib.lib()
+FN = "cloudaae_gemm_bf16" if os.environ.get("BF16") else "cloudaae_gemm_f32"
 def run(ta, tb, M, N, K, iters=20):
     A = torch.randn((K, M) if ta else (M, K), device="cuda"); B = torch.randn((N, K) if tb else (K, N), device="cuda")
     C = torch.empty((M, N), device="cuda")
     def go():
-        _lib.check(L.cloudaae_gemm_f32(ta, tb, M, N, K, A.data_ptr(), A.shape[1], B.data_ptr(), B.shape[1], C.data_ptr(), N, None, 0, _lib.stream()), "g")
+        _lib.check(getattr(L, FN)(ta, tb, M, N, K, A.data_ptr(), A.shape[1], B.data_ptr(), B.shape[1], C.data_ptr(), N, None, 0, _lib.stream()), "g")
     for _ in range(3): go()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
