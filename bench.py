@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--per-gpu-batch", type=int, default=32)
     ap.add_argument("--num-point", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=10, help="neighbours of the edge convolution (BASELINE config 4: 20)")
     ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="train steps of the CPU-baseline sample")
     ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "bf16"], help="bf16: BASELINE config 3's "
@@ -142,7 +143,7 @@ def main():
     F.TIMED_SITES["agg_fwd"] = []
     graph = T.TrainGraph({"num_point": N, "gpu": local}, {"optimizer": "adam"},
                          {"batch_size": B * world, "learning_rate": 0.0008}, replay=not args.eager,
-                         gemm_dtype=args.gemm_dtype)
+                         gemm_dtype=args.gemm_dtype, k_neighbor=args.k)
     el = T.synthetic_element(B, N, graph.device, seed=123456789, rank=rank)
 
     for _ in range(args.warmup):
@@ -194,7 +195,7 @@ def main():
             "dtype": "f32" if args.gemm_dtype == "f32" else "bf16 dense-layer operands, f32 accumulate and everything else",
             "data": "synthetic",
             "config": {"workload": "CloudAAE train step: get_model_dgcnn_mean_6d, all 21 YCB classes, "
-                                   "batch %d/GPU, N=%d points, k=10, 4N-point Chamfer target, TF-Adam" % (B, N),
+                                   "batch %d/GPU, N=%d points, k=%d, 4N-point Chamfer target, TF-Adam" % (B, N, args.k),
                        "global_batch": B * world, "num_point": N, "parallelism": "dp%d" % world,
                        "step_issue": "recorded step replay" if graph.replay else "eager",
                        "final_total_loss": round(loss, 4)},
