@@ -173,26 +173,32 @@ struct Cons {
     double a, b, c;
 };
 
-// constraint of point q against p in chart (axis, sign): d = (x, y) on the other two axes, d_axis = sign
-//   d.g <= -eps |g|,  g = q - p
-__device__ __forceinline__ Cons hpr_constraint(const float *__restrict__ pts, int q, double px, double py,
-                                               double pz, int axis, double sgn)
+// Frame of one candidate vertex p: r = unit vector from the cloud's centroid to p, (u, w) a unit
+// basis of the plane perpendicular to it.  The centroid is strictly inside the hull, so every
+// supporting plane at a vertex p has an outward normal d with d.r > 0, i.e. d = r + s u + t w after
+// scaling: ONE two-variable chart covers every certificate (the six axis charts of the first version
+// made every non-vertex pay for six refuted LPs).  (s, t) are tangents of the angle to r; the box
+// |s|, |t| <= HPR_TAN cuts off normals within 1e-4 rad of the tangent plane, which a vertex of a
+// flipped cloud (a thin near-spherical shell) never needs.
+struct Frame {
+    double px, py, pz, rx, ry, rz, ux, uy, uz, wx, wy, wz;
+};
+constexpr double HPR_TAN = 1e4;
+
+// constraint of point q against p:  d.g <= -eps |g|,  g = q - p,  d = r + s u + t w
+//   (u.g) s + (w.g) t <= -(r.g) - eps |g|
+__device__ __forceinline__ Cons hpr_constraint(const float *__restrict__ pts, int q, const Frame &f)
 {
-    const double gx = (double)pts[3 * q] - px, gy = (double)pts[3 * q + 1] - py, gz = (double)pts[3 * q + 2] - pz;
+    const double gx = (double)pts[3 * q] - f.px, gy = (double)pts[3 * q + 1] - f.py, gz = (double)pts[3 * q + 2] - f.pz;
     const double nrm = (fabs(gx) + fabs(gy)) + fabs(gz);   // L1 >= L2: the margin only has to be "tiny but positive"
     Cons k;
-    if (axis == 2) {
-        k.a = gx; k.b = gy; k.c = -sgn * gz;
-    } else if (axis == 0) {
-        k.a = gy; k.b = gz; k.c = -sgn * gx;
-    } else {
-        k.a = gx; k.b = gz; k.c = -sgn * gy;
-    }
-    k.c -= HPR_EPS * nrm;
+    k.a = (f.ux * gx + f.uy * gy) + f.uz * gz;
+    k.b = (f.wx * gx + f.wy * gy) + f.wz * gz;
+    k.c = -((f.rx * gx + f.ry * gy) + f.rz * gz) - HPR_EPS * nrm;
     return k;
 }
 
-// Seidel's incremental 2-variable LP on [-1,1]^2, objective x + y/2; returns feasibility.
+// Seidel's incremental 2-variable LP on [-HPR_TAN, HPR_TAN]^2, objective x + y/2; returns feasibility.
 // ONE WAVE per point: the 64 lanes test 64 consecutive constraints against the current optimum
 // (ballot -> first violated one, which keeps Seidel's sequential semantics), and share the 1-D
 // re-solve over the constraints seen so far (per-lane lo/hi as FRACTIONS -- compared by cross
@@ -206,11 +212,9 @@ struct Frac {
 };
 __device__ __forceinline__ bool frac_less(const Frac &x, const Frac &y) { return x.num * y.den < y.num * x.den; }
 
-__device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, int bits, int axis, double sgn,
-                              int lane)
+__device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, int bits, const Frame &fr, int lane)
 {
-    const double px = pts[3 * self], py = pts[3 * self + 1], pz = pts[3 * self + 2];
-    double vx = 1.0, vy = 1.0;
+    double vx = HPR_TAN, vy = HPR_TAN;
     const int span = 1 << bits;
     int i = 0;
     while (i < span) {
@@ -219,7 +223,7 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
         const bool valid = q < n1 && q != self;
         Cons k = {0.0, 0.0, 0.0};
         if (valid)
-            k = hpr_constraint(pts, q, px, py, pz, axis, sgn);
+            k = hpr_constraint(pts, q, fr);
         const bool viol = valid && (k.a * vx + k.b * vy > k.c);
         const unsigned long long mask = __ballot(viol);
         if (mask == 0ull) {
@@ -249,14 +253,14 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
                 bad = true;
             }
         };
-        if (lane < 4)      // the box |x| <= 1, |y| <= 1
-            add(lane == 0 ? 1.0 : (lane == 1 ? -1.0 : 0.0), lane == 2 ? 1.0 : (lane == 3 ? -1.0 : 0.0), 1.0);
+        if (lane < 4)      // the box |x| <= HPR_TAN, |y| <= HPR_TAN
+            add(lane == 0 ? 1.0 : (lane == 1 ? -1.0 : 0.0), lane == 2 ? 1.0 : (lane == 3 ? -1.0 : 0.0), HPR_TAN);
         const int upto = i + first;            // sequence positions [0, upto) were already accepted
         for (int jpos = lane; jpos < upto; jpos += 64) {
             const int r = (int)(__brev((unsigned)jpos) >> (32 - bits));
             if (r >= n1 || r == self)
                 continue;
-            const Cons m = hpr_constraint(pts, r, px, py, pz, axis, sgn);
+            const Cons m = hpr_constraint(pts, r, fr);
             add(m.a, m.b, m.c);
         }
         // wave reduction of lo (max) and hi (min) as fractions
@@ -288,17 +292,70 @@ __global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, con
                                                                     int bits, unsigned char *__restrict__ flags)
 {
     extern __shared__ float pts[];
+    __shared__ double cen[3][HPR_WAVES];
     const float *P = points + (size_t)blockIdx.y * n1 * 3;
     for (int f = threadIdx.x; f < n1 * 3; f += 64 * HPR_WAVES)
         pts[f] = P[f];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int axes[3] = {2, 0, 1};   // most visible points separate along +-z first
+    // centroid of the cloud (strictly inside its hull)
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int q = threadIdx.x; q < n1; q += 64 * HPR_WAVES) {
+        sx += (double)pts[3 * q];
+        sy += (double)pts[3 * q + 1];
+        sz += (double)pts[3 * q + 2];
+    }
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    sz = wave_sum(sz);
+    if (lane == 0) {
+        cen[0][wave] = sx;
+        cen[1][wave] = sy;
+        cen[2][wave] = sz;
+    }
+    __syncthreads();
+    double cx = 0.0, cy = 0.0, cz = 0.0;
+    for (int w = 0; w < HPR_WAVES; ++w) {
+        cx += cen[0][w];
+        cy += cen[1][w];
+        cz += cen[2][w];
+    }
+    cx /= (double)n1;
+    cy /= (double)n1;
+    cz /= (double)n1;
     for (int j = blockIdx.x * HPR_WAVES + wave; j < n1; j += HPR_WAVES * gridDim.x) {
+        Frame f;
+        f.px = pts[3 * j];
+        f.py = pts[3 * j + 1];
+        f.pz = pts[3 * j + 2];
+        double rx = f.px - cx, ry = f.py - cy, rz = f.pz - cz;
+        const double rn = sqrt((rx * rx + ry * ry) + rz * rz);
         bool vertex = false;
-#pragma unroll 1
-        for (int c = 0; c < 6 && !vertex; ++c)
-            vertex = hpr_lp2d_wave(pts, n1, j, bits, axes[c >> 1], (c & 1) ? -1.0 : 1.0, lane);
+        if (rn > 0.0) {
+            rx /= rn;
+            ry /= rn;
+            rz /= rn;
+            // u = r x e (e = the axis r is least aligned with), w = r x u
+            const double ax = fabs(rx), ay = fabs(ry), az = fabs(rz);
+            double ux, uy, uz;
+            if (ax <= ay && ax <= az) {
+                ux = 0.0; uy = rz; uz = -ry;
+            } else if (ay <= az) {
+                ux = -rz; uy = 0.0; uz = rx;
+            } else {
+                ux = ry; uy = -rx; uz = 0.0;
+            }
+            const double un = sqrt((ux * ux + uy * uy) + uz * uz);
+            ux /= un;
+            uy /= un;
+            uz /= un;
+            f.rx = rx; f.ry = ry; f.rz = rz;
+            f.ux = ux; f.uy = uy; f.uz = uz;
+            f.wx = ry * uz - rz * uy;
+            f.wy = rz * ux - rx * uz;
+            f.wz = rx * uy - ry * ux;
+            vertex = hpr_lp2d_wave(pts, n1, j, bits, f, lane);
+        }
         if (lane == 0)
             flags[(size_t)blockIdx.y * n1 + j] = vertex ? 1 : 0;
     }
