@@ -22,6 +22,7 @@
 // This is an algebraic refactoring of the reference arithmetic: results agree with
 // the edge-tensor formulation to fp32 round-off, not bitwise.
 #include "bn_common.h"
+#include "gemm.h"
 #include "../../include/cloudaae_hip.h"
 
 namespace cloudaae {
@@ -497,16 +498,16 @@ static int ec_apply_grid(int P)
 
 using namespace cloudaae;
 
-extern "C" int cloudaae_gemm_f32(int, int, int, int, int, const float *, int, const float *, int, float *, int,
-                                 const float *, int, cloudaae_stream_t);
-extern "C" int cloudaae_gemm_bf16(int, int, int, int, int, const float *, int, const float *, int, float *, int,
-                                  const float *, int, cloudaae_stream_t);
-// the block's dense products: fp32 operands, or rounded to bf16 on the way to the matrix cores
-static int ec_gemm(int bf16, int ta, int tb, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
-                   float *C, int ldc, int accumulate, cloudaae_stream_t stream)
+// the block's dense products: fp32 operands, or rounded to bf16 on the way to the matrix cores; B and/or C
+// may be the FOLDED view of the [2*cin, cout] kernel as [cin, 2*cout] = [W_centre | W_neighbour] (gemm.h)
+static int ec_gemm(const char *name, int bf16, int ta, int tb, int M, int N, int K, const float *A, int lda,
+                   const float *B, int ldb, float *C, int ldc, int accumulate, int fold_b, int fold_c,
+                   cloudaae_stream_t stream)
 {
-    return bf16 ? cloudaae_gemm_bf16(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, nullptr, accumulate, stream)
-                : cloudaae_gemm_f32(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, nullptr, accumulate, stream);
+    return bf16 ? gemm_bf16_launch(name, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, nullptr, accumulate, fold_b, fold_c,
+                                   (hipStream_t)stream)
+                : gemm_f32_launch(name, ta, tb, M, N, K, A, lda, B, ldb, C, ldc, nullptr, accumulate, fold_b, fold_c,
+                                  (hipStream_t)stream);
 }
 
 CLOUDAAE_API long long cloudaae_edgeconv_workspace_bytes(int cout)
@@ -538,12 +539,8 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
     CLOUDAAE_REQUIRE(pool_mode != 2 || tie_count != nullptr, name, "max pool needs the tie_count output");
     hipStream_t s = (hipStream_t)stream;
     const int P = b * n;
-    // P' = X W[0:cin], Q = X W[cin:2cin]   (two column blocks of pq)
-    int rc = ec_gemm(gemm_bf16, 0, 0, P, cout, cin, x, ldx, weights, cout, pq, 2 * cout, 0, stream);
-    if (rc)
-        return rc;
-    rc = ec_gemm(gemm_bf16, 0, 0, P, cout, cin, x, ldx, weights + (size_t)cin * cout, cout, pq + cout, 2 * cout, 0,
-                 stream);
+    // [P' | Q] = X [W_centre | W_neighbour]: ONE product over the folded kernel (cout is 64 or 128)
+    int rc = ec_gemm(name, gemm_bf16, 0, 0, P, 2 * cout, cin, x, ldx, weights, cout, pq, 2 * cout, 0, cout, 0, stream);
     if (rc)
         return rc;
     double *partial = (double *)workspace;
@@ -633,24 +630,18 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
 #undef EC_BA
     }
     CLOUDAAE_CHECK_LAUNCH(name);
-    // dX = dP' W_c^T + dQ W_n^T ; dW_c = X^T dP' ; dW_n = X^T dQ
+    // dX = [dP' | dQ] [W_c | W_n]^T ; [dW_c | dW_n] = X^T [dP' | dQ] : one product each over the folded kernel
     int rc = 0;
     if (dx != nullptr) {
-        rc = ec_gemm(gemm_bf16, 0, 1, P, cin, cout, dpq, 2 * cout, weights, cout, dx, lddx, accumulate_dx, stream);
-        if (rc)
-            return rc;
-        rc = ec_gemm(gemm_bf16, 0, 1, P, cin, cout, dpq + cout, 2 * cout, weights + (size_t)cin * cout, cout, dx,
-                     lddx, 1, stream);
+        rc = ec_gemm(name, gemm_bf16, 0, 1, P, cin, 2 * cout, dpq, 2 * cout, weights, cout, dx, lddx, accumulate_dx,
+                     cout, 0, stream);
         if (rc)
             return rc;
     }
     if (dweights != nullptr) {
         const int wacc = dweights_zeroed ? 2 : 0;     // 2: the caller cleared dweights already
-        rc = ec_gemm(gemm_bf16, 1, 0, cin, cout, P, x, ldx, dpq, 2 * cout, dweights, cout, wacc, stream);
-        if (rc)
-            return rc;
-        rc = ec_gemm(gemm_bf16, 1, 0, cin, cout, P, x, ldx, dpq + cout, 2 * cout, dweights + (size_t)cin * cout, cout,
-                     wacc, stream);
+        rc = ec_gemm(name, gemm_bf16, 1, 0, cin, 2 * cout, P, x, ldx, dpq, 2 * cout, dweights, cout, wacc, 0, cout,
+                     stream);
         if (rc)
             return rc;
     }

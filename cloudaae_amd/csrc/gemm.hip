@@ -24,6 +24,7 @@
 // slices then combine with hardware fp32 atomics.
 #include <cstdlib>
 #include "common.h"
+#include "gemm.h"
 #include "../../include/cloudaae_hip.h"
 
 namespace cloudaae {
@@ -35,6 +36,21 @@ constexpr int GEMM_THREADS = 256;
 #define GEMM_ATTR
 
 enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_ATOMIC = 2 };
+
+// A row-major matrix whose logical columns are FOLDED into stacked row blocks: logical (r, c) lives
+// at physical row (c >> shift) * rows + r, column c & (width - 1).  That is how the edge convolution's
+// [2*cin, cout] kernel looks when it is used as [cin, 2*cout] = [W_centre | W_neighbour]: with it the
+// P/Q products, their dX and their dW are ONE product each instead of two (edgeconv.hip).
+// shift < 0: no folding.
+struct Fold {
+    int shift, rows;
+};
+__device__ __forceinline__ size_t fold_off(int r, int c, int ld, Fold f)
+{
+    if (f.shift < 0)
+        return (size_t)r * ld + c;
+    return (size_t)((c >> f.shift) * f.rows + r) * ld + (c & ((1 << f.shift) - 1));
+}
 
 // One operand panel: ROWS "outer" indices (m for A, n for B) x BK k-values.
 // KC = true : memory is [outer][k] (k contiguous)   -> LDS [ROWS][BK+1]
@@ -52,7 +68,7 @@ struct Panel {
     // straight global_load_dwordx4, no per-element predicates in the loop.
     template <bool FAST>
     __device__ __forceinline__ void load(const float *__restrict__ P, int ld, int outer0, int nouter,
-                                         int k0, int kend, bool vec_ok)
+                                         int k0, int kend, bool vec_ok, Fold fold)
     {
 #pragma unroll
         for (int it = 0; it < PER_THREAD; ++it) {
@@ -61,8 +77,8 @@ struct Panel {
             if (FAST) {
                 if (VECS % GEMM_THREADS != 0 && v >= VECS)
                     break;
-                const size_t off = KC ? (size_t)(outer0 + v / (GEMM_BK / 4)) * ld + k0 + (v % (GEMM_BK / 4)) * 4
-                                      : (size_t)(k0 + v / (ROWS / 4)) * ld + outer0 + (v % (ROWS / 4)) * 4;
+                const size_t off = KC ? fold_off(outer0 + v / (GEMM_BK / 4), k0 + (v % (GEMM_BK / 4)) * 4, ld, fold)
+                                      : fold_off(k0 + v / (ROWS / 4), outer0 + (v % (ROWS / 4)) * 4, ld, fold);
                 reg[it] = *reinterpret_cast<const float4v *>(P + off);
                 continue;
             } else if (VECS % GEMM_THREADS == 0 || v < VECS) {
@@ -70,7 +86,7 @@ struct Panel {
                     const int o = v / (GEMM_BK / 4), kq = v % (GEMM_BK / 4);
                     const int go = outer0 + o, gk = k0 + kq * 4;
                     if (go < nouter) {
-                        const float *src = P + (size_t)go * ld + gk;
+                        const float *src = P + fold_off(go, gk, ld, fold);
                         if (vec_ok && gk + 3 < kend) {
                             r = *reinterpret_cast<const float4v *>(src);
                         } else {
@@ -84,7 +100,7 @@ struct Panel {
                     const int kk = v / (ROWS / 4), oq = v % (ROWS / 4);
                     const int gk = k0 + kk, go = outer0 + oq * 4;
                     if (gk < kend) {
-                        const float *src = P + (size_t)gk * ld + go;
+                        const float *src = P + fold_off(gk, go, ld, fold);
                         if (vec_ok && go + 3 < nouter) {
                             r = *reinterpret_cast<const float4v *>(src);
                         } else {
@@ -135,7 +151,7 @@ template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool FAST>
 __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
     int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
     float *__restrict__ C, int ldc, const float *__restrict__ bias, int epilogue, int kchunk,
-    int vecA, int vecB)
+    int vecA, int vecB, Fold foldB, Fold foldC)
 {
     static_assert(WM * WN * 64 == GEMM_THREADS, "4 waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;   // 32x32 tiles per wave
@@ -166,8 +182,9 @@ __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
 
     PA pa;
     PB pb;
-    pa.template load<FAST>(A, lda, m0, M, kbeg, kend, vecA != 0);
-    pb.template load<FAST>(B, ldb, n0, N, kbeg, kend, vecB != 0);
+    const Fold nofold = {-1, 0};
+    pa.template load<FAST>(A, lda, m0, M, kbeg, kend, vecA != 0, nofold);
+    pb.template load<FAST>(B, ldb, n0, N, kbeg, kend, vecB != 0, foldB);
 
     const int fr = lane & 31, fk = lane >> 5;
     for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
@@ -176,8 +193,8 @@ __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
         pb.stage(ldsB);
         __syncthreads();
         if (k0 + GEMM_BK < kend) {  // prefetch the next slab behind the MFMAs
-            pa.template load<FAST>(A, lda, m0, M, k0 + GEMM_BK, kend, vecA != 0);
-            pb.template load<FAST>(B, ldb, n0, N, k0 + GEMM_BK, kend, vecB != 0);
+            pa.template load<FAST>(A, lda, m0, M, k0 + GEMM_BK, kend, vecA != 0, nofold);
+            pb.template load<FAST>(B, ldb, n0, N, k0 + GEMM_BK, kend, vecB != 0, foldB);
         }
         // operand fragments are read one k-step ahead of the MFMAs that consume them
         float a[2][TM], b[2][TN];
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 if (FAST || row < M) {
-                    float *dst = C + (size_t)row * ldc + col;
+                    float *dst = C + fold_off(row, col, ldc, foldC);
                     const float v = acc[i][j][r] + bv;
                     if (epilogue == EPI_STORE)
                         *dst = v;
@@ -241,36 +258,36 @@ __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
 template <int BM, int BN, int WM, int WN, bool FAST>
 static void launch_fast(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A,
                         int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int epi,
-                        int kchunk, int vecA, int vecB)
+                        int kchunk, int vecA, int vecB, Fold fb, Fold fc)
 {
     dim3 block(GEMM_THREADS);
     if (!ta && !tb)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false, FAST>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
     else if (!ta && tb)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true, FAST>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
     else if (ta && !tb)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false, FAST>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
     else
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, FAST>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
 }
 
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A,
                        int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int epi,
-                       int kchunk, int vecA, int vecB)
+                       int kchunk, int vecA, int vecB, Fold fb, Fold fc)
 {
     // every tile and every K-slab whole, both operands float4-loadable: the predicate-free kernel
     const bool fast = M % BM == 0 && N % BN == 0 && K % kchunk == 0 && kchunk % GEMM_BK == 0 && vecA && vecB;
     if (fast)
         launch_fast<BM, BN, WM, WN, true>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                          vecA, vecB);
+                                          vecA, vecB, fb, fc);
     else
         launch_fast<BM, BN, WM, WN, false>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                           vecA, vecB);
+                                           vecA, vecB, fb, fc);
 }
 
 } // namespace cloudaae
@@ -334,17 +351,30 @@ CLOUDAAE_API int cloudaae_gemm_f32_splits(int M, int N, int K)
     return ceil_div(K, kchunk);
 }
 
-CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A,
-                                   int lda, const float *B, int ldb, float *C, int ldc,
-                                   const float *bias, int accumulate, cloudaae_stream_t stream)
+// The launcher behind cloudaae_gemm_f32 and the folded products of edgeconv.hip.
+// fold_b / fold_c: 0, or the power-of-two width at which B's / C's logical columns fold into stacked
+// row blocks (see Fold); the folded matrix has leading dimension == width.
+int cloudaae::gemm_f32_launch(const char *name, int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                              const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
+                              int fold_b, int fold_c, hipStream_t s)
 {
-    const char *name = "cloudaae_gemm_f32";
     CLOUDAAE_REQUIRE(M >= 0 && N >= 0 && K >= 0, name, "negative size");
     if (M == 0 || N == 0)
         return 0;
-    hipStream_t s = (hipStream_t)stream;
-    CLOUDAAE_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, name,
-                     "leading dimension too small");
+    CLOUDAAE_REQUIRE(lda >= (trans_a ? M : K), name, "leading dimension too small");
+    CLOUDAAE_REQUIRE(fold_b ? ldb == fold_b : ldb >= (trans_b ? K : N), name, "leading dimension too small");
+    CLOUDAAE_REQUIRE(fold_c ? ldc == fold_c : ldc >= N, name, "leading dimension too small");
+    CLOUDAAE_REQUIRE((fold_b & (fold_b - 1)) == 0 && (fold_c & (fold_c - 1)) == 0 && fold_b % 4 == 0 &&
+                         fold_c % 4 == 0, name, "fold width must be a power of two >= 4");
+    Fold fb = {-1, 0}, fc = {-1, 0};
+    if (fold_b) {           // B's folded index: n for [K][N] storage, k for [N][K] storage
+        fb.shift = __builtin_ctz((unsigned)fold_b);
+        fb.rows = trans_b ? N : K;
+    }
+    if (fold_c) {
+        fc.shift = __builtin_ctz((unsigned)fold_c);
+        fc.rows = M;
+    }
 
     int BM, BN, splits;
     gemm_plan(M, N, K, BM, BN, splits);
@@ -358,9 +388,13 @@ CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K
     int epi = accumulate == 1 ? EPI_ACCUM : EPI_STORE;
     if (splits > 1) {
         epi = EPI_ATOMIC;
-        if (!accumulate)  // slices add into a zeroed output
-            CLOUDAAE_CHECK_HIP(hipMemset2DAsync(C, sizeof(float) * (size_t)ldc, 0,
-                                                sizeof(float) * (size_t)N, (size_t)M, s), name);
+        if (!accumulate) {  // slices add into a zeroed output
+            if (fold_c)     // the folded output is one contiguous [N/width * M][width] block
+                CLOUDAAE_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * (size_t)N, s), name);
+            else
+                CLOUDAAE_CHECK_HIP(hipMemset2DAsync(C, sizeof(float) * (size_t)ldc, 0, sizeof(float) * (size_t)N,
+                                                    (size_t)M, s), name);
+        }
     }
     const bool a16 = ((uintptr_t)A & 15) == 0 && lda % 4 == 0;
     const bool b16 = ((uintptr_t)B & 15) == 0 && ldb % 4 == 0;
@@ -369,16 +403,24 @@ CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K
     const bool ta = trans_a != 0, tb = trans_b != 0;
     if (BM == 32)
         launch_cfg<32, 128, 1, 4>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                  vecA, vecB);
+                                  vecA, vecB, fb, fc);
     else if (BN == 64)
         launch_cfg<128, 64, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                  vecA, vecB);
+                                  vecA, vecB, fb, fc);
     else if (BM == 64)
         launch_cfg<64, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                  vecA, vecB);
+                                  vecA, vecB, fb, fc);
     else
         launch_cfg<128, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                   vecA, vecB);
+                                   vecA, vecB, fb, fc);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
+}
+
+CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A,
+                                   int lda, const float *B, int ldb, float *C, int ldc,
+                                   const float *bias, int accumulate, cloudaae_stream_t stream)
+{
+    return gemm_f32_launch("cloudaae_gemm_f32", trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate,
+                           0, 0, (hipStream_t)stream);
 }

@@ -17,6 +17,7 @@
 // memory layout is [k][outer] is transposed on the way in by packing two k-rows per 32-bit store.
 #include <cstdlib>
 #include "common.h"
+#include "gemm.h"
 #include "../../include/cloudaae_hip.h"
 
 namespace cloudaae {
@@ -31,6 +32,17 @@ constexpr int GB_LDK = 40;           // bf16 per staged row (32 + 8 pad)
 constexpr int GB_THREADS = 256;
 
 enum { GB_STORE = 0, GB_ACCUM = 1, GB_ATOMIC = 2 };
+
+// folded row-major matrix (see gemm.hip): logical (r, c) -> row (c >> shift) * rows + r, column c & mask
+struct FoldB {
+    int shift, rows;
+};
+__device__ __forceinline__ size_t foldb_off(int r, int c, int ld, FoldB f)
+{
+    if (f.shift < 0)
+        return (size_t)r * ld + c;
+    return (size_t)((c >> f.shift) * f.rows + r) * ld + (c & ((1 << f.shift) - 1));
+}
 
 // One operand slab: ROWS outer indices x 32 k.  KC: memory is [outer][k]; else [k][outer].
 template <int ROWS, bool KC>
@@ -56,7 +68,7 @@ struct SlabB {
     }
 
     __device__ __forceinline__ void load(const float *__restrict__ P, int ld, int outer0, int nouter, int k0,
-                                         int kend, bool vec)
+                                         int kend, bool vec, FoldB fold)
     {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -67,15 +79,15 @@ struct SlabB {
                     const int o = it / (GB_BK / 4), kq = it % (GB_BK / 4);
                     const int go = outer0 + o, gk = k0 + 4 * kq;
                     if (go < nouter && gk < kend)
-                        a = fetch4(P + (size_t)go * ld + gk, kend - gk, vec);
+                        a = fetch4(P + foldb_off(go, gk, ld, fold), kend - gk, vec);
                 } else {
                     const int kp = it / (ROWS / 4), oq = it % (ROWS / 4);
                     const int gk = k0 + 2 * kp, go = outer0 + 4 * oq;
                     if (go < nouter) {
                         if (gk < kend)
-                            a = fetch4(P + (size_t)gk * ld + go, nouter - go, vec);
+                            a = fetch4(P + foldb_off(gk, go, ld, fold), nouter - go, vec);
                         if (gk + 1 < kend)
-                            b = fetch4(P + (size_t)(gk + 1) * ld + go, nouter - go, vec);
+                            b = fetch4(P + foldb_off(gk + 1, go, ld, fold), nouter - go, vec);
                     }
                 }
             }
@@ -116,7 +128,8 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
                                                                int lda, const float *__restrict__ B, int ldb,
                                                                float *__restrict__ C, int ldc,
                                                                const float *__restrict__ bias, int epilogue,
-                                                               int kchunk, int vecA, int vecB)
+                                                               int kchunk, int vecA, int vecB, FoldB foldB,
+                                                               FoldB foldC)
 {
     static_assert(WM * WN * 64 == GB_THREADS, "4 waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -144,8 +157,9 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
 
     SA sa;
     SB sb;
-    sa.load(A, lda, m0, M, kbeg, kend, vecA != 0);
-    sb.load(B, ldb, n0, N, kbeg, kend, vecB != 0);
+    const FoldB nofold = {-1, 0};
+    sa.load(A, lda, m0, M, kbeg, kend, vecA != 0, nofold);
+    sb.load(B, ldb, n0, N, kbeg, kend, vecB != 0, foldB);
 
     const int fr = lane & 31, fk = lane >> 5;
     for (int k0 = kbeg; k0 < kend; k0 += GB_BK) {
@@ -154,8 +168,8 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
         sb.stage(ldsB);
         __syncthreads();
         if (k0 + GB_BK < kend) {
-            sa.load(A, lda, m0, M, k0 + GB_BK, kend, vecA != 0);
-            sb.load(B, ldb, n0, N, k0 + GB_BK, kend, vecB != 0);
+            sa.load(A, lda, m0, M, k0 + GB_BK, kend, vecA != 0, nofold);
+            sb.load(B, ldb, n0, N, k0 + GB_BK, kend, vecB != 0, foldB);
         }
 #pragma unroll
         for (int s = 0; s < GB_BK / 16; ++s) {
@@ -188,7 +202,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 if (row < M) {
-                    float *dst = C + (size_t)row * ldc + col;
+                    float *dst = C + foldb_off(row, col, ldc, foldC);
                     const float v = acc[i][j][r] + bv;
                     if (epilogue == GB_STORE)
                         *dst = v;
@@ -205,21 +219,21 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
 template <int BM, int BN, int WM, int WN>
 static void launch_bf16(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A, int lda,
                         const float *B, int ldb, float *C, int ldc, const float *bias, int epi, int kchunk,
-                        int vecA, int vecB)
+                        int vecA, int vecB, FoldB fb, FoldB fc)
 {
     dim3 block(GB_THREADS);
     if (!ta && !tb)
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
     else if (!ta && tb)
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
     else if (ta && !tb)
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
     else
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
 }
 
 // tile shape and K slices (same policy as gemm.hip's gemm_plan, slabs of 32)
@@ -265,17 +279,27 @@ CLOUDAAE_API int cloudaae_gemm_bf16_splits(int M, int N, int K)
     return ceil_div(K, kchunk);
 }
 
-CLOUDAAE_API int cloudaae_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
-                                    const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
-                                    cloudaae_stream_t stream)
+int cloudaae::gemm_bf16_launch(const char *name, int trans_a, int trans_b, int M, int N, int K, const float *A,
+                               int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
+                               int fold_b, int fold_c, hipStream_t s)
 {
-    const char *name = "cloudaae_gemm_bf16";
     CLOUDAAE_REQUIRE(M >= 0 && N >= 0 && K >= 0, name, "negative size");
     if (M == 0 || N == 0)
         return 0;
-    hipStream_t s = (hipStream_t)stream;
-    CLOUDAAE_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, name,
-                     "leading dimension too small");
+    CLOUDAAE_REQUIRE(lda >= (trans_a ? M : K), name, "leading dimension too small");
+    CLOUDAAE_REQUIRE(fold_b ? ldb == fold_b : ldb >= (trans_b ? K : N), name, "leading dimension too small");
+    CLOUDAAE_REQUIRE(fold_c ? ldc == fold_c : ldc >= N, name, "leading dimension too small");
+    CLOUDAAE_REQUIRE((fold_b & (fold_b - 1)) == 0 && (fold_c & (fold_c - 1)) == 0 && fold_b % 4 == 0 &&
+                         fold_c % 4 == 0, name, "fold width must be a power of two >= 4");
+    FoldB fb = {-1, 0}, fc = {-1, 0};
+    if (fold_b) {
+        fb.shift = __builtin_ctz((unsigned)fold_b);
+        fb.rows = trans_b ? N : K;
+    }
+    if (fold_c) {
+        fc.shift = __builtin_ctz((unsigned)fold_c);
+        fc.rows = M;
+    }
     int BM, BN, splits;
     gemm_bf16_plan(M, N, K, BM, BN, splits);
     const int tm = ceil_div(M, BM), tn = ceil_div(N, BN);
@@ -285,22 +309,38 @@ CLOUDAAE_API int cloudaae_gemm_bf16(int trans_a, int trans_b, int M, int N, int 
     int epi = accumulate == 1 ? GB_ACCUM : GB_STORE;
     if (splits > 1) {
         epi = GB_ATOMIC;
-        if (!accumulate)
-            CLOUDAAE_CHECK_HIP(hipMemset2DAsync(C, sizeof(float) * (size_t)ldc, 0, sizeof(float) * (size_t)N,
-                                                (size_t)M, s), name);
+        if (!accumulate) {
+            if (fold_c)
+                CLOUDAAE_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * (size_t)N, s), name);
+            else
+                CLOUDAAE_CHECK_HIP(hipMemset2DAsync(C, sizeof(float) * (size_t)ldc, 0, sizeof(float) * (size_t)N,
+                                                    (size_t)M, s), name);
+        }
     }
     const int vecA = (((uintptr_t)A & 15) == 0 && lda % 4 == 0) ? 1 : 0;
     const int vecB = (((uintptr_t)B & 15) == 0 && ldb % 4 == 0) ? 1 : 0;
     dim3 grid(tn, tm, splits);
     const bool ta = trans_a != 0, tb = trans_b != 0;
     if (BM == 32)
-        launch_bf16<32, 128, 1, 4>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+        launch_bf16<32, 128, 1, 4>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
+                                   fc);
     else if (BN == 64)
-        launch_bf16<128, 64, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+        launch_bf16<128, 64, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
+                                   fc);
     else if (BM == 64)
-        launch_bf16<64, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+        launch_bf16<64, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
+                                   fc);
     else
-        launch_bf16<128, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB);
+        launch_bf16<128, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB,
+                                    fb, fc);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
+}
+
+CLOUDAAE_API int cloudaae_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                                    const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
+                                    cloudaae_stream_t stream)
+{
+    return gemm_bf16_launch("cloudaae_gemm_bf16", trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate,
+                            0, 0, (hipStream_t)stream);
 }

@@ -28,8 +28,9 @@ def test_evaluate_batch_vs_oracle(hip, oracle, B, N):
     warm = MO.synthetic_batch(4, N, seed=1)
     with torch.no_grad():
         MO.forward_losses(warm, V, N, is_training=False)             # creates the variables
-    for _ in range(2):                                               # moves the moving averages off zero
-        MO.train_step(warm, V, MO.AdamTF(), 0, N, 4)
+    opt = MO.AdamTF()
+    for step in range(10):                                           # moving averages close to batch statistics
+        MO.train_step(warm, V, opt, step, N, 4)
     graph.store.load_state_dict(V.state_dict())
     el = _element(B, N, seed=B * 100 + N)
     out = E.evaluate_batch(graph, {k: v.cuda() for k, v in el.items()})
@@ -40,8 +41,8 @@ def test_evaluate_batch_vs_oracle(hip, oracle, B, N):
         recon_res, rot, trans_res, _ = MO.get_model_dgcnn_6d(pc, False, False, 10, V)
         recon = recon_res + mean.unsqueeze(1)
         trans = trans_res + mean
-    # (two steps after initialisation the moving variances are still tiny, the eval-mode network
-    # amplifies by ~1e3 and a neighbour near-tie can swap: 5e-4 relative, not round-off)
+    # (ten steps after initialisation the moving variances still lag the batch variances, the
+    # eval-mode network amplifies round-off and a neighbour near-tie can swap: 5e-4 relative)
     assert float((out["xyz_recon"].cpu() - recon).abs().max()) <= 5e-4 * float(recon.abs().max())
     assert float((out["trans_pred"].cpu() - trans).abs().max()) <= 5e-4 * max(1.0, float(trans.abs().max()))
     assert float((out["rot_pred"].cpu() - rot).abs().max()) <= 5e-4 * max(1.0, float(rot.abs().max()))
