@@ -313,6 +313,13 @@ static void gemm_plan(int M, int N, int K, int &BM, int &BN, int &splits)
         BM = 128;
         BN = 128;
     }
+    // tall, short-K products (the edge convolution's: 32768 rows, K = 24..256, 64..256 columns) are
+    // bound by streaming A and C, not by the matrix pipe: with 128-row tiles they make one workgroup per
+    // CU, each a handful of slabs long, and nothing hides the load latency (0.9-1.8 TB/s measured).
+    // Halve the tile height until there are two workgroups per CU.
+    if (BM == 128 && M >= 1024 && K <= 512 && (long long)ceil_div(M, 128) * ceil_div(N, BN) < 512 &&
+        !getenv("CLOUDAAE_GEMM_TALL128"))
+        BM = 64;
     const int tm = ceil_div(M, BM), tn = ceil_div(N, BN);
     // split K until one full wave of workgroups exists (tiles * splits ~ the workgroups the chip
     // holds at once for this tile shape: registers allow 3 per CU for 128x128, 5 for 64x128, 6 for
@@ -322,7 +329,7 @@ static void gemm_plan(int M, int N, int K, int &BM, int &BN, int &splits)
     // 64 slices 203 us, 128 slices 219 us.
     splits = 1;
     const long long tiles = (long long)tm * tn;
-    const int resident = 256 * (BM == 32 ? 2 : BN == 64 ? 6 : BM == 64 ? 5 : 3);   // (32-row tiles: 2 measured best)
+    const int resident = 256 * (BM == 32 ? 2 : (BN == 64 || BM == 64) ? (BN == 64 ? 6 : 5) : 3);   // (32-row tiles: 2 measured best)
     if (tiles < 256 && K >= 128) {
         splits = (int)((tiles <= 4 ? 256 : resident) / tiles);
         const int max_splits = K / 64 > 0 ? K / 64 : 1;
@@ -404,6 +411,9 @@ int cloudaae::gemm_f32_launch(const char *name, int trans_a, int trans_b, int M,
     if (BM == 32)
         launch_cfg<32, 128, 1, 4>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
                                   vecA, vecB, fb, fc);
+    else if (BM == 64 && BN == 64)
+        launch_cfg<64, 64, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
+                                 vecA, vecB, fb, fc);
     else if (BN == 64)
         launch_cfg<128, 64, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
                                   vecA, vecB, fb, fc);

@@ -18,7 +18,7 @@ def run(ta, tb, M, N, K, iters=20):
     return us, 2.0 * M * N * K / us / 1e6
 if __name__ == "__main__":
   for name, args in [("agg fwd", (0, 0, 32768, 1024, 320)), ("agg dX", (0, 1, 32768, 320, 1024)), ("agg dW", (1, 0, 320, 1024, 32768)),
-                     ("edge fwd", (0, 0, 32768, 64, 64)), ("edge dX", (0, 1, 32768, 64, 64)), ("edge dW", (1, 0, 64, 64, 32768)),
+                     ("edge fwd", (0, 0, 32768, 64, 64)), ("ec fwd2", (0, 0, 32768, 128, 64)), ("ec fwd4", (0, 0, 32768, 256, 64)), ("ec dX2", (0, 1, 32768, 64, 128)), ("ec dX4", (0, 1, 32768, 64, 256)), ("edge dX", (0, 1, 32768, 64, 64)), ("edge dW", (1, 0, 64, 64, 32768)),
                      ("edge dW2", (1, 0, 64, 128, 32768)), ("edge dW1", (1, 0, 24, 64, 32768)), ("fc fwd", (0, 0, 32, 1024, 1024)), ("fc dW", (1, 0, 1024, 1024, 32)), ("fc dX", (0, 1, 32, 1024, 1024)), ("out fwd", (0, 0, 32, 12288, 1024)), ("out dW", (1, 0, 1024, 12288, 32)),
                      ("big sq", (0, 0, 8192, 8192, 8192))]:
       us, tf = run(*args)
