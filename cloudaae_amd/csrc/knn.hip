@@ -725,6 +725,149 @@ static hipError_t launch_knn_scan(int b, int n, int ld, int k, const float *x, i
     return hipSuccess;
 }
 
+// ---- C = 3, second generation: the selection split into filter + queued drain ------------------
+// knn3_kernel above runs the sorted insert for every candidate of every lane (a wave executes it
+// whenever ANY lane needs it, i.e. always): ~45 instructions per candidate against 8 for the
+// distance.  Here (as in knn64_scan_kernel) a candidate is compared with the lane's current k-th
+// best and pushed on a per-lane LDS queue (4 instructions); the queue is drained through the
+// insert in batches, max-over-lanes pops per batch.  The whole cloud (x, y, z, |.|^2) sits in LDS, a
+// wave owns 64 queries and one of CS candidate ranges, the CS lists of a query are merged
+// lexicographically by (d, j) at the end.  Same arithmetic and tie rule as knn3_kernel.
+constexpr int K3_QCAP = 24, K3_STEP = 8;
+
+template <int K, int CS>
+__global__ __launch_bounds__(256) void knn3_scan_kernel(int n, int ld, int k, const float *__restrict__ x,
+                                                        int *__restrict__ nn_idx)
+{
+    constexpr int WAVES = 4, QT = WAVES / CS;             // query tiles (of 64) per workgroup
+    extern __shared__ __attribute__((aligned(16))) char k3_smem[];
+    // layout: cloud float4[n] | queue d[WAVES][QCAP][64] | queue i[WAVES][QCAP][64]
+    float4v *cand = reinterpret_cast<float4v *>(k3_smem);
+    float *qd_all = reinterpret_cast<float *>(cand + n);
+    int *qi_all = reinterpret_cast<int *>(qd_all + WAVES * K3_QCAP * 64);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qt = wave / CS, cs = wave % CS;
+    int qgroup, cloud;
+    xcd_cloud_tile(qgroup, cloud);
+    const float *X = x + (size_t)cloud * n * ld;
+    for (int j = tid; j < n; j += 256) {
+        const float *row = X + (size_t)j * ld;
+        const float cx = row[0], cy = row[1], cz = row[2];
+        const float a = cx * cx, b = cy * cy, c = cz * cz;
+        float sq = 0.0f + a;
+        sq = sq + b;
+        sq = sq + c;
+        cand[j] = float4v{cx, cy, cz, sq};
+    }
+    __syncthreads();
+    const int qi0 = (qgroup * QT + qt) * 64 + lane;
+    const bool valid = qi0 < n;
+    const float4v me = cand[valid ? qi0 : 0];
+    const float qx = me.x, qy = me.y, qz = me.z, sqi = me.w;
+    float *qd = qd_all + wave * K3_QCAP * 64;
+    int *qi = qi_all + wave * K3_QCAP * 64;
+
+    TopK<K> top;
+    top.init();
+    float thr = __builtin_inff();
+    int cnt = 0;
+    auto drain = [&]() {
+        float nd = cnt > 0 ? qd[lane] : 0.0f;
+        int ni = cnt > 0 ? qi[lane] : 0;
+        for (int t = 0; __any(t < cnt); ++t) {
+            const float cd = nd;
+            const int ci = ni;
+            if (t + 1 < cnt) {
+                nd = qd[(t + 1) * 64 + lane];
+                ni = qi[(t + 1) * 64 + lane];
+            }
+            if (t < cnt)
+                top.insert(cd, ci);
+        }
+        cnt = 0;
+        thr = top.d[K - 1];
+    };
+
+    const int per = (n + CS - 1) / CS;
+    const int j_begin = min(cs * per, n), j_end = min(j_begin + per, n);
+    for (int j0 = j_begin; j0 < j_end; j0 += K3_STEP) {
+        if (__any(cnt > K3_QCAP - K3_STEP - 1))
+            drain();
+        float4v c[K3_STEP];
+#pragma unroll
+        for (int u = 0; u < K3_STEP; ++u)
+            c[u] = cand[min(j0 + u, n - 1)];              // broadcast reads
+#pragma unroll
+        for (int u = 0; u < K3_STEP; ++u) {
+            float inner = fmaf(qx, c[u].x, 0.0f);
+            inner = fmaf(qy, c[u].y, inner);
+            inner = fmaf(qz, c[u].z, inner);
+            const float m2 = -2.0f * inner;
+            const float t = sqi + m2;
+            const float d = t + c[u].w;
+            qd[cnt * 64 + lane] = d;                      // branch-free push
+            qi[cnt * 64 + lane] = j0 + u;
+            cnt += (j0 + u < j_end && d < thr) ? 1 : 0;
+        }
+    }
+    drain();
+
+    // merge the CS lists of every query: [list][p][lane], through the queue area of the tile's first wave
+    __syncthreads();
+    float *md = qd_all + (qt * CS) * K3_QCAP * 64;
+    int *mi = qi_all + (qt * CS) * K3_QCAP * 64;
+    static_assert(K <= K3_QCAP, "merge lists must fit the queue area");
+#pragma unroll
+    for (int p = 0; p < K; ++p) {
+        md[(cs * K + p) * 64 + lane] = top.d[p];
+        mi[(cs * K + p) * 64 + lane] = top.i[p];
+    }
+    __syncthreads();
+    if (cs == 0 && valid) {
+        int head[CS];
+#pragma unroll
+        for (int l = 0; l < CS; ++l)
+            head[l] = 0;
+        int *dst = nn_idx + ((size_t)cloud * n + qi0) * k;
+        for (int p = 0; p < k; ++p) {
+            float bd = __builtin_inff();
+            int bi = 0x7fffffff, bl = 0;
+#pragma unroll
+            for (int l = 0; l < CS; ++l) {
+                const int h = head[l];
+                const float d = h < K ? md[(l * K + h) * 64 + lane] : __builtin_inff();
+                const int i = h < K ? mi[(l * K + h) * 64 + lane] : 0x7fffffff;
+                const bool better = d < bd || (d == bd && i < bi);
+                bd = better ? d : bd;
+                bi = better ? i : bi;
+                bl = better ? l : bl;
+            }
+#pragma unroll
+            for (int l = 0; l < CS; ++l)
+                head[l] += (l == bl) ? 1 : 0;
+            dst[p] = bi == 0x7fffffff ? 0 : bi;
+        }
+    }
+}
+
+template <int K, int CS>
+static hipError_t launch_knn3_scan(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
+{
+    const size_t lds = 16 * (size_t)n + 8 * 4 * K3_QCAP * 64;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn3_scan_kernel<K, CS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess)
+            return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL((knn3_scan_kernel<K, CS>), dim3(ceil_div(n, 64 * (4 / CS)), b), dim3(256), lds, s, n, ld, k, x,
+                       nn_idx);
+    return hipSuccess;
+}
+
 // Which C = 64 kernel for `tiles` 32-query tiles (measured, B x N = 1024 points, k = 10, us):
 //   tiles      knn64_mfma   scan, 1 wave/tile   scan, 2 waves/tile
 //    256 (B=8)      61            108                 82
@@ -742,7 +885,15 @@ template <int K>
 static void launch_knn(int b, int n, int c, int ld, int k, const float *x, int *nn_idx,
                        hipStream_t s)
 {
-    if (c == 3)
+    if (c == 3 && K <= 20 && n <= 6144 && !(getenv("CLOUDAAE_KNN_SCAN") && atoi(getenv("CLOUDAAE_KNN_SCAN")) == 0)) {
+        if constexpr (K <= 20) {
+            // candidate ranges per query tile: 2 when that still gives every SIMD a wave, else 4
+            if ((long long)ceil_div(n, 64) * b * 2 >= 4096)
+                (void)launch_knn3_scan<K, 2>(b, n, ld, k, x, nn_idx, s);
+            else
+                (void)launch_knn3_scan<K, 4>(b, n, ld, k, x, nn_idx, s);
+        }
+    } else if (c == 3)
         hipLaunchKernelGGL(knn3_kernel<K>, dim3(ceil_div(n, 64), b), dim3(KNN_THREADS), 0, s, n, ld,
                            k, x, nn_idx);
     else if (c == 64 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && K <= 20 && n <= 16384 &&
