@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
 __global__ __launch_bounds__(BN_FIN_THREADS) void colsum_finalize_kernel(int C, const double *__restrict__ partial,
                                                              int parts, float *__restrict__ out, int accumulate)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    const int c = bn_fin_channel(), pl = bn_fin_lane();
     double s, s2;
     bn_reduce_partials(partial, parts, C, c, pl, s, s2);
     if (c >= C || pl != 0)
@@ -451,7 +451,7 @@ CLOUDAAE_API int cloudaae_bn_forward(int M, int C, const float *y, int ldy, cons
     const int cb = ceil_div(C, 64);
     if (training)
         hipLaunchKernelGGL(bn_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, M, C, y, ldy, partial, parts);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts,
                        (double)M, training, decay, ema_mean, ema_var, gamma, beta, save_mean, save_var,
                        scale_shift);
     if (pool_mode == 0) {
@@ -507,7 +507,7 @@ CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, con
     const int parts = bn_parts(M);
     const int cb = ceil_div(C, 64);
     hipLaunchKernelGGL(bn_bwd_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, a, partial, parts);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts,
                        (double)M, training, dgamma, dbeta, accumulate_param_grads, m12, dbias, gamma, save_var);
     const int slab = 64;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cb, ceil_div(M, slab)), dim3(256), 0, s, a, m12, dy, lddy,
@@ -526,7 +526,7 @@ CLOUDAAE_API int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, floa
     const int parts = bn_parts(M);
     hipLaunchKernelGGL(bn_colsum_kernel, dim3(ceil_div(C, 64), parts), dim3(256), 0, s, M, C, x, ldx, partial,
                        parts);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 64)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts, out,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts, out,
                        accumulate);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;

@@ -26,18 +26,26 @@ __device__ __forceinline__ void bn_scale_shift_of(const float *__restrict__ gamm
     sh = beta[c] - mean[c] * inv;
 }
 
-// Sum the [parts][2][C] partial sums of one 64-channel group.  The finalise kernels run
-// BN_FIN_THREADS = 1024 threads = 64 channels x 16 part-lanes, each lane with independent
-// accumulators: the partial loads are what costs (a single thread walking 1024 dependent
-// loads took ~250 us; 4 part-lanes still ~20 us at 256 parts).  Fixed-shape tree, so the
-// result does not depend on scheduling.
-constexpr int BN_FIN_LANES = 16;
-constexpr int BN_FIN_THREADS = 64 * BN_FIN_LANES;
+// Sum the [parts][2][C] partial sums of one group of BN_FIN_CH channels.  A finalise kernel runs
+// BN_FIN_THREADS = 1024 threads = 32 channels x 32 part-lanes, each lane with independent accumulators:
+// what costs is the CHAIN of dependent partial loads, so the shape is chosen for short chains (a single
+// thread walking 1024 loads took ~250 us; 64 channels x 16 lanes 16 us at 256 parts; this one 8 loads
+// per lane in two rounds).  Fixed-shape tree, so the result does not depend on scheduling.
+constexpr int BN_FIN_CH = 32;
+constexpr int BN_FIN_LANES = 32;
+constexpr int BN_FIN_THREADS = BN_FIN_CH * BN_FIN_LANES;
+__device__ __forceinline__ int bn_fin_channel() { return blockIdx.x * BN_FIN_CH + (int)(threadIdx.x % BN_FIN_CH); }
+__device__ __forceinline__ int bn_fin_lane() { return (int)(threadIdx.x / BN_FIN_CH); }
+
+// s = sum_p partial[p][0][c], s2 = sum_p partial[p][1][c]; with partial3 != nullptr also
+// s3 = sum_p partial3[p][0][c] in the same pass (its loads travel with the others)
 __device__ __forceinline__ void bn_reduce_partials(const double *__restrict__ partial, int parts, int C, int c,
-                                                   int pl, double &s, double &s2)
+                                                   int pl, double &s, double &s2,
+                                                   const double *__restrict__ partial3 = nullptr,
+                                                   double *s3 = nullptr)
 {
-    __shared__ double red[2][BN_FIN_LANES][64];
-    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    __shared__ double red[3][BN_FIN_LANES][BN_FIN_CH];
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, c0 = 0.0, c1 = 0.0;
     if (c < C) {
         int p = pl;
         for (; p + BN_FIN_LANES < parts; p += 2 * BN_FIN_LANES) {
@@ -45,27 +53,37 @@ __device__ __forceinline__ void bn_reduce_partials(const double *__restrict__ pa
             b0 += partial[((size_t)p * 2 + 1) * C + c];
             a1 += partial[((size_t)(p + BN_FIN_LANES) * 2 + 0) * C + c];
             b1 += partial[((size_t)(p + BN_FIN_LANES) * 2 + 1) * C + c];
+            if (partial3 != nullptr) {
+                c0 += partial3[((size_t)p * 2 + 0) * C + c];
+                c1 += partial3[((size_t)(p + BN_FIN_LANES) * 2 + 0) * C + c];
+            }
         }
         for (; p < parts; p += BN_FIN_LANES) {
             a0 += partial[((size_t)p * 2 + 0) * C + c];
             b0 += partial[((size_t)p * 2 + 1) * C + c];
+            if (partial3 != nullptr)
+                c0 += partial3[((size_t)p * 2 + 0) * C + c];
         }
     }
-    const int l = threadIdx.x & 63;
+    const int l = threadIdx.x % BN_FIN_CH;
     red[0][pl][l] = a0 + a1;
     red[1][pl][l] = b0 + b1;
+    red[2][pl][l] = c0 + c1;
     __syncthreads();
-    double t0 = 0.0, t1 = 0.0;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
 #pragma unroll
     for (int q = 0; q < BN_FIN_LANES; q += 4) {
         t0 += (red[0][q][l] + red[0][q + 1][l]) + (red[0][q + 2][l] + red[0][q + 3][l]);
         t1 += (red[1][q][l] + red[1][q + 1][l]) + (red[1][q + 2][l] + red[1][q + 3][l]);
+        t2 += (red[2][q][l] + red[2][q + 1][l]) + (red[2][q + 2][l] + red[2][q + 3][l]);
     }
     s = t0;
     s2 = t1;
+    if (s3 != nullptr)
+        *s3 = t2;
 }
 
-// per-channel finalise (grid = ceil(C/64) blocks of BN_FIN_THREADS threads).  training: moments from
+// per-channel finalise (grid = ceil(C/BN_FIN_CH) blocks of BN_FIN_THREADS threads).  training: moments from
 // the partial sums + EMA update; inference: moments = EMA shadows.  Also derives inv/shift
 // for the apply pass.
 static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_kernel(
@@ -74,7 +92,7 @@ static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_kernel(
     const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ save_mean,
     float *__restrict__ save_var, float *__restrict__ scale_shift)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    const int c = bn_fin_channel(), pl = bn_fin_lane();
     double s = 0.0, s2 = 0.0;
     if (training)
         bn_reduce_partials(partial, parts, C, c, pl, s, s2);
@@ -104,19 +122,16 @@ static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_kernel(
 }
 
 // dbeta = sum dz, dgamma = sum dz*xhat; m1/m2 = their means (0 in inference mode,
-// where the statistics do not depend on the batch).  grid = ceil(C/64) x BN_FIN_THREADS threads.
+// where the statistics do not depend on the batch).  grid = ceil(C/BN_FIN_CH) x BN_FIN_THREADS threads.
 static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_bwd_finalize_kernel(
     int C, const double *__restrict__ partial, int parts, double count, int training,
     float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate, float *__restrict__ m12,
     float *__restrict__ dbias, const float *__restrict__ gamma, const float *__restrict__ save_var)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-    double s, s2, s3 = 0.0, unused;
-    bn_reduce_partials(partial, parts, C, c, pl, s, s2);
-    if (dbias != nullptr) {
-        __syncthreads();
-        bn_reduce_partials(partial + (size_t)BN_MAX_PARTS * 2 * C, parts, C, c, pl, s3, unused);
-    }
+    const int c = bn_fin_channel(), pl = bn_fin_lane();
+    double s, s2, s3 = 0.0;
+    bn_reduce_partials(partial, parts, C, c, pl, s, s2,
+                       dbias != nullptr ? partial + (size_t)BN_MAX_PARTS * 2 * C : nullptr, &s3);
     if (c >= C || pl != 0)
         return;
     if (dbeta != nullptr)

@@ -281,11 +281,9 @@ static __global__ __launch_bounds__(BN_FIN_THREADS) void ec_bwd_finalize_kernel(
     int training, const float *__restrict__ gamma, const float *__restrict__ save_var,
     float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dbias, float *__restrict__ m12)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-    double s, s2, s3, unused;
-    bn_reduce_partials(partial, parts, C, c, pl, s, s2);
-    __syncthreads();
-    bn_reduce_partials(partial3, parts, C, c, pl, s3, unused);
+    const int c = bn_fin_channel(), pl = bn_fin_lane();
+    double s, s2, s3;
+    bn_reduce_partials(partial, parts, C, c, pl, s, s2, partial3, &s3);
     if (c >= C || pl != 0)
         return;
     if (dbeta != nullptr)
@@ -555,7 +553,7 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
         EC_DISPATCH(EC_STATS);
 #undef EC_STATS
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(cout, 64)), dim3(BN_FIN_THREADS), 0, s, cout, partial, grid,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(cout, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, cout, partial, grid,
                        (double)P * (double)k, training, decay, ema_mean, ema_var, gamma, beta, save_mean,
                        save_var, scale_shift);
     if (pool_mode == 1) {
@@ -609,7 +607,7 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
         EC_DISPATCH(EC_BS);
 #undef EC_BS
     }
-    hipLaunchKernelGGL(ec_bwd_finalize_kernel, dim3(ceil_div(cout, 64)), dim3(BN_FIN_THREADS), 0, s, cout, partial,
+    hipLaunchKernelGGL(ec_bwd_finalize_kernel, dim3(ceil_div(cout, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, cout, partial,
                        partial + (size_t)EC_MAX_PARTS * 2 * cout, grid, (double)P * (double)k, training, gamma,
                        save_var, dgamma, dbeta, dbiases, m12);
     int *rev_off = rev_scratch, *rev_src = rev_scratch + (size_t)b * (n + 1);
