@@ -318,8 +318,20 @@ __global__ __launch_bounds__(512) void ec_revlist_kernel(int N, int k, const int
     for (int m = t; m < N; m += 512)
         cnt[m] = 0;
     __syncthreads();
-    for (int e = t; e < E; e += 512)
-        atomicAdd(&cnt[idx[e]], 1);
+    // the index loads are issued eight at a time ahead of the LDS atomics that consume them: one global
+    // round trip per batch instead of one per edge (a loop of load -> atomic pairs costs the latency
+    // E/512 times over)
+    constexpr int RU = 8;
+    for (int e0 = t; e0 < E; e0 += 512 * RU) {
+        int v[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+            v[u] = e0 + 512 * u < E ? idx[e0 + 512 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+            if (v[u] >= 0)
+                atomicAdd(&cnt[v[u]], 1);
+    }
     __syncthreads();
     const int per = (N + 511) / 512;
     const int lo = min(N, t * per), hi = min(N, lo + per);
@@ -349,9 +361,17 @@ __global__ __launch_bounds__(512) void ec_revlist_kernel(int N, int k, const int
     if (t == 0)
         off[N] = E;
     __syncthreads();
-    for (int e = t; e < E; e += 512) {
-        const int pos = atomicAdd(&cnt[idx[e]], 1);
-        src[pos] = e / k;
+    for (int e0 = t; e0 < E; e0 += 512 * RU) {
+        int v[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+            v[u] = e0 + 512 * u < E ? idx[e0 + 512 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+            if (v[u] >= 0) {
+                const int pos = atomicAdd(&cnt[v[u]], 1);
+                src[pos] = (e0 + 512 * u) / k;
+            }
     }
 }
 
