@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(int M, int C, const float
 //                                                 the gradient among equal maxima)
 // times the ReLU mask [z > 0].
 struct BnBwdArgs {
-    int M, C, ldy, lddo, rows, pool, relu, training, want_xhat_sum;
+    int M, C, ldy, lddo, rows, rows_shift, pool, relu, training, want_xhat_sum;   // rows_shift: log2(rows) or -1
     const float *y, *dout, *dpooled, *pooled, *ties;
     const float *gamma, *beta, *save_mean, *save_var;
 };
@@ -152,10 +152,13 @@ __device__ __forceinline__ float bn_upstream(const BnBwdArgs &a, int r, int c, f
     float g = 0.0f;
     if (a.dout != nullptr)
         g = a.dout[(size_t)r * a.lddo + c];
+    // group of row r (a power-of-two group size -- N points per cloud usually is -- avoids an integer
+    // division per element of a 134 MB tensor)
+    const int grp = a.rows_shift >= 0 ? (r >> a.rows_shift) : (r / a.rows);
     if (a.pool == 1) {
-        g += a.dpooled[(size_t)(r / a.rows) * a.C + c] / (float)a.rows;
+        g += a.dpooled[(size_t)grp * a.C + c] / (float)a.rows;
     } else if (a.pool == 2) {
-        const size_t gi = (size_t)(r / a.rows) * a.C + c;
+        const size_t gi = (size_t)grp * a.C + c;
         if (z == a.pooled[gi])
             g += a.dpooled[gi] / a.ties[gi];
     }
@@ -175,26 +178,35 @@ __global__ __launch_bounds__(256) void bn_bwd_colsum_kernel(BnBwdArgs a, double 
         float sc, sh;
         bn_scale_shift_of(a.gamma, a.beta, a.save_mean, a.save_var, c, sc, sh);
         const float mean = a.save_mean[c], rstd = bn_rsqrt(a.save_var[c] + BN_EPS);
-        const int step = 4 * parts;
-        for (int rb = blockIdx.y * 4 + rl; rb < a.M; rb += step * BN_U) {
+        // a block walks one contiguous slice of rows; when the slice lies inside one pooling group
+        // (256 of a cloud's 1024 points, typically) and the only upstream is the mean pool, its
+        // gradient dpooled[g][c] / rows is a per-lane constant instead of a load and a divide per element
+        const int chunk = ((a.M + parts - 1) / parts + 3) / 4 * 4;
+        const int r_lo = blockIdx.y * chunk, r_hi = min(a.M, r_lo + chunk);
+        const int g_lo = r_lo < a.M ? (a.rows_shift >= 0 ? (r_lo >> a.rows_shift) : r_lo / a.rows) : 0;
+        const int g_hi = r_hi > r_lo ? (a.rows_shift >= 0 ? ((r_hi - 1) >> a.rows_shift) : (r_hi - 1) / a.rows) : g_lo;
+        const bool hoist = a.pool == 1 && a.dout == nullptr && g_lo == g_hi;
+        const float gconst = hoist && r_lo < a.M ? a.dpooled[(size_t)g_lo * a.C + c] / (float)a.rows : 0.0f;
+        for (int rb = r_lo + rl; rb < r_hi; rb += 4 * BN_U) {
             float v[BN_U];
 #pragma unroll
             for (int u = 0; u < BN_U; ++u) {
-                const int r = rb + u * step;
-                v[u] = r < a.M ? a.y[(size_t)r * a.ldy + c] : 0.0f;
+                const int r = rb + 4 * u;
+                v[u] = r < r_hi ? a.y[(size_t)r * a.ldy + c] : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < BN_U; ++u) {
-                const int r = rb + u * step;
-                if (r < a.M) {
+                const int r = rb + 4 * u;
+                if (r < r_hi) {
                     float z = v[u] * sc + sh;
                     if (a.relu)
                         z = fmaxf(z, 0.0f);
-                    const float dz = bn_upstream(a, r, c, z);
+                    const float dz = hoist ? ((a.relu && !(z > 0.0f)) ? 0.0f : gconst) : bn_upstream(a, r, c, z);
                     const float xh = (v[u] - mean) * rstd;
                     s += (double)dz;
                     s2 += (double)dz * (double)xh;
-                    s3 += (double)xh;
+                    if (a.want_xhat_sum)
+                        s3 += (double)xh;
                 }
             }
         }
@@ -227,6 +239,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
     const float m1 = m12[c], m2 = m12[a.C + c];
     const float gr = a.gamma[c] * rstd;
     const int r0 = blockIdx.y * slab, r1 = min(a.M, r0 + slab);
+    const int g_lo = a.rows_shift >= 0 ? (r0 >> a.rows_shift) : r0 / a.rows;
+    const int g_hi = a.rows_shift >= 0 ? ((r1 - 1) >> a.rows_shift) : (r1 - 1) / a.rows;
+    const bool hoist = a.pool == 1 && a.dout == nullptr && g_lo == g_hi;      // see bn_bwd_colsum_kernel
+    const float gconst = hoist ? a.dpooled[(size_t)g_lo * a.C + c] / (float)a.rows : 0.0f;
     for (int rb = r0 + rl; rb < r1; rb += 4 * BN_U) {
         float v[BN_U];
 #pragma unroll
@@ -241,7 +257,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const fl
                 float z = v[u] * sc + sh;
                 if (a.relu)
                     z = fmaxf(z, 0.0f);
-                const float dz = bn_upstream(a, r, c, z);
+                const float dz = hoist ? ((a.relu && !(z > 0.0f)) ? 0.0f : gconst) : bn_upstream(a, r, c, z);
                 const float xh = (v[u] - mean) * rstd;
                 dy[(size_t)r * lddy + c] = gr * ((dz - m1) - xh * m2);
             }
@@ -501,6 +517,7 @@ CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, con
     BnBwdArgs a;
     a.want_xhat_sum = dbias != nullptr;
     a.M = M; a.C = C; a.ldy = ldy; a.lddo = lddo; a.rows = pool_rows > 0 ? pool_rows : 1;
+    a.rows_shift = (a.rows & (a.rows - 1)) == 0 ? __builtin_ctz((unsigned)a.rows) : -1;
     a.pool = pool_mode; a.relu = relu; a.training = training;
     a.y = y; a.dout = dout; a.dpooled = dpooled; a.pooled = pooled; a.ties = tie_count;
     a.gamma = gamma; a.beta = beta; a.save_mean = save_mean; a.save_var = save_var;
