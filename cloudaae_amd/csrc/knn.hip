@@ -490,7 +490,11 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_scan_kernel(int n, int ld,
                                                                   int *__restrict__ nn_idx)
 {
     constexpr int WAVES = QW * CS, THREADS = 64 * WAVES;
-    constexpr int TILE_FLOATS = KM_TILE * KM_LD;
+    // staged tile row = [32 even channels | 32 odd channels | 4 pad]: a lane's 32 MFMA operands (channel
+    // parity = lane half) are contiguous, eight ds_read_b128 instead of 32 ds_read_b32; 68-float rows keep
+    // the 16-byte reads of 16 consecutive rows on distinct banks
+    constexpr int KS_LD = 68;
+    constexpr int TILE_FLOATS = KM_TILE * KS_LD;
     extern __shared__ __attribute__((aligned(16))) char ks_smem[];
     // layout: tile[2][CS][TILE_FLOATS] | queue d[WAVES][QCAP][64] | queue i[WAVES][QCAP][64] | sq[n]
     float *tiles = reinterpret_cast<float *>(ks_smem);
@@ -558,11 +562,10 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_scan_kernel(int n, int ld,
             const int v = u * THREADS + tid;
             if (VECS % THREADS == 0 || v < VECS) {
                 const int row = v >> 4, q4 = v & 15;      // row in [0, CS*32): tile row / 32, line row % 32
-                float *dst = buf + (row >> 5) * TILE_FLOATS + (row & 31) * KM_LD + 4 * q4;
-                dst[0] = stage[u].x;
-                dst[1] = stage[u].y;
-                dst[2] = stage[u].z;
-                dst[3] = stage[u].w;
+                // channels 4*q4 .. 4*q4+3: (x, z) are even channels 2*q4, 2*q4+1 of the even half, (y, w) odd
+                float *dst = buf + (row >> 5) * TILE_FLOATS + (row & 31) * KS_LD + 2 * q4;
+                *reinterpret_cast<float2v *>(dst) = float2v{stage[u].x, stage[u].z};
+                *reinterpret_cast<float2v *>(dst + 32) = float2v{stage[u].y, stage[u].w};
             }
         }
     };
@@ -624,11 +627,16 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_scan_kernel(int n, int ld,
     for (int r = 0; r < rounds; ++r) {
         const int c0 = (r * CS + cs) * KM_TILE;           // this wave's tile of the round
         const float *cur = tiles + ((r & 1) * CS + cs) * TILE_FLOATS;
-        const float *arow = cur + col * KM_LD + half;     // A operand: candidate row `col`, parity `half`
+        const float4v *arow = reinterpret_cast<const float4v *>(cur + col * KS_LD + 32 * half);   // candidate row `col`
         float aop[32], ccsq[16];
 #pragma unroll
-        for (int s = 0; s < 32; ++s)
-            aop[s] = arow[2 * s];                         // all LDS reads of the tile in flight at once
+        for (int s = 0; s < 8; ++s) {                     // all LDS reads of the tile in flight at once
+            const float4v v = arow[s];
+            aop[4 * s] = v.x;
+            aop[4 * s + 1] = v.y;
+            aop[4 * s + 2] = v.z;
+            aop[4 * s + 3] = v.w;
+        }
         load_csq(ccsq, c0);
         if (r + 1 < rounds)
             fetch(r + 1);                                 // global -> registers behind the MFMAs
@@ -711,7 +719,7 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_scan_kernel(int n, int ld,
 template <int K, int QW, int CS>
 static hipError_t launch_knn_scan(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
-    const size_t lds = sizeof(float) * (2 * CS * KM_TILE * KM_LD + 2 * QW * CS * KS_QCAP * 64 + (size_t)n);
+    const size_t lds = sizeof(float) * (2 * CS * KM_TILE * 68 + 2 * QW * CS * KS_QCAP * 64 + (size_t)n);
     static bool raised = false;       // >64 KiB of dynamic LDS needs the attribute once per kernel
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn64_scan_kernel<K, QW, CS>),
