@@ -142,7 +142,7 @@ class TrainGraph(object):
         dummy[:, :, :3] = torch.rand((B, N, 3), device=self.device)
         with torch.no_grad():
             self._call_model(dummy, False)
-        self.store.flatten()
+        self.store.flatten(last=('dgcnn_output/weights', 'pn_output/weights'))
         n = self.store.flat_params.numel()
         self.adam_m = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.adam_v = torch.zeros(n, dtype=torch.float32, device=self.device)

@@ -117,9 +117,11 @@ class VariableStore(object):
     def num_params(self):
         return sum(v.data.numel() for v in self.trainable_variables())
 
-    def flatten(self):
+    def flatten(self, last=()):
         """Pack trainables (and, separately, non-trainable state) into flat buffers;
-        every Variable.data becomes a view.  Offsets are 16-byte aligned."""
+        every Variable.data becomes a view.  Offsets are 16-byte aligned.  `last`: names of
+        variables to place at the END of the flat buffer (the data-parallel exchange reduces the
+        decoder output weights on their own, early; with them last the rest is ONE contiguous piece)."""
         if self.flat_params is not None:
             return
 
@@ -140,6 +142,7 @@ class VariableStore(object):
             return flat, offs
 
         tv = self.trainable_variables()
+        tv = [x for x in tv if x.name not in last] + [x for x in tv if x.name in last]
         self.flat_params, offs = pack(tv, True)
         self.flat_grads = torch.zeros_like(self.flat_params)
         self._zero = torch.zeros(1, dtype=torch.float32, device=self.device)
