@@ -34,13 +34,16 @@ __global__ __launch_bounds__(256) void bn_colsum_kernel(int M, int C, const floa
     if (c < C) {
         // BN_U loads in flight per thread: these passes are pure HBM streaming and a single
         // dependent load per iteration leaves them latency-bound (1.6 TB/s measured)
-        const int step = 4 * parts;
-        for (int r = blockIdx.y * 4 + rl; r < M; r += step * BN_U) {
+        // (a block walks one contiguous slice of rows: consecutive 256-byte row pieces of the same
+        // channel group, kinder to DRAM pages than rows interleaved across all blocks)
+        const int chunk = ((M + parts - 1) / parts + 3) / 4 * 4;
+        const int r_lo = blockIdx.y * chunk, r_hi = min(M, r_lo + chunk);
+        for (int r = r_lo + rl; r < r_hi; r += 4 * BN_U) {
             float v[BN_U];
 #pragma unroll
             for (int u = 0; u < BN_U; ++u) {
-                const int rr = r + u * step;
-                v[u] = rr < M ? y[(size_t)rr * ldy + c] : 0.0f;
+                const int rr = r + 4 * u;
+                v[u] = rr < r_hi ? y[(size_t)rr * ldy + c] : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < BN_U; ++u) {
