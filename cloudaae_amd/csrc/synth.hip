@@ -166,6 +166,137 @@ __global__ __launch_bounds__(256) void spherical_flip_kernel(int na, int nb, con
     }
 }
 
+// ---- spatial order of a flipped cloud -------------------------------------------------------
+// Seidel's LP is exact for ANY constraint order; its cost is not.  In a random order the violated
+// constraints turn up at random positions i and each costs a 1-D re-solve over i earlier constraints.
+// But the planes that decide whether p is a hull vertex are those of p's angular neighbours on the
+// shell.  So every cloud is sorted once by direction from its centroid (cube-map face, then a 16x16
+// grid in Morton order), a point's LP sees its neighbours in sorted order FIRST (j+1, j-1, j+2, ...)
+// and then everything in the bit-reversed order: after the short local pass the optimum is almost
+// always final (or the LP already infeasible), so the full pass is one scan without re-solves.
+constexpr int HS_CELLS = 6 * 256;
+constexpr int HS_THREADS = 1024;
+
+__device__ __forceinline__ unsigned hs_morton8(unsigned x, unsigned y)     // 4 + 4 bits interleaved
+{
+    x = (x | (x << 2)) & 0x33u;
+    x = (x | (x << 1)) & 0x55u;
+    y = (y | (y << 2)) & 0x33u;
+    y = (y | (y << 1)) & 0x55u;
+    return x | (y << 1);
+}
+
+// sorted[h][pos] = points[h][perm[h][pos]]; one workgroup per cloud, counting sort on the cell id
+__global__ __launch_bounds__(HS_THREADS) void hpr_sort_kernel(int n1, const float *__restrict__ points,
+                                                              float *__restrict__ sorted, int *__restrict__ perm)
+{
+    __shared__ int cell_cnt[HS_CELLS];
+    __shared__ double cen[3][HS_THREADS / 64];
+    __shared__ int wsum[HS_THREADS / 64];
+    const float *P = points + (size_t)blockIdx.x * n1 * 3;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int q = t; q < n1; q += HS_THREADS) {
+        sx += (double)P[3 * q];
+        sy += (double)P[3 * q + 1];
+        sz += (double)P[3 * q + 2];
+    }
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    sz = wave_sum(sz);
+    if (lane == 0) {
+        cen[0][wave] = sx;
+        cen[1][wave] = sy;
+        cen[2][wave] = sz;
+    }
+    for (int c = t; c < HS_CELLS; c += HS_THREADS)
+        cell_cnt[c] = 0;
+    __syncthreads();
+    double cx = 0.0, cy = 0.0, cz = 0.0;
+    for (int w = 0; w < HS_THREADS / 64; ++w) {
+        cx += cen[0][w];
+        cy += cen[1][w];
+        cz += cen[2][w];
+    }
+    const float fx = (float)(cx / n1), fy = (float)(cy / n1), fz = (float)(cz / n1);
+    auto cell_of = [&](int q) {
+        const float x = P[3 * q] - fx, y = P[3 * q + 1] - fy, z = P[3 * q + 2] - fz;
+        const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+        int face;
+        float u, v, m;
+        if (ax >= ay && ax >= az) {
+            face = x >= 0.f ? 0 : 1; u = y; v = z; m = ax;
+        } else if (ay >= az) {
+            face = y >= 0.f ? 2 : 3; u = x; v = z; m = ay;
+        } else {
+            face = z >= 0.f ? 4 : 5; u = x; v = y; m = az;
+        }
+        const float inv = m > 0.f ? 1.0f / m : 0.f;
+        const int ui = min(15, max(0, (int)((u * inv * 0.5f + 0.5f) * 16.0f)));
+        const int vi = min(15, max(0, (int)((v * inv * 0.5f + 0.5f) * 16.0f)));
+        return face * 256 + (int)hs_morton8((unsigned)ui, (unsigned)vi);
+    };
+    for (int q = t; q < n1; q += HS_THREADS)
+        atomicAdd(&cell_cnt[cell_of(q)], 1);
+    __syncthreads();
+    // exclusive prefix over the 1536 cells (2 per thread for the first 768 threads)
+    int c0 = 0, c1 = 0;
+    if (2 * t < HS_CELLS) {
+        c0 = cell_cnt[2 * t];
+        c1 = cell_cnt[2 * t + 1];
+    }
+    int incl = c0 + c1;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d)
+            incl += o;
+    }
+    if (lane == 63)
+        wsum[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w)
+        base += wsum[w];
+    if (2 * t < HS_CELLS) {
+        cell_cnt[2 * t] = base + incl - c0 - c1;
+        cell_cnt[2 * t + 1] = base + incl - c1;
+    }
+    __syncthreads();
+    float *S = sorted + (size_t)blockIdx.x * n1 * 3;
+    int *PM = perm + (size_t)blockIdx.x * n1;
+    for (int q = t; q < n1; q += HS_THREADS) {
+        const int pos = atomicAdd(&cell_cnt[cell_of(q)], 1);
+        PM[pos] = q;
+        S[3 * pos] = P[3 * q];
+        S[3 * pos + 1] = P[3 * q + 1];
+        S[3 * pos + 2] = P[3 * q + 2];
+    }
+}
+
+// constraint sequence of point `self` (sorted position): HPR_NEAR neighbours in sorted order, alternating
+// sides, then all OTHER positions in bit-reversed order
+constexpr int HPR_NEAR = 192;
+__device__ __forceinline__ int hpr_seq(int pos, int self, int n1, int bits)
+{
+    if (pos < HPR_NEAR) {
+        const int d = (pos >> 1) + 1;
+        int q = (pos & 1) ? self - d : self + d;
+        q = q < 0 ? q + n1 : (q >= n1 ? q - n1 : q);
+        return q;
+    }
+    const int p2 = pos - HPR_NEAR;
+    if (p2 >= (1 << bits))
+        return n1;
+    const int q = (int)(__brev((unsigned)p2) >> (32 - bits));
+    // a neighbour already seen in the local pass is NOT offered again: the optimum sits exactly on its
+    // binding constraints, and re-testing those in floating point reports round-off as a violation
+    int d = q - self;
+    d = d < 0 ? -d : d;
+    d = min(d, n1 - d);
+    return (q < n1 && d >= 1 && d <= HPR_NEAR / 2) ? n1 : q;
+}
+
 // ---- hull vertex test ---------------------------------------------------------------------
 constexpr double HPR_EPS = 1e-12;   // relative separation margin (qhull-like coplanarity tolerance)
 
@@ -215,11 +346,11 @@ __device__ __forceinline__ bool frac_less(const Frac &x, const Frac &y) { return
 __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, int bits, const Frame &fr, int lane)
 {
     double vx = HPR_TAN, vy = HPR_TAN;
-    const int span = 1 << bits;
+    const int span = HPR_NEAR + (1 << bits);
     int i = 0;
     while (i < span) {
         const int pos = i + lane;
-        const int q = pos < span ? (int)(__brev((unsigned)pos) >> (32 - bits)) : n1;
+        const int q = pos < span ? hpr_seq(pos, self, n1, bits) : n1;
         const bool valid = q < n1 && q != self;
         Cons k = {0.0, 0.0, 0.0};
         if (valid)
@@ -257,7 +388,7 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
             add(lane == 0 ? 1.0 : (lane == 1 ? -1.0 : 0.0), lane == 2 ? 1.0 : (lane == 3 ? -1.0 : 0.0), HPR_TAN);
         const int upto = i + first;            // sequence positions [0, upto) were already accepted
         for (int jpos = lane; jpos < upto; jpos += 64) {
-            const int r = (int)(__brev((unsigned)jpos) >> (32 - bits));
+            const int r = hpr_seq(jpos, self, n1, bits);
             if (r >= n1 || r == self)
                 continue;
             const Cons m = hpr_constraint(pts, r, fr);
@@ -289,7 +420,8 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
 // dynamic LDS and walks points j = blockIdx.x*8 + wave, + 8*gridDim.x, ...
 constexpr int HPR_WAVES = 8;
 __global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, const float *__restrict__ points,
-                                                                    int bits, unsigned char *__restrict__ flags)
+                                                                    const int *__restrict__ perm, int bits,
+                                                                    unsigned char *__restrict__ flags)
 {
     extern __shared__ float pts[];
     __shared__ double cen[3][HPR_WAVES];
@@ -356,8 +488,8 @@ __global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, con
             f.wz = rx * uy - ry * ux;
             vertex = hpr_lp2d_wave(pts, n1, j, bits, f, lane);
         }
-        if (lane == 0)
-            flags[(size_t)blockIdx.y * n1 + j] = vertex ? 1 : 0;
+        if (lane == 0)     // `points` is the spatially sorted cloud: the flag goes back to the original index
+            flags[(size_t)blockIdx.y * n1 + perm[(size_t)blockIdx.y * n1 + j]] = vertex ? 1 : 0;
     }
 }
 
@@ -472,7 +604,12 @@ CLOUDAAE_API int cloudaae_spherical_flip(int b, int na, const float *a, int nb, 
     return 0;
 }
 
-CLOUDAAE_API long long cloudaae_hpr_workspace_bytes(int b, int n1) { return (long long)b * n1; }
+// flags [b*n1] bytes (padded to 16) | sorted points [b*n1*3] floats | permutation [b*n1] ints
+CLOUDAAE_API long long cloudaae_hpr_workspace_bytes(int b, int n1)
+{
+    const long long pts = (long long)b * n1;
+    return (pts + 15) / 16 * 16 + pts * 12 + pts * 4;
+}
 
 CLOUDAAE_API int cloudaae_hidden_point_removal(int b, int n1, const float *flipped, const float *org,
                                                unsigned long long seed, float *visible, long long *num_vis,
@@ -485,6 +622,10 @@ CLOUDAAE_API int cloudaae_hidden_point_removal(int b, int n1, const float *flipp
         return 0;
     hipStream_t s = (hipStream_t)stream;
     unsigned char *flags = (unsigned char *)workspace;
+    const size_t pts = (size_t)b * n1;
+    float *sorted = (float *)(flags + (pts + 15) / 16 * 16);
+    int *perm = (int *)(sorted + pts * 3);
+    hipLaunchKernelGGL(hpr_sort_kernel, dim3(b), dim3(HS_THREADS), 0, s, n1, flipped, sorted, perm);
     const size_t lds = (size_t)n1 * 3 * sizeof(float);
     if (lds > 48 * 1024)
         CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)hull_vertex_kernel,
@@ -492,7 +633,7 @@ CLOUDAAE_API int cloudaae_hidden_point_removal(int b, int n1, const float *flipp
     // ~16 points per wave: enough workgroups to fill the chip at small batch, few enough that the
     // cloud is not re-staged into LDS too often
     int gx = ceil_div(n1, HPR_WAVES * 16);
-    hipLaunchKernelGGL(hull_vertex_kernel, dim3(gx, b), dim3(64 * HPR_WAVES), lds, s, n1, flipped,
+    hipLaunchKernelGGL(hull_vertex_kernel, dim3(gx, b), dim3(64 * HPR_WAVES), lds, s, n1, sorted, perm,
                        index_bits(n1), flags);
     hipLaunchKernelGGL(hpr_gather_kernel, dim3(b), dim3(512), (size_t)n1 * sizeof(int), s, n1, flags, org, seed,
                        visible, num_vis, visible_id);
