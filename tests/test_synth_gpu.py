@@ -90,6 +90,32 @@ def test_hidden_point_removal_equals_qhull(hip, data):
         assert np.array_equal(ids2[i, :int(num2[i])].cpu().numpy(), want)
 
 
+def test_hidden_point_removal_random_poses(hip, data):
+    """24 random poses of the object model, each with a random occluder blob and without: the visible-id
+    sets equal qhull's (the per-point LPs see their constraints in a data-dependent order -- spatially
+    sorted neighbours first -- so this exercises many different orders)."""
+    from cloudaae_amd.utils import hidden_point_removal as hpr
+    from oracle import synth_oracle as SO
+    models, _ = data
+    rng = np.random.default_rng(2024)
+    clouds = []
+    for i in range(24):
+        ax = rng.standard_normal(3)
+        ax = (ax / np.linalg.norm(ax) * rng.uniform(0, np.pi)).astype(np.float32)
+        t = np.array([rng.uniform(-0.25, 0.25), rng.uniform(-0.25, 0.25), rng.uniform(0.5, 1.5)], np.float32)
+        pts = SO.transform_object_model(models[0][:, :3], ax, t)
+        occ = (rng.standard_normal((400, 3)) * rng.uniform(0.005, 0.03) +
+               [t[0] + rng.uniform(-.05, .05), t[1] + rng.uniform(-.05, .05), t[2] * rng.uniform(0.4, 0.9)])
+        clouds.append(np.concatenate([pts, occ.astype(np.float32)], 0))
+    for sl in (slice(None), slice(0, 2048)):
+        fl, org = zip(*[SO.spherical_flip(c[sl]) for c in clouds])
+        _, num, ids = hpr.convexHull(torch.from_numpy(np.stack(fl)).cuda(), torch.from_numpy(np.stack(org)).cuda(),
+                                     return_ids=True)
+        for i in range(len(clouds)):
+            want, _ = SO.convex_hull_visible(fl[i])
+            assert np.array_equal(ids[i, :int(num[i])].cpu().numpy(), want), i
+
+
 def test_hull_vertices_random_clouds(hip):
     """Generic clouds (not HPR-shaped): Gaussian blob, points on a sphere (all vertices), a cube
     lattice (many coplanar/interior points)."""
