@@ -349,20 +349,28 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
     const int span = HPR_NEAR + (1 << bits);
     int i = 0;
     while (i < span) {
+        // the scan tests the current plane itself: with d = r + vx u + vy w the constraint of q reads
+        // d.(q - p) <= -eps |q - p| -- a 3-D dot product per point instead of building its 2-D form
+        const double dx = (fr.rx + vx * fr.ux) + vy * fr.wx, dy = (fr.ry + vx * fr.uy) + vy * fr.wy,
+                     dz = (fr.rz + vx * fr.uz) + vy * fr.wz;
         const int pos = i + lane;
         const int q = pos < span ? hpr_seq(pos, self, n1, bits) : n1;
         const bool valid = q < n1 && q != self;
-        Cons k = {0.0, 0.0, 0.0};
-        if (valid)
-            k = hpr_constraint(pts, q, fr);
-        const bool viol = valid && (k.a * vx + k.b * vy > k.c);
+        bool viol = false;
+        if (valid) {
+            const double gx = (double)pts[3 * q] - fr.px, gy = (double)pts[3 * q + 1] - fr.py,
+                         gz = (double)pts[3 * q + 2] - fr.pz;
+            const double nrm = (fabs(gx) + fabs(gy)) + fabs(gz);
+            viol = (dx * gx + dy * gy) + dz * gz > -HPR_EPS * nrm;
+        }
         const unsigned long long mask = __ballot(viol);
         if (mask == 0ull) {
             i += 64;
             continue;
         }
         const int first = __ffsll((long long)mask) - 1;
-        const double ka = __shfl(k.a, first, 64), kb = __shfl(k.b, first, 64), kc = __shfl(k.c, first, 64);
+        const Cons kf = hpr_constraint(pts, __shfl(q, first, 64), fr);     // 2-D form of the violated one only
+        const double ka = kf.a, kb = kf.b, kc = kf.c;
         const double nn = ka * ka + kb * kb;
         if (nn == 0.0)
             return false;
