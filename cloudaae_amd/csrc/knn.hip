@@ -482,6 +482,10 @@ __global__ __launch_bounds__(KNN_THREADS) void knn64_mfma_kernel(int n, int ld, 
 // defines it) and kept in LDS.  Arithmetic and tie rule are those of the kernels above, so the
 // indices stay bit-identical to oracle_knn.
 constexpr int KS_QCAP = 24;          // queue slots per lane; a round pushes at most 16
+#ifndef KS_POP_V
+#define KS_POP_V 6
+#endif
+constexpr int KS_POP = KS_POP_V;      // entries popped per round when the queue is not about to overflow
 
 // QW query tiles per workgroup, CS waves per query tile (wave cs scans the candidate tiles t = r*CS + cs)
 template <int K, int QW, int CS>
@@ -574,23 +578,23 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_scan_kernel(int n, int ld,
     top.init();
     float thr = __builtin_inff();
     int cnt = 0;
-    auto drain = [&]() {
-        // the queue entry of the NEXT pop is read while the current one goes through the insert
-        float nd = cnt > 0 ? qd[lane] : 0.0f;
-        int ni = cnt > 0 ? qi[lane] : 0;
-        for (int t = 0; __any(t < cnt); ++t) {
-            const float cd = nd;
-            const int ci = ni;
-            if (t + 1 < cnt) {
-                nd = qd[(t + 1) * 64 + lane];
-                ni = qi[(t + 1) * 64 + lane];
+    // The queue is popped a few entries per round (pop_some) rather than all at once when it fills up:
+    // the waves of a workgroup meet at a barrier every round, and a wave that stops to pop twenty
+    // entries makes the other seven wait -- with eight waves nearly every round had such a wave.
+    int head = 0;
+    auto pop_some = [&](int limit) {
+        for (int t = 0; t < limit && __any(head < cnt); ++t)
+            if (head < cnt) {
+                top.insert(qd[head * 64 + lane], qi[head * 64 + lane]);
+                ++head;
             }
-            if (t < cnt)
-                top.insert(cd, ci);
+        if (head >= cnt) {
+            head = 0;
+            cnt = 0;
         }
-        cnt = 0;
         thr = top.d[K - 1];
     };
+    auto drain = [&]() { pop_some(KS_QCAP); };
 
     const int ntiles = (n + KM_TILE - 1) / KM_TILE;
     const int rounds = (ntiles + CS - 1) / CS;
@@ -645,8 +649,12 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_scan_kernel(int n, int ld,
 #pragma unroll
         for (int e = 0; e < 16; ++e)
             acc[e] = 0.0f;
-        if (r > 0 && __any(cnt > KS_QCAP - 17))
-            drain();
+        if (r > 0) {
+            if (__any(cnt > KS_QCAP - 17))
+                drain();
+            else
+                pop_some(KS_POP);
+        }
         // the filter of the PREVIOUS tile (VALU + LDS pushes, independent of acc) is issued between the
         // MFMAs of this tile, two MFMAs per candidate row, so it runs in their shadow
 #pragma unroll
