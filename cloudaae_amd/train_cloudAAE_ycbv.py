@@ -133,6 +133,7 @@ class TrainGraph(object):
         self.replay = bool(replay)
         self.reuse_staged_inputs = False
         self._plan = self._plan_key = self._plan_out = self._static = self._staged = None
+        self._plans = {}                     # parked recordings of other input shapes
         self._build()
 
     # -- graph construction: create every variable once, then pack them ---------------------
@@ -252,11 +253,22 @@ class TrainGraph(object):
                   'translation': torch.float32, 'axisangle': torch.float64, 'class_id': torch.int64}
         key = tuple((k, tuple(v.shape), str(dtypes[k])) for k, v in src.items())
         if key != self._plan_key:
-            self._plan = self._plan_out = self._staged = None
+            # another input shape: park the current recording (up to 4 are kept, e.g. a training and a
+            # shorter last batch alternating) and pick up / start the one for this shape
+            if self._plan_key is not None and self._plan is not None:
+                self._plans[self._plan_key] = (self._plan, self._plan_out, self._static)
+                while len(self._plans) > 4:
+                    self._plans.pop(next(iter(self._plans)))
+            self._staged = None
             self._plan_key = key
-            self._static = {k: torch.empty(tuple(v.shape), dtype=dtypes[k], device=self.device) for k, v in src.items()}
-            B = src['visiblePoints'].shape[0]
-            self._static['noise'] = torch.empty((B, N, 3), dtype=torch.float32, device=self.device)
+            if key in self._plans:
+                self._plan, self._plan_out, self._static = self._plans.pop(key)
+            else:
+                self._plan = self._plan_out = None
+                self._static = {k: torch.empty(tuple(v.shape), dtype=dtypes[k], device=self.device)
+                                for k, v in src.items()}
+                B = src['visiblePoints'].shape[0]
+                self._static['noise'] = torch.empty((B, N, 3), dtype=torch.float32, device=self.device)
         # reuse_staged_inputs (off by default): the caller promises that passing the very same tensor
         # objects again means the same contents (a fixed batch, as in bench.py) -- then they are not
         # copied again.  It cannot be detected safely: kernels that fill a tensor through its raw

@@ -68,6 +68,11 @@ def test_replay_draws_fresh_noise_and_rerecords_on_new_shape(hip):
     el8["visiblePoints"] = torch.cat([el8["visiblePoints"], el8["visiblePoints"]], 1)   # [4,256,3]: new shape
     o = g.train_step(el8)
     assert g._plan is not plan and np.isfinite(float(o["total_loss"]))
+    plan8 = g._plan
+    g.train_step(el)                                    # back to the first shape: its recording is reused
+    assert g._plan is plan
+    g.train_step(el8)
+    assert g._plan is plan8 and float(g.batch) == 5.0
 
 
 def test_replay_timed_site_and_eval(hip):
