@@ -21,10 +21,50 @@ from .train_cloudAAE_ycbv import NUM_CLASS
 from .utils import _functions as F
 
 
-def evaluate_batch(graph, element):
+def evaluate_batch(graph, element, replay=False):
     """One pass of evaluate_cloudAAE_ycbv.py:421-477 on a batch.  Returns the tensors its loop
     fetches (:546-560): xyz_recon [B,4N,3], xyz_recon_FPS [B,N,3], rot_pred, trans_pred, the three
-    losses with their per-sample values, mean_dist_loss, element_mean."""
+    losses with their per-sample values, mean_dist_loss, element_mean.
+    replay=True: the pass is recorded once per input shape (_lib.StepPlan) and re-issued afterwards
+    without Python layers in between -- the batch-1 latency is then the kernels', not the host's;
+    the returned tensors are the same objects every call, overwritten in place."""
+    if replay:
+        return _replayed(graph, element)
+    return _evaluate(graph, element)
+
+
+def _replayed(graph, element):
+    N = graph.NUM_POINT
+    src = {'xyz_inlier': (element['xyz_inlier'], torch.float32),
+           'visiblePoints_org': (element['visiblePoints_org'][:, 0:N, :], torch.float32),
+           'class_id': (element['class_id'], torch.int64), 'translation': (element['translation'], torch.float32),
+           'axisangle': (element['axisangle'], torch.float64)}
+    key = tuple((k, tuple(v.shape)) for k, (v, _) in src.items())
+    plans = graph.__dict__.setdefault('_eval_plans', {})
+    if key not in plans:
+        static = {k: torch.empty(tuple(v.shape), dtype=dt, device=graph.device) for k, (v, dt) in src.items()}
+        plans[key] = [None, None, static]
+        while len(plans) > 4:
+            plans.pop(next(iter(plans)))
+    plan, out, static = plans[key]
+    for k, (v, _) in src.items():
+        static[k].copy_(v, non_blocking=True)
+    if plan is None:
+        plan = _lib.StepPlan(graph.device)
+        with _lib.record(plan):
+            out = _evaluate(graph, static)
+        if plan.foreign_ops:
+            import warnings
+            warnings.warn("evaluation pass not replayable (torch kernels inside: %s)" % sorted(set(plan.foreign_ops)))
+            plans.pop(key)
+            return out
+        plans[key][0], plans[key][1] = plan, out
+        return out
+    plan.replay()
+    return out
+
+
+def _evaluate(graph, element):
     N = graph.NUM_POINT
     xyz = element['xyz_inlier']
     require(xyz.dim() == 3 and xyz.shape[1] >= N and xyz.shape[2] == 3, "xyz_inlier must be [B, >=num_point, 3]")
@@ -33,8 +73,8 @@ def evaluate_batch(graph, element):
     cls = element['class_id'].to(torch.int64).contiguous()
     with torch.no_grad():
         # :421-438 -- first N inlier points, centroid, centring, one-hot class; no noise in evaluation
-        pc = torch.empty((B, N, 3 + NUM_CLASS), dtype=torch.float32, device=xyz.device)
-        element_mean = torch.empty((B, 3), dtype=torch.float32, device=xyz.device)
+        pc = _lib.empty((B, N, 3 + NUM_CLASS), dtype=torch.float32, device=xyz.device)
+        element_mean = _lib.empty((B, 3), dtype=torch.float32, device=xyz.device)
         _lib.check(_lib.lib().cloudaae_input_assemble(B, P, N, NUM_CLASS, ptr(xyz), None, ptr(cls), ptr(pc),
                                                       ptr(element_mean), None, stream()), "cloudaae_input_assemble")
         xyz_recon_res, rot_pred, trans_pred_res, end_points = graph._call_model(pc, False)      # :441-444

@@ -26,8 +26,8 @@ returns:
     inpr = inpr.detach().contiguous()
     b, n = inp.shape
     m = inpr.shape[1]
-    out = torch.empty((b, m), dtype=torch.int32, device=inp.device)
-    temp = torch.empty((b, n), dtype=torch.float32, device=inp.device)
+    out = _lib.empty((b, m), dtype=torch.int32, device=inp.device)
+    temp = _lib.empty((b, n), dtype=torch.float32, device=inp.device)
     _lib.check(_lib.lib().cloudaae_prob_sample(b, n, m, ptr(inp), ptr(inpr), ptr(temp), ptr(out), stream()),
                "cloudaae_prob_sample")
     return out
@@ -48,10 +48,10 @@ returns:
     require(inp.dtype == torch.float32, "FarthestPointSample: inp must be float32")
     inp = inp.detach().contiguous()
     b, n, _ = inp.shape
-    out = torch.empty((b, int(npoint)), dtype=torch.int32, device=inp.device)
+    out = _lib.empty((b, int(npoint)), dtype=torch.int32, device=inp.device)
     temp = None
     if n > 16384:  # the reference's 32*n workspace (tf_sampling.cpp:115)
-        temp = torch.empty((32, n), dtype=torch.float32, device=inp.device)
+        temp = _lib.empty((32, n), dtype=torch.float32, device=inp.device)
     _lib.check(_lib.lib().cloudaae_farthest_point_sample(b, n, int(npoint), ptr(inp), ptr(temp),
                                                          ptr(out), stream()),
                "cloudaae_farthest_point_sample")
@@ -71,7 +71,7 @@ class _GatherPoint(torch.autograd.Function):
         idx = idx.contiguous()
         b, n, _ = inp.shape
         m = idx.shape[1]
-        out = torch.empty((b, m, 3), dtype=torch.float32, device=inp.device)
+        out = _lib.empty((b, m, 3), dtype=torch.float32, device=inp.device)
         _lib.check(_lib.lib().cloudaae_gather_point(b, n, m, ptr(inp), ptr(idx), ptr(out), stream()),
                    "cloudaae_gather_point")
         ctx.save_for_backward(idx)
@@ -82,7 +82,7 @@ class _GatherPoint(torch.autograd.Function):
     def backward(ctx, out_g):
         (idx,) = ctx.saved_tensors
         b, m = idx.shape
-        inp_g = torch.empty((b, ctx.n, 3), dtype=torch.float32, device=out_g.device)
+        inp_g = _lib.empty((b, ctx.n, 3), dtype=torch.float32, device=out_g.device)
         _lib.check(_lib.lib().cloudaae_gather_point_grad(b, ctx.n, m, ptr(out_g.contiguous()),
                                                          ptr(idx), ptr(inp_g), stream()),
                    "cloudaae_gather_point_grad")
@@ -107,7 +107,7 @@ def gather_point_grad(inp, idx, out_g):
     require(idx.dim() == 2 and idx.shape[0] == b, "GatherPointGradGpuOp expects (batch_size,num_result) idx shape")
     m = idx.shape[1]
     require(tuple(out_g.shape) == (b, m, 3), "GatherPointGradGpuOp expects (batch_size,num_result,3) out_g shape")
-    inp_g = torch.empty((b, n, 3), dtype=torch.float32, device=out_g.device)
+    inp_g = _lib.empty((b, n, 3), dtype=torch.float32, device=out_g.device)
     _lib.check(_lib.lib().cloudaae_gather_point_grad(b, n, m, ptr(out_g.contiguous()),
                                                      ptr(idx.contiguous()), ptr(inp_g), stream()),
                "cloudaae_gather_point_grad")

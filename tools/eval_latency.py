@@ -7,10 +7,11 @@ for B, N in ((1, 256), (1, 1024), (8, 1024), (32, 1024)):
     graph = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": max(B, 2)})
     el = T.synthetic_element(B, N, graph.device)
     el["xyz_inlier"] = el["visiblePoints"]
-    for _ in range(5):
-        E.evaluate_batch(graph, el)
-    torch.cuda.synchronize(); t0 = time.time()
-    for _ in range(30):
-        E.evaluate_batch(graph, el)
-    torch.cuda.synchronize()
-    print("B=%d N=%d: %.3f ms per batch" % (B, N, (time.time() - t0) / 30 * 1e3), flush=True)
+    for rp in (False, True):
+        for _ in range(5):
+            E.evaluate_batch(graph, el, replay=rp)
+        torch.cuda.synchronize(); t0 = time.time()
+        for _ in range(30):
+            E.evaluate_batch(graph, el, replay=rp)
+        torch.cuda.synchronize()
+        print("B=%d N=%d %s: %.3f ms per batch" % (B, N, "replay" if rp else "eager ", (time.time() - t0) / 30 * 1e3), flush=True)
