@@ -179,6 +179,97 @@ def read_and_decode_obj_model(filename):
     return np.stack(models), np.array(labels, np.int64)
 
 
+def _decode_pose_group(body):
+    """Vectorised decode of pose-record payloads body[n, length] that share ONE byte layout (same bytes
+    outside the three value fields).  Returns (translation, axisangle, class_id) or None."""
+    n, length = body.shape
+    first = body[0].tobytes()
+    d0 = decode(first)
+    spans = {}
+    for key in ("translation", "axisangle"):
+        blob = d0[key].astype("<f4").tobytes()
+        at = first.find(blob)
+        if at < 0 or first.find(blob, at + 1) >= 0:
+            return None
+        spans[key] = (at, at + 12)
+    # class_id is a one-byte varint: the byte whose change moves class_id (and nothing else) under the
+    # generic decoder
+    cid_at = None
+    for pos in range(length):
+        if any(lo <= pos < hi for lo, hi in spans.values()) or first[pos] != int(d0["class_id"]) or first[pos] >= 0x7f:
+            continue
+        probe = bytearray(first)
+        probe[pos] = first[pos] + 1
+        try:
+            dp = decode(bytes(probe))
+        except Exception:
+            continue
+        if (int(dp["class_id"]) == int(d0["class_id"]) + 1 and np.array_equal(dp["translation"], d0["translation"])
+                and np.array_equal(dp["axisangle"], d0["axisangle"])):
+            cid_at = pos
+            break
+    if cid_at is None:
+        return None
+    fixed = np.ones(length, bool)
+    for lo, hi in spans.values():
+        fixed[lo:hi] = False
+    fixed[cid_at] = False
+    if not (body[:, fixed] == body[0, fixed]).all() or (body[:, cid_at] >= 0x80).any():
+        return None
+    t = np.ascontiguousarray(body[:, spans["translation"][0]:spans["translation"][1]]).view("<f4").reshape(n, 3)
+    a = np.ascontiguousarray(body[:, spans["axisangle"][0]:spans["axisangle"][1]]).view("<f4").reshape(n, 3)
+    c = body[:, cid_at].astype(np.int64)
+    for i in {0, n // 2, n - 1}:                         # spot check against the generic decoder
+        d = decode(body[i].tobytes())
+        if not (np.array_equal(d["translation"], t[i]) and np.array_equal(d["axisangle"], a[i]) and
+                int(d["class_id"]) == int(c[i])):
+            return None
+    return t.astype(np.float32), a.astype(np.float32), c
+
+
+def _decode_pose_file_fast(path):
+    """Whole-file decode of a pose-record file: all records have one length, and the protobuf map of
+    an Example is written in one of a few entry orders -- records are grouped by their bytes at the
+    (few) positions that tell the orders apart and every group is decoded as one array operation
+    (the shipped train_syn files: ~100x faster than record by record).  Returns (translation [n,3],
+    axisangle [n,3], class_id [n]) in file order, or None when the file does not fit the pattern (the
+    caller then decodes record by record)."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    if raw.size < 16:
+        return None
+    length = int(raw[:8].view("<u8")[0])
+    stride = 12 + length + 4
+    if length < 8 or raw.size % stride != 0:
+        return None
+    n = raw.size // stride
+    recs = raw.reshape(n, stride)
+    if not (recs[:, :8] == recs[0, :8]).all():          # every length field equal
+        return None
+    body = recs[:, 12:12 + length]
+    # entry order signature: the length bytes of the three map entries (Features{ map entry* })
+    o1 = 2
+    l1 = body[:, o1 + 1].astype(np.int64)
+    o2 = o1 + 2 + l1
+    if (o2 + 1 >= length).any():
+        return None
+    rows = np.arange(n)
+    l2 = body[rows, o2 + 1].astype(np.int64)
+    sig = l1 * 256 + l2
+    t = np.zeros((n, 3), np.float32)
+    a = np.zeros((n, 3), np.float32)
+    c = np.zeros((n,), np.int64)
+    groups = np.unique(sig)
+    if groups.size > 6:
+        return None
+    for gsig in groups:
+        sel = np.nonzero(sig == gsig)[0]
+        got = _decode_pose_group(np.ascontiguousarray(body[sel]))
+        if got is None:
+            return None
+        t[sel], a[sel], c[sel] = got
+    return t, a, c
+
+
 class PoseRecords(object):
     """All pose records of a list of train_syn files in memory (381,553 records x 28 B for the
     shipped set), with the reference's epoch semantics: full shuffle (its shuffle buffer exceeds
@@ -188,14 +279,25 @@ class PoseRecords(object):
     def __init__(self, filenames, verify=False):
         t, a, c = [], [], []
         for fn in filenames:
+            fast = None if verify else _decode_pose_file_fast(fn)
+            if fast is not None:
+                t.append(fast[0])
+                a.append(fast[1])
+                c.append(fast[2])
+                continue
+            ft, fa, fc = [], [], []
             for rec in tf_record_iterator(fn, verify=verify):
                 d = decode(rec)
-                t.append(d["translation"])
-                a.append(d["axisangle"])
-                c.append(d["class_id"])
-        self.translation = np.stack(t).astype(np.float32) if t else np.zeros((0, 3), np.float32)
-        self.axisangle = np.stack(a).astype(np.float32) if a else np.zeros((0, 3), np.float32)
-        self.class_id = np.array(c, np.int64)
+                ft.append(d["translation"])
+                fa.append(d["axisangle"])
+                fc.append(d["class_id"])
+            if ft:
+                t.append(np.stack(ft).astype(np.float32))
+                a.append(np.stack(fa).astype(np.float32))
+                c.append(np.array(fc, np.int64))
+        self.translation = np.concatenate(t) if t else np.zeros((0, 3), np.float32)
+        self.axisangle = np.concatenate(a) if a else np.zeros((0, 3), np.float32)
+        self.class_id = np.concatenate(c) if c else np.zeros((0,), np.int64)
 
     def __len__(self):
         return len(self.class_id)

@@ -79,3 +79,29 @@ def test_negative_int64_and_unpacked_lists():
     feats = ld(1, ld(1, b"ids") + ld(2, int_list)) + ld(1, ld(1, b"v") + ld(2, flt_list))
     ex = T.parse_example(ld(1, feats))
     assert ex["ids"].tolist() == [-3, 7] and ex["v"].tolist() == [1.5, -2.0]
+
+
+def test_fast_pose_decode_equals_record_by_record(golden_dir, tmp_path):
+    """PoseRecords decodes a whole file as array operations (records grouped by the order their
+    protobuf map entries were written in); it must give exactly what the record-by-record decoder
+    gives, and files that do not fit the pattern must still load through the slow path."""
+    import numpy as np
+    from cloudaae_amd import tfrecord_io as R
+    fn = os.path.join(golden_dir, "pose_records_cls0_first4.tfrecords")
+    fast = R._decode_pose_file_fast(fn)
+    slow = [R.decode(x) for x in R.tf_record_iterator(fn, verify=True)]
+    assert fast is not None
+    assert np.array_equal(fast[0], np.stack([d["translation"] for d in slow]))
+    assert np.array_equal(fast[1], np.stack([d["axisangle"] for d in slow]))
+    assert np.array_equal(fast[2], np.array([d["class_id"] for d in slow]))
+    recs = R.PoseRecords([fn])
+    assert len(recs) == 4 and np.array_equal(recs.translation, fast[0])
+    # a file with a ragged tail does not fit the fixed-stride pattern: fast path declines, slow path reads it
+    raw = open(fn, "rb").read()
+    extra = b"\x0a\x00"                                   # an Example with an empty feature map
+    rec = len(extra).to_bytes(8, "little") + R.masked_crc32c(len(extra).to_bytes(8, "little")).to_bytes(4, "little") \
+        + extra + R.masked_crc32c(extra).to_bytes(4, "little")
+    odd = tmp_path / "odd.tfrecords"
+    odd.write_bytes(raw + rec)
+    assert R._decode_pose_file_fast(str(odd)) is None
+    assert sum(1 for _ in R.tf_record_iterator(str(odd), verify=True)) == 5
