@@ -341,27 +341,49 @@ __device__ __forceinline__ Cons hpr_constraint(const float *__restrict__ pts, in
 struct Frac {
     double num, den;   // den > 0
 };
+// value of lane DPP(ctrl) of this lane's row: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E,
+// row_half_mirror = 0x141, row_mirror = 0x140
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const unsigned long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
 __device__ __forceinline__ bool frac_less(const Frac &x, const Frac &y) { return x.num * y.den < y.num * x.den; }
 
 __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, int bits, const Frame &fr, int lane)
 {
     double vx = HPR_TAN, vy = HPR_TAN;
+    const float pxf = (float)fr.px, pyf = (float)fr.py, pzf = (float)fr.pz;     // exact: p is a float
     const int span = HPR_NEAR + (1 << bits);
     int i = 0;
     while (i < span) {
         // the scan tests the current plane itself: with d = r + vx u + vy w the constraint of q reads
-        // d.(q - p) <= -eps |q - p| -- a 3-D dot product per point instead of building its 2-D form
+        // d.(q - p) <= -eps |q - p| -- a 3-D dot product per point instead of building its 2-D form.
+        // It runs in fp32 first (fp64 issues at half rate and this loop is instruction-bound): a point
+        // whose fp32 value is below -margin, margin = 4e-6 |d|_1 |g|_1 (>> the rounding error of the three
+        // products, the sum and the fp32 copies of d and g), is satisfied for certain; only lanes inside
+        // the margin repeat the test in fp64.  The decision is therefore exactly the fp64 one.
         const double dx = (fr.rx + vx * fr.ux) + vy * fr.wx, dy = (fr.ry + vx * fr.uy) + vy * fr.wy,
                      dz = (fr.rz + vx * fr.uz) + vy * fr.wz;
+        const float dxf = (float)dx, dyf = (float)dy, dzf = (float)dz;
+        const float dl1 = (fabsf(dxf) + fabsf(dyf)) + fabsf(dzf);
         const int pos = i + lane;
         const int q = pos < span ? hpr_seq(pos, self, n1, bits) : n1;
         const bool valid = q < n1 && q != self;
         bool viol = false;
         if (valid) {
-            const double gx = (double)pts[3 * q] - fr.px, gy = (double)pts[3 * q + 1] - fr.py,
-                         gz = (double)pts[3 * q + 2] - fr.pz;
-            const double nrm = (fabs(gx) + fabs(gy)) + fabs(gz);
-            viol = (dx * gx + dy * gy) + dz * gz > -HPR_EPS * nrm;
+            const float qx = pts[3 * q], qy = pts[3 * q + 1], qz = pts[3 * q + 2];
+            const float gxf = qx - pxf, gyf = qy - pyf, gzf = qz - pzf;
+            const float nrmf = (fabsf(gxf) + fabsf(gyf)) + fabsf(gzf);
+            const float v32 = (dxf * gxf + dyf * gyf) + dzf * gzf;
+            if (v32 > -4e-6f * dl1 * nrmf) {
+                const double gx = (double)qx - fr.px, gy = (double)qy - fr.py, gz = (double)qz - fr.pz;
+                const double nrm = (fabs(gx) + fabs(gy)) + fabs(gz);
+                viol = (dx * gx + dy * gy) + dz * gz > -HPR_EPS * nrm;
+            }
         }
         const unsigned long long mask = __ballot(viol);
         if (mask == 0ull) {
@@ -402,16 +424,24 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
             const Cons m = hpr_constraint(pts, r, fr);
             add(m.a, m.b, m.c);
         }
-        // wave reduction of lo (max) and hi (min) as fractions
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            Frac ol = {__shfl_xor(lo.num, off, 64), __shfl_xor(lo.den, off, 64)};
-            Frac oh = {__shfl_xor(hi.num, off, 64), __shfl_xor(hi.den, off, 64)};
+        // wave reduction of lo (max) and hi (min) as fractions.  Inside a row of 16 lanes the partner
+        // comes through DPP (quad swaps, then the half-row and row mirrors: after the quad steps a quad
+        // is uniform, so the mirrors act as "xor 4" and "xor 8"); only the two cross-row steps go through
+        // the LDS crossbar (ds_bpermute), which cost ~3/4 of a re-solve when all six steps used it.
+        auto fold = [&](Frac ol, Frac oh) {
             if (frac_less(lo, ol))
                 lo = ol;
             if (frac_less(oh, hi))
                 hi = oh;
-        }
+        };
+        fold(Frac{dpp_f64<0xB1>(lo.num), dpp_f64<0xB1>(lo.den)}, Frac{dpp_f64<0xB1>(hi.num), dpp_f64<0xB1>(hi.den)});
+        fold(Frac{dpp_f64<0x4E>(lo.num), dpp_f64<0x4E>(lo.den)}, Frac{dpp_f64<0x4E>(hi.num), dpp_f64<0x4E>(hi.den)});
+        fold(Frac{dpp_f64<0x141>(lo.num), dpp_f64<0x141>(lo.den)}, Frac{dpp_f64<0x141>(hi.num), dpp_f64<0x141>(hi.den)});
+        fold(Frac{dpp_f64<0x140>(lo.num), dpp_f64<0x140>(lo.den)}, Frac{dpp_f64<0x140>(hi.num), dpp_f64<0x140>(hi.den)});
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1)
+            fold(Frac{__shfl_xor(lo.num, off, 64), __shfl_xor(lo.den, off, 64)},
+                 Frac{__shfl_xor(hi.num, off, 64), __shfl_xor(hi.den, off, 64)});
         if (__ballot(bad) != 0ull || frac_less(hi, lo))
             return false;
         const Frac pick = (ux + 0.5 * uy) > 0.0 ? hi : lo;
@@ -638,9 +668,21 @@ CLOUDAAE_API int cloudaae_hidden_point_removal(int b, int n1, const float *flipp
     if (lds > 48 * 1024)
         CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)hull_vertex_kernel,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
-    // ~16 points per wave: enough workgroups to fill the chip at small batch, few enough that the
-    // cloud is not re-staged into LDS too often
-    int gx = ceil_div(n1, HPR_WAVES * 16);
+    // workgroups per cloud: the kernel holds 108 VGPRs, i.e. two 8-wave workgroups per CU, 512 on the chip;
+    // a grid of 640 ran as one full round plus a quarter-full one.  Pick the split whose (rounds x points per
+    // wave) is smallest -- e.g. 16 x 32 clouds = 512 workgroups of 20 points per wave for the 2449-point hull.
+    int gx = 1;
+    {
+        long long best = -1;
+        for (int cand = ceil_div(n1, HPR_WAVES * 32); cand <= ceil_div(n1, HPR_WAVES * 4); ++cand) {
+            const long long rounds = ((long long)cand * b + 511) / 512;
+            const long long cost = rounds * ceil_div(n1, HPR_WAVES * cand);
+            if (best < 0 || cost < best) {
+                best = cost;
+                gx = cand;
+            }
+        }
+    }
     hipLaunchKernelGGL(hull_vertex_kernel, dim3(gx, b), dim3(64 * HPR_WAVES), lds, s, n1, sorted, perm,
                        index_bits(n1), flags);
     hipLaunchKernelGGL(hpr_gather_kernel, dim3(b), dim3(512), (size_t)n1 * sizeof(int), s, n1, flags, org, seed,
