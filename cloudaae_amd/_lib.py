@@ -106,6 +106,7 @@ class StepPlan(object):
         # one ~4 us clear pass per product
         self.zchunks = []          # [tensor, used bytes]
         self.internal = False      # allocator-internal torch calls are not "foreign"
+        self.poison = os.environ.get("CLOUDAAE_POISON_ARENA") == "1"
 
     # -- arena ------------------------------------------------------------------------------
     def alloc(self, shape, dtype, device):
@@ -124,6 +125,19 @@ class StepPlan(object):
         view = self.chunks[-1][self.offset:self.offset + max(n, 1) * item].view(dtype)
         self.offset += padded
         self.bytes += padded
+        if self.poison and n and dtype.is_floating_point:
+            # debugging aid (CLOUDAAE_POISON_ARENA=1, used by the tests): every buffer starts as NaN, so a
+            # kernel that reads what no kernel wrote shows up in the losses instead of seeing stale data
+            # (through the library, not torch: an in-place torch op would bump the version counter of
+            # the whole chunk, which autograd views of other buffers in it would trip over)
+            if getattr(self, "_nan", None) is None:
+                self.internal = True
+                try:
+                    self._nan = torch.full((1,), float("nan"), dtype=torch.float32, device=self.device)
+                finally:
+                    self.internal = False
+            check(lib()._cdll.cloudaae_fill_scaled(n * item // 4, self._nan.data_ptr(), 1.0, None, view.data_ptr(),
+                                                   stream()), "cloudaae_fill_scaled")
         return view[:n].view(shape) if n else view[:0].view(shape)
 
     ZCHUNK = 32 << 20

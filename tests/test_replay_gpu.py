@@ -8,6 +8,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _poisoned_arena(monkeypatch):
+    """Buffers of a recording start as NaN: an uninitialised read cannot hide behind stale data."""
+    monkeypatch.setenv("CLOUDAAE_POISON_ARENA", "1")
+
+
 def _pair(B, N, model_fn="get_model_dgcnn_mean_6d"):
     from cloudaae_amd import train_cloudAAE_ycbv as T
     mk = lambda r: T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, model_fn=model_fn, replay=r)
