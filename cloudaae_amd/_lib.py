@@ -33,6 +33,11 @@ _SIGNATURES = {
     "cloudaae_bn_backward": [_I, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I,
                              _P, _P, _P, _I, _P, _P],
     "cloudaae_colsum_f32": [_I, _I, _P, _I, _P, _I, _P, _P],
+    "cloudaae_fc_forward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
+    "cloudaae_fc_backward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P,
+                             _P, _I, _P],
+    "cloudaae_fc_forward_group": [_I, _I, _P, _I, _P, _I, _P],
+    "cloudaae_fc_backward_group": [_I, _I, _P, _I, _P],
     "cloudaae_edgeconv_forward": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P,
                                   _P, _P, _P, _I, _P, _I, _P, _P],
     "cloudaae_edgeconv_backward": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P,
@@ -65,6 +70,16 @@ _SIGNATURES = {
     "cloudaae_spherical_flip": [_I, _I, _P, _I, _P, _P, _F, _P, _P, _P],
     "cloudaae_hidden_point_removal": [_I, _I, _P, _P, _U, _P, _P, _P, _P, _P],
 }
+
+
+class FcLayer(ctypes.Structure):
+    """struct cloudaae_fc_layer (include/cloudaae_hip.h): one layer of a grouped fully connected launch."""
+    _fields_ = [("K", _I), ("N", _I), ("x", _P), ("ldx", _I), ("w", _P), ("bias", _P), ("gamma", _P), ("beta", _P),
+                ("ema_mean", _P), ("ema_var", _P), ("save_mean", _P), ("save_var", _P), ("relu", _I), ("y", _P),
+                ("out", _P), ("tickets", _P), ("dout", _P), ("lddo", _I), ("dx", _P), ("lddx", _I), ("dw", _P),
+                ("accumulate_dw", _I), ("dgamma", _P), ("dbeta", _P), ("dbias", _P), ("accumulate_param_grads", _I)]
+
+
 _LONGLONG_RESULTS = ["cloudaae_bn_workspace_bytes", "cloudaae_edgeconv_workspace_bytes",
                      "cloudaae_mean_workspace_bytes"]
 
@@ -233,6 +248,11 @@ def lib():
         cdll.cloudaae_gemm_bf16_splits.argtypes = [_I, _I, _I]
         cdll.cloudaae_gemm_bf16_splits.restype = ctypes.c_int
         cdll.cloudaae_bn_workspace_bytes.argtypes = [_I]
+        for q in ("cloudaae_fc_max_rows", "cloudaae_fc_max_group"):
+            getattr(cdll, q).argtypes = []
+            getattr(cdll, q).restype = ctypes.c_int
+        cdll.cloudaae_fc_forward_tickets.argtypes = [_I]
+        cdll.cloudaae_fc_forward_tickets.restype = ctypes.c_int
         cdll.cloudaae_edgeconv_workspace_bytes.argtypes = [_I]
         _lib = _Library(cdll)
     return _lib

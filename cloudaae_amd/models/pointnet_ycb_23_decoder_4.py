@@ -50,31 +50,21 @@ def _dgcnn_encoder(point_cloud, is_training_pl_encoder, k, bn_decay, pool, prefi
                                  is_training=is_training_pl_encoder, pool=pool, slot=slot)
 
 
+def _decoder_chain(out_units, prefix='', stem='dgcnn'):
+    # FC decoder (models/...:413-421): 1024 -> 1024 -> num_point*4*3, batch norm + ReLU on the first two
+    return [(prefix + stem + '_fc1', 1024, True), (prefix + stem + '_fc2', 1024, True),
+            (prefix + stem + '_output', out_units, False)]
+
+
+def _pose_chains(prefix='', stem='dgcnn'):
+    # rotation and translation heads (models/...:424-441): 512 -> 256 -> 3 each
+    return [[(prefix + '%s_%s_fc1' % (stem, h), 512, True), (prefix + '%s_%s_fc2' % (stem, h), 256, True),
+             (prefix + '%s_output_%s' % (stem, h), 3, False)] for h in ('rot', 'trans')]
+
+
 def _decoder(net, out_units, is_training, bn_decay, prefix=''):
-    net, _, _ = tf_util.fully_connected(net, 1024, bn=True, is_training=is_training,
-                                        scope=prefix + 'dgcnn_fc1', bn_decay=bn_decay)
-    net, _, _ = tf_util.fully_connected(net, 1024, bn=True, is_training=is_training,
-                                        scope=prefix + 'dgcnn_fc2', bn_decay=bn_decay)
-    net, out_weight, out_biases = tf_util.fully_connected(net, out_units, activation_fn=None,
-                                                          scope=prefix + 'dgcnn_output')
-    return net
-
-
-def _pose_heads(embedding, is_training, bn_decay, prefix=''):
-    # two consumers: the sum of their input gradients is made by our add kernel (F.FanOutFn)
-    embedding, emb_trans = F.FanOutFn.apply(embedding, 2)
-    net_rot, _, _ = tf_util.fully_connected(embedding, 512, bn=True, is_training=is_training,
-                                            scope=prefix + 'dgcnn_rot_fc1', bn_decay=bn_decay)
-    net_rot, _, _ = tf_util.fully_connected(net_rot, 256, bn=True, is_training=is_training,
-                                            scope=prefix + 'dgcnn_rot_fc2', bn_decay=bn_decay)
-    net_rot, _, _ = tf_util.fully_connected(net_rot, 3, activation_fn=None, scope=prefix + 'dgcnn_output_rot')
-    net_trans, _, _ = tf_util.fully_connected(emb_trans, 512, bn=True, is_training=is_training,
-                                              scope=prefix + 'dgcnn_trans_fc1', bn_decay=bn_decay)
-    net_trans, _, _ = tf_util.fully_connected(net_trans, 256, bn=True, is_training=is_training,
-                                              scope=prefix + 'dgcnn_trans_fc2', bn_decay=bn_decay)
-    net_trans, _, _ = tf_util.fully_connected(net_trans, 3, activation_fn=None,
-                                              scope=prefix + 'dgcnn_output_trans')
-    return net_rot, net_trans
+    return tf_util.fully_connected_chains(net, [_decoder_chain(out_units, prefix)], bn_decay=bn_decay,
+                                          is_training=is_training)[0]
 
 
 def _dgcnn_6d(point_cloud, is_training_pl_encoder, is_training, k_neighbor, bn_decay, pool, prefix='',
@@ -88,10 +78,11 @@ def _dgcnn_6d(point_cloud, is_training_pl_encoder, is_training, k_neighbor, bn_d
     end_points['layer_before_embedding'] = before          # lazy [B,N,1,1024] (see LazyActivation)
     end_points['embedding'] = embedding                    # [B,1024]
     mult, dim = point_out
-    emb_dec, emb_pose = F.FanOutFn.apply(embedding, 2)
-    net = _decoder(emb_dec, num_point * mult * dim, is_training, bn_decay, prefix)
+    # decoder and both heads read the embedding: three chains, evaluated depth by depth
+    net, net_rot, net_trans = tf_util.fully_connected_chains(
+        embedding, [_decoder_chain(num_point * mult * dim, prefix)] + _pose_chains(prefix), bn_decay=bn_decay,
+        is_training=is_training)
     net_recon = net.reshape(batch_size, num_point * mult, dim)
-    net_rot, net_trans = _pose_heads(emb_pose, is_training, bn_decay, prefix)
     return net_recon, net_rot, net_trans, end_points
 
 
@@ -183,27 +174,14 @@ def get_model_pn(point_cloud, is_training, bn_decay=None):
                                          is_training=is_training, pool='max')
     end_points['embedding'] = embedding
 
-    emb_dec, emb_rot, emb_trans = F.FanOutFn.apply(embedding, 3)     # three consumers, one summed gradient
-    # FC Decoder
-    net, _, _ = tf_util.fully_connected(emb_dec, 1024, bn=True, is_training=is_training,
-                                        scope='pn_fc1_decoder', bn_decay=bn_decay)
-    net, _, _ = tf_util.fully_connected(net, 1024, bn=True, is_training=is_training,
-                                        scope='pn_fc2_decoder', bn_decay=bn_decay)
-    net, out_weight, out_biases = tf_util.fully_connected(net, num_point * 3 * 4, activation_fn=None,
-                                                          scope='pn_output')
+    # FC decoder (models/...:63-70) and the 6d pose heads (:73-86): three chains over the embedding,
+    # evaluated depth by depth
+    net, net_rot, net_trans = tf_util.fully_connected_chains(
+        embedding,
+        [[('pn_fc1_decoder', 1024, True), ('pn_fc2_decoder', 1024, True), ('pn_output', num_point * 3 * 4, False)],
+         [('pn_rot_fc1', 512, True), ('pn_rot_fc2', 256, True), ('pn_output_rot', 3, False)],
+         [('pn_trans_fc1', 512, True), ('pn_trans_fc2', 256, True), ('pn_output_trans', 3, False)]],
+        bn_decay=bn_decay, is_training=is_training)
     net_recon = net.reshape(batch_size, num_point * 4, 3)
-
-    # 6d pose
-    net_rot, _, _ = tf_util.fully_connected(emb_rot, 512, bn=True, is_training=is_training,
-                                            scope='pn_rot_fc1', bn_decay=bn_decay)
-    net_rot, _, _ = tf_util.fully_connected(net_rot, 256, bn=True, is_training=is_training,
-                                            scope='pn_rot_fc2', bn_decay=bn_decay)
-    net_rot, _, _ = tf_util.fully_connected(net_rot, 3, activation_fn=None, scope='pn_output_rot')
-
-    net_trans, _, _ = tf_util.fully_connected(emb_trans, 512, bn=True, is_training=is_training,
-                                              scope='pn_trans_fc1', bn_decay=bn_decay)
-    net_trans, _, _ = tf_util.fully_connected(net_trans, 256, bn=True, is_training=is_training,
-                                              scope='pn_trans_fc2', bn_decay=bn_decay)
-    net_trans, _, _ = tf_util.fully_connected(net_trans, 3, activation_fn=None, scope='pn_output_trans')
 
     return net_recon, net_rot, net_trans, end_points

@@ -143,6 +143,187 @@ class LinearFn(torch.autograd.Function):
         return dx, gw.done(), gb_ret, None, None
 
 
+def fc_fits(M):
+    """Rows of a fully connected layer that the one-launch-per-direction kernels take."""
+    return 0 < M <= L().cloudaae_fc_max_rows()
+
+
+def fc_max_group():
+    return int(L().cloudaae_fc_max_group())
+
+
+class FcFn(torch.autograd.Function):
+    """tf_util.fully_connected as a whole (utils/tf_util.py:321-365): matmul + bias [+ batch norm + ReLU]
+    for a batch of at most 32 rows, one launch forward and one backward (csrc/fc.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, ema_mean, ema_var, decay, training, relu):
+        require(x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[0], "FcFn: shape mismatch")
+        ctx.set_materialize_grads(False)
+        xp, ldx = rows_ptr(x)
+        M, K = x.shape
+        N = w.shape[1]
+        dev = x.device
+        bn = gamma is not None
+        save_mean = save_var = out = tickets = None
+        if bn:
+            out = _lib.empty((M, N), dtype=torch.float32, device=dev)
+            save_mean = _lib.empty(N, dtype=torch.float32, device=dev)
+            save_var = _lib.empty(N, dtype=torch.float32, device=dev)
+            # arrival counters of the column tiles (zero before and after every launch)
+            tickets = _lib.zeros(L().cloudaae_fc_forward_tickets(N), dtype=torch.int32, device=dev)
+        # the product is cut over K and its slices add into y: while a step is recorded y comes from the
+        # plan's zero zone (one clear per replay), otherwise the call clears it
+        if _lib.recording() is not None:
+            y, zeroed = _lib.zeros((M, N), dtype=torch.float32, device=dev), 1
+        else:
+            y, zeroed = _lib.empty((M, N), dtype=torch.float32, device=dev), 0
+        _lib.check(L().cloudaae_fc_forward(
+            M, K, N, xp, ldx, ptr(w), ptr(b), ptr(gamma), ptr(beta), int(bool(training)), ptr(decay), ptr(ema_mean),
+            ptr(ema_var), ptr(save_mean), ptr(save_var), int(bool(relu)), ptr(y), ptr(out), zeroed, ptr(tickets), stream()),
+            "cloudaae_fc_forward")
+        ctx.save_for_backward(x, w, y if bn else None, gamma, beta, save_mean, save_var)
+        ctx.cfg = (int(bool(training)), int(bool(relu)))
+        ctx.bvar = b
+        return out if bn else y
+
+    @staticmethod
+    def backward(ctx, dout):
+        if dout is None:
+            return (None,) * 10
+        x, w, y, gamma, beta, save_mean, save_var = ctx.saved_tensors
+        training, relu = ctx.cfg
+        M, K = x.shape
+        N = w.shape[1]
+        dout = dout.contiguous() if dout.stride(-1) != 1 else dout
+        dop, lddo = rows_ptr(dout)
+        xp, ldx = rows_ptr(x)
+        dx = _lib.zeros((M, K), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
+        gw = _ParamGrad(w, ctx.needs_input_grad[1])
+        gbias = _ParamGrad(ctx.bvar, ctx.bvar is not None and ctx.needs_input_grad[2])
+        gg = _ParamGrad(gamma, gamma is not None and ctx.needs_input_grad[3])
+        gbeta = _ParamGrad(beta, beta is not None and ctx.needs_input_grad[4])
+        grads = [g for g in (gbias, gg, gbeta) if g.needed]
+        acc = 1 if any(g.accumulate for g in grads) else 0
+        if acc:                                             # mixed freshness: zero the fresh ones
+            for g in grads:
+                if not g.accumulate:
+                    g.buf.zero_()
+        _lib.check(L().cloudaae_fc_backward(
+            M, K, N, xp, ldx, ptr(w), ptr(y), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_var), training, relu,
+            dop, lddo, ptr(dx), K, ptr(gw.buf), int(gw.accumulate), ptr(gg.buf), ptr(gbeta.buf), ptr(gbias.buf),
+            acc, stream()), "cloudaae_fc_backward")
+        return (dx, gw.done() if gw.needed else None, gbias.done() if gbias.needed else None,
+                gg.done() if gg.needed else None, gbeta.done() if gbeta.needed else None, None, None, None, None,
+                None)
+
+
+class FcGroupFn(torch.autograd.Function):
+    """Several independent fully connected layers of one batch (<= 32 rows) in ONE launch per direction
+    (cloudaae_fc_forward_group / _backward_group): depth by depth, the decoder and the two pose heads
+    (models/pointnet_ycb_23_decoder_4.py:413-455).
+
+    apply(cfg, decay, *tensors): cfg = (n_inputs, x_index per layer, training, relu per layer);
+    tensors = the n_inputs input matrices, then per layer (w, b, gamma, beta, ema_mean, ema_var) with
+    gamma .. ema_var None for a layer without batch norm.  Returns one output per layer.  Layers that
+    read the same input add their input gradients into one buffer (no separate sum)."""
+
+    @staticmethod
+    def forward(ctx, cfg, decay, *tensors):
+        n_in, x_index, training, relus = cfg
+        ctx.set_materialize_grads(False)
+        xs = tensors[:n_in]
+        per = [tensors[n_in + 6 * i:n_in + 6 * i + 6] for i in range(len(x_index))]
+        dev = xs[0].device
+        M = xs[0].shape[0]
+        rec = _lib.recording() is not None
+        layers = (_lib.FcLayer * len(per))()
+        outs, keep = [], []
+        for i, (w, b, gamma, beta, ema_mean, ema_var) in enumerate(per):
+            x = xs[x_index[i]]
+            require(x.dim() == 2 and x.shape[0] == M and x.shape[1] == w.shape[0], "FcGroupFn: shape mismatch")
+            xp, ldx = rows_ptr(x)
+            K, N = w.shape
+            bn = gamma is not None
+            # a product cut over K adds its slices into y: while a step is recorded y comes from the
+            # plan's zero zone (one clear per replay), otherwise the call clears it
+            y = _lib.zeros((M, N), dtype=torch.float32, device=dev) if rec else \
+                _lib.empty((M, N), dtype=torch.float32, device=dev)
+            out = save_mean = save_var = tickets = None
+            if bn:
+                out = _lib.empty((M, N), dtype=torch.float32, device=dev)
+                save_mean = _lib.empty(N, dtype=torch.float32, device=dev)
+                save_var = _lib.empty(N, dtype=torch.float32, device=dev)
+                # arrival counters of the column tiles (zero before and after every launch)
+                tickets = _lib.zeros(L().cloudaae_fc_forward_tickets(N), dtype=torch.int32, device=dev)
+            l = layers[i]
+            l.K, l.N, l.x, l.ldx, l.w, l.bias = K, N, xp, ldx, ptr(w), ptr(b)
+            l.gamma, l.beta, l.ema_mean, l.ema_var = ptr(gamma), ptr(beta), ptr(ema_mean), ptr(ema_var)
+            l.save_mean, l.save_var, l.relu = ptr(save_mean), ptr(save_var), int(bool(relus[i]))
+            l.y, l.out, l.tickets = ptr(y), ptr(out), ptr(tickets)
+            outs.append(out if bn else y)
+            keep.append((y if bn else None, save_mean, save_var, tickets))
+        _lib.check(L().cloudaae_fc_forward_group(M, len(per), layers, int(bool(training)), ptr(decay),
+                                                 1 if rec else 0, stream()), "cloudaae_fc_forward_group")
+        ctx.cfg, ctx.xs, ctx.per, ctx.keep, ctx.fwd_layers = cfg, xs, per, keep, layers
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        n_in, x_index, training, relus = ctx.cfg
+        xs, per, keep = ctx.xs, ctx.per, ctx.keep
+        M = xs[0].shape[0]
+        live = [i for i, d in enumerate(douts) if d is not None]
+        grads = [None] * (2 + n_in + 6 * len(per))
+        if not live:
+            return tuple(grads)
+        dxs = [None] * n_in
+        for j in range(n_in):
+            if ctx.needs_input_grad[2 + j] and any(x_index[i] == j for i in live):
+                dxs[j] = _lib.zeros(xs[j].shape, dtype=torch.float32, device=xs[j].device)
+        layers = (_lib.FcLayer * len(live))()
+        hold, done = [], []
+        for n, i in enumerate(live):
+            w, b, gamma, beta, _, _ = per[i]
+            y, save_mean, save_var, _ = keep[i]
+            x = xs[x_index[i]]
+            dout = douts[i]
+            dout = dout.contiguous() if dout.stride(-1) != 1 else dout
+            dop, lddo = rows_ptr(dout)
+            xp, ldx = rows_ptr(x)
+            base = 2 + n_in + 6 * i
+            gw = _ParamGrad(w, ctx.needs_input_grad[base])
+            gbias = _ParamGrad(b, b is not None and ctx.needs_input_grad[base + 1])
+            gg = _ParamGrad(gamma, gamma is not None and ctx.needs_input_grad[base + 2])
+            gbeta = _ParamGrad(beta, beta is not None and ctx.needs_input_grad[base + 3])
+            col = [g for g in (gbias, gg, gbeta) if g.needed]
+            acc = 1 if any(g.accumulate for g in col) else 0
+            if acc:                                             # mixed freshness: zero the fresh ones
+                for g in col:
+                    if not g.accumulate:
+                        g.buf.zero_()
+            l = layers[n]
+            l.K, l.N, l.x, l.ldx, l.w = w.shape[0], w.shape[1], xp, ldx, ptr(w)
+            l.gamma, l.beta, l.save_mean, l.save_var = ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_var)
+            l.relu, l.y = int(bool(relus[i])), ptr(y)
+            l.dout, l.lddo = dop, lddo
+            dx = dxs[x_index[i]]
+            l.dx, l.lddx = ptr(dx), (x.shape[1] if dx is not None else 0)
+            l.dw, l.accumulate_dw = ptr(gw.buf), int(gw.accumulate)
+            l.dgamma, l.dbeta, l.dbias, l.accumulate_param_grads = ptr(gg.buf), ptr(gbeta.buf), ptr(gbias.buf), acc
+            hold.append(dout)
+            done.append((base, gw, gbias, gg, gbeta))
+        _lib.check(L().cloudaae_fc_backward_group(M, len(live), layers, int(bool(training)), stream()),
+                   "cloudaae_fc_backward_group")
+        ctx.bwd_layers = layers
+        for base, gw, gbias, gg, gbeta in done:
+            for k, g in enumerate((gw, gbias, gg, gbeta)):
+                grads[base + k] = g.done() if g.needed else None
+        for j in range(n_in):
+            grads[2 + j] = dxs[j]
+        return tuple(grads)
+
+
 class ConcatSlot(object):
     """The one [B,N,Ctot] buffer the encoder's layer outputs are written into as column slices
     (the tf.concat of models/...:410 without a copy) and, in backward, its gradient twin: the agg

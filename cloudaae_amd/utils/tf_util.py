@@ -194,22 +194,81 @@ def fully_connected(inputs,
     """
     require(inputs.dim() == 2, "fully_connected: inputs must be BxN")
     act = _check_activation(activation_fn)
-    num_input_units = inputs.shape[-1]
+    weights, biases, gamma, beta, ema_mean, ema_var = _fc_variables(
+        scope, inputs.shape[-1], num_outputs, bn, use_xavier=use_xavier, stddev=stddev, weight_decay=weight_decay,
+        trainable=trainable)
+    if F.fc_fits(inputs.shape[0]):      # a batch of <= 32 clouds: the whole layer is one launch
+        require(bn or not act, "fully_connected: ReLU without batch norm does not occur in CloudAAE")
+        outputs = F.FcFn.apply(inputs, weights, biases, gamma, beta, ema_mean, ema_var,
+                               _decay_tensor(bn_decay) if bn else None, bool(is_training), act)
+        return outputs, weights, biases
+    outputs = F.LinearFn.apply(inputs, weights, biases, bool(bn), False)   # FC stack: always fp32
+    if bn:
+        outputs, _, _ = F.BatchNormFn.apply(outputs, gamma, beta, ema_mean, ema_var, _decay_tensor(bn_decay),
+                                            bool(is_training), act, 0, 0, True, biases)
+    elif act:
+        outputs = _relu_rows(outputs)
+    return outputs, weights, biases
+
+
+def _fc_variables(scope, num_inputs, num_outputs, bn, use_xavier=True, stddev=1e-3, weight_decay=0.0,
+                  trainable=None):
+    """The variables of one fully_connected layer, created (first call) in the reference's order
+    (tf_util.py:345-355): weights, biases, then bn/beta, bn/gamma and the two EMA shadows."""
+    gamma = beta = ema_mean = ema_var = None
     with variable_scope(scope):
-        weights = _variable_with_weight_decay('weights', [num_input_units, num_outputs], stddev=stddev,
+        weights = _variable_with_weight_decay('weights', [num_inputs, num_outputs], stddev=stddev,
                                               wd=weight_decay, use_xavier=use_xavier, trainable=trainable,
-                                              fan=(num_input_units, num_outputs))
+                                              fan=(num_inputs, num_outputs))
         biases = _variable_on_cpu('biases', [num_outputs], VariableStore.constant(0.0), trainable=trainable)
-        outputs = F.LinearFn.apply(inputs, weights.data, biases.data, bool(bn), False)   # FC stack: always fp32
         if bn:
             with variable_scope('bn'):
                 beta, gamma, ema_mean, ema_var = _bn_variables(num_outputs)
-            outputs, _, _ = F.BatchNormFn.apply(outputs, gamma.data, beta.data, ema_mean.data, ema_var.data,
-                                                _decay_tensor(bn_decay), bool(is_training), act, 0, 0, True,
-                                                biases.data)
-        elif act:
-            outputs = _relu_rows(outputs)
-    return outputs, weights.data, biases.data
+            beta, gamma, ema_mean, ema_var = beta.data, gamma.data, ema_mean.data, ema_var.data
+    return weights.data, biases.data, gamma, beta, ema_mean, ema_var
+
+
+def fully_connected_chains(inputs, chains, bn_decay=None, is_training=None):
+    """Several independent chains of fully_connected layers over one input -- the decoder and the two
+    pose heads of models/pointnet_ycb_23_decoder_4.py:413-455 -- evaluated depth by depth: with a batch of
+    <= 32 clouds the layers of one depth share a launch per direction (F.FcGroupFn), otherwise each layer
+    runs as fully_connected() does.  chains: list of chains; a chain is a list of
+    (scope, num_outputs, bn) with ReLU exactly on the bn layers.  Variables are created chain by chain,
+    i.e. in the order separate fully_connected() calls would create them.  Returns the chain outputs."""
+    require(inputs.dim() == 2, "fully_connected_chains: inputs must be BxN")
+    if not F.fc_fits(inputs.shape[0]) or len(chains) > F.fc_max_group():
+        outs = []
+        branches = F.FanOutFn.apply(inputs, len(chains)) if len(chains) > 1 else (inputs,)
+        for net, chain in zip(branches, chains):
+            for scope, num_outputs, bn in chain:
+                net, _, _ = fully_connected(net, num_outputs, scope, bn=bn, is_training=is_training,
+                                            bn_decay=bn_decay, activation_fn=relu if bn else None)
+            outs.append(net)
+        return outs
+    variables = []
+    for chain in chains:
+        cin, row = inputs.shape[-1], []
+        for scope, num_outputs, bn in chain:
+            row.append(_fc_variables(scope, cin, num_outputs, bn))
+            cin = num_outputs
+        variables.append(row)
+    decay = _decay_tensor(bn_decay) if any(bn for chain in chains for _, _, bn in chain) else None
+    depth = max(len(c) for c in chains)
+    nets = [None] * len(chains)
+    for d in range(depth):
+        members = [i for i, c in enumerate(chains) if d < len(c)]
+        if d == 0:
+            xs, x_index = [inputs], [0] * len(members)      # one input: the consumers' gradients add up in place
+        else:
+            xs, x_index = [nets[i] for i in members], list(range(len(members)))
+        flat = []
+        for i in members:
+            flat.extend(variables[i][d])
+        cfg = (len(xs), tuple(x_index), bool(is_training), tuple(bool(chains[i][d][2]) for i in members))
+        outs = F.FcGroupFn.apply(cfg, decay, *(xs + flat))
+        for i, o in zip(members, outs):
+            nets[i] = o
+    return nets
 
 
 def _relu_rows(x):

@@ -148,6 +148,71 @@ int cloudaae_bn_backward(int M, int C, const float *y, int ldy, const float *gam
 int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, float *out, int accumulate, void *workspace,
                         cloudaae_stream_t stream);
 
+/* ---- a whole fully connected layer at small batch ------------------------ */
+
+/* tf_util.fully_connected (utils/tf_util.py:321-365: tf.matmul :351, bias_add :352, batch_norm_for_fc
+ * :355, activation :358) as ONE launch per direction when the rows are the clouds of a batch of at
+ * most cloudaae_fc_max_rows() (= 32): the decoder and pose heads of
+ * models/pointnet_ycb_23_decoder_4.py:413-455.  Larger batches take cloudaae_gemm_f32 + cloudaae_bn_*.
+ *
+ * forward: y[M,N] = x[M,K] w[K,N] + bias (bias may be NULL); with gamma != NULL also the batch norm of
+ * y (arguments as cloudaae_bn_forward) into out[M,N], y keeping the pre-normalisation values the
+ * backward needs.  gamma == NULL: no batch norm, only y is written.  y_zeroed != 0: y is known to hold
+ * zeros (a product cut over K adds its slices into it; otherwise the call clears it first).
+ * tickets: cloudaae_fc_forward_tickets(N) ints holding ZERO, left zero by the call (arrival counters
+ * that let a layer WITH batch norm be cut over K: the last slice to arrive normalises the column tile);
+ * NULL = such a layer keeps K whole in one workgroup per 128 columns (slower).  Two calls in flight at
+ * the same time (different streams) need separate counters. */
+int cloudaae_fc_max_rows(void);
+int cloudaae_fc_forward_tickets(int N);
+int cloudaae_fc_forward(int M, int K, int N, const float *x, int ldx, const float *w, const float *bias,
+                        const float *gamma, const float *beta, int training, const float *decay,
+                        float *ema_mean, float *ema_var, float *save_mean, float *save_var, int relu,
+                        float *y, float *out, int y_zeroed, int *tickets, cloudaae_stream_t stream);
+/* backward of the same layer from dout[M,N] (gradient of `out`, or of y when gamma == NULL):
+ *   dx[M,K] += d(y) w^T      (ADDED with fp32 atomics: pass zeros, or a buffer that other consumers
+ *                             of x add their gradients to as well; NULL = not wanted)
+ *   dw[K,N] (+)= x^T d(y)    (accumulate_dw; NULL = not wanted)
+ *   dgamma, dbeta, dbias (+)= as cloudaae_bn_backward (accumulate_param_grads; NULL = not wanted;
+ *                             without batch norm dbias = column sums of dout). */
+int cloudaae_fc_backward(int M, int K, int N, const float *x, int ldx, const float *w, const float *y,
+                         const float *gamma, const float *beta, const float *save_mean,
+                         const float *save_var, int training, int relu, const float *dout, int lddo,
+                         float *dx, int lddx, float *dw, int accumulate_dw, float *dgamma, float *dbeta,
+                         float *dbias, int accumulate_param_grads, cloudaae_stream_t stream);
+
+/* Up to cloudaae_fc_max_group() (= 4) INDEPENDENT layers of the same batch in one launch per
+ * direction: the decoder and the two pose heads are three chains of three layers
+ * (models/pointnet_ycb_23_decoder_4.py:413-455), so depth by depth they are three launches forward and
+ * three backward instead of nine each.  One record per layer, fields as the arguments of
+ * cloudaae_fc_forward / cloudaae_fc_backward above (forward reads the first block, backward both).
+ * Layers that share their input x may share dx: the gradients of all consumers add up in it. */
+typedef struct cloudaae_fc_layer {
+    int K, N;
+    const float *x;
+    int ldx;
+    const float *w, *bias;
+    const float *gamma, *beta;          /* gamma NULL: no batch norm */
+    float *ema_mean, *ema_var, *save_mean, *save_var;
+    int relu;
+    float *y, *out;
+    int *tickets;
+    /* backward */
+    const float *dout;
+    int lddo;
+    float *dx;
+    int lddx;
+    float *dw;
+    int accumulate_dw;
+    float *dgamma, *dbeta, *dbias;
+    int accumulate_param_grads;
+} cloudaae_fc_layer;
+int cloudaae_fc_max_group(void);
+int cloudaae_fc_forward_group(int M, int count, const cloudaae_fc_layer *layers, int training,
+                              const float *decay, int y_zeroed, cloudaae_stream_t stream);
+int cloudaae_fc_backward_group(int M, int count, const cloudaae_fc_layer *layers, int training,
+                               cloudaae_stream_t stream);
+
 /* ---- the DGCNN edge-convolution block, fused ---------------------------- */
 
 /* get_edge_feature + conv2d 1x1 + batch norm + ReLU + pool over k

@@ -1,0 +1,181 @@
+"""GPU: a whole fully connected layer per launch (csrc/fc.hip, batches of <= 32 clouds) against the
+oracle's fully_connected (oracle/model_oracle.py: matmul + bias + batch_norm + ReLU, autograd for the
+gradients) on the same seeded inputs.  fp32 sums in a different order: compared to round-off."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(got, want):
+    got = got.detach().cpu().double().numpy()
+    want = want.detach().cpu().double().numpy()
+    return np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
+
+
+def _oracle_layer(oracle, x, W, b, gamma, beta, sm, sv, training, relu, decay=0.9):
+    MO = oracle
+    V = MO.Vars(0)
+    V.p["s/weights"], V.p["s/biases"] = W, b
+    bn = gamma is not None
+    if bn:
+        V.p["s/bn/beta"], V.p["s/bn/gamma"] = beta, gamma
+        V.s["s/bn/moments/Squeeze/ExponentialMovingAverage"] = sm
+        V.s["s/bn/moments/Squeeze_1/ExponentialMovingAverage"] = sv
+    return MO.fully_connected(x, W.shape[1], "s", V, bn=bn, is_training=training, bn_decay=decay, relu=relu)
+
+
+@pytest.fixture(scope="module")
+def model_oracle():
+    from oracle import model_oracle as MO
+    return MO
+
+
+SHAPES = [(32, 1024, 1024, True), (32, 1024, 512, True), (32, 512, 256, True), (32, 256, 3, False),
+          (32, 1024, 12288, False), (8, 1024, 1024, True), (1, 64, 40, False), (5, 100, 37, True),
+          (31, 33, 130, True), (32, 1000, 516, False), (2, 8, 4, True)]
+
+
+@pytest.mark.parametrize("M,K,N,bn", SHAPES)
+@pytest.mark.parametrize("training", [True, False])
+def test_fc_layer_vs_oracle(hip, model_oracle, M, K, N, bn, training):
+    from cloudaae_amd.utils import _functions as F
+    if M == 1 and bn and training:
+        pytest.skip("variance of one row")
+    g = torch.Generator().manual_seed(M * 7 + K + N)
+    x = torch.randn(M, K, generator=g).requires_grad_(True)
+    W = (torch.randn(K, N, generator=g) / np.sqrt(K)).requires_grad_(True)
+    b = (torch.randn(N, generator=g) * 0.1).requires_grad_(True)
+    gamma = beta = sm = sv = None
+    if bn:
+        gamma = (torch.rand(N, generator=g) + 0.5).requires_grad_(True)
+        beta = (torch.randn(N, generator=g) * 0.1).requires_grad_(True)
+        sm, sv = torch.randn(N, generator=g) * 0.1, torch.rand(N, generator=g) + 0.5
+    up = torch.randn(M, N, generator=g)
+    ref_sm, ref_sv = (sm.clone(), sv.clone()) if bn else (None, None)
+    want = _oracle_layer(model_oracle, x, W, b, gamma, beta, ref_sm, ref_sv, training, bn)
+    (want * up).sum().backward()
+
+    def dev(t):
+        return None if t is None else t.detach().cuda().requires_grad_(t.requires_grad)
+    xd, Wd, bd, gd, betad = dev(x), dev(W), dev(b), dev(gamma), dev(beta)
+    smd, svd = dev(sm), dev(sv)
+    decay = torch.full((1,), 0.9, device="cuda") if bn else None
+    out = F.FcFn.apply(xd, Wd, bd, gd, betad, smd, svd, decay, training, bn)
+    (out * up.cuda()).sum().backward()
+    assert _rel(out, want) < 3e-5
+    assert _rel(xd.grad, x.grad) < 3e-4
+    assert _rel(Wd.grad, W.grad) < 3e-4
+    assert _rel(bd.grad, b.grad) < 3e-4 or (bn and training and b.grad.abs().max() < 1e-4)
+    if bn:
+        assert _rel(gd.grad, gamma.grad) < 3e-4 and _rel(betad.grad, beta.grad) < 3e-4
+        if training:
+            assert _rel(smd, ref_sm) < 1e-5 and _rel(svd, ref_sv) < 1e-5
+
+
+def test_fc_backward_accumulates(hip):
+    """dx is ADDED into what the buffer holds (several consumers of one input share it), dw and the
+    per-column gradients add on request."""
+    from cloudaae_amd import _lib
+    L = _lib.lib()
+    M, K, N = 32, 96, 200
+    g = torch.Generator().manual_seed(5)
+    x, W = torch.randn(M, K, generator=g).cuda(), torch.randn(K, N, generator=g).cuda()
+    dout = torch.randn(M, N, generator=g).cuda()
+    dx0, dw0, db0 = torch.randn(M, K, generator=g).cuda(), torch.randn(K, N, generator=g).cuda(), \
+        torch.randn(N, generator=g).cuda()
+    dx, dw, db = dx0.clone(), dw0.clone(), db0.clone()
+    s = _lib.stream()
+    _lib.check(L.cloudaae_fc_backward(M, K, N, x.data_ptr(), K, W.data_ptr(), None, None, None, None, None, 1, 0,
+                                      dout.data_ptr(), N, dx.data_ptr(), K, dw.data_ptr(), 1, None, None,
+                                      db.data_ptr(), 1, s), "fc_backward")
+    torch.cuda.synchronize()
+    xd, Wd, dd = x.double(), W.double(), dout.double()
+    assert _rel(dx, dx0.double() + dd @ Wd.T) < 1e-5
+    assert _rel(dw, dw0.double() + xd.T @ dd) < 1e-5
+    assert _rel(db, db0.double() + dd.sum(0)) < 1e-5
+
+
+def test_fc_rejects_large_batches(hip):
+    from cloudaae_amd import _lib
+    L = _lib.lib()
+    assert L.cloudaae_fc_max_rows() == 32
+    x, W, y = torch.zeros(33, 8).cuda(), torch.zeros(8, 8).cuda(), torch.zeros(33, 8).cuda()
+    rc = L.cloudaae_fc_forward(33, 8, 8, x.data_ptr(), 8, W.data_ptr(), None, None, None, 0, None, None, None, None,
+                               None, 0, y.data_ptr(), None, 0, None, _lib.stream())
+    assert rc != 0 and "rows" in L.cloudaae_last_error().decode()
+
+
+def test_fc_forward_without_tickets_keeps_k_whole(hip):
+    """Batch norm over a product cut over K (arrival counters) and with K whole in one workgroup
+    (no counters) are the same layer; the counters are left at zero."""
+    from cloudaae_amd import _lib
+    L = _lib.lib()
+    M, K, N = 32, 1024, 512
+    g = torch.Generator().manual_seed(11)
+    x, W = torch.randn(M, K, generator=g).cuda(), (torch.randn(K, N, generator=g) / 32).cuda()
+    b, gamma, beta = torch.randn(N, generator=g).cuda(), torch.rand(N, generator=g).cuda() + 0.5, \
+        torch.randn(N, generator=g).cuda()
+    decay = torch.full((1,), 0.9, device="cuda")
+    res = []
+    for use in (True, False):
+        tk = torch.zeros(L.cloudaae_fc_forward_tickets(N), dtype=torch.int32, device="cuda") if use else None
+        y, out = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        sm, sv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+        mean, var = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+        for _ in range(3):      # repeated launches reuse the counters
+            _lib.check(L.cloudaae_fc_forward(M, K, N, x.data_ptr(), K, W.data_ptr(), b.data_ptr(), gamma.data_ptr(),
+                                             beta.data_ptr(), 1, decay.data_ptr(), sm.data_ptr(), sv.data_ptr(),
+                                             mean.data_ptr(), var.data_ptr(), 1, y.data_ptr(), out.data_ptr(), 0,
+                                             None if tk is None else tk.data_ptr(), _lib.stream()), "fc_forward")
+        torch.cuda.synchronize()
+        if use:
+            assert int(tk.abs().sum()) == 0
+        res.append((y, out, mean, var, sm))
+    for a, c in zip(*res):
+        assert _rel(a, c) < 1e-5
+    want = x.double() @ W.double() + b.double()
+    assert _rel(res[0][0], want) < 1e-5
+
+
+def test_fc_chains_vs_oracle(hip, model_oracle):
+    """Decoder + two pose heads over one embedding (three chains, three grouped launches per direction)
+    against the oracle's layer-by-layer evaluation: outputs, every parameter gradient, and the summed
+    gradient of the shared input."""
+    from cloudaae_amd.utils import tf_util
+    from cloudaae_amd.utils.variables import VariableStore, set_default_store
+    MO = model_oracle
+    B, E, P = 32, 1024, 3 * 4 * 64
+    chains = [[('d_fc1', 1024, True), ('d_fc2', 1024, True), ('d_out', P, False)],
+              [('r_fc1', 512, True), ('r_fc2', 256, True), ('r_out', 3, False)],
+              [('t_fc1', 512, True), ('t_fc2', 256, True), ('t_out', 3, False)]]
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(B, E, generator=g)
+    ups = [torch.randn(B, c[-1][1], generator=g) for c in chains]
+
+    store = VariableStore(device="cuda", seed=1)
+    set_default_store(store)
+    xd = emb.cuda().requires_grad_(True)
+    outs = tf_util.fully_connected_chains(xd, chains, bn_decay=0.9, is_training=True)
+    sum((o * u.cuda()).sum() for o, u in zip(outs, ups)).backward()
+
+    V = MO.Vars(0)
+    for name, var in store.vars.items():
+        if var.trainable:
+            V.p[name] = var.data.detach().cpu().clone().requires_grad_(True)
+    x = emb.clone().requires_grad_(True)
+    want = []
+    for chain in chains:
+        net = x
+        for scope, n, bn in chain:
+            net = MO.fully_connected(net, n, scope, V, bn=bn, is_training=True, bn_decay=0.9, relu=bn)
+        want.append(net)
+    sum((o * u).sum() for o, u in zip(want, ups)).backward()
+    for o, w in zip(outs, want):
+        assert _rel(o, w) < 1e-4
+    assert _rel(xd.grad, x.grad) < 1e-3
+    for name, p in V.p.items():
+        got = store.vars[name].data.grad
+        assert got is not None, name
+        assert _rel(got, p.grad) < 2e-3 or p.grad.abs().max() < 1e-5, name
