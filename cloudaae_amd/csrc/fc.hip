@@ -401,6 +401,57 @@ __device__ __forceinline__ void fc_bwd_dx(const FcBwdArgs &a, const float *dyl, 
         }
 }
 
+// The same product for the wide output layer (VEC only), W read the way it lies in memory.  Above, a lane
+// follows ONE row of W, so a load instruction touches 32 rows x 32 bytes: every 128-byte line is
+// requested by four instructions and crosses the L2 -> L1 path four times (2.1 TB/s on the 50 MB of the
+// output layer).  Here the wave reads 64-column halves of the tile row by row (half-wave = 256
+// contiguous bytes), parks them in its own LDS patch and takes the MFMA operand (lane = row) from
+// there.  Both halves are requested before the first is consumed.
+constexpr int FC_WLD = 64 + 4;      // LDS row stride of the half tile (floats)
+
+__device__ __forceinline__ void fc_bwd_dx_staged(const FcBwdArgs &a, const float *dyl, float *patch, int kr0,
+                                                 int n0, int r32, int half, int lane)
+{
+    // load h, i: rows 4 i + (lane >> 4), columns 64 h + 4 (lane & 15)
+    const int lrow = lane >> 4, lcol = 4 * (lane & 15);
+    float4v wq[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = min(kr0 + 4 * i + lrow, a.K - 1);       // past K: an existing row, never written
+            const int col = min(n0 + 64 * h + lcol, a.N - 4);       // past N: meets zeros of dY
+            wq[h][i] = *reinterpret_cast<const float4v *>(a.w + (size_t)row * a.N + col);
+        }
+    f32x16 d;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        d[r] = 0.0f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<float4v *>(patch + (4 * i + lrow) * FC_WLD + lcol) = wq[h][i];
+        // (wave-private patch: program order and the LDS counter are all the synchronisation needed)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4v aq = *reinterpret_cast<const float4v *>(dyl + r32 * FC_LD + 64 * h + 8 * q + 4 * half);
+            const float4v bq = *reinterpret_cast<const float4v *>(patch + r32 * FC_WLD + 8 * q + 4 * half);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j], bq[j], d, 0, 0, 0);
+        }
+    }
+    const int kr = kr0 + r32;
+    if (kr < a.K)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = mfma_row(r, half);
+            if (b < a.M)
+                atomicAdd(&a.dx[(size_t)b * a.lddx + kr], d[r]);
+        }
+}
+
 struct FcBwdGroup {
     int count;
     FcBwdArgs p[FC_MAX_GROUP];
@@ -413,7 +464,7 @@ struct FcBwdGroup {
 //            workgroup, every workgroup resident at once).
 template <bool VEC>
 __device__ __forceinline__ void fc_bwd_body(const FcBwdArgs &a, int slice_x, int group_y, float *dyl,
-                                            double (*red)[2][FC_TN])
+                                            double (*red)[2][FC_TN], float *patches)
 {
     constexpr int HF = 2, RP = FC_M / HF;       // row groups of the first phase, rows per thread
     const int n0 = slice_x * FC_TN;
@@ -528,8 +579,12 @@ __device__ __forceinline__ void fc_bwd_body(const FcBwdArgs &a, int slice_x, int
         for (int t = group_y * a.tiles_per_block + wv; t < t_end; t += 4) {
             if (a.dw != nullptr)
                 fc_bwd_dw<VEC, 4>(a, dyl, t * 32, n0 + 4 * r32, 4 * r32, r32, half);
-            if (a.dx != nullptr)
-                fc_bwd_dx<VEC, 16>(a, dyl, t * 32, n0, 0, r32, half);
+            if (a.dx != nullptr) {
+                if (VEC)
+                    fc_bwd_dx_staged(a, dyl, patches + wv * (FC_M * FC_WLD), t * 32, n0, r32, half, lane);
+                else
+                    fc_bwd_dx<VEC, 16>(a, dyl, t * 32, n0, 0, r32, half);
+            }
         }
     } else {
         const int side = wv & 1;
@@ -548,13 +603,14 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdGroup g)
 {
     __shared__ float4v dy4[FC_M * (FC_LD / 4)];
     __shared__ double red[2][2][FC_TN];
+    __shared__ float4v patch4[4 * FC_M * (FC_WLD / 4)];
     const FcBwdArgs a = g.p[fc_group_member(g)];
     const int local = (int)blockIdx.x - a.block0;
     const int slice_x = local % a.slices, group_y = local / a.slices;
     if (a.vec)
-        fc_bwd_body<true>(a, slice_x, group_y, reinterpret_cast<float *>(dy4), red);
+        fc_bwd_body<true>(a, slice_x, group_y, reinterpret_cast<float *>(dy4), red, reinterpret_cast<float *>(patch4));
     else
-        fc_bwd_body<false>(a, slice_x, group_y, reinterpret_cast<float *>(dy4), red);
+        fc_bwd_body<false>(a, slice_x, group_y, reinterpret_cast<float *>(dy4), red, reinterpret_cast<float *>(patch4));
 }
 
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
