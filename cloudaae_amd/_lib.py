@@ -36,12 +36,13 @@ _SIGNATURES = {
     "cloudaae_fc_forward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
     "cloudaae_fc_backward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P,
                              _P, _I, _P],
+    "cloudaae_stream_wait": [_P, _P],
     "cloudaae_fc_forward_group": [_I, _I, _P, _I, _P, _I, _P],
     "cloudaae_fc_backward_group": [_I, _I, _P, _I, _P],
     "cloudaae_edgeconv_forward": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P,
                                   _P, _P, _P, _I, _P, _I, _P, _P],
     "cloudaae_edgeconv_backward": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P,
-                                   _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P],
+                                   _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P],
     "cloudaae_input_assemble": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "cloudaae_add_rowvec": [_I, _I, _I, _P, _P, _P, _P],
     "cloudaae_add_f32": [_L, _P, _P, _P, _P],
@@ -251,6 +252,8 @@ def lib():
         for q in ("cloudaae_fc_max_rows", "cloudaae_fc_max_group"):
             getattr(cdll, q).argtypes = []
             getattr(cdll, q).restype = ctypes.c_int
+        cdll.cloudaae_side_stream.argtypes = []
+        cdll.cloudaae_side_stream.restype = ctypes.c_void_p
         cdll.cloudaae_fc_forward_tickets.argtypes = [_I]
         cdll.cloudaae_fc_forward_tickets.restype = ctypes.c_int
         cdll.cloudaae_edgeconv_workspace_bytes.argtypes = [_I]
@@ -347,6 +350,20 @@ def check(rc, what):
     if rc != 0:
         msg = lib().cloudaae_last_error().decode("utf-8", "replace")
         raise HipLibraryError("%s failed with hipError %d: %s" % (what, rc, msg))
+
+
+def side_stream():
+    """The library's low-priority stream for work off the critical path (raw hipStream_t)."""
+    p = lib()._cdll.cloudaae_side_stream()
+    if not p:
+        raise HipLibraryError("cloudaae_side_stream failed: %s" % lib().cloudaae_last_error().decode("utf-8", "replace"))
+    return p
+
+
+def stream_wait(waiter, signaller):
+    """Everything enqueued on `signaller` so far precedes what `waiter` gets from now on (recorded
+    into the plan like any launching call)."""
+    check(lib().cloudaae_stream_wait(waiter, signaller), "cloudaae_stream_wait")
 
 
 def stream():

@@ -598,7 +598,7 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
                                             int *rev_scratch, float *dx, int lddx, int accumulate_dx,
                                             float *dweights, int dweights_zeroed, float *dbiases, float *dgamma,
                                             float *dbeta, int gemm_bf16, void *workspace,
-                                            cloudaae_stream_t stream)
+                                            cloudaae_stream_t stream, cloudaae_stream_t side_stream)
 {
     const char *name = "cloudaae_edgeconv_backward";
     if (int rc = ec_check(name, b, n, k, cin, cout, pool_mode))
@@ -607,10 +607,25 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
     CLOUDAAE_REQUIRE(pool_mode != 2 || (out && tie_count), name, "max pool backward needs the forward output and tie count");
     CLOUDAAE_REQUIRE((size_t)n * sizeof(int) <= 150 * 1024, name, "cloud too large for the LDS counting sort");
     hipStream_t s = (hipStream_t)stream;
+    // side stream (optional): the reverse neighbour lists depend on nothing this call computes, so they
+    // are built there while the statistics pass runs here; the weight gradient, which nothing waits for
+    // until the optimiser, follows them there.  The CALLER joins (cloudaae_stream_wait(stream, side)).
+    const bool two = side_stream != nullptr && side_stream != stream;
+    hipStream_t side = two ? (hipStream_t)side_stream : s;
     const int P = b * n;
     double *partial = (double *)workspace;
     float *scratch = (float *)(partial + (size_t)EC_MAX_PARTS * 4 * cout);
     float *m12 = scratch + 2 * (size_t)cout;
+    int *rev_off = rev_scratch, *rev_src = rev_scratch + (size_t)b * (n + 1);
+    if (two) {
+        if (int rc = cloudaae_stream_wait(side_stream, stream))
+            return rc;
+        const size_t lds = (size_t)n * sizeof(int);
+        if (lds > 48 * 1024)
+            CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)ec_revlist_kernel,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
+        hipLaunchKernelGGL(ec_revlist_kernel, dim3(b), dim3(512), lds, side, n, k, nn_idx, rev_off, rev_src);
+    }
     EcArgs a = {};
     a.P = P; a.N = n; a.k = k; a.cout = cout; a.ldpq = 2 * cout;
     a.pq = pq; a.bias = biases; a.nn_idx = nn_idx; a.scale_shift = nullptr;   // backward kernels derive it per lane
@@ -630,8 +645,10 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
     hipLaunchKernelGGL(ec_bwd_finalize_kernel, dim3(ceil_div(cout, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, cout, partial,
                        partial + (size_t)EC_MAX_PARTS * 2 * cout, grid, (double)P * (double)k, training, gamma,
                        save_var, dgamma, dbeta, dbiases, m12);
-    int *rev_off = rev_scratch, *rev_src = rev_scratch + (size_t)b * (n + 1);
-    {
+    if (two) {
+        if (int rc = cloudaae_stream_wait(stream, side_stream))    // the lists are ready before the apply pass
+            return rc;
+    } else {
         const size_t lds = (size_t)n * sizeof(int);
         if (lds > 48 * 1024)
             CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)ec_revlist_kernel,
@@ -658,8 +675,11 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
     }
     if (dweights != nullptr) {
         const int wacc = dweights_zeroed ? 2 : 0;     // 2: the caller cleared dweights already
+        if (two)
+            if (int rcw = cloudaae_stream_wait(side_stream, stream))   // dpq is complete
+                return rcw;
         rc = ec_gemm(name, gemm_bf16, 1, 0, cin, 2 * cout, P, x, ldx, dpq, 2 * cout, dweights, cout, wacc, 0, cout,
-                     stream);
+                     (cloudaae_stream_t)side);
         if (rc)
             return rc;
     }

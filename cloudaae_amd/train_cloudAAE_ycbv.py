@@ -88,7 +88,7 @@ class TrainGraph(object):
 
     def __init__(self, general_opts=None, train_opts=None, hyperparameters=None, device=None,
                  model_fn='get_model_dgcnn_mean_6d', k_neighbor=K_NEIGHBOR, process_group=None, seed=123456789,
-                 replay=False, gemm_dtype='f32'):
+                 replay=False, gemm_dtype='f32', side_stream=None):
         general_opts = dict(general_opts or {})
         train_opts = dict(train_opts or {})
         hyperparameters = dict(hyperparameters or {})
@@ -99,6 +99,13 @@ class TrainGraph(object):
         require(self.OPTIMIZER in ('adam', 'gd'), "optimizer must be adam or gd")
         self.device = torch.device(device if device is not None else 'cuda:%d' % int(general_opts.get('gpu', 0)))
         self.k = int(k_neighbor)
+        # side_stream: weight-gradient products of the per-point layers and the reverse neighbour lists on
+        # the library's low-priority stream.  OFF by default: measured SLOWER at B=32 (2.35 ms/step with
+        # every edge-conv layer using it, 2.32 with only the dgcnn_agg weight gradient, 2.25 without) --
+        # the concurrent GEMM takes L2 and CUs from the gather-bound kernels it overlaps, and every
+        # cross-stream dependency costs microseconds.  CLOUDAAE_SIDE_STREAM=1 (or =agg) switches it on.
+        self.side_stream = (os.environ.get("CLOUDAAE_SIDE_STREAM", "0") != "0") if side_stream is None \
+            else bool(side_stream)
         # process_group: None = the default group when torch.distributed is initialised;
         # False = single-process even then; or an explicit group
         solo = process_group is False or not (dist.is_available() and dist.is_initialized())
@@ -224,8 +231,18 @@ class TrainGraph(object):
         _lib.check(L.cloudaae_bn_decay_schedule(ptr(self.batch), float(self.BATCH_SIZE), BN_INIT_DECAY,
                                                 BN_DECAY_DECAY_STEP, BN_DECAY_DECAY_RATE, BN_DECAY_CLIP,
                                                 ptr(self.bn_decay), s), "cloudaae_bn_decay_schedule")
-        out = self.forward(element, is_training=True)
-        out['total_loss'].backward(self._one)
+        # weight-gradient products of the per-point layers and the reverse neighbour lists run on the
+        # library's low-priority side stream (F.SIDE_STREAM) and are joined before anyone reads a gradient
+        side = _lib.side_stream() if self.side_stream else None
+        F.SIDE_STREAM = side
+        F.SIDE_EDGE = os.environ.get("CLOUDAAE_SIDE_STREAM", "0") != "agg"
+        try:
+            out = self.forward(element, is_training=True)
+            out['total_loss'].backward(self._one)
+        finally:
+            F.SIDE_STREAM = None
+        if side is not None:
+            _lib.stream_wait(stream(), side)
         _lib.host(self.exchange.finish)   # RCCL all-reduce of the flat gradient buffer (no-op for 1 rank)
         n = self.store.flat_params.numel()
         scale = self.exchange.scale

@@ -79,12 +79,21 @@ def gemm_is_bf16():
     return GEMM_DTYPE == "bf16"
 
 
-def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, accumulate=0, site=None, bf16=False):
+# Work nobody waits for until the optimiser runs (the weight-gradient products of the per-point layers) and
+# the reverse neighbour lists go to SIDE_STREAM when it is set (a raw hipStream_t, _lib.side_stream()): they
+# fill the CUs the critical path leaves idle.  Whoever sets it joins -- _lib.stream_wait(stream(), SIDE_STREAM)
+# -- before consuming gradients (TrainGraph does, around backward); None = everything on the current stream.
+SIDE_STREAM = None
+SIDE_EDGE = True      # edge-convolution layers use it too (else only the dgcnn_agg weight gradient)
+
+
+def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, accumulate=0, site=None, bf16=False, on=None):
     rec = TIMED_SITES.get(site) if site is not None else None
     if rec is not None:
         _lib.host(_mark, rec)
     fn = L().cloudaae_gemm_bf16 if bf16 else L().cloudaae_gemm_f32
-    _lib.check(fn(int(ta), int(tb), M, N, K, A, lda, B, ldb, C, ldc, bias, int(accumulate), stream()),
+    _lib.check(fn(int(ta), int(tb), M, N, K, A, lda, B, ldb, C, ldc, bias, int(accumulate),
+                  stream() if on is None else on),
                "cloudaae_gemm_bf16" if bf16 else "cloudaae_gemm_f32")
     if rec is not None:
         _lib.host(_mark, rec)
@@ -390,7 +399,10 @@ class ConcatLinearFn(torch.autograd.Function):
                 ctx.slot.dcat = dcat
         gw = _ParamGrad(w, ctx.needs_input_grad[1])
         if gw.needed:
-            gemm(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.gemm_acc, bf16=ctx.bf16)
+            side = SIDE_STREAM if gw.own is None else None          # (a returned gradient is consumed at once)
+            if side is not None:
+                _lib.stream_wait(side, stream())                    # dy is complete
+            gemm(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.gemm_acc, bf16=ctx.bf16, on=side)
         gb_ret = None
         if ctx.bias_here and ctx.needs_input_grad[2]:
             gb = _ParamGrad(ctx.bvar, True)
@@ -567,7 +579,7 @@ class EdgeConvFn(torch.autograd.Function):
             fwd_out.data_ptr() if fwd_out is not None else None, fwd_out.stride(1) if fwd_out is not None else 0,
             ptr(ties), dout.data_ptr(), dout.stride(1), ptr(dpq), ptr(rev), dx_ptr, lddx, acc_dx, ptr(gw.buf),
             1 if (gw.needed and gw.gemm_acc == 2) else 0, ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), int(ctx.bf16),
-            ptr(ws), stream()),
+            ptr(ws), stream(), SIDE_STREAM if (SIDE_EDGE and not shared and gw.needed and gw.own is None) else None),
             "cloudaae_edgeconv_backward")
         for g in shared:
             L().cloudaae_add_f32(g.buf.numel(), ptr(tmp[id(g)]), ptr(g.buf), ptr(tmp[id(g)]), stream())

@@ -28,6 +28,15 @@ typedef void *cloudaae_stream_t; /* hipStream_t */
 int cloudaae_version(void);
 const char *cloudaae_last_error(void);
 
+/* Two-stream plumbing.  cloudaae_side_stream(): a low-priority stream owned by the library (one per
+ * process), for work off the critical path; NULL on failure.  cloudaae_stream_wait(waiter, signaller):
+ * everything enqueued on `signaller` so far completes before anything enqueued on `waiter` from now on
+ * (an event record + a stream wait; no host synchronisation).  A caller that hands a side stream to
+ * cloudaae_edgeconv_backward, or launches on it itself, joins with cloudaae_stream_wait(main, side)
+ * before it consumes the results. */
+cloudaae_stream_t cloudaae_side_stream(void);
+int cloudaae_stream_wait(cloudaae_stream_t waiter, cloudaae_stream_t signaller);
+
 /* ---- tf_ops/nn_distance ------------------------------------------------- */
 
 /* NnDistance forward, both directions in one launch.
@@ -241,7 +250,7 @@ int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int cout, const flo
                                int lddo, float *dpq, int *rev_scratch, float *dx, int lddx,
                                int accumulate_dx, float *dweights, int dweights_zeroed, float *dbiases,
                                float *dgamma, float *dbeta, int gemm_bf16, void *workspace,
-                               cloudaae_stream_t stream);
+                               cloudaae_stream_t stream, cloudaae_stream_t side_stream);
 
 /* ---- train_cloudAAE_ycbv.py:194-273: the step around the network --------- */
 

@@ -98,3 +98,29 @@ def test_replay_timed_site_and_eval(hip):
         F.TIMED_SITES.pop("agg_fwd", None)
     e = g.eval_step(el)                                  # the ordinary path still works next to a plan
     assert np.isfinite(float(e["xyz_loss"]))
+
+
+def test_side_stream_step_matches(hip):
+    """The optional side stream (weight gradients and reverse neighbour lists off the critical path) changes
+    scheduling only: one recorded step from the same state gives the same losses and gradients."""
+    from cloudaae_amd import train_cloudAAE_ycbv as T
+    B, N = 8, 128
+    mk = lambda side: T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, replay=True, side_stream=side)
+    one, two = mk(False), mk(True)
+    assert torch.equal(one.store.flat_params, two.store.flat_params)
+    for step in range(3):
+        with torch.no_grad():
+            for dst, src in ((two.store.flat_params, one.store.flat_params), (two.store.flat_state, one.store.flat_state),
+                             (two.adam_m, one.adam_m), (two.adam_v, one.adam_v), (two.batch, one.batch),
+                             (two.beta1_power, one.beta1_power), (two.beta2_power, one.beta2_power)):
+                dst.copy_(src)
+        el = T.synthetic_element(B, N, one.device, seed=40 + step)
+        el["noise"] = torch.randn((B, N, 3), device="cuda") * 0.001
+        o1, o2 = one.train_step(el), two.train_step(el)
+        torch.cuda.synchronize()
+        for k in ("xyz_loss", "trans_loss", "axag_loss", "total_loss"):
+            a, b = float(o1[k]), float(o2[k])
+            assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (step, k, a, b)
+        g1, g2 = one.store.flat_grads, two.store.flat_grads
+        assert float((g1 - g2).abs().max()) <= 2e-3 * float(g1.abs().max()), step
+    assert not two._plan.foreign_ops
