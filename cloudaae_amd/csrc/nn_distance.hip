@@ -148,6 +148,294 @@ __global__ __launch_bounds__(NN_THREADS) void nn_distance_kernel(
     }
 }
 
+// ---- second generation: matrix-core filter + exact verification -----------------------------------
+// The hot loop above spends 8.6 lane-operations per pair on arithmetic whose only purpose is to find
+// WHICH candidate is nearest.  Here the search runs on the matrix cores with a cheaper, differently
+// rounded score, and the reference's arithmetic is applied only where the answer is decided:
+//   * score s_ij = |b'_j|^2 - 2 a'_i . b'_j  (= d^2_ij - |a'_i|^2, the same order over j), primes =
+//     coordinates relative to the candidate cloud's first point (keeps the magnitudes, hence the
+//     rounding errors, small).  One 32 x 32 tile of scores is two v_mfma_f32_32x32x2_f32 (K = 4:
+//     [bx by bz |b|^2] x [-2ax -2ay -2az 1]); rows = candidates, columns = queries, so a lane's 16
+//     accumulator registers are 16 candidates of ITS query and the minimum is taken in the lane.
+//   * per query: the three best UNIT scores (a unit = the 16 rows of a tile in one lane half) and the
+//     units of the first two.
+//   * afterwards the 32 candidates of the two best units are evaluated with the reference's un-fused
+//     arithmetic (first index of the exact minimum wins).  That is the answer if no third unit can
+//     hold a candidate that is as near in the reference's arithmetic: s3 > s1 + M with
+//     M = 32 * 2^-24 * (|a'| + max_j |b'_j|)^2.  Bound: a score is a 4-term fp32 sum of exact products
+//     plus the rounded |b'|^2 (<= 7 ulp-units of R = (|a'|+|b'|max)^2), the translation by the centre
+//     moves a squared distance by <= 4 * 2^-24 * sqrt(R d^2) <= 4 * 2^-24 * R, and the reference's
+//     value is within 8 * 2^-24 * d^2 of the true one; two candidates whose scores differ by more than
+//     2 * (7 + 4 + 4) * 2^-24 * R = 30 * 2^-24 * R are therefore ordered the same way by the reference.
+//   * otherwise (three units within the margin: about one query in 10^4 of a 4096-point cloud; always
+//     when the data overflow or are NaN, the comparison being false) the wave scans ALL candidates of
+//     that query together with the reference's arithmetic.
+// Results are the reference's bit for bit; 2 MFMA + ~13 VALU instructions per 1024 pairs instead of
+// ~140.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int NF_QT = 4;            // query tiles (32 queries each) per wave
+constexpr int NF_WAVES = 4;
+constexpr int NF_QBLOCK = NF_WAVES * NF_QT * 32;   // queries per workgroup
+constexpr int NF_CHUNK = 2048;      // candidates per LDS chunk: 64 tiles x 64 lanes x 8 bytes = 32 KiB
+
+__device__ __forceinline__ bool key_less(unsigned d, int i, unsigned bd, int bi)
+{
+    return d < bd || (d == bd && i < bi);
+}
+
+// the 16 accumulator rows a lane holds: smallest score of its query among 16 candidates
+__device__ __forceinline__ float nf_min16(const f32x16 &v)
+{
+    float tm = fminf(fminf(v[0], v[1]), v[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2)
+        tm = fminf(fminf(tm, v[r]), v[r + 1]);
+    return fminf(tm, v[15]);
+}
+
+// the three best unit scores of a query seen so far (s1 <= s2 <= s3) and the units of the first two;
+// a unit = the 16 rows of one 32-candidate tile that one lane half holds
+struct NfTop {
+    float s1, s2, s3;
+    int u1, u2;
+    __device__ __forceinline__ void init()
+    {
+        s1 = s2 = s3 = __builtin_inff();
+        u1 = u2 = 0;
+    }
+    // units arrive in ascending order within a lane: strict '<' keeps the earlier one on ties
+    __device__ __forceinline__ void push(float v, int u)
+    {
+        const bool lt1 = v < s1, lt2 = v < s2, lt3 = v < s3;
+        s3 = lt2 ? s2 : (lt3 ? v : s3);
+        s2 = lt1 ? s1 : (lt2 ? v : s2);
+        u2 = lt1 ? u1 : (lt2 ? u : u2);
+        s1 = lt1 ? v : s1;
+        u1 = lt1 ? u : u1;
+    }
+    // the same with ties broken by the unit id (merging the two lane halves: both lanes of a query must
+    // arrive at the same order)
+    __device__ __forceinline__ void merge(float v, int u)
+    {
+        const bool lt1 = v < s1 || (v == s1 && u < u1), lt2 = v < s2 || (v == s2 && u < u2), lt3 = v < s3;
+        s3 = lt2 ? s2 : (lt3 ? v : s3);
+        s2 = lt1 ? s1 : (lt2 ? v : s2);
+        u2 = lt1 ? u1 : (lt2 ? u : u2);
+        s1 = lt1 ? v : s1;
+        u1 = lt1 ? u : u1;
+    }
+};
+
+__global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
+    int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    float *__restrict__ dist1, int *__restrict__ idx1, float *__restrict__ dist2,
+    int *__restrict__ idx2, int blocks1)
+{
+    __shared__ float2v cand[NF_CHUNK / 32 + 1][64];     // (+1: the pipeline reads one tile ahead)
+    __shared__ float bmax_s[NF_WAVES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c32 = lane & 31, half = lane >> 5;
+    const int cloud = blockIdx.y;
+    const bool second = (int)blockIdx.x >= blocks1;
+    const int blk = second ? (int)blockIdx.x - blocks1 : (int)blockIdx.x;
+    const int nq = second ? m : n, nc = second ? n : m;
+    const float *from = (second ? xyz2 : xyz1) + (size_t)cloud * nq * 3;
+    const float *to = (second ? xyz1 : xyz2) + (size_t)cloud * nc * 3;
+    float *dist = (second ? dist2 : dist1) + (size_t)cloud * nq;
+    int *idx = (second ? idx2 : idx1) + (size_t)cloud * nq;
+
+    const float cx = to[0], cy = to[1], cz = to[2];
+    float qx[NF_QT], qy[NF_QT], qz[NF_QT], b0[NF_QT], b1[NF_QT], a2[NF_QT];
+    NfTop top[NF_QT];
+#pragma unroll
+    for (int q = 0; q < NF_QT; ++q) {
+        const int j = min(blk * NF_QBLOCK + (wv * NF_QT + q) * 32 + c32, nq - 1);
+        qx[q] = from[3 * (size_t)j];
+        qy[q] = from[3 * (size_t)j + 1];
+        qz[q] = from[3 * (size_t)j + 2];
+        const float ax = qx[q] - cx, ay = qy[q] - cy, az = qz[q] - cz;
+        a2[q] = ax * ax + ay * ay + az * az;
+        b0[q] = half ? -2.0f * ay : -2.0f * ax;
+        b1[q] = half ? 1.0f : -2.0f * az;
+        top[q].init();
+    }
+
+    // scores of one candidate tile for the wave's four query tiles: 8 MFMAs
+    auto issue = [&](f32x16 (&acc)[NF_QT], int t) {
+        const float2v A = cand[t][lane];
+#pragma unroll
+        for (int q = 0; q < NF_QT; ++q) {
+            f32x16 zero;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                zero[r] = 0.0f;
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, b0[q], zero, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < NF_QT; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, b1[q], acc[q], 0, 0, 0);
+    };
+    auto consume = [&](const f32x16 (&acc)[NF_QT], int tile) {
+#pragma unroll
+        for (int q = 0; q < NF_QT; ++q)
+            top[q].push(nf_min16(acc[q]), tile);
+    };
+    // The MFMAs of tile t+1 are interleaved with the ~80 VALU instructions that digest tile t: one
+    // MFMA (64 cycles of the pipe), then ten VALU instructions in its shadow.  Without this two waves
+    // of a SIMD fall into step -- both queue on the matrix pipe, then both on the VALU -- and the loop
+    // costs the SUM of the two (1000 cycles per tile instead of 512).
+    auto interleave = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);     // ten VALU
+        }
+    };
+
+    float bmax2 = 0.0f;
+    for (int c0 = 0; c0 < nc; c0 += NF_CHUNK) {
+        const int cnt = min(NF_CHUNK, nc - c0);
+        const int padded = (cnt + 31) & ~31;
+        __syncthreads();
+        for (int k = tid; k < padded + 32; k += NF_WAVES * 64) {
+            float x = 0.0f, y = 0.0f, z = 0.0f, bb = __builtin_inff();     // padding never wins
+            if (k < cnt) {
+                const float *p = to + (size_t)(c0 + k) * 3;
+                x = p[0] - cx;
+                y = p[1] - cy;
+                z = p[2] - cz;
+                bb = x * x + y * y + z * z;
+                bmax2 = fmaxf(bmax2, bb);
+            }
+            // MFMA A operand: lane r holds k = 0 of row r, lane 32 + r holds k = 1
+            cand[k >> 5][k & 31] = float2v{x, z};
+            cand[k >> 5][32 + (k & 31)] = float2v{y, bb};
+        }
+        __syncthreads();
+        const int ntile = padded >> 5, t0 = c0 >> 5;
+        f32x16 accA[NF_QT], accB[NF_QT];
+        issue(accA, 0);
+        for (int t = 0; t < ntile; t += 2) {
+            issue(accB, t + 1);             // (tile ntile is all padding: computed, never consumed)
+            consume(accA, t0 + t);
+            interleave();
+            if (t + 1 < ntile) {
+                issue(accA, min(t + 2, ntile));
+                consume(accB, t0 + t + 1);
+                interleave();
+            }
+        }
+    }
+
+    // radius of the candidate cloud around its first point (for the margin)
+    {
+        float v = bmax2;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            v = fmaxf(v, __shfl_xor(v, off, 64));
+        if (lane == 0)
+            bmax_s[wv] = v;
+        __syncthreads();
+        bmax2 = fmaxf(fmaxf(bmax_s[0], bmax_s[1]), fmaxf(bmax_s[2], bmax_s[3]));
+    }
+    const float rb = sqrtf(bmax2);
+
+#pragma unroll
+    for (int q = 0; q < NF_QT; ++q) {
+        const int j = blk * NF_QBLOCK + (wv * NF_QT + q) * 32 + c32;
+        // the two lanes of a query merge what they saw: units 2 t + half are disjoint between them
+        NfTop g = top[q];
+        g.u1 = 2 * g.u1 + half;
+        g.u2 = 2 * g.u2 + half;
+        const float p1 = __shfl_xor(g.s1, 32, 64), p2 = __shfl_xor(g.s2, 32, 64), p3 = __shfl_xor(g.s3, 32, 64);
+        const int pu1 = __shfl_xor(g.u1, 32, 64), pu2 = __shfl_xor(g.u2, 32, 64);
+        g.merge(p1, pu1);
+        g.merge(p2, pu2);
+        g.merge(p3, 0x7fffffff);
+        const float r = sqrtf(a2[q]) + rb;
+        // (+ an absolute floor: below ~1e-37 the matrix cores may flush denormal terms, so relative bounds
+        // mean nothing there and such clouds always take the full scan)
+        const float margin = 32.0f * 5.9604645e-8f * (r * r) + 1e-36f;
+        // only the two best units can hold a candidate within the margin of the best score?
+        const bool decided = g.s3 > g.s1 + margin;      // false for NaN / overflow as well
+
+        // those two units in the reference's arithmetic: one per lane of the pair, 16 candidates each
+        unsigned kb = 0xffffffffu;
+        int ki = 0x7fffffff;
+        const int unit = half ? g.u2 : g.u1;
+        const int base = (unit >> 1) * 32 + 4 * (unit & 1);
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int k = base + (s & 3) + 8 * (s >> 2);
+            if (k < nc) {
+                const float d = sqdist(to[3 * (size_t)k], to[3 * (size_t)k + 1], to[3 * (size_t)k + 2], qx[q],
+                                       qy[q], qz[q]);
+                const unsigned u = __float_as_uint(d);
+                if (u < kb) {       // ascending k: the first minimum stays
+                    kb = u;
+                    ki = k;
+                }
+            }
+        }
+        {
+            const unsigned od = __shfl_xor(kb, 32, 64);
+            const int oi = __shfl_xor(ki, 32, 64);
+            if (key_less(od, oi, kb, ki)) {
+                kb = od;
+                ki = oi;
+            }
+        }
+        // a third unit within the margin (rare): the wave scans every candidate of that query together
+        unsigned long long todo = __ballot(!decided && half == 0 && j < nq);
+        while (todo) {
+            const int L = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float fx = __shfl(qx[q], L, 64), fy = __shfl(qy[q], L, 64), fz = __shfl(qz[q], L, 64);
+            unsigned sb = 0xffffffffu;
+            int si = 0x7fffffff;
+            constexpr int RU = 4;       // loads of four candidates in flight per lane
+            for (int k0 = lane; k0 < nc; k0 += 64 * RU) {
+                float px[RU], py[RU], pz[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int k = min(k0 + 64 * u, nc - 1);
+                    px[u] = to[3 * (size_t)k];
+                    py[u] = to[3 * (size_t)k + 1];
+                    pz[u] = to[3 * (size_t)k + 2];
+                }
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int k = k0 + 64 * u;
+                    const unsigned v = __float_as_uint(sqdist(px[u], py[u], pz[u], fx, fy, fz));
+                    if (k < nc && v < sb) {     // ascending k within the lane: the first minimum stays
+                        sb = v;
+                        si = k;
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned od = __shfl_xor(sb, off, 64);
+                const int oi = __shfl_xor(si, off, 64);
+                if (key_less(od, oi, sb, si)) {
+                    sb = od;
+                    si = oi;
+                }
+            }
+            if (c32 == L) {
+                kb = sb;
+                ki = si;
+            }
+        }
+        if (half == 0 && j < nq) {
+            dist[j] = __uint_as_float(kb);
+            idx[j] = ki;
+        }
+    }
+}
+
 // Backward: one thread per point and direction.  grad_a[j] += 2 g (a_j - b_t),
 // grad_b[t] -= same (tf_nndistance.cpp:131-161).  Both sweeps run concurrently
 // and accumulate with hardware fp32 atomics into zero-filled outputs, i.e. the
@@ -196,6 +484,18 @@ CLOUDAAE_API int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, co
         return 0;
     CLOUDAAE_REQUIRE(b <= 65535, name, "batch > 65535");
     hipStream_t s = (hipStream_t)stream;
+    // large clouds: the search on the matrix cores, the reference's arithmetic where it decides
+    // (CLOUDAAE_NN_FILTER=0/1 forces the choice, for tests and measurements)
+    bool filter = n >= 512 && m >= 512 && (long long)b * ((long long)n + m) >= 64 * NF_QBLOCK;
+    if (const char *env = getenv("CLOUDAAE_NN_FILTER"))
+        filter = atoi(env) != 0 && n > 0 && m > 0;
+    if (filter) {
+        const int t1 = ceil_div(n, NF_QBLOCK), t2 = ceil_div(m, NF_QBLOCK);
+        hipLaunchKernelGGL(nn_distance_filter_kernel, dim3(t1 + t2, b), dim3(NF_WAVES * 64), 0, s, n, m, xyz1,
+                           xyz2, dist1, idx1, dist2, idx2, t1);
+        CLOUDAAE_CHECK_LAUNCH(name);
+        return 0;
+    }
     // queries per lane: enough workgroups to fill 256 CUs first, then amortise
     // LDS reads over more queries
     const long long total = (long long)b * ((long long)n + m);

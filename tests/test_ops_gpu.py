@@ -39,8 +39,10 @@ def test_nn_distance_golden_bit_exact(hip, golden_dir, name):
 
 @pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 3, 1000), (3, 257, 255), (4, 1024, 4096),
                                    (2, 4096, 4096), (2, 5000, 17), (40, 512, 300)])
-def test_nn_distance_vs_oracle(hip, oracle, b, n, m):
+@pytest.mark.parametrize("kernel", ["0", "1"])
+def test_nn_distance_vs_oracle(hip, oracle, b, n, m, kernel, monkeypatch):
     from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
+    monkeypatch.setenv("CLOUDAAE_NN_FILTER", kernel)       # both kernels on every shape
     rng = np.random.default_rng(b * 1000 + n + m)
     a = (rng.standard_normal((b, n, 3)) * 0.05 + [0.1, -0.2, 0.9]).astype(np.float32)
     c = (rng.standard_normal((b, m, 3)) * 0.05 + [0.1, -0.2, 0.9]).astype(np.float32)
@@ -222,3 +224,39 @@ def test_prob_sample_vs_oracle(hip, oracle, b, n, m):
     if n == 21:
         freq = np.bincount(want.reshape(-1), minlength=n) / want.size
         assert np.abs(freq - p.sum(0) / p.sum()).max() < 0.05
+
+
+@pytest.mark.parametrize("case", ["lattice", "far_from_origin", "huge", "tiny_scale", "one_candidate", "ragged"])
+def test_nn_distance_filter_kernel_adversarial(hip, oracle, case, monkeypatch):
+    """The matrix-core search + exact verification (nn_distance_filter_kernel) on inputs built to defeat a
+    filter: exact ties everywhere (lattice), coordinates far from the origin (the filter's scores lose all
+    their digits and every query falls back to the full scan), overflow, denormal-sized clouds.
+    Bit-exact against the oracle, first index wins."""
+    from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
+    monkeypatch.setenv("CLOUDAAE_NN_FILTER", "1")
+    rng = np.random.default_rng(7)
+    if case == "lattice":
+        g = np.stack(np.meshgrid(np.arange(12), np.arange(12), np.arange(8), indexing="ij"), -1).reshape(-1, 3)
+        a = np.stack([rng.permutation(g) for _ in range(2)]).astype(np.float32) * 0.01
+        c = np.stack([rng.permutation(g) for _ in range(2)]).astype(np.float32) * 0.01 + np.float32(0.005)
+    elif case == "far_from_origin":
+        a = (rng.standard_normal((2, 700, 3)) * 0.05 + [300.0, -200.0, 900.0]).astype(np.float32)
+        c = (rng.standard_normal((2, 900, 3)) * 0.05 + [300.0, -200.0, 900.0]).astype(np.float32)
+        c[:, 0] += 5000.0      # the centre the scores are taken around is an outlier
+    elif case == "huge":
+        a = (rng.standard_normal((1, 600, 3)) * 1e19).astype(np.float32)
+        c = (rng.standard_normal((1, 640, 3)) * 1e19).astype(np.float32)
+    elif case == "tiny_scale":
+        a = (rng.standard_normal((1, 600, 3)) * 1e-21).astype(np.float32)
+        c = (rng.standard_normal((1, 640, 3)) * 1e-21).astype(np.float32)
+    elif case == "one_candidate":
+        a = rng.standard_normal((3, 70, 3)).astype(np.float32)
+        c = rng.standard_normal((3, 1, 3)).astype(np.float32)
+    else:
+        a = (rng.standard_normal((5, 1031, 3)) * 0.05).astype(np.float32)
+        c = (rng.standard_normal((5, 2077, 3)) * 0.05).astype(np.float32)
+        c[:, 1000:1040] = c[:, :40]
+    want = oracle.nn_distance(a, c, threads=8)
+    got = tf_nndistance.nn_distance(_dev(a), _dev(c))
+    for w, g_ in zip(want, got):
+        assert np.array_equal(w, g_.cpu().numpy())
