@@ -157,9 +157,9 @@ __global__ __launch_bounds__(NN_THREADS) void nn_distance_kernel(
 //     rounding errors, small).  One 32 x 32 tile of scores is two v_mfma_f32_32x32x2_f32 (K = 4:
 //     [bx by bz |b|^2] x [-2ax -2ay -2az 1]); rows = candidates, columns = queries, so a lane's 16
 //     accumulator registers are 16 candidates of ITS query and the minimum is taken in the lane.
-//   * per query: the three best UNIT scores (a unit = the 16 rows of a tile in one lane half) and the
-//     units of the first two.
-//   * afterwards the 32 candidates of the two best units are evaluated with the reference's un-fused
+//   * per query: the three best UNIT scores (a unit = the 32 rows of two consecutive tiles that one lane
+//     half holds) and the units of the first two.
+//   * afterwards the 64 candidates of the two best units are evaluated with the reference's un-fused
 //     arithmetic (first index of the exact minimum wins).  That is the answer if no third unit can
 //     hold a candidate that is as near in the reference's arithmetic: s3 > s1 + M with
 //     M = 32 * 2^-24 * (|a'| + max_j |b'_j|)^2.  Bound: a score is a 4-term fp32 sum of exact products
@@ -184,18 +184,26 @@ __device__ __forceinline__ bool key_less(unsigned d, int i, unsigned bd, int bi)
     return d < bd || (d == bd && i < bi);
 }
 
-// the 16 accumulator rows a lane holds: smallest score of its query among 16 candidates
-__device__ __forceinline__ float nf_min16(const f32x16 &v)
+// v_min3_f32 without the canonicalising v_max_f32 the compiler puts in front of fminf() on values it
+// cannot prove quiet (a NaN score only has to make the final comparison fail, which it does)
+__device__ __forceinline__ float nf_min3(float a, float b, float c)
 {
-    float tm = fminf(fminf(v[0], v[1]), v[2]);
+    float r;
+    __asm__("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// the 16 accumulator rows a lane holds (16 candidates of its query) folded into a running minimum
+__device__ __forceinline__ float nf_min16(float tm, const f32x16 &v)
+{
 #pragma unroll
-    for (int r = 3; r < 15; r += 2)
-        tm = fminf(fminf(tm, v[r]), v[r + 1]);
-    return fminf(tm, v[15]);
+    for (int r = 0; r < 16; r += 2)
+        tm = nf_min3(tm, v[r], v[r + 1]);
+    return tm;
 }
 
 // the three best unit scores of a query seen so far (s1 <= s2 <= s3) and the units of the first two;
-// a unit = the 16 rows of one 32-candidate tile that one lane half holds
+// a unit = the 32 rows of a PAIR of 32-candidate tiles that one lane half holds
 struct NfTop {
     float s1, s2, s3;
     int u1, u2;
@@ -277,23 +285,11 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
         for (int q = 0; q < NF_QT; ++q)
             acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, b1[q], acc[q], 0, 0, 0);
     };
-    auto consume = [&](const f32x16 (&acc)[NF_QT], int tile) {
-#pragma unroll
-        for (int q = 0; q < NF_QT; ++q)
-            top[q].push(nf_min16(acc[q]), tile);
-    };
-    // The MFMAs of tile t+1 are interleaved with the ~80 VALU instructions that digest tile t: one
-    // MFMA (64 cycles of the pipe), then ten VALU instructions in its shadow.  Without this two waves
-    // of a SIMD fall into step -- both queue on the matrix pipe, then both on the VALU -- and the loop
-    // costs the SUM of the two (1000 cycles per tile instead of 512).
-    auto interleave = [&]() {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);     // ten VALU
-        }
-    };
-
+    // The digest of a tile (8 v_min3 per query tile; the insertion into the top three once per PAIR of
+    // tiles) is NOT hidden behind the MFMAs of the next one: measured, the loop costs the matrix time
+    // (78 us at B=32, 4096^2, 70 % of the pipe) PLUS the VALU time whether the two are interleaved by
+    // hand, left to two waves per SIMD, or both -- so the VALU work is what gets minimised.
+    float run[NF_QT];
     float bmax2 = 0.0f;
     for (int c0 = 0; c0 < nc; c0 += NF_CHUNK) {
         const int cnt = min(NF_CHUNK, nc - c0);
@@ -318,14 +314,14 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
         f32x16 accA[NF_QT], accB[NF_QT];
         issue(accA, 0);
         for (int t = 0; t < ntile; t += 2) {
-            issue(accB, t + 1);             // (tile ntile is all padding: computed, never consumed)
-            consume(accA, t0 + t);
-            interleave();
-            if (t + 1 < ntile) {
-                issue(accA, min(t + 2, ntile));
-                consume(accB, t0 + t + 1);
-                interleave();
-            }
+            issue(accB, t + 1);             // (tile ntile is all padding: inf scores)
+#pragma unroll
+            for (int q = 0; q < NF_QT; ++q)
+                run[q] = nf_min16(__builtin_inff(), accA[q]);
+            issue(accA, min(t + 2, ntile));
+#pragma unroll
+            for (int q = 0; q < NF_QT; ++q)
+                top[q].push(nf_min16(run[q], accB[q]), (t0 + t) >> 1);
         }
     }
 
@@ -361,13 +357,14 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
         // only the two best units can hold a candidate within the margin of the best score?
         const bool decided = g.s3 > g.s1 + margin;      // false for NaN / overflow as well
 
-        // those two units in the reference's arithmetic: one per lane of the pair, 16 candidates each
+        // those two units in the reference's arithmetic: one per lane of the pair, 32 candidates each
+        // (unit = 2 * tile pair + lane half: rows 4h..4h+3, 8+4h.. of tiles 2p and 2p+1)
         unsigned kb = 0xffffffffu;
         int ki = 0x7fffffff;
         const int unit = half ? g.u2 : g.u1;
-        const int base = (unit >> 1) * 32 + 4 * (unit & 1);
+        const int base = (unit >> 1) * 64 + 4 * (unit & 1);
 #pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < 32; ++s) {
             const int k = base + (s & 3) + 8 * (s >> 2);
             if (k < nc) {
                 const float d = sqdist(to[3 * (size_t)k], to[3 * (size_t)k + 1], to[3 * (size_t)k + 2], qx[q],
