@@ -441,14 +441,14 @@ using namespace cloudaae;
 
 CLOUDAAE_API long long cloudaae_bn_workspace_bytes(int C) { return (long long)(bn_ws_doubles(C) * sizeof(double)); }
 
-CLOUDAAE_API int cloudaae_bn_forward(int M, int C, const float *y, int ldy, const float *gamma,
-                                     const float *beta, int training, const float *decay,
-                                     float *ema_mean, float *ema_var, float *save_mean, float *save_var,
-                                     int relu, float *out, int ldo, int pool_rows, int pool_mode,
-                                     float *pooled, float *tie_count, void *workspace,
-                                     cloudaae_stream_t stream)
+// colstats_parts > 0: the first colstats_parts x 2 x C doubles of the workspace already hold the column
+// sums of y (written by cloudaae_gemm_f32_colstats): the statistics pass over y is skipped
+static int bn_forward_impl(const char *name, int M, int C, const float *y, int ldy, const float *gamma,
+                           const float *beta, int training, const float *decay, float *ema_mean, float *ema_var,
+                           float *save_mean, float *save_var, int relu, float *out, int ldo, int pool_rows,
+                           int pool_mode, float *pooled, float *tie_count, void *workspace, int colstats_parts,
+                           cloudaae_stream_t stream)
 {
-    const char *name = "cloudaae_bn_forward";
     CLOUDAAE_REQUIRE(M > 0 && C > 0 && ldy >= C, name, "bad size");
     CLOUDAAE_REQUIRE(workspace != nullptr && gamma && beta && save_mean && save_var, name, "null argument");
     CLOUDAAE_REQUIRE(training || (ema_mean && ema_var), name, "inference needs the EMA statistics");
@@ -466,9 +466,9 @@ CLOUDAAE_API int cloudaae_bn_forward(int M, int C, const float *y, int ldy, cons
     }
     double *partial = (double *)workspace;
     float *scale_shift = (float *)(partial + (size_t)BN_MAX_PARTS * 4 * C);
-    const int parts = bn_parts(M);
+    const int parts = colstats_parts > 0 ? colstats_parts : bn_parts(M);
     const int cb = ceil_div(C, 64);
-    if (training)
+    if (training && colstats_parts <= 0)
         hipLaunchKernelGGL(bn_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, M, C, y, ldy, partial, parts);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts,
                        (double)M, training, decay, ema_mean, ema_var, gamma, beta, save_mean, save_var,
@@ -488,6 +488,32 @@ CLOUDAAE_API int cloudaae_bn_forward(int M, int C, const float *y, int ldy, cons
     }
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
+}
+
+CLOUDAAE_API int cloudaae_bn_forward(int M, int C, const float *y, int ldy, const float *gamma,
+                                     const float *beta, int training, const float *decay,
+                                     float *ema_mean, float *ema_var, float *save_mean, float *save_var,
+                                     int relu, float *out, int ldo, int pool_rows, int pool_mode,
+                                     float *pooled, float *tie_count, void *workspace,
+                                     cloudaae_stream_t stream)
+{
+    return bn_forward_impl("cloudaae_bn_forward", M, C, y, ldy, gamma, beta, training, decay, ema_mean, ema_var,
+                           save_mean, save_var, relu, out, ldo, pool_rows, pool_mode, pooled, tie_count, workspace,
+                           0, stream);
+}
+
+CLOUDAAE_API int cloudaae_bn_forward_colstats(int M, int C, const float *y, int ldy, const float *gamma,
+                                              const float *beta, int training, const float *decay,
+                                              float *ema_mean, float *ema_var, float *save_mean, float *save_var,
+                                              int relu, float *out, int ldo, int pool_rows, int pool_mode,
+                                              float *pooled, float *tie_count, void *workspace,
+                                              int colstats_parts, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_bn_forward_colstats";
+    CLOUDAAE_REQUIRE(colstats_parts > 0 && colstats_parts <= 2 * BN_MAX_PARTS, name, "bad number of column-sum rows");
+    CLOUDAAE_REQUIRE(M > BN_SMALL_M || pool_mode != 0, name, "small batches take cloudaae_bn_forward");
+    return bn_forward_impl(name, M, C, y, ldy, gamma, beta, training, decay, ema_mean, ema_var, save_mean, save_var,
+                           relu, out, ldo, pool_rows, pool_mode, pooled, tie_count, workspace, colstats_parts, stream);
 }
 
 CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, const float *gamma,

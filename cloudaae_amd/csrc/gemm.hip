@@ -151,7 +151,7 @@ template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool FAST>
 __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
     int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
     float *__restrict__ C, int ldc, const float *__restrict__ bias, int epilogue, int kchunk,
-    int vecA, int vecB, Fold foldB, Fold foldC)
+    int vecA, int vecB, Fold foldB, Fold foldC, double *__restrict__ colstats)
 {
     static_assert(WM * WN * 64 == GEMM_THREADS, "4 waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;   // 32x32 tiles per wave
@@ -229,6 +229,47 @@ __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
 
     // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool add_bias = bias != nullptr && (epilogue != EPI_ATOMIC || blockIdx.z == 0);
+    if (colstats != nullptr) {
+        // Column sums of this tile (values as stored, bias included) for the batch norm that consumes C:
+        // colstats[tile row][0][col] = sum, [1][col] = sum of squares, in fp64 -- what bn_colsum_kernel
+        // would recompute by reading all of C again (134 MB for dgcnn_agg).  Fixed order: rows of a lane,
+        // the two lane halves, then the WM waves stacked along M.
+        __shared__ double cs[2][WM][BN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cl = (wn * TN + j) * 32 + fr;
+            const float bv = (add_bias && (FAST || n0 + cl < N)) ? bias[n0 + cl] : 0.0f;
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    if (FAST || row < M) {
+                        const double v = (double)(acc[i][j][r] + bv);
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (fk == 0) {
+                cs[0][wm][cl] = s1;
+                cs[1][wm][cl] = s2;
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * BN; t += GEMM_THREADS) {
+            const int which = t / BN, cl = t % BN;
+            if (n0 + cl < N) {
+                double v = cs[which][0][cl];
+#pragma unroll
+                for (int w = 1; w < WM; ++w)
+                    v += cs[which][w][cl];
+                colstats[((size_t)(m0 / BM) * 2 + which) * N + n0 + cl] = v;
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wn * TN + j) * 32 + fr;
@@ -258,36 +299,36 @@ __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
 template <int BM, int BN, int WM, int WN, bool FAST>
 static void launch_fast(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A,
                         int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int epi,
-                        int kchunk, int vecA, int vecB, Fold fb, Fold fc)
+                        int kchunk, int vecA, int vecB, Fold fb, Fold fc, double *cs)
 {
     dim3 block(GEMM_THREADS);
     if (!ta && !tb)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false, FAST>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
     else if (!ta && tb)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true, FAST>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
     else if (ta && !tb)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false, FAST>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
     else
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, FAST>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
 }
 
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A,
                        int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int epi,
-                       int kchunk, int vecA, int vecB, Fold fb, Fold fc)
+                       int kchunk, int vecA, int vecB, Fold fb, Fold fc, double *cs)
 {
     // every tile and every K-slab whole, both operands float4-loadable: the predicate-free kernel
     const bool fast = M % BM == 0 && N % BN == 0 && K % kchunk == 0 && kchunk % GEMM_BK == 0 && vecA && vecB;
     if (fast)
         launch_fast<BM, BN, WM, WN, true>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                          vecA, vecB, fb, fc);
+                                          vecA, vecB, fb, fc, cs);
     else
         launch_fast<BM, BN, WM, WN, false>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                           vecA, vecB, fb, fc);
+                                           vecA, vecB, fb, fc, cs);
 }
 
 } // namespace cloudaae
@@ -363,7 +404,7 @@ CLOUDAAE_API int cloudaae_gemm_f32_splits(int M, int N, int K)
 // row blocks (see Fold); the folded matrix has leading dimension == width.
 int cloudaae::gemm_f32_launch(const char *name, int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                               const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
-                              int fold_b, int fold_c, hipStream_t s)
+                              int fold_b, int fold_c, hipStream_t s, double *colstats)
 {
     CLOUDAAE_REQUIRE(M >= 0 && N >= 0 && K >= 0, name, "negative size");
     if (M == 0 || N == 0)
@@ -387,6 +428,8 @@ int cloudaae::gemm_f32_launch(const char *name, int trans_a, int trans_b, int M,
     gemm_plan(M, N, K, BM, BN, splits);
     const int tm = ceil_div(M, BM), tn = ceil_div(N, BN);
     CLOUDAAE_REQUIRE(tm <= 65535, name, "M too large");
+    CLOUDAAE_REQUIRE(colstats == nullptr || (splits == 1 && accumulate == 0 && !fold_c), name,
+                     "column statistics need an unsplit, overwriting product");
     int kchunk = K > 0 ? ceil_div(ceil_div(K, splits), GEMM_BK) * GEMM_BK : GEMM_BK;
     splits = K > 0 ? ceil_div(K, kchunk) : 1;
     // accumulate: 0 = overwrite C, 1 = add to C, 2 = C is known to hold zeros (the caller cleared
@@ -410,19 +453,19 @@ int cloudaae::gemm_f32_launch(const char *name, int trans_a, int trans_b, int M,
     const bool ta = trans_a != 0, tb = trans_b != 0;
     if (BM == 32)
         launch_cfg<32, 128, 1, 4>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                  vecA, vecB, fb, fc);
+                                  vecA, vecB, fb, fc, colstats);
     else if (BM == 64 && BN == 64)
         launch_cfg<64, 64, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                 vecA, vecB, fb, fc);
+                                 vecA, vecB, fb, fc, colstats);
     else if (BN == 64)
         launch_cfg<128, 64, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                  vecA, vecB, fb, fc);
+                                  vecA, vecB, fb, fc, colstats);
     else if (BM == 64)
         launch_cfg<64, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                  vecA, vecB, fb, fc);
+                                  vecA, vecB, fb, fc, colstats);
     else
         launch_cfg<128, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                   vecA, vecB, fb, fc);
+                                   vecA, vecB, fb, fc, colstats);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }
@@ -433,4 +476,23 @@ CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K
 {
     return gemm_f32_launch("cloudaae_gemm_f32", trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate,
                            0, 0, (hipStream_t)stream);
+}
+
+CLOUDAAE_API int cloudaae_gemm_f32_colstats_parts(int M, int N, int K)
+{
+    if (M <= 0 || N <= 0 || K <= 0)
+        return 0;
+    int BM, BN, splits;
+    gemm_plan(M, N, K, BM, BN, splits);
+    return splits == 1 ? ceil_div(M, BM) : 0;
+}
+
+CLOUDAAE_API int cloudaae_gemm_f32_colstats(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                                            const float *B, int ldb, float *C, int ldc, const float *bias,
+                                            double *colstats, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_gemm_f32_colstats";
+    CLOUDAAE_REQUIRE(colstats != nullptr, name, "null argument");
+    return gemm_f32_launch(name, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, 0, 0, 0,
+                           (hipStream_t)stream, colstats);
 }

@@ -333,6 +333,11 @@ class FcGroupFn(torch.autograd.Function):
         return tuple(grads)
 
 
+# hand-off from a product that computed the column sums of its output to the batch norm that consumes it:
+# (data_ptr of y, workspace holding the sums, number of tile rows), taken once by BatchNormFn.forward
+_COLSTATS = None
+
+
 class ConcatSlot(object):
     """The one [B,N,Ctot] buffer the encoder's layer outputs are written into as column slices
     (the tf.concat of models/...:410 without a copy) and, in backward, its gradient twin: the agg
@@ -356,7 +361,7 @@ class ConcatLinearFn(torch.autograd.Function):
     def forward(ctx, slot, w, b, bias_grad_by_bn, *nets):
         M = nets[0].shape[0]
         ctx.slot = slot
-        ctx.bias_here = b is not None and not bias_grad_by_bn
+        ctx.bias_here = b is not None and not (int(bias_grad_by_bn) & 1)
         widths = [t.shape[1] for t in nets]
         Ktot = sum(widths)
         require(w.shape[0] == Ktot, "ConcatLinearFn: weight rows != total input channels")
@@ -377,8 +382,24 @@ class ConcatLinearFn(torch.autograd.Function):
         N = w.shape[1]
         y = _lib.empty((M, N), dtype=torch.float32, device=w.device)
         ctx.bf16 = gemm_is_bf16()
-        gemm(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, site="agg_fwd",
-             bf16=ctx.bf16)
+        # bias_grad_by_bn & 2: a training-mode batch norm consumes y next -- the product leaves the column
+        # sums of its tiles in the batch norm's workspace and the statistics pass over y is skipped
+        parts = int(L().cloudaae_gemm_f32_colstats_parts(M, N, Ktot)) if (int(bias_grad_by_bn) & 2 and not ctx.bf16) else 0
+        if parts > 0:
+            ws = _ws(L().cloudaae_bn_workspace_bytes(N), w.device)
+            rec = TIMED_SITES.get("agg_fwd")
+            if rec is not None:
+                _lib.host(_mark, rec)
+            _lib.check(L().cloudaae_gemm_f32_colstats(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N,
+                                                      ptr(b) if b is not None else None, ptr(ws), stream()),
+                       "cloudaae_gemm_f32_colstats")
+            if rec is not None:
+                _lib.host(_mark, rec)
+            global _COLSTATS
+            _COLSTATS = (y.data_ptr(), ws, parts)
+        else:
+            gemm(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, site="agg_fwd",
+                 bf16=ctx.bf16)
         ctx.save_for_backward(w, *nets)
         ctx.widths, ctx.xp, ctx.bvar = widths, xp, b
         return y
@@ -439,11 +460,19 @@ class BatchNormFn(torch.autograd.Function):
             pooled = _lib.empty((M // pool_rows, C), dtype=torch.float32, device=dev)
             if pool_mode == 2:
                 ties = _lib.empty_like(pooled)
-        ws = _ws(L().cloudaae_bn_workspace_bytes(C), dev)
-        _lib.check(L().cloudaae_bn_forward(
-            M, C, yp, ldy, ptr(gamma), ptr(beta), int(training), ptr(decay), ptr(ema_mean), ptr(ema_var),
-            ptr(save_mean), ptr(save_var), int(relu), ptr(out), C, int(pool_rows), int(pool_mode), ptr(pooled),
-            ptr(ties), ptr(ws), stream()), "cloudaae_bn_forward")
+        global _COLSTATS
+        pre, _COLSTATS = _COLSTATS, None
+        if pre is not None and pre[0] == yp and ldy == C and training:
+            _lib.check(L().cloudaae_bn_forward_colstats(
+                M, C, yp, ldy, ptr(gamma), ptr(beta), int(training), ptr(decay), ptr(ema_mean), ptr(ema_var),
+                ptr(save_mean), ptr(save_var), int(relu), ptr(out), C, int(pool_rows), int(pool_mode), ptr(pooled),
+                ptr(ties), ptr(pre[1]), int(pre[2]), stream()), "cloudaae_bn_forward_colstats")
+        else:
+            ws = _ws(L().cloudaae_bn_workspace_bytes(C), dev)
+            _lib.check(L().cloudaae_bn_forward(
+                M, C, yp, ldy, ptr(gamma), ptr(beta), int(training), ptr(decay), ptr(ema_mean), ptr(ema_var),
+                ptr(save_mean), ptr(save_var), int(relu), ptr(out), C, int(pool_rows), int(pool_mode), ptr(pooled),
+                ptr(ties), ptr(ws), stream()), "cloudaae_bn_forward")
         ctx.save_for_backward(y, gamma, beta, save_mean, save_var, pooled, ties)
         ctx.cfg = (int(training), int(relu), int(pool_rows), int(pool_mode))
         ctx.mark_non_differentiable(save_mean, save_var)

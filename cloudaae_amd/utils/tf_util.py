@@ -403,7 +403,9 @@ def conv2d_concat(inputs_list, num_output_channels, scope, bn_decay=None, is_tra
             beta, gamma, ema_mean, ema_var = _bn_variables(num_output_channels)
     w2 = kernel.data.reshape(cin, num_output_channels)
     w2._cloudaae_var = kernel
-    y = F.ConcatLinearFn.apply(slot, w2, biases.data, True, *rows)
+    # (flag 1: the batch norm writes the bias gradient; 2: it runs in training mode right after, so the
+    # product leaves it the column sums of y)
+    y = F.ConcatLinearFn.apply(slot, w2, biases.data, 3 if is_training else 1, *rows)
     mode = {None: 0, 'mean': 1, 'max': 2}[pool]
     if mode == 0:
         act, mean, var = F.BatchNormFn.apply(y, gamma.data, beta.data, ema_mean.data, ema_var.data,

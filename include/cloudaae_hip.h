@@ -117,6 +117,13 @@ int cloudaae_knn(int b, int n, int c, int ld, int k, const float *x, int *nn_idx
 int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                       const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
                       cloudaae_stream_t stream);
+/* cloudaae_gemm_f32 (overwrite mode) that also leaves, per tile row of the product, the column sums and
+ * sums of squares of C in fp64: colstats[parts][2][N], parts = cloudaae_gemm_f32_colstats_parts(M, N, K)
+ * (0: this shape is split over K and has no such variant).  Feeds cloudaae_bn_forward_colstats. */
+int cloudaae_gemm_f32_colstats_parts(int M, int N, int K);
+int cloudaae_gemm_f32_colstats(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                               const float *B, int ldb, float *C, int ldc, const float *bias, double *colstats,
+                               cloudaae_stream_t stream);
 /* K slices cloudaae_gemm_f32 will use for this shape (> 1: the output is combined with atomics and
  * must hold zeros first -- the call clears it itself unless accumulate is 1 or 2). */
 int cloudaae_gemm_f32_splits(int M, int N, int K);
@@ -142,6 +149,14 @@ int cloudaae_bn_forward(int M, int C, const float *y, int ldy, const float *gamm
                         float *save_mean, float *save_var, int relu, float *out, int ldo, int pool_rows,
                         int pool_mode, float *pooled, float *tie_count, void *workspace,
                         cloudaae_stream_t stream);
+/* The same with the statistics pass skipped: the first colstats_parts x 2 x C doubles of `workspace`
+ * already hold per-row-tile column sums / sums of squares of y, written by cloudaae_gemm_f32_colstats
+ * (the product that made y had the tile in registers anyway: for dgcnn_agg this saves reading 134 MB). */
+int cloudaae_bn_forward_colstats(int M, int C, const float *y, int ldy, const float *gamma, const float *beta,
+                                 int training, const float *decay, float *ema_mean, float *ema_var,
+                                 float *save_mean, float *save_var, int relu, float *out, int ldo, int pool_rows,
+                                 int pool_mode, float *pooled, float *tie_count, void *workspace,
+                                 int colstats_parts, cloudaae_stream_t stream);
 /* gradient of the above: upstream = dout[M,C] (may be NULL) and/or dpooled[M/pool_rows,C]
  * (mean: /pool_rows; max: shared among equal maxima, as tf.reduce_max does);
  * produces dy[M,C], dgamma[C], dbeta[C] (NULL = not wanted), and dbias[C] (NULL = not wanted): the

@@ -482,3 +482,47 @@ def test_training_reduces_loss(hip):
     last = float(out["total_loss"])
     assert math.isfinite(last) and last < 0.7 * first
     assert float(graph.batch) == 30.0
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1024, 320), (1000, 130, 70), (32768, 1024, 320)])
+def test_gemm_colstats_feed_batch_norm(hip, M, N, K):
+    """The product that leaves the column sums of its tiles (cloudaae_gemm_f32_colstats) + the batch norm
+    that starts from them (cloudaae_bn_forward_colstats) = the plain product + cloudaae_bn_forward."""
+    L = hip.lib()
+    parts = L.cloudaae_gemm_f32_colstats_parts(M, N, K)
+    assert parts > 0
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (torch.randn(K, N, generator=g) / math.sqrt(K)).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    gamma, beta = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda()
+    decay = torch.full((1,), 0.9, device="cuda")
+    rows = 64 if M % 64 == 0 else 0
+    res = []
+    for fused in (False, True):
+        C = torch.empty(M, N, device="cuda")
+        ws = torch.zeros(int(L.cloudaae_bn_workspace_bytes(N)) // 8 + 1, dtype=torch.float64, device="cuda")
+        sm, sv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+        mean, var = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+        out = torch.empty(M, N, device="cuda")
+        pooled = torch.empty(M // rows, N, device="cuda") if rows else None
+        P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        s = hip.stream()
+        if fused:
+            hip.check(L.cloudaae_gemm_f32_colstats(0, 0, M, N, K, P(A), K, P(B), N, P(C), N, P(bias), P(ws), s), "g")
+            hip.check(L.cloudaae_bn_forward_colstats(M, N, P(C), N, P(gamma), P(beta), 1, P(decay), P(sm), P(sv), P(mean),
+                                                     P(var), 1, P(out), N, rows, 1 if rows else 0, P(pooled), None,
+                                                     P(ws), parts, s), "bn")
+            stats = ws[:parts * 2 * N].reshape(parts, 2, N).sum(0)
+            Cd = C.double()
+            assert _rel(stats[0], Cd.sum(0)) < 1e-9 and _rel(stats[1], (Cd * Cd).sum(0)) < 1e-9
+        else:
+            hip.check(L.cloudaae_gemm_f32(0, 0, M, N, K, P(A), K, P(B), N, P(C), N, P(bias), 0, s), "g")
+            hip.check(L.cloudaae_bn_forward(M, N, P(C), N, P(gamma), P(beta), 1, P(decay), P(sm), P(sv), P(mean), P(var),
+                                            1, P(out), N, rows, 1 if rows else 0, P(pooled), None, P(ws), s), "bn")
+        torch.cuda.synchronize()
+        res.append((C, mean, var, sm, sv, out, pooled))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1:], res[1][1:]):
+        if a is not None:
+            assert _rel(a, b) < 1e-6
