@@ -69,18 +69,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(int M, int C, const float
                                                       int ldy, const float *__restrict__ scale_shift,
                                                       int relu, float *__restrict__ out, int ldo,
                                                       int rows, float *__restrict__ pooled,
-                                                      float *__restrict__ ties)
+                                                      float *__restrict__ ties, const float *__restrict__ save_mean,
+                                                      const float *__restrict__ save_var,
+                                                      double *__restrict__ pool_stats)
 {
     __shared__ float red[4][64];
     __shared__ float redc[4][64];
+    __shared__ double redd[2][4][64];
     const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int r0 = blockIdx.y * rows;
     const int r1 = min(M, r0 + rows);
     float acc = POOL == 2 ? -__builtin_inff() : 0.0f;
     float cnt = 0.0f;
+    // mean pool, training: what the backward pass needs of this group besides the pooled value -- rows
+    // that pass the ReLU, the sum of their x_hat, the sum of all x_hat (see bn_bwd_pool_partials_kernel)
+    const bool stats = POOL == 1 && pool_stats != nullptr;
+    double sx = 0.0, sall = 0.0;
     if (c < C) {
         const float sc = scale_shift[c], sh = scale_shift[C + c];
+        const float mean = stats ? save_mean[c] : 0.0f, rstd = stats ? bn_rsqrt(save_var[c] + BN_EPS) : 0.0f;
         for (int rb = r0 + rl; rb < r1; rb += 4 * BN_U) {
             float v[BN_U];
 #pragma unroll
@@ -99,6 +107,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(int M, int C, const float
                         out[(size_t)r * ldo + c] = z;
                     if (POOL == 1)
                         acc = acc + z;
+                    if (stats) {
+                        const float xh = (v[u] - mean) * rstd;
+                        sall += (double)xh;
+                        if (z > 0.0f) {
+                            cnt += 1.0f;
+                            sx += (double)xh;
+                        }
+                    }
                     if (POOL == 2) {
                         if (z > acc) {
                             acc = z;
@@ -114,11 +130,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(int M, int C, const float
     if (POOL != 0) {
         red[rl][lane] = acc;
         redc[rl][lane] = cnt;
+        if (stats) {
+            redd[0][rl][lane] = sx;
+            redd[1][rl][lane] = sall;
+        }
         __syncthreads();
         if (rl == 0 && c < C) {
             if (POOL == 1) {
                 const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
                 pooled[(size_t)blockIdx.y * C + c] = s / (float)(r1 - r0);
+                if (stats) {
+                    double *ps = pool_stats + (size_t)blockIdx.y * 3 * C + c;
+                    ps[0] = (double)((redc[0][lane] + redc[1][lane]) + (redc[2][lane] + redc[3][lane]));
+                    ps[C] = (redd[0][0][lane] + redd[0][1][lane]) + (redd[0][2][lane] + redd[0][3][lane]);
+                    ps[2 * (size_t)C] = (redd[1][0][lane] + redd[1][1][lane]) + (redd[1][2][lane] + redd[1][3][lane]);
+                }
             } else {
                 float m = red[0][lane], n = redc[0][lane];
                 for (int i = 1; i < 4; ++i) {
@@ -227,6 +253,28 @@ __global__ __launch_bounds__(256) void bn_bwd_colsum_kernel(BnBwdArgs a, double 
             p3[((size_t)blockIdx.y * 2 + 1) * a.C + c] = 0.0;
         }
     }
+}
+
+// Mean pool over groups of `rows` rows with nothing else consuming the activation: the upstream gradient
+// of every row of group g is the same number dpooled[g][c] / rows (times the ReLU mask), so the column
+// sums the backward pass starts with are that number times what the FORWARD apply pass counted per group
+// (rows passing the ReLU, sum of their x_hat, sum of all x_hat).  One partial-sum row per group replaces a
+// pass over y (134 MB for dgcnn_agg).
+__global__ __launch_bounds__(256) void bn_bwd_pool_partials_kernel(int C, int groups, int rows,
+                                                                  const float *__restrict__ dpooled,
+                                                                  const double *__restrict__ pool_stats,
+                                                                  double *__restrict__ partial)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (c >= C)
+        return;
+    const double gv = (double)(dpooled[(size_t)g * C + c] / (float)rows);
+    const double *ps = pool_stats + (size_t)g * 3 * C + c;
+    partial[((size_t)g * 2 + 0) * C + c] = gv * ps[0];
+    partial[((size_t)g * 2 + 1) * C + c] = gv * ps[C];
+    double *p3 = partial + (size_t)BN_MAX_PARTS * 2 * C;
+    p3[((size_t)g * 2 + 0) * C + c] = ps[2 * (size_t)C];
+    p3[((size_t)g * 2 + 1) * C + c] = 0.0;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const float *__restrict__ m12,
@@ -446,8 +494,8 @@ CLOUDAAE_API long long cloudaae_bn_workspace_bytes(int C) { return (long long)(b
 static int bn_forward_impl(const char *name, int M, int C, const float *y, int ldy, const float *gamma,
                            const float *beta, int training, const float *decay, float *ema_mean, float *ema_var,
                            float *save_mean, float *save_var, int relu, float *out, int ldo, int pool_rows,
-                           int pool_mode, float *pooled, float *tie_count, void *workspace, int colstats_parts,
-                           cloudaae_stream_t stream)
+                           int pool_mode, float *pooled, float *tie_count, double *pool_stats, void *workspace,
+                           int colstats_parts, cloudaae_stream_t stream)
 {
     CLOUDAAE_REQUIRE(M > 0 && C > 0 && ldy >= C, name, "bad size");
     CLOUDAAE_REQUIRE(workspace != nullptr && gamma && beta && save_mean && save_var, name, "null argument");
@@ -476,15 +524,16 @@ static int bn_forward_impl(const char *name, int M, int C, const float *y, int l
     if (pool_mode == 0) {
         const int slab = 64;
         hipLaunchKernelGGL(bn_apply_kernel<0>, dim3(cb, ceil_div(M, slab)), dim3(256), 0, s, M, C, y, ldy,
-                           scale_shift, relu, out, ldo, slab, nullptr, nullptr);
+                           scale_shift, relu, out, ldo, slab, nullptr, nullptr, nullptr, nullptr, nullptr);
     } else {
         CLOUDAAE_REQUIRE(M / pool_rows <= 65535, name, "too many pooling groups");
         if (pool_mode == 1)
             hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(cb, M / pool_rows), dim3(256), 0, s, M, C, y, ldy,
-                               scale_shift, relu, out, ldo, pool_rows, pooled, tie_count);
+                               scale_shift, relu, out, ldo, pool_rows, pooled, tie_count, save_mean, save_var,
+                               (relu && training) ? pool_stats : nullptr);
         else
             hipLaunchKernelGGL(bn_apply_kernel<2>, dim3(cb, M / pool_rows), dim3(256), 0, s, M, C, y, ldy,
-                               scale_shift, relu, out, ldo, pool_rows, pooled, tie_count);
+                               scale_shift, relu, out, ldo, pool_rows, pooled, tie_count, nullptr, nullptr, nullptr);
     }
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
@@ -494,26 +543,27 @@ CLOUDAAE_API int cloudaae_bn_forward(int M, int C, const float *y, int ldy, cons
                                      const float *beta, int training, const float *decay,
                                      float *ema_mean, float *ema_var, float *save_mean, float *save_var,
                                      int relu, float *out, int ldo, int pool_rows, int pool_mode,
-                                     float *pooled, float *tie_count, void *workspace,
+                                     float *pooled, float *tie_count, double *pool_stats, void *workspace,
                                      cloudaae_stream_t stream)
 {
     return bn_forward_impl("cloudaae_bn_forward", M, C, y, ldy, gamma, beta, training, decay, ema_mean, ema_var,
-                           save_mean, save_var, relu, out, ldo, pool_rows, pool_mode, pooled, tie_count, workspace,
-                           0, stream);
+                           save_mean, save_var, relu, out, ldo, pool_rows, pool_mode, pooled, tie_count, pool_stats,
+                           workspace, 0, stream);
 }
 
 CLOUDAAE_API int cloudaae_bn_forward_colstats(int M, int C, const float *y, int ldy, const float *gamma,
                                               const float *beta, int training, const float *decay,
                                               float *ema_mean, float *ema_var, float *save_mean, float *save_var,
                                               int relu, float *out, int ldo, int pool_rows, int pool_mode,
-                                              float *pooled, float *tie_count, void *workspace,
+                                              float *pooled, float *tie_count, double *pool_stats, void *workspace,
                                               int colstats_parts, cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_bn_forward_colstats";
     CLOUDAAE_REQUIRE(colstats_parts > 0 && colstats_parts <= 2 * BN_MAX_PARTS, name, "bad number of column-sum rows");
     CLOUDAAE_REQUIRE(M > BN_SMALL_M || pool_mode != 0, name, "small batches take cloudaae_bn_forward");
     return bn_forward_impl(name, M, C, y, ldy, gamma, beta, training, decay, ema_mean, ema_var, save_mean, save_var,
-                           relu, out, ldo, pool_rows, pool_mode, pooled, tie_count, workspace, colstats_parts, stream);
+                           relu, out, ldo, pool_rows, pool_mode, pooled, tie_count, pool_stats, workspace,
+                           colstats_parts, stream);
 }
 
 CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, const float *gamma,
@@ -521,8 +571,8 @@ CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, con
                                       int training, int relu, const float *dout, int lddo, int pool_rows,
                                       int pool_mode, const float *dpooled, const float *pooled,
                                       const float *tie_count, float *dy, int lddy, float *dgamma,
-                                      float *dbeta, float *dbias, int accumulate_param_grads, void *workspace,
-                                      cloudaae_stream_t stream)
+                                      float *dbeta, float *dbias, int accumulate_param_grads,
+                                      const double *pool_stats, void *workspace, cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_bn_backward";
     CLOUDAAE_REQUIRE(M > 0 && C > 0 && ldy >= C, name, "bad size");
@@ -550,9 +600,16 @@ CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, con
     a.pool = pool_mode; a.relu = relu; a.training = training;
     a.y = y; a.dout = dout; a.dpooled = dpooled; a.pooled = pooled; a.ties = tie_count;
     a.gamma = gamma; a.beta = beta; a.save_mean = save_mean; a.save_var = save_var;
-    const int parts = bn_parts(M);
+    int parts = bn_parts(M);
     const int cb = ceil_div(C, 64);
-    hipLaunchKernelGGL(bn_bwd_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, a, partial, parts);
+    const int groups = pool_mode == 1 ? M / pool_rows : 0;
+    if (pool_stats != nullptr && pool_mode == 1 && dout == nullptr && relu && training && groups <= BN_MAX_PARTS) {
+        parts = groups;     // one partial-sum row per group, from what the forward pass counted
+        hipLaunchKernelGGL(bn_bwd_pool_partials_kernel, dim3(ceil_div(C, 256), groups), dim3(256), 0, s, C, groups,
+                           pool_rows, dpooled, pool_stats, partial);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, a, partial, parts);
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts,
                        (double)M, training, dgamma, dbeta, accumulate_param_grads, m12, dbias, gamma, save_var);
     const int slab = 64;

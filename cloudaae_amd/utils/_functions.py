@@ -460,20 +460,26 @@ class BatchNormFn(torch.autograd.Function):
             pooled = _lib.empty((M // pool_rows, C), dtype=torch.float32, device=dev)
             if pool_mode == 2:
                 ties = _lib.empty_like(pooled)
+        # mean pool + ReLU in training mode: the apply pass counts per group what backward needs (see
+        # cloudaae_bn_backward: pool_stats), so backward starts without a pass over y
+        pstats = None
+        if pool_mode == 1 and training and relu and not want_activation:
+            pstats = _lib.empty((M // pool_rows) * 3 * C, dtype=torch.float64, device=dev)
         global _COLSTATS
         pre, _COLSTATS = _COLSTATS, None
         if pre is not None and pre[0] == yp and ldy == C and training:
             _lib.check(L().cloudaae_bn_forward_colstats(
                 M, C, yp, ldy, ptr(gamma), ptr(beta), int(training), ptr(decay), ptr(ema_mean), ptr(ema_var),
                 ptr(save_mean), ptr(save_var), int(relu), ptr(out), C, int(pool_rows), int(pool_mode), ptr(pooled),
-                ptr(ties), ptr(pre[1]), int(pre[2]), stream()), "cloudaae_bn_forward_colstats")
+                ptr(ties), ptr(pstats), ptr(pre[1]), int(pre[2]), stream()), "cloudaae_bn_forward_colstats")
         else:
             ws = _ws(L().cloudaae_bn_workspace_bytes(C), dev)
             _lib.check(L().cloudaae_bn_forward(
                 M, C, yp, ldy, ptr(gamma), ptr(beta), int(training), ptr(decay), ptr(ema_mean), ptr(ema_var),
                 ptr(save_mean), ptr(save_var), int(relu), ptr(out), C, int(pool_rows), int(pool_mode), ptr(pooled),
-                ptr(ties), ptr(ws), stream()), "cloudaae_bn_forward")
+                ptr(ties), ptr(pstats), ptr(ws), stream()), "cloudaae_bn_forward")
         ctx.save_for_backward(y, gamma, beta, save_mean, save_var, pooled, ties)
+        ctx.pstats = pstats
         ctx.cfg = (int(training), int(relu), int(pool_rows), int(pool_mode))
         ctx.mark_non_differentiable(save_mean, save_var)
         if pool_mode == 0:
@@ -514,7 +520,7 @@ class BatchNormFn(torch.autograd.Function):
         _lib.check(L().cloudaae_bn_backward(
             M, C, yp, ldy, ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_var), training, relu, ptr(dout), C,
             pool_rows, pool_mode, ptr(dpooled), ptr(pooled), ptr(ties), ptr(dy), C, ptr(gg.buf), ptr(gb.buf),
-            ptr(glb.buf), acc, ptr(ws), stream()), "cloudaae_bn_backward")
+            ptr(glb.buf), acc, ptr(ctx.pstats) if dout is None else None, ptr(ws), stream()), "cloudaae_bn_backward")
         return (dy, gg.done(), gb.done()) + (None,) * 8 + (glb.done() if glb.needed else None,)
 
 

@@ -142,12 +142,14 @@ int cloudaae_gemm_bf16_splits(int M, int N, int K);
  * training != 0: batch moments (biased variance), EMA shadows updated as
  * s -= (s - stat) * (1 - decay[0]) when ema_mean != NULL; training == 0: moments =
  * EMA shadows.  save_mean/save_var[C] receive the moments used.  eps = 1e-3.
- * workspace: cloudaae_bn_workspace_bytes(C) bytes. */
+ * workspace: cloudaae_bn_workspace_bytes(C) bytes.  * pool_stats (optional, mean pool + ReLU in training mode): 3 x C doubles per group -- rows passing the
+ * ReLU, sum of their x_hat, sum of all x_hat -- which cloudaae_bn_backward(pool_stats=...) turns into its
+ * column sums without a pass over y when the pooled value is the only consumer (dout == NULL). */
 long long cloudaae_bn_workspace_bytes(int C);
 int cloudaae_bn_forward(int M, int C, const float *y, int ldy, const float *gamma, const float *beta,
                         int training, const float *decay, float *ema_mean, float *ema_var,
                         float *save_mean, float *save_var, int relu, float *out, int ldo, int pool_rows,
-                        int pool_mode, float *pooled, float *tie_count, void *workspace,
+                        int pool_mode, float *pooled, float *tie_count, double *pool_stats, void *workspace,
                         cloudaae_stream_t stream);
 /* The same with the statistics pass skipped: the first colstats_parts x 2 x C doubles of `workspace`
  * already hold per-row-tile column sums / sums of squares of y, written by cloudaae_gemm_f32_colstats
@@ -155,7 +157,7 @@ int cloudaae_bn_forward(int M, int C, const float *y, int ldy, const float *gamm
 int cloudaae_bn_forward_colstats(int M, int C, const float *y, int ldy, const float *gamma, const float *beta,
                                  int training, const float *decay, float *ema_mean, float *ema_var,
                                  float *save_mean, float *save_var, int relu, float *out, int ldo, int pool_rows,
-                                 int pool_mode, float *pooled, float *tie_count, void *workspace,
+                                 int pool_mode, float *pooled, float *tie_count, double *pool_stats, void *workspace,
                                  int colstats_parts, cloudaae_stream_t stream);
 /* gradient of the above: upstream = dout[M,C] (may be NULL) and/or dpooled[M/pool_rows,C]
  * (mean: /pool_rows; max: shared among equal maxima, as tf.reduce_max does);
@@ -166,8 +168,8 @@ int cloudaae_bn_backward(int M, int C, const float *y, int ldy, const float *gam
                          const float *save_mean, const float *save_var, int training, int relu,
                          const float *dout, int lddo, int pool_rows, int pool_mode, const float *dpooled,
                          const float *pooled, const float *tie_count, float *dy, int lddy, float *dgamma,
-                         float *dbeta, float *dbias, int accumulate_param_grads, void *workspace,
-                         cloudaae_stream_t stream);
+                         float *dbeta, float *dbias, int accumulate_param_grads, const double *pool_stats,
+                         void *workspace, cloudaae_stream_t stream);
 /* out[c] (+)= sum_r x[r][c] (bias gradients); workspace as for bn (same C). */
 int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, float *out, int accumulate, void *workspace,
                         cloudaae_stream_t stream);

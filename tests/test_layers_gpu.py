@@ -512,14 +512,14 @@ def test_gemm_colstats_feed_batch_norm(hip, M, N, K):
             hip.check(L.cloudaae_gemm_f32_colstats(0, 0, M, N, K, P(A), K, P(B), N, P(C), N, P(bias), P(ws), s), "g")
             hip.check(L.cloudaae_bn_forward_colstats(M, N, P(C), N, P(gamma), P(beta), 1, P(decay), P(sm), P(sv), P(mean),
                                                      P(var), 1, P(out), N, rows, 1 if rows else 0, P(pooled), None,
-                                                     P(ws), parts, s), "bn")
+                                                     None, P(ws), parts, s), "bn")
             stats = ws[:parts * 2 * N].reshape(parts, 2, N).sum(0)
             Cd = C.double()
             assert _rel(stats[0], Cd.sum(0)) < 1e-9 and _rel(stats[1], (Cd * Cd).sum(0)) < 1e-9
         else:
             hip.check(L.cloudaae_gemm_f32(0, 0, M, N, K, P(A), K, P(B), N, P(C), N, P(bias), 0, s), "g")
             hip.check(L.cloudaae_bn_forward(M, N, P(C), N, P(gamma), P(beta), 1, P(decay), P(sm), P(sv), P(mean), P(var),
-                                            1, P(out), N, rows, 1 if rows else 0, P(pooled), None, P(ws), s), "bn")
+                                            1, P(out), N, rows, 1 if rows else 0, P(pooled), None, None, P(ws), s), "bn")
         torch.cuda.synchronize()
         res.append((C, mean, var, sm, sv, out, pooled))
     assert torch.equal(res[0][0], res[1][0])

@@ -57,7 +57,7 @@ def main():
             L.cloudaae_gemm_f32(0, 0, M, N, K, P(x), K, P(W), N, P(y), N, P(b), 0, s)
             if bn:
                 L.cloudaae_bn_forward(M, N, P(y), N, gp, bp, 1, P(decay), P(sm), P(sv), P(mean), P(var), 1, P(out), N,
-                                      0, 0, None, None, P(ws), s)
+                                      0, 0, None, None, None, P(ws), s)
 
         def fused_bwd():
             L.cloudaae_fc_backward(M, K, N, P(x), K, P(W), P(y), gp, bp, P(mean) if bn else None,
@@ -68,7 +68,7 @@ def main():
             src = dout
             if bn:
                 L.cloudaae_bn_backward(M, N, P(y), N, gp, bp, P(mean), P(var), 1, 1, P(dout), N, 0, 0, None, None, None,
-                                       P(dy), N, P(dg), P(db), P(dbias), 0, P(ws), s)
+                                       P(dy), N, P(dg), P(db), P(dbias), 0, None, P(ws), s)
                 src = dy
             else:
                 L.cloudaae_colsum_f32(M, N, P(dout), N, P(dbias), 0, P(ws), s)
