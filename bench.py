@@ -79,13 +79,12 @@ def chamfer_cpu_rate(n, m, clouds=4):
 
 def chamfer_kernel_rate(batch, n, m, iters=20):
     """The second half of BASELINE's metric: Chamfer nn_distance forward kernel rate.
-    Algorithmic bytes = B*(n+m)*20 (12 B read + 4 B dist + 4 B idx per point, SURVEY 8d);
-    the kernel is fp32-VALU-bound (~1640 flop/B), so pairs/s against the VALU ceiling is the
-    meaningful fraction.  Un-fused arithmetic (bit parity with the CPU reference) costs 8
-    lane-ops per pair (3 sub, 3 mul, 2 add) + 0.5 (v_min3_u32 per two pairs) + ~0.1 tile
-    bookkeeping; v_pk_add/mul_f32 retire two lanes-worth per 4-cycle issue, i.e. no faster
-    than two scalar ops (measured: identical rate for 1, 2 or 4 queries per lane), so the
-    ceiling is 256 CU x 4 SIMD x 32 lanes x 2.4 GHz / 8.6 = 9.1 T pairs/s."""
+    Algorithmic bytes = B*(n+m)*20 (12 B read + 4 B dist + 4 B idx per point): arithmetic-bound
+    by three orders of magnitude.  Large clouds take nn_distance_filter_kernel: the nearest candidate is
+    searched with scores on the matrix cores (two v_mfma_f32_32x32x2_f32 per 32 x 32 pairs) and the
+    reference's un-fused arithmetic decides among the candidates of the two best units (bit parity with
+    the CPU reference).  Its bound is the matrix pipe: 1024 pairs per 128 cycles per SIMD = 19.7 T pairs/s
+    (the first-generation kernel: 8.6 fp32 lane-operations per pair, 9.1 T pairs/s at best)."""
     from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
     g = torch.Generator(device="cuda").manual_seed(100)       # tf_nndistance.py:45-46 seeds
     a = torch.randn((batch, n, 3), generator=g, device="cuda")
@@ -100,10 +99,10 @@ def chamfer_kernel_rate(batch, n, m, iters=20):
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     pairs = 2.0 * batch * n * m
-    ceiling = 78.6e12 / 8.6
+    bound = 256 * 4 * 2.4e9 * 1024 / 128
     return {"shape": "[%d,%d,3]x[%d,%d,3]" % (batch, n, batch, m), "us_per_launch": round(sec * 1e6, 2),
             "GB/s": round(batch * (n + m) * 20 / sec / 1e9, 3), "Tpairs/s": round(pairs / sec / 1e12, 3),
-            "clouds/s": round(batch / sec, 1), "frac_of_valu_ceiling": round(pairs / sec / ceiling, 4)}
+            "clouds/s": round(batch / sec, 1), "frac_of_matrix_pipe_bound": round(pairs / sec / bound, 4)}
 
 
 def main():

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(int M, int C, const float
         const float mean = stats ? save_mean[c] : 0.0f, rstd = stats ? bn_rsqrt(save_var[c] + BN_EPS) : 0.0f;
         for (int rb = r0 + rl; rb < r1; rb += 4 * BN_U) {
             float v[BN_U];
+            float bx = 0.0f, ball = 0.0f;
 #pragma unroll
             for (int u = 0; u < BN_U; ++u) {
                 const int r = rb + 4 * u;
@@ -107,13 +108,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(int M, int C, const float
                         out[(size_t)r * ldo + c] = z;
                     if (POOL == 1)
                         acc = acc + z;
-                    if (stats) {
+                    if (stats) {    // fp32 inside the batch of BN_U rows, fp64 across batches
                         const float xh = (v[u] - mean) * rstd;
-                        sall += (double)xh;
-                        if (z > 0.0f) {
-                            cnt += 1.0f;
-                            sx += (double)xh;
-                        }
+                        ball += xh;
+                        cnt += z > 0.0f ? 1.0f : 0.0f;
+                        bx += z > 0.0f ? xh : 0.0f;
                     }
                     if (POOL == 2) {
                         if (z > acc) {
@@ -124,6 +123,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(int M, int C, const float
                         }
                     }
                 }
+            }
+            if (stats) {
+                sx += (double)bx;
+                sall += (double)ball;
             }
         }
     }
