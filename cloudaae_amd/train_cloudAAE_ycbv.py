@@ -150,23 +150,22 @@ class TrainGraph(object):
         dummy[:, :, :3] = torch.rand((B, N, 3), device=self.device)
         with torch.no_grad():
             self._call_model(dummy, False)
-        self.store.flatten(last=('dgcnn_output/weights', 'pn_output/weights'))
+        # the fully connected stack (tag 'fc': decoder + pose heads) goes to the END of the flat buffers: its
+        # gradients are the first ones backward produces, and the exchange reduces them as one early piece
+        self.store.flatten(last=lambda v: v.tag == 'fc')
         n = self.store.flat_params.numel()
         self.adam_m = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.adam_v = torch.zeros(n, dtype=torch.float32, device=self.device)
-        # overlap bucket: the decoder output weights (12*N*1024 floats), first gradient of backward
+        fc = [v for v in self.store.trainable_variables() if v.tag == 'fc']
         early = None
-        for name in ('dgcnn_output/weights', 'pn_output/weights'):
-            v = self.store.vars.get(name)
-            if v is not None:
-                o = self.store.offsets[name]
-                early = (o, o + v.data.numel())
-        self.exchange = GradExchange(self.store.flat_grads, early, self.pg, world=self.world)
+        if fc:
+            lo = min(self.store.offsets[v.name] for v in fc)
+            early = (lo, n)
+        self.exchange = GradExchange(self.store.flat_grads, early, self.pg, world=self.world, early_count=len(fc))
         self.exchange.broadcast_params(self.store.flat_params)     # identical initial weights on every rank
         if early is not None and self.exchange.active:
-            for name in ('dgcnn_output/weights', 'pn_output/weights'):
-                if name in self.store.vars:
-                    self.store.vars[name].on_ready = self.exchange.early_ready
+            for v in fc:
+                v.on_ready = self.exchange.early_ready
 
     def _call_model(self, pc, is_training):
         set_default_store(self.store)      # several graphs may live in one process (cf. tf.Graph.as_default)

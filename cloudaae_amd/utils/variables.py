@@ -22,7 +22,7 @@ import torch
 
 
 class Variable(object):
-    __slots__ = ("name", "shape", "trainable", "data", "grad", "fresh", "zeroed", "on_ready")
+    __slots__ = ("name", "shape", "trainable", "data", "grad", "fresh", "zeroed", "on_ready", "tag")
 
     def __init__(self, name, data, trainable):
         self.name = name
@@ -33,6 +33,7 @@ class Variable(object):
         self.fresh = True     # first gradient write of a backward pass stores, later ones add
         self.zeroed = False   # begin_step(zero_grads=True) cleared the gradient slot as part of one big fill
         self.on_ready = None  # called right after the gradient kernel is enqueued (comm overlap)
+        self.tag = None       # 'fc' for the fully connected stack (the early gradient bucket)
 
 
 class VariableStore(object):
@@ -119,8 +120,8 @@ class VariableStore(object):
 
     def flatten(self, last=()):
         """Pack trainables (and, separately, non-trainable state) into flat buffers;
-        every Variable.data becomes a view.  Offsets are 16-byte aligned.  `last`: names of
-        variables to place at the END of the flat buffer (the data-parallel exchange reduces the
+        every Variable.data becomes a view.  Offsets are 16-byte aligned.  `last`: names of (or a
+        predicate selecting) variables to place at the END of the flat buffer (the data-parallel exchange reduces the
         decoder output weights on their own, early; with them last the rest is ONE contiguous piece)."""
         if self.flat_params is not None:
             return
@@ -142,7 +143,8 @@ class VariableStore(object):
             return flat, offs
 
         tv = self.trainable_variables()
-        tv = [x for x in tv if x.name not in last] + [x for x in tv if x.name in last]
+        is_last = last if callable(last) else (lambda v: v.name in last)
+        tv = [x for x in tv if not is_last(x)] + [x for x in tv if is_last(x)]
         self.flat_params, offs = pack(tv, True)
         self.flat_grads = torch.zeros_like(self.flat_params)
         self._zero = torch.zeros(1, dtype=torch.float32, device=self.device)

@@ -57,7 +57,21 @@ def _worker(rank, world, port, out):
         w2 = torch.tensor([0.5], requires_grad=True)
         ((w2 * x - 1.0) ** 2).mean().backward()
         ok5 = torch.allclose(gw / world, w2.grad, rtol=1e-6) and (hi - lo) == 8 // world
-        out[rank] = all([ok1, ok2, ok3, ok4, ok5])
+        # (6) an early range fed by several variables: the piece leaves at the LAST of their hooks, once,
+        # and the count starts over with the next step
+        g6 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        ex6 = GradExchange(g6, early=(400, n), early_count=3)
+        sent = []
+        for step in range(2):
+            for call in range(3):
+                ex6.early_ready()
+                sent.append(ex6._early_sent)
+            ex6.finish()
+            if step == 0:
+                ok6 = torch.equal(g6, want)
+                g6.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1))
+        ok6 = ok6 and torch.equal(g6, want) and sent == [False, False, True] * 2
+        out[rank] = all([ok1, ok2, ok3, ok4, ok5, ok6])
     finally:
         dist.destroy_process_group()
 
