@@ -149,23 +149,31 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_stats_kernel(EcArgs a, 
 
 template <int CPL, int KCAP, int POOL>
 __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float *__restrict__ out, int ldo,
-                                                                float *__restrict__ ties)
+                                                                float *__restrict__ ties,
+                                                                float *__restrict__ edge_stats)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float sc[CPL], sh[CPL];
+    // mean pool in training mode: per point and channel, what the backward statistics need of its k
+    // edges -- how many pass the ReLU, the sum of their x_hat, the sum of all x_hat (edge_stats[P][3][cout]).
+    // The upstream gradient of every edge of a point is the same number, so backward gets its column
+    // sums from these without gathering a single neighbour (ec_bwd_stats_pool_kernel).
+    const bool stats = POOL == 1 && edge_stats != nullptr;
+    float sc[CPL], sh[CPL], mean[CPL], rstd[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e) {
         sc[e] = a.scale_shift[lane + 64 * e];
         sh[e] = a.scale_shift[a.cout + lane + 64 * e];
+        mean[e] = stats ? a.save_mean[lane + 64 * e] : 0.0f;
+        rstd[e] = stats ? bn_rsqrt(a.save_var[lane + 64 * e] + BN_EPS) : 0.0f;
     }
     ec_for_each_point<EC_WAVES>(a, wave, [&](int pt) {
         EcPoint<CPL, KCAP> p;
         p.load(a, pt, lane);
-        float acc[CPL], cnt[CPL];
+        float acc[CPL], cnt[CPL], sx[CPL], sall[CPL];
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
             acc[e] = POOL == 2 ? -__builtin_inff() : 0.0f;
-            cnt[e] = 0.0f;
+            cnt[e] = sx[e] = sall[e] = 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < KCAP; ++j)
@@ -178,6 +186,12 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
                         acc[e] = fmaxf(acc[e], z);
                     } else {
                         acc[e] = acc[e] + z;
+                        if (stats) {
+                            const float xh = (p.y[j][e] - mean[e]) * rstd[e];
+                            sall[e] += xh;
+                            cnt[e] += z > 0.0f ? 1.0f : 0.0f;
+                            sx[e] += z > 0.0f ? xh : 0.0f;
+                        }
                     }
                 }
             }
@@ -186,6 +200,12 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
             out[(size_t)pt * ldo + lane + 64 * e] = POOL == 2 ? acc[e] : acc[e] / (float)a.k;
             if (POOL == 2 && ties != nullptr)
                 ties[(size_t)pt * a.cout + lane + 64 * e] = cnt[e];
+            if (stats) {
+                float *es = edge_stats + (size_t)pt * 3 * a.cout + lane + 64 * e;
+                es[0] = cnt[e];
+                es[a.cout] = sx[e];
+                es[2 * a.cout] = sall[e];
+            }
         }
     });
 }
@@ -268,6 +288,36 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_bwd_stats_kernel(EcArgs
     ec_block_reduce_store<CPL>(s, s2, partial, a.cout, lane, wave);
     __syncthreads();
     // third sum (sum of x_hat, ~0): needed for the conv-bias gradient, see ec_bwd_finalize_kernel
+    ec_block_reduce_store<CPL>(s3, zero, partial + (size_t)EC_MAX_PARTS * 2 * a.cout, a.cout, lane, wave);
+}
+
+// The same three sums for the mean pool, from what the forward apply pass left per point (edge_stats):
+// every edge of point i has the upstream gradient dout_i / k (times its ReLU mask), so
+//   sum dz = sum_i (dout_i / k) cnt_i,  sum dz x_hat = sum_i (dout_i / k) sx_i,  sum x_hat = sum_i sall_i
+// -- a streaming pass over four [P][cout] arrays instead of k gathers per point.
+template <int CPL>
+__global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_bwd_stats_pool_kernel(EcArgs a,
+                                                                              const float *__restrict__ edge_stats,
+                                                                              double *__restrict__ partial)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double s[CPL], s2[CPL], s3[CPL], zero[CPL];
+#pragma unroll
+    for (int e = 0; e < CPL; ++e)
+        s[e] = s2[e] = s3[e] = zero[e] = 0.0;
+    ec_for_each_point<EC_STAT_WAVES>(a, wave, [&](int pt) {
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) {
+            const int c = lane + 64 * e;
+            const float *es = edge_stats + (size_t)pt * 3 * a.cout + c;
+            const double g = (double)(a.dout[(size_t)pt * a.lddo + c] / (float)a.k);
+            s[e] += g * (double)es[0];
+            s2[e] += g * (double)es[a.cout];
+            s3[e] += (double)es[2 * a.cout];
+        }
+    });
+    ec_block_reduce_store<CPL>(s, s2, partial, a.cout, lane, wave);
+    __syncthreads();
     ec_block_reduce_store<CPL>(s3, zero, partial + (size_t)EC_MAX_PARTS * 2 * a.cout, a.cout, lane, wave);
 }
 
@@ -547,8 +597,8 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
                                            const float *gamma, const float *beta, int training,
                                            const float *decay, float *ema_mean, float *ema_var,
                                            int pool_mode, float *pq, float *save_mean, float *save_var,
-                                           float *out, int ldo, float *tie_count, int gemm_bf16,
-                                           void *workspace, cloudaae_stream_t stream)
+                                           float *out, int ldo, float *tie_count, float *edge_stats,
+                                           int gemm_bf16, void *workspace, cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_edgeconv_forward";
     if (int rc = ec_check(name, b, n, k, cin, cout, pool_mode))
@@ -566,6 +616,8 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
     EcArgs a = {};
     a.P = P; a.N = n; a.k = k; a.cout = cout; a.ldpq = 2 * cout;
     a.pq = pq; a.bias = biases; a.nn_idx = nn_idx; a.scale_shift = scale_shift;
+    a.save_mean = save_mean; a.save_var = save_var;
+    float *es = (training && pool_mode == 1) ? edge_stats : nullptr;
     const int cpl = cout / 64, kcap = k <= 10 ? 10 : (k <= 20 ? 20 : 32);
     const int grid = ec_stat_grid(P), agrid = ec_apply_grid(P);
     if (training) {
@@ -577,11 +629,11 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
                        (double)P * (double)k, training, decay, ema_mean, ema_var, gamma, beta, save_mean,
                        save_var, scale_shift);
     if (pool_mode == 1) {
-#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count)
+#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, es)
         EC_DISPATCH(EC_APPLY);
 #undef EC_APPLY
     } else {
-#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 2>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count)
+#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 2>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, nullptr)
         EC_DISPATCH(EC_APPLY);
 #undef EC_APPLY
     }
@@ -597,7 +649,7 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
                                             const float *tie_count, const float *dout, int lddo, float *dpq,
                                             int *rev_scratch, float *dx, int lddx, int accumulate_dx,
                                             float *dweights, int dweights_zeroed, float *dbiases, float *dgamma,
-                                            float *dbeta, int gemm_bf16, void *workspace,
+                                            float *dbeta, const float *edge_stats, int gemm_bf16, void *workspace,
                                             cloudaae_stream_t stream, cloudaae_stream_t side_stream)
 {
     const char *name = "cloudaae_edgeconv_backward";
@@ -633,7 +685,14 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
     a.training = training;
     const int cpl = cout / 64, kcap = k <= 10 ? 10 : (k <= 20 ? 20 : 32);
     const int grid = ec_stat_grid(P), agrid = ec_apply_grid(P);
-    if (pool_mode == 1) {
+    if (pool_mode == 1 && edge_stats != nullptr && training) {
+        if (cpl == 1)
+            hipLaunchKernelGGL(ec_bwd_stats_pool_kernel<1>, dim3(grid), dim3(64 * EC_STAT_WAVES), 0, s, a, edge_stats,
+                               partial);
+        else
+            hipLaunchKernelGGL(ec_bwd_stats_pool_kernel<2>, dim3(grid), dim3(64 * EC_STAT_WAVES), 0, s, a, edge_stats,
+                               partial);
+    } else if (pool_mode == 1) {
 #define EC_BS(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_stats_kernel<CPL_, KC_, 1>), dim3(grid), dim3(64 * EC_STAT_WAVES), 0, s, a, partial)
         EC_DISPATCH(EC_BS);
 #undef EC_BS

@@ -558,12 +558,15 @@ class EdgeConvFn(torch.autograd.Function):
         save_var = _lib.empty(cout, dtype=torch.float32, device=dev)
         ties = _lib.empty((B * N, cout), dtype=torch.float32, device=dev) if pool_mode == 2 else None
         ws = _ws(L().cloudaae_edgeconv_workspace_bytes(cout), dev)
+        # mean pool, training: per point what backward's statistics need of its k edges (see the C header)
+        estats = _lib.empty((B * N, 3, cout), dtype=torch.float32, device=dev) if (training and pool_mode == 1) else None
         _lib.check(L().cloudaae_edgeconv_forward(
             B, N, k, cin, cout, x.data_ptr(), ldx, ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
             int(training), ptr(decay), ptr(ema_mean), ptr(ema_var), int(pool_mode), ptr(pq), ptr(save_mean),
-            ptr(save_var), out.data_ptr(), ldo, ptr(ties), int(gemm_is_bf16()), ptr(ws), stream()),
+            ptr(save_var), out.data_ptr(), ldo, ptr(ties), ptr(estats), int(gemm_is_bf16()), ptr(ws), stream()),
             "cloudaae_edgeconv_forward")
         ctx.bf16 = gemm_is_bf16()
+        ctx.estats = estats
         ctx.save_for_backward(x, nn_idx, w, b, gamma, beta, pq, save_mean, save_var, ties,
                               out if pool_mode == 2 else None)
         ctx.cfg = (int(training), int(pool_mode))
@@ -613,8 +616,8 @@ class EdgeConvFn(torch.autograd.Function):
             training, pool_mode, ptr(pq), ptr(save_mean), ptr(save_var),
             fwd_out.data_ptr() if fwd_out is not None else None, fwd_out.stride(1) if fwd_out is not None else 0,
             ptr(ties), dout.data_ptr(), dout.stride(1), ptr(dpq), ptr(rev), dx_ptr, lddx, acc_dx, ptr(gw.buf),
-            1 if (gw.needed and gw.gemm_acc == 2) else 0, ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), int(ctx.bf16),
-            ptr(ws), stream(), SIDE_STREAM if (SIDE_EDGE and not shared and gw.needed and gw.own is None) else None),
+            1 if (gw.needed and gw.gemm_acc == 2) else 0, ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), ptr(ctx.estats),
+            int(ctx.bf16), ptr(ws), stream(), SIDE_STREAM if (SIDE_EDGE and not shared and gw.needed and gw.own is None) else None),
             "cloudaae_edgeconv_backward")
         for g in shared:
             L().cloudaae_add_f32(g.buf.numel(), ptr(tmp[id(g)]), ptr(g.buf), ptr(tmp[id(g)]), stream())
