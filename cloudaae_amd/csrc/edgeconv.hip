@@ -45,6 +45,7 @@ struct EcArgs {
     const float *dout;     // [P][lddo]
     int lddo;
     int training;
+    int u_stored;          // the P' half of pq holds U = P' - Q + bias (every forward call leaves it so)
 };
 
 // all k pre-activation rows of one point, for this lane's CPL channels
@@ -62,7 +63,7 @@ struct EcPoint {
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
             const int c = lane + 64 * e;
-            u[e] = (row[c] - row[a.cout + c]) + a.bias[c];
+            u[e] = a.u_stored ? row[c] : (row[c] - row[a.cout + c]) + a.bias[c];
         }
 #pragma unroll
         for (int j = 0; j < KCAP; ++j) {
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_stats_kernel(EcArgs a, 
 template <int CPL, int KCAP, int POOL>
 __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float *__restrict__ out, int ldo,
                                                                 float *__restrict__ ties,
-                                                                float *__restrict__ edge_stats)
+                                                                float *__restrict__ edge_stats,
+                                                                float *__restrict__ u_out)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // mean pool in training mode: per point and channel, what the backward statistics need of its k
@@ -205,6 +207,13 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
                 es[0] = cnt[e];
                 es[a.cout] = sx[e];
                 es[2 * a.cout] = sall[e];
+            }
+            if (u_out != nullptr) {
+                // U_i = P'_i - Q_i + b replaces P'_i (only this wave reads that half-row): the backward
+                // passes fetch ONE row per source point instead of two
+                const int c = lane + 64 * e;
+                const float *row = a.pq + (size_t)pt * a.ldpq;
+                u_out[(size_t)pt * a.ldpq + c] = (row[c] - row[a.cout + c]) + a.bias[c];
             }
         }
     });
@@ -434,7 +443,7 @@ template <int CPL, int KCAP, int POOL>
 __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
     EcArgs a, const float *__restrict__ m12, const int *__restrict__ rev_off, const int *__restrict__ rev_src,
     const float *__restrict__ fwd_out, int ldo, const float *__restrict__ ties, float *__restrict__ dpq,
-    float *__restrict__ /*unused*/)
+    const float *__restrict__ edge_stats)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float sc[CPL], sh[CPL], mean[CPL], rstd[CPL], gr[CPL], m1[CPL], m2[CPL], bias[CPL];
@@ -461,7 +470,17 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
         const int beg = off[m], end = off[m + 1];
         int mine = (beg + lane < end) ? src[beg + lane] : 0;
         float S[CPL], T[CPL], Qm[CPL];
-        {
+        if (POOL == 1 && edge_stats != nullptr) {
+            // S_i = sum_j gr ((dz_ij - m1) - x_hat_ij m2) with dz_ij = mask_ij dout_i / k: from the point's
+            // edge statistics of the forward pass, no neighbour is fetched
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+                const int c = lane + 64 * e;
+                const float *es = edge_stats + (size_t)pt * 3 * a.cout + c;
+                const float gk = a.dout[(size_t)pt * a.lddo + c] / (float)a.k;
+                S[e] = gr[e] * ((gk * es[0] - (float)a.k * m1[e]) - es[2 * a.cout] * m2[e]);
+            }
+        } else {
             EcPoint<CPL, KCAP> p;
             p.load(a, pt, lane);
             float dz[KCAP][CPL];
@@ -500,7 +519,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
 #pragma unroll
                     for (int e = 0; e < CPL; ++e) {
                         pi[u][e] = row[64 * e];
-                        qi[u][e] = row[a.cout + 64 * e];
+                        qi[u][e] = a.u_stored ? 0.0f : row[a.cout + 64 * e];
                         gi[u][e] = on ? a.dout[(size_t)i * a.lddo + lane + 64 * e] : 0.0f;
                         if (POOL == 2) {
                             oi[u][e] = fwd_out[(size_t)i * ldo + lane + 64 * e];
@@ -513,7 +532,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
                     if (q0 + u < cntc) {
 #pragma unroll
                         for (int e = 0; e < CPL; ++e) {
-                            const float uu = (pi[u][e] - qi[u][e]) + bias[e];
+                            const float uu = a.u_stored ? pi[u][e] : (pi[u][e] - qi[u][e]) + bias[e];
                             const float y = uu + Qm[e];
                             const float z = fmaxf(y * sc[e] + sh[e], 0.0f);
                             float d = POOL == 2 ? (z == oi[u][e] ? gi[u][e] / ti[u][e] : 0.0f)
@@ -629,11 +648,11 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
                        (double)P * (double)k, training, decay, ema_mean, ema_var, gamma, beta, save_mean,
                        save_var, scale_shift);
     if (pool_mode == 1) {
-#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, es)
+#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, es, pq)
         EC_DISPATCH(EC_APPLY);
 #undef EC_APPLY
     } else {
-#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 2>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, nullptr)
+#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 2>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, nullptr, pq)
         EC_DISPATCH(EC_APPLY);
 #undef EC_APPLY
     }
@@ -683,6 +702,7 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
     a.pq = pq; a.bias = biases; a.nn_idx = nn_idx; a.scale_shift = nullptr;   // backward kernels derive it per lane
     a.gamma = gamma; a.beta = beta; a.save_mean = save_mean; a.save_var = save_var; a.dout = dout; a.lddo = lddo;
     a.training = training;
+    a.u_stored = 1;     // cloudaae_edgeconv_forward left U in the P' half of pq
     const int cpl = cout / 64, kcap = k <= 10 ? 10 : (k <= 20 ? 20 : 32);
     const int grid = ec_stat_grid(P), agrid = ec_apply_grid(P);
     if (pool_mode == 1 && edge_stats != nullptr && training) {
@@ -715,11 +735,11 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
         hipLaunchKernelGGL(ec_revlist_kernel, dim3(b), dim3(512), lds, s, n, k, nn_idx, rev_off, rev_src);
     }
     if (pool_mode == 1) {
-#define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src, out, ldo, tie_count, dpq, dbiases)
+#define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src, out, ldo, tie_count, dpq, training ? edge_stats : nullptr)
         EC_DISPATCH(EC_BA);
 #undef EC_BA
     } else {
-#define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 2>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src, out, ldo, tie_count, dpq, dbiases)
+#define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 2>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src, out, ldo, tie_count, dpq, nullptr)
         EC_DISPATCH(EC_BA);
 #undef EC_BA
     }

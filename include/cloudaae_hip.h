@@ -254,7 +254,9 @@ int cloudaae_fc_backward_group(int M, int count, const cloudaae_fc_layer *layers
  * dweights_zeroed != 0: the caller already cleared dweights (skips the clear pass of the split-K products).  * edge_stats (optional, used with mean pool in training mode): [b*n][3][cout] floats the forward call
  * fills per point -- edges passing the ReLU, sum of their x_hat, sum of all x_hat -- and the backward
  * call, given the same buffer, turns into its column sums with a streaming pass instead of gathering
- * every neighbour again (24.7 -> 7 us per 64-channel layer at B=32, N=1024). */
+ * every neighbour again (24.7 -> 7 us per 64-channel layer at B=32, N=1024).  * pq: [b*n][2*cout] scratch of the call; on return its first cout columns hold U = X W_centre' + b
+ * (centre term of every edge of the point) and the last cout columns Q = X W_neighbour, which is how
+ * cloudaae_edgeconv_backward expects to find it. */
 long long cloudaae_edgeconv_workspace_bytes(int cout);
 int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cout, const float *x, int ldx,
                               const int *nn_idx, const float *weights, const float *biases,
