@@ -45,11 +45,12 @@ struct EcArgs {
     const float *dout;     // [P][lddo]
     int lddo;
     int training;
-    int u_stored;          // the P' half of pq holds U = P' - Q + bias (every forward call leaves it so)
 };
 
 // all k pre-activation rows of one point, for this lane's CPL channels
-template <int CPL, int KCAP>
+// US: the P' half of pq already holds U = P' - Q + bias (true in the backward kernels: every forward
+// call leaves it so)
+template <int CPL, int KCAP, bool US = false>
 struct EcPoint {
     float y[KCAP][CPL];
     int nb[KCAP];
@@ -63,7 +64,7 @@ struct EcPoint {
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
             const int c = lane + 64 * e;
-            u[e] = a.u_stored ? row[c] : (row[c] - row[a.cout + c]) + a.bias[c];
+            u[e] = US ? row[c] : (row[c] - row[a.cout + c]) + a.bias[c];
         }
 #pragma unroll
         for (int j = 0; j < KCAP; ++j) {
@@ -77,6 +78,58 @@ struct EcPoint {
         }
     }
 };
+
+// Two points at once: both index loads, then both own rows, then all 2k neighbour rows -- two dependent
+// memory round trips for the PAIR.  A wave that handles its points one after the other pays the two
+// round trips per point, and (vmcnt retires in order) the stores of one point in front of the loads of
+// the next: ec_apply_kernel went from 11.5 to 26 us per layer when it got four more rows to store.
+template <int CPL, int KCAP, bool US>
+__device__ __forceinline__ void ec_load_pair(const EcArgs &a, int pt0, int pt1, int lane, EcPoint<CPL, KCAP, US> &p0,
+                                             EcPoint<CPL, KCAP, US> &p1)
+{
+    const int mine0 = lane < a.k ? a.nn_idx[(size_t)pt0 * a.k + lane] : 0;
+    const int mine1 = lane < a.k ? a.nn_idx[(size_t)pt1 * a.k + lane] : 0;
+    const float *row0 = a.pq + (size_t)pt0 * a.ldpq, *row1 = a.pq + (size_t)pt1 * a.ldpq;
+    float u0[CPL], u1[CPL], r0[2][CPL], r1[2][CPL];
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) {
+        const int c = lane + 64 * e;
+        r0[0][e] = row0[c];
+        r1[0][e] = row1[c];
+        r0[1][e] = US ? 0.0f : row0[a.cout + c];
+        r1[1][e] = US ? 0.0f : row1[a.cout + c];
+    }
+    const int base0 = (pt0 / a.N) * a.N, base1 = (pt1 / a.N) * a.N;
+    float q0[KCAP][CPL], q1[KCAP][CPL];
+#pragma unroll
+    for (int j = 0; j < KCAP; ++j)
+        if (j < a.k) {
+            p0.nb[j] = base0 + __shfl(mine0, j, 64);
+            p1.nb[j] = base1 + __shfl(mine1, j, 64);
+            const float *g0 = a.pq + (size_t)p0.nb[j] * a.ldpq + a.cout + lane;
+            const float *g1 = a.pq + (size_t)p1.nb[j] * a.ldpq + a.cout + lane;
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+                q0[j][e] = g0[64 * e];
+                q1[j][e] = g1[64 * e];
+            }
+        }
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) {
+        const float b = US ? 0.0f : a.bias[lane + 64 * e];
+        u0[e] = US ? r0[0][e] : (r0[0][e] - r0[1][e]) + b;
+        u1[e] = US ? r1[0][e] : (r1[0][e] - r1[1][e]) + b;
+    }
+#pragma unroll
+    for (int j = 0; j < KCAP; ++j)
+        if (j < a.k) {
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+                p0.y[j][e] = u0[e] + q0[j][e];
+                p1.y[j][e] = u1[e] + q1[j][e];
+            }
+        }
+}
 
 // Point -> wave assignment.  MI355X has 8 XCDs with private 4 MiB L2s and workgroup b runs
 // on XCD b % 8 (observed placement; used for speed only).  A cloud's P'/Q/dOut rows are
@@ -96,6 +149,23 @@ __device__ __forceinline__ void ec_for_each_point(const EcArgs &a, int wave, F &
         for (int pt = blockIdx.x * NW + wave; pt < a.P; pt += gridDim.x * NW)
             body(pt);
     }
+}
+
+// the same sequence of points, handed out two at a time (pt1 = -1 when the wave's count is odd)
+template <int NW, typename F>
+__device__ __forceinline__ void ec_for_each_pair(const EcArgs &a, int wave, F &&body)
+{
+    int pend = -1;
+    ec_for_each_point<NW>(a, wave, [&](int pt) {
+        if (pend < 0) {
+            pend = pt;
+        } else {
+            body(pend, pt);
+            pend = -1;
+        }
+    });
+    if (pend >= 0)
+        body(pend, -1);
 }
 
 template <int CPL>
@@ -132,16 +202,26 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_stats_kernel(EcArgs a, 
 #pragma unroll
     for (int e = 0; e < CPL; ++e)
         s[e] = s2[e] = 0.0;
-    ec_for_each_point<EC_STAT_WAVES>(a, wave, [&](int pt) {
-        EcPoint<CPL, KCAP> p;
-        p.load(a, pt, lane);
+    ec_for_each_pair<EC_STAT_WAVES>(a, wave, [&](int pt0, int pt1) {
+        EcPoint<CPL, KCAP> p0, p1;
+        ec_load_pair(a, pt0, pt1 >= 0 ? pt1 : pt0, lane, p0, p1);
+        const double w1 = pt1 >= 0 ? 1.0 : 0.0;
 #pragma unroll
         for (int j = 0; j < KCAP; ++j)
             if (j < a.k) {
 #pragma unroll
                 for (int e = 0; e < CPL; ++e) {
-                    s[e] += (double)p.y[j][e];
-                    s2[e] += (double)p.y[j][e] * (double)p.y[j][e];
+                    s[e] += (double)p0.y[j][e];
+                    s2[e] += (double)p0.y[j][e] * (double)p0.y[j][e];
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < KCAP; ++j)
+            if (j < a.k) {
+#pragma unroll
+                for (int e = 0; e < CPL; ++e) {
+                    s[e] += w1 * (double)p1.y[j][e];
+                    s2[e] += w1 * ((double)p1.y[j][e] * (double)p1.y[j][e]);
                 }
             }
     });
@@ -168,9 +248,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
         mean[e] = stats ? a.save_mean[lane + 64 * e] : 0.0f;
         rstd[e] = stats ? bn_rsqrt(a.save_var[lane + 64 * e] + BN_EPS) : 0.0f;
     }
-    ec_for_each_point<EC_WAVES>(a, wave, [&](int pt) {
-        EcPoint<CPL, KCAP> p;
-        p.load(a, pt, lane);
+    auto finish = [&](const EcPoint<CPL, KCAP> &p, int pt, bool store) {
         float acc[CPL], cnt[CPL], sx[CPL], sall[CPL];
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
@@ -197,6 +275,8 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
                     }
                 }
             }
+        if (!store)
+            return;
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
             out[(size_t)pt * ldo + lane + 64 * e] = POOL == 2 ? acc[e] : acc[e] / (float)a.k;
@@ -216,13 +296,19 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
                 u_out[(size_t)pt * a.ldpq + c] = (row[c] - row[a.cout + c]) + a.bias[c];
             }
         }
+    };
+    ec_for_each_pair<EC_WAVES>(a, wave, [&](int pt0, int pt1) {
+        EcPoint<CPL, KCAP> p0, p1;
+        ec_load_pair(a, pt0, pt1 >= 0 ? pt1 : pt0, lane, p0, p1);
+        finish(p0, pt0, true);
+        finish(p1, pt1, pt1 >= 0);
     });
 }
 
 // upstream gradient of z_ij for one point: mean -> dout/k; max -> dout shared among
 // the equal maxima (tf.reduce_max gradient), both masked by ReLU.
 template <int CPL, int KCAP, int POOL>
-__device__ __forceinline__ void ec_upstream(const EcArgs &a, const EcPoint<CPL, KCAP> &p, int pt, int lane,
+__device__ __forceinline__ void ec_upstream(const EcArgs &a, const EcPoint<CPL, KCAP, true> &p, int pt, int lane,
                                             const float (&sc)[CPL], const float (&sh)[CPL],
                                             float (&dz)[KCAP][CPL])
 {
@@ -278,7 +364,7 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_bwd_stats_kernel(EcArgs
         s[e] = s2[e] = s3[e] = zero[e] = 0.0;
     }
     ec_for_each_point<EC_STAT_WAVES>(a, wave, [&](int pt) {
-        EcPoint<CPL, KCAP> p;
+        EcPoint<CPL, KCAP, true> p;
         p.load(a, pt, lane);
         float dz[KCAP][CPL];
         ec_upstream<CPL, KCAP, POOL>(a, p, pt, lane, sc, sh, dz);
@@ -314,15 +400,31 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_bwd_stats_pool_kernel(E
 #pragma unroll
     for (int e = 0; e < CPL; ++e)
         s[e] = s2[e] = s3[e] = zero[e] = 0.0;
-    ec_for_each_point<EC_STAT_WAVES>(a, wave, [&](int pt) {
+    ec_for_each_pair<EC_STAT_WAVES>(a, wave, [&](int pt0, int pt1) {
+        const int q1 = pt1 >= 0 ? pt1 : pt0;
+        const double w1 = pt1 >= 0 ? 1.0 : 0.0;
+        float v0[4][CPL], v1[4][CPL];       // both points' loads first
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
             const int c = lane + 64 * e;
-            const float *es = edge_stats + (size_t)pt * 3 * a.cout + c;
-            const double g = (double)(a.dout[(size_t)pt * a.lddo + c] / (float)a.k);
-            s[e] += g * (double)es[0];
-            s2[e] += g * (double)es[a.cout];
-            s3[e] += (double)es[2 * a.cout];
+            const float *e0 = edge_stats + (size_t)pt0 * 3 * a.cout + c, *e1 = edge_stats + (size_t)q1 * 3 * a.cout + c;
+            v0[0][e] = a.dout[(size_t)pt0 * a.lddo + c];
+            v1[0][e] = a.dout[(size_t)q1 * a.lddo + c];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                v0[1 + t][e] = e0[t * a.cout];
+                v1[1 + t][e] = e1[t * a.cout];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) {
+            const double g0 = (double)(v0[0][e] / (float)a.k), g1 = w1 * (double)(v1[0][e] / (float)a.k);
+            s[e] += g0 * (double)v0[1][e];
+            s2[e] += g0 * (double)v0[2][e];
+            s3[e] += (double)v0[3][e];
+            s[e] += g1 * (double)v1[1][e];
+            s2[e] += g1 * (double)v1[2][e];
+            s3[e] += w1 * (double)v1[3][e];
         }
     });
     ec_block_reduce_store<CPL>(s, s2, partial, a.cout, lane, wave);
@@ -481,7 +583,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
                 S[e] = gr[e] * ((gk * es[0] - (float)a.k * m1[e]) - es[2 * a.cout] * m2[e]);
             }
         } else {
-            EcPoint<CPL, KCAP> p;
+            EcPoint<CPL, KCAP, true> p;
             p.load(a, pt, lane);
             float dz[KCAP][CPL];
             ec_upstream<CPL, KCAP, POOL>(a, p, pt, lane, sc, sh, dz);
@@ -510,7 +612,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
             if (s0 != beg)
                 mine = lane < cntc ? src[s0 + lane] : 0;
             for (int q0 = 0; q0 < cntc; q0 += RU) {
-                float pi[RU][CPL], qi[RU][CPL], gi[RU][CPL], oi[RU][CPL], ti[RU][CPL];
+                float pi[RU][CPL], gi[RU][CPL], oi[RU][CPL], ti[RU][CPL];
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
                     const bool on = q0 + u < cntc;
@@ -519,7 +621,6 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
 #pragma unroll
                     for (int e = 0; e < CPL; ++e) {
                         pi[u][e] = row[64 * e];
-                        qi[u][e] = a.u_stored ? 0.0f : row[a.cout + 64 * e];
                         gi[u][e] = on ? a.dout[(size_t)i * a.lddo + lane + 64 * e] : 0.0f;
                         if (POOL == 2) {
                             oi[u][e] = fwd_out[(size_t)i * ldo + lane + 64 * e];
@@ -532,7 +633,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
                     if (q0 + u < cntc) {
 #pragma unroll
                         for (int e = 0; e < CPL; ++e) {
-                            const float uu = a.u_stored ? pi[u][e] : (pi[u][e] - qi[u][e]) + bias[e];
+                            const float uu = pi[u][e];      // U of the source point
                             const float y = uu + Qm[e];
                             const float z = fmaxf(y * sc[e] + sh[e], 0.0f);
                             float d = POOL == 2 ? (z == oi[u][e] ? gi[u][e] / ti[u][e] : 0.0f)
@@ -702,7 +803,6 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
     a.pq = pq; a.bias = biases; a.nn_idx = nn_idx; a.scale_shift = nullptr;   // backward kernels derive it per lane
     a.gamma = gamma; a.beta = beta; a.save_mean = save_mean; a.save_var = save_var; a.dout = dout; a.lddo = lddo;
     a.training = training;
-    a.u_stored = 1;     // cloudaae_edgeconv_forward left U in the P' half of pq
     const int cpl = cout / 64, kcap = k <= 10 ? 10 : (k <= 20 ? 20 : 32);
     const int grid = ec_stat_grid(P), agrid = ec_apply_grid(P);
     if (pool_mode == 1 && edge_stats != nullptr && training) {
