@@ -45,7 +45,8 @@ _SIGNATURES = {
     "cloudaae_edgeconv_forward": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P,
                                   _P, _P, _P, _I, _P, _P, _I, _P, _P],
     "cloudaae_edgeconv_backward": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P,
-                                   _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P],
+                                   _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P],
+    "cloudaae_edgeconv_revlists": [_I, _I, _I, _I, _P, _P, _P],
     "cloudaae_input_assemble": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "cloudaae_add_rowvec": [_I, _I, _I, _P, _P, _P, _P],
     "cloudaae_add_f32": [_L, _P, _P, _P, _P],

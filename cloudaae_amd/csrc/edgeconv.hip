@@ -466,12 +466,22 @@ static __global__ __launch_bounds__(BN_FIN_THREADS) void ec_bwd_finalize_kernel(
 // rev_src[N*k] (source point i, cloud-local).  Counting sort in LDS; the order inside a
 // list depends on LDS-atomic arrival order (so dQ sums are reproducible to fp32 round-off,
 // not bitwise, exactly like the atomic scatter it replaces).
-__global__ __launch_bounds__(512) void ec_revlist_kernel(int N, int k, const int *__restrict__ nn_idx,
-                                                         int *__restrict__ rev_off, int *__restrict__ rev_src)
+constexpr int EC_REV_MAX = 8;       // layers whose lists one launch can build
+struct EcRevJobs {
+    const int *nn_idx[EC_REV_MAX];
+    int *rev[EC_REV_MAX];           // rev_off [b][N+1] followed by rev_src [b][N*k]
+};
+
+// grid (clouds, layers): the neighbour lists of every layer of the encoder exist once its forward pass
+// is over, so the backward pass builds all their reverse lists with ONE launch (four ~11 us launches of
+// 32 workgroups each otherwise).
+__global__ __launch_bounds__(512) void ec_revlist_kernel(int B, int N, int k, EcRevJobs jobs)
 {
     extern __shared__ int cnt[];
     __shared__ int wsum[8];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int *nn_idx = jobs.nn_idx[blockIdx.y];
+    int *rev_off = jobs.rev[blockIdx.y], *rev_src = rev_off + (size_t)B * (N + 1);
     const int *idx = nn_idx + (size_t)blockIdx.x * N * k;
     int *off = rev_off + (size_t)blockIdx.x * (N + 1);
     int *src = rev_src + (size_t)blockIdx.x * N * k;
@@ -698,6 +708,34 @@ static int ec_gemm(const char *name, int bf16, int ta, int tb, int M, int N, int
                                   (hipStream_t)stream);
 }
 
+static int ec_launch_revlists(const char *name, int count, int b, int n, int k, const int *const *nn_idx,
+                              int *const *rev, hipStream_t s)
+{
+    CLOUDAAE_REQUIRE(count >= 1 && count <= EC_REV_MAX, name, "1 to 8 neighbour lists per launch");
+    EcRevJobs jobs = {};
+    for (int i = 0; i < count; ++i) {
+        CLOUDAAE_REQUIRE(nn_idx[i] != nullptr && rev[i] != nullptr, name, "null argument");
+        jobs.nn_idx[i] = nn_idx[i];
+        jobs.rev[i] = rev[i];
+    }
+    const size_t lds = (size_t)n * sizeof(int);
+    CLOUDAAE_REQUIRE(lds <= 150 * 1024, name, "cloud too large for the LDS counting sort");
+    if (lds > 48 * 1024)
+        CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)ec_revlist_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
+    hipLaunchKernelGGL(ec_revlist_kernel, dim3(b, count), dim3(512), lds, s, b, n, k, jobs);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_edgeconv_revlists(int count, int b, int n, int k, const int *const *nn_idx,
+                                            int *const *rev_scratch, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_edgeconv_revlists";
+    CLOUDAAE_REQUIRE(b > 0 && n > 0 && k > 0 && nn_idx && rev_scratch, name, "bad argument");
+    return ec_launch_revlists(name, count, b, n, k, nn_idx, rev_scratch, (hipStream_t)stream);
+}
+
 CLOUDAAE_API long long cloudaae_edgeconv_workspace_bytes(int cout)
 {
     return (long long)(ec_ws_doubles(cout) * sizeof(double));
@@ -767,7 +805,7 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
                                             int pool_mode, const float *pq, const float *save_mean,
                                             const float *save_var, const float *out, int ldo,
                                             const float *tie_count, const float *dout, int lddo, float *dpq,
-                                            int *rev_scratch, float *dx, int lddx, int accumulate_dx,
+                                            int *rev_scratch, int rev_ready, float *dx, int lddx, int accumulate_dx,
                                             float *dweights, int dweights_zeroed, float *dbiases, float *dgamma,
                                             float *dbeta, const float *edge_stats, int gemm_bf16, void *workspace,
                                             cloudaae_stream_t stream, cloudaae_stream_t side_stream)
@@ -789,14 +827,13 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
     float *scratch = (float *)(partial + (size_t)EC_MAX_PARTS * 4 * cout);
     float *m12 = scratch + 2 * (size_t)cout;
     int *rev_off = rev_scratch, *rev_src = rev_scratch + (size_t)b * (n + 1);
-    if (two) {
+    const int *const idx1[1] = {nn_idx};
+    int *const rev1[1] = {rev_scratch};
+    if (two && !rev_ready) {
         if (int rc = cloudaae_stream_wait(side_stream, stream))
             return rc;
-        const size_t lds = (size_t)n * sizeof(int);
-        if (lds > 48 * 1024)
-            CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)ec_revlist_kernel,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
-        hipLaunchKernelGGL(ec_revlist_kernel, dim3(b), dim3(512), lds, side, n, k, nn_idx, rev_off, rev_src);
+        if (int rc = ec_launch_revlists(name, 1, b, n, k, idx1, rev1, side))
+            return rc;
     }
     EcArgs a = {};
     a.P = P; a.N = n; a.k = k; a.cout = cout; a.ldpq = 2 * cout;
@@ -824,15 +861,13 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
     hipLaunchKernelGGL(ec_bwd_finalize_kernel, dim3(ceil_div(cout, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, cout, partial,
                        partial + (size_t)EC_MAX_PARTS * 2 * cout, grid, (double)P * (double)k, training, gamma,
                        save_var, dgamma, dbeta, dbiases, m12);
-    if (two) {
+    if (rev_ready) {
+        // (built for all layers at once: cloudaae_edgeconv_revlists)
+    } else if (two) {
         if (int rc = cloudaae_stream_wait(stream, side_stream))    // the lists are ready before the apply pass
             return rc;
-    } else {
-        const size_t lds = (size_t)n * sizeof(int);
-        if (lds > 48 * 1024)
-            CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)ec_revlist_kernel,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
-        hipLaunchKernelGGL(ec_revlist_kernel, dim3(b), dim3(512), lds, s, n, k, nn_idx, rev_off, rev_src);
+    } else if (int rc = ec_launch_revlists(name, 1, b, n, k, idx1, rev1, s)) {
+        return rc;
     }
     if (pool_mode == 1) {
 #define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src, out, ldo, tie_count, dpq, training ? edge_stats : nullptr)

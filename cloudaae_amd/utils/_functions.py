@@ -5,6 +5,8 @@ Variable in `_cloudaae_var`; its gradient is written by the kernel straight into
 store's flat gradient buffer (first write of a backward pass stores, later ones add)
 and `None` is returned to autograd.  Foreign tensors get ordinary returned gradients.
 """
+import ctypes
+
 import torch
 
 from .. import _lib
@@ -348,6 +350,10 @@ class ConcatSlot(object):
     def __init__(self, buf):
         self.buf = buf
         self.dcat = None
+        # (nn_idx, reverse-list buffer) of every edge-conv layer writing into this slot: the first backward
+        # call builds all their reverse neighbour lists with one launch
+        self.revs = []
+        self.revs_built = False
 
 
 class ConcatLinearFn(torch.autograd.Function):
@@ -567,6 +573,11 @@ class EdgeConvFn(torch.autograd.Function):
             "cloudaae_edgeconv_forward")
         ctx.bf16 = gemm_is_bf16()
         ctx.estats = estats
+        ctx.rev, ctx.rev_slot = None, None
+        if training and out_slot is not None and isinstance(out_slot[0], ConcatSlot):
+            ctx.rev = _lib.empty(B * (N + 1) + B * N * k, dtype=torch.int32, device=dev)
+            ctx.rev_slot = out_slot[0]
+            ctx.rev_slot.revs.append((nn_idx, ctx.rev, (B, N, k)))
         ctx.save_for_backward(x, nn_idx, w, b, gamma, beta, pq, save_mean, save_var, ties,
                               out if pool_mode == 2 else None)
         ctx.cfg = (int(training), int(pool_mode))
@@ -589,7 +600,18 @@ class EdgeConvFn(torch.autograd.Function):
         if not (dout.stride(2) == 1 and dout.stride(0) == N * dout.stride(1)):
             dout = dout.contiguous()
         dpq = _lib.empty((B * N, 2 * cout), dtype=torch.float32, device=dev)
-        rev = _lib.empty(B * (N + 1) + B * N * k, dtype=torch.int32, device=dev)
+        rev, rev_ready = ctx.rev, 0
+        slot_r = ctx.rev_slot
+        if slot_r is not None and len(slot_r.revs) <= 8 and len(set(r[2] for r in slot_r.revs)) == 1:
+            if not slot_r.revs_built:
+                cnt = len(slot_r.revs)
+                idxs = (ctypes.c_void_p * cnt)(*[r[0].data_ptr() for r in slot_r.revs])
+                revs = (ctypes.c_void_p * cnt)(*[r[1].data_ptr() for r in slot_r.revs])
+                _lib.check(L().cloudaae_edgeconv_revlists(cnt, B, N, k, idxs, revs, stream()), "cloudaae_edgeconv_revlists")
+                slot_r.revs_built = True
+            rev_ready = 1
+        else:
+            rev = _lib.empty(B * (N + 1) + B * N * k, dtype=torch.int32, device=dev)
         dx, dx_ptr, lddx, acc_dx = None, None, cin, 0
         if ctx.needs_input_grad[0]:
             slot = ctx.in_slot[0] if ctx.in_slot is not None else None
@@ -615,7 +637,7 @@ class EdgeConvFn(torch.autograd.Function):
             B, N, k, cin, cout, x.data_ptr(), x.stride(1), ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
             training, pool_mode, ptr(pq), ptr(save_mean), ptr(save_var),
             fwd_out.data_ptr() if fwd_out is not None else None, fwd_out.stride(1) if fwd_out is not None else 0,
-            ptr(ties), dout.data_ptr(), dout.stride(1), ptr(dpq), ptr(rev), dx_ptr, lddx, acc_dx, ptr(gw.buf),
+            ptr(ties), dout.data_ptr(), dout.stride(1), ptr(dpq), ptr(rev), rev_ready, dx_ptr, lddx, acc_dx, ptr(gw.buf),
             1 if (gw.needed and gw.gemm_acc == 2) else 0, ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), ptr(ctx.estats),
             int(ctx.bf16), ptr(ws), stream(), SIDE_STREAM if (SIDE_EDGE and not shared and gw.needed and gw.own is None) else None),
             "cloudaae_edgeconv_backward")

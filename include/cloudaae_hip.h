@@ -264,12 +264,18 @@ int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cout, const floa
                               float *ema_mean, float *ema_var, int pool_mode, float *pq, float *save_mean,
                               float *save_var, float *out, int ldo, float *tie_count, float *edge_stats,
                               int gemm_bf16, void *workspace, cloudaae_stream_t stream);
+/* Reverse neighbour lists (for every point m: the points that have m among their k neighbours) of up to 8
+ * layers in one launch: rev_scratch[i] (b*(n+1) + b*n*k ints, the buffer later passed to
+ * cloudaae_edgeconv_backward with rev_ready = 1) from nn_idx[i] ([b,n,k]).  The encoder's layers all have
+ * their neighbour lists by the end of the forward pass, so backward builds them together. */
+int cloudaae_edgeconv_revlists(int count, int b, int n, int k, const int *const *nn_idx, int *const *rev_scratch,
+                               cloudaae_stream_t stream);
 int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int cout, const float *x, int ldx,
                                const int *nn_idx, const float *weights, const float *biases,
                                const float *gamma, const float *beta, int training, int pool_mode,
                                const float *pq, const float *save_mean, const float *save_var,
                                const float *out, int ldo, const float *tie_count, const float *dout,
-                               int lddo, float *dpq, int *rev_scratch, float *dx, int lddx,
+                               int lddo, float *dpq, int *rev_scratch, int rev_ready, float *dx, int lddx,
                                int accumulate_dx, float *dweights, int dweights_zeroed, float *dbiases,
                                float *dgamma, float *dbeta, const float *edge_stats, int gemm_bf16,
                                void *workspace, cloudaae_stream_t stream, cloudaae_stream_t side_stream);
