@@ -67,6 +67,7 @@ _SIGNATURES = {
     "cloudaae_loss_mix": [_P, _P, _P, _F, _F, _F, _P, _P],
     "cloudaae_loss_mix_grad": [_P, _F, _F, _F, _P, _P, _P, _P],
     "cloudaae_adam_tf": [_L, _P, _P, _P, _P, _F, _F, _F, _F, _P, _P, _F, _I, _P],
+    "cloudaae_adam_tf_step": [_L, _P, _P, _P, _P, _F, _F, _F, _F, _P, _P, _F, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P],
     "cloudaae_sgd": [_L, _P, _P, _F, _F, _P],
     "cloudaae_bn_decay_schedule": [_P, _F, _F, _F, _F, _F, _P, _P],
     "cloudaae_increment": [_P, _F, _P],

@@ -505,11 +505,22 @@ __global__ void pose_losses_grad_kernel(int b, const float *__restrict__ tpred, 
 //   lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
 //   m += (g - m) * (1 - beta1);  v += (g*g - v) * (1 - beta2)
 //   var -= lr_t * m / (sqrt(v) + eps)
+// What the end of a training step does to its device scalars, done by the LAST workgroup of the optimiser
+// kernel to finish (it is the last reader of the beta powers): beta powers advance, the step counter
+// (`batch`, train...:192) goes up, and the batch-norm decay of the NEXT step is derived from it
+// (train...:194-202).  Three one-thread launches (~14 us of timeline) otherwise.  ticket: one int holding
+// zero, left zero.
+struct AdamTail {
+    int *ticket;        // NULL: none of this
+    float *b1p, *b2p, *step, *bn_decay;
+    float step_inc, batch_size, bn_init, bn_decay_step, bn_rate, bn_clip;
+};
+
 __global__ __launch_bounds__(256) void adam_tf_kernel(long long n, float *__restrict__ param,
                                                      const float *__restrict__ grad, float *__restrict__ m,
                                                      float *__restrict__ v, float lr, float beta1, float beta2,
-                                                     float eps, const float *__restrict__ b1p,
-                                                     const float *__restrict__ b2p, float gscale)
+                                                     float eps, const float *b1p, const float *b2p, float gscale,
+                                                     AdamTail tail)
 {
     const float lr_t = lr * sqrtf(1.0f - b2p[0]) / (1.0f - b1p[0]);
     const float om1 = 1.0f - beta1, om2 = 1.0f - beta2;
@@ -539,6 +550,23 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(long long n, float *__rest
         param[i] = param[i] - (mm * lr_t) / (sqrtf(vv) + eps);
         m[i] = mm;
         v[i] = vv;
+    }
+    if (tail.ticket != nullptr) {
+        __syncthreads();    // every thread of this workgroup has read the beta powers
+        if (threadIdx.x == 0) {
+            const int t = __hip_atomic_fetch_add(tail.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == (int)gridDim.x - 1) {
+                __hip_atomic_store(tail.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tail.b1p[0] = tail.b1p[0] * beta1;
+                tail.b2p[0] = tail.b2p[0] * beta2;
+                const float step = tail.step[0] + tail.step_inc;
+                tail.step[0] = step;
+                if (tail.bn_decay != nullptr) {
+                    const float p = floorf(step * tail.batch_size / tail.bn_decay_step);
+                    tail.bn_decay[0] = fminf(tail.bn_clip, 1.0f - tail.bn_init * powf(tail.bn_rate, p));
+                }
+            }
+        }
     }
 }
 __global__ void adam_advance_kernel(float *b1p, float *b2p, float beta1, float beta2)
@@ -788,11 +816,32 @@ CLOUDAAE_API int cloudaae_adam_tf(long long n, float *param, const float *grad, 
     CLOUDAAE_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0, name,
                      "buffers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    AdamTail none = {};
     if (n > 0)
         hipLaunchKernelGGL(adam_tf_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, s, n, param, grad, m, v,
-                           lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale);
+                           lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale, none);
     if (advance)
         hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, beta1_power, beta2_power, beta1, beta2);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_adam_tf_step(long long n, float *param, const float *grad, float *m, float *v, float lr,
+                                       float beta1, float beta2, float eps, float *beta1_power, float *beta2_power,
+                                       float grad_scale, float *step, float step_inc, float batch_size,
+                                       float bn_init, float bn_decay_step, float bn_rate, float bn_clip,
+                                       float *bn_decay, int *ticket, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_adam_tf_step";
+    CLOUDAAE_REQUIRE(n > 0 && beta1_power && beta2_power && step && ticket, name, "bad argument");
+    CLOUDAAE_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0, name,
+                     "buffers must be 16-byte aligned");
+    AdamTail tail;
+    tail.ticket = ticket; tail.b1p = beta1_power; tail.b2p = beta2_power; tail.step = step; tail.bn_decay = bn_decay;
+    tail.step_inc = step_inc; tail.batch_size = batch_size; tail.bn_init = bn_init; tail.bn_decay_step = bn_decay_step;
+    tail.bn_rate = bn_rate; tail.bn_clip = bn_clip;
+    hipLaunchKernelGGL(adam_tf_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n, param,
+                       grad, m, v, lr, beta1, beta2, eps, beta1_power, beta2_power, grad_scale, tail);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }

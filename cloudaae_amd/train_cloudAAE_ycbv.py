@@ -128,6 +128,7 @@ class TrainGraph(object):
         self.beta1_power = torch.full((1,), 0.9, dtype=torch.float32, device=dev)
         self.beta2_power = torch.full((1,), 0.999, dtype=torch.float32, device=dev)
         self._one = torch.ones((), dtype=torch.float32, device=dev)           # d(total_loss)/d(total_loss)
+        self._adam_ticket = torch.zeros(1, dtype=torch.int32, device=dev)   # arrival counter of the optimiser kernel
         # replay=True: the first train_step of a given input shape is RECORDED (_lib.StepPlan: the
         # C-ABI calls in issue order, buffers from the plan's arena) and later steps re-issue it
         # without Python layers or autograd in between -- the host cost of a step drops from ~3 ms
@@ -162,6 +163,7 @@ class TrainGraph(object):
             lo = min(self.store.offsets[v.name] for v in fc)
             early = (lo, n)
         self.exchange = GradExchange(self.store.flat_grads, early, self.pg, world=self.world, early_count=len(fc))
+        self._zero_limit = early[0] if (early is not None and F.fc_fits(self.local_batch)) else None
         self.exchange.broadcast_params(self.store.flat_params)     # identical initial weights on every rank
         if early is not None and self.exchange.active:
             for v in fc:
@@ -225,11 +227,12 @@ class TrainGraph(object):
     def _step(self, element):
         L = _lib.lib()
         s = stream()
-        self.store.begin_step(zero_grads=True)
-        # bn_decay = min(0.99, 1 - 0.5 * 0.5^floor(batch*BATCH_SIZE/40)), :194-202
-        _lib.check(L.cloudaae_bn_decay_schedule(ptr(self.batch), float(self.BATCH_SIZE), BN_INIT_DECAY,
-                                                BN_DECAY_DECAY_STEP, BN_DECAY_DECAY_RATE, BN_DECAY_CLIP,
-                                                ptr(self.bn_decay), s), "cloudaae_bn_decay_schedule")
+        # gradients of the fully connected stack are stored whole by its grouped kernels (batch <= 32):
+        # only the encoder's slots (split-K products add into them) are cleared
+        self.store.begin_step(zero_grads=True, zero_limit=self._zero_limit)
+        # self.bn_decay holds min(0.99, 1 - 0.5 * 0.5^floor(batch*BATCH_SIZE/40)) (:194-202) for THIS step: the
+        # previous step's optimiser kernel derived it when it advanced `batch` (refresh_bn_decay() after
+        # setting `batch` by hand)
         # weight-gradient products of the per-point layers and the reverse neighbour lists run on the
         # library's low-priority side stream (F.SIDE_STREAM) and are joined before anyone reads a gradient
         side = _lib.side_stream() if self.side_stream else None
@@ -246,15 +249,27 @@ class TrainGraph(object):
         n = self.store.flat_params.numel()
         scale = self.exchange.scale
         if self.OPTIMIZER == 'adam':      # tf.train.AdamOptimizer(learning_rate), :266
-            _lib.check(L.cloudaae_adam_tf(n, ptr(self.store.flat_params), ptr(self.store.flat_grads),
-                                          ptr(self.adam_m), ptr(self.adam_v), self.BASE_LEARNING_RATE, 0.9,
-                                          0.999, 1e-8, ptr(self.beta1_power), ptr(self.beta2_power), scale, 1,
-                                          stream()), "cloudaae_adam_tf")
+            # ... whose last workgroup also advances the beta powers and global_step (`batch`) and derives
+            # the next step's bn_decay
+            _lib.check(L.cloudaae_adam_tf_step(n, ptr(self.store.flat_params), ptr(self.store.flat_grads),
+                                               ptr(self.adam_m), ptr(self.adam_v), self.BASE_LEARNING_RATE, 0.9,
+                                               0.999, 1e-8, ptr(self.beta1_power), ptr(self.beta2_power), scale,
+                                               ptr(self.batch), 1.0, float(self.BATCH_SIZE), BN_INIT_DECAY,
+                                               BN_DECAY_DECAY_STEP, BN_DECAY_DECAY_RATE, BN_DECAY_CLIP,
+                                               ptr(self.bn_decay), ptr(self._adam_ticket), stream()),
+                       "cloudaae_adam_tf_step")
         else:                             # GradientDescentOptimizer(learning_rate*10), :264
             _lib.check(L.cloudaae_sgd(n, ptr(self.store.flat_params), ptr(self.store.flat_grads),
                                       self.BASE_LEARNING_RATE * 10, scale, stream()), "cloudaae_sgd")
-        _lib.check(L.cloudaae_increment(ptr(self.batch), 1.0, stream()), "cloudaae_increment")  # global_step
+            _lib.check(L.cloudaae_increment(ptr(self.batch), 1.0, stream()), "cloudaae_increment")  # global_step
+            self.refresh_bn_decay()
         return out
+
+    def refresh_bn_decay(self):
+        """bn_decay = min(0.99, 1 - 0.5 * 0.5^floor(batch*BATCH_SIZE/40)) (:194-202) from the current `batch`."""
+        _lib.check(_lib.lib().cloudaae_bn_decay_schedule(ptr(self.batch), float(self.BATCH_SIZE), BN_INIT_DECAY,
+                                                         BN_DECAY_DECAY_STEP, BN_DECAY_DECAY_RATE, BN_DECAY_CLIP,
+                                                         ptr(self.bn_decay), stream()), "cloudaae_bn_decay_schedule")
 
     # -- the same iteration, recorded once and replayed -----------------------------------------
     def _stage_inputs(self, element):
@@ -372,6 +387,7 @@ class TrainGraph(object):
             for key, t in (('beta1_power', self.beta1_power), ('beta2_power', self.beta2_power), ('Variable', self.batch)):
                 if key in ck:
                     t.fill_(float(ck[key]))
+        self.refresh_bn_decay()      # the decay of the next step follows the restored global_step
 
 
 # ---- the data pipeline of train_cloudAAE_ycbv.py:42-117, batched on the GPU --------------------

@@ -286,6 +286,14 @@ class FcGroupFn(torch.autograd.Function):
         M = xs[0].shape[0]
         live = [i for i, d in enumerate(douts) if d is not None]
         grads = [None] * (2 + n_in + 6 * len(per))
+        # a layer nobody took a gradient of: its slots in the flat gradient buffer are not cleared at the
+        # start of a step (see VariableStore.begin_step: zero_limit), so they are cleared here
+        for i in range(len(per)):
+            if i not in live:
+                for t in per[i][:4]:
+                    v = _var(t) if t is not None else None
+                    if v is not None and v.grad is not None and v.fresh:
+                        v.grad.zero_()
         if not live:
             return tuple(grads)
         dxs = [None] * n_in

@@ -347,6 +347,14 @@ int cloudaae_loss_mix_grad(const float *g, float w0, float w1, float w2, float *
 int cloudaae_adam_tf(long long n, float *param, const float *grad, float *m, float *v, float lr,
                      float beta1, float beta2, float eps, float *beta1_power, float *beta2_power,
                      float grad_scale, int advance, cloudaae_stream_t stream);
+/* The same plus the end-of-step bookkeeping, done by the last workgroup of the kernel to finish: beta powers
+ * advance, *step += step_inc (the `batch` counter, :192) and, if bn_decay != NULL, the batch-norm decay of the
+ * NEXT step = min(bn_clip, 1 - bn_init * bn_rate^floor(step * batch_size / bn_decay_step)) (:194-202, what
+ * cloudaae_bn_decay_schedule computes).  ticket: one int holding zero, left zero. */
+int cloudaae_adam_tf_step(long long n, float *param, const float *grad, float *m, float *v, float lr, float beta1,
+                          float beta2, float eps, float *beta1_power, float *beta2_power, float grad_scale,
+                          float *step, float step_inc, float batch_size, float bn_init, float bn_decay_step,
+                          float bn_rate, float bn_clip, float *bn_decay, int *ticket, cloudaae_stream_t stream);
 int cloudaae_sgd(long long n, float *param, const float *grad, float lr, float grad_scale,
                  cloudaae_stream_t stream);
 /* :194-202  out[0] = min(clip, 1 - init * rate^floor(step[0]*batch_size/decay_step)) */
