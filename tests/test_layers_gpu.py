@@ -491,6 +491,8 @@ def test_gemm_colstats_feed_batch_norm(hip, M, N, K):
     L = hip.lib()
     parts = L.cloudaae_gemm_f32_colstats_parts(M, N, K)
     assert parts > 0
+    # taller than the batch norm's workspace has rows for (B = 256 per GPU): no fused statistics
+    assert L.cloudaae_gemm_f32_colstats_parts(262144, 1024, 320) == 0
     g = torch.Generator().manual_seed(M + N)
     A = torch.randn(M, K, generator=g).cuda()
     B = (torch.randn(K, N, generator=g) / math.sqrt(K)).cuda()
