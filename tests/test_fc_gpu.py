@@ -179,3 +179,38 @@ def test_fc_chains_vs_oracle(hip, model_oracle):
         got = store.vars[name].data.grad
         assert got is not None, name
         assert _rel(got, p.grad) < 2e-3 or p.grad.abs().max() < 1e-5, name
+
+
+def test_fc_forward_ticket_stress(hip):
+    """The arrival-counter protocol of the batch-norm forward (slices add their sums with agent-scope
+    atomics, the last one to arrive reads them back -- no fence) over many launches with other work in
+    between: every launch must reproduce the K-whole result and leave the counters at zero."""
+    from cloudaae_amd import _lib
+    L = _lib.lib()
+    M, K, N = 32, 1024, 1024
+    g = torch.Generator().manual_seed(21)
+    x, W = torch.randn(M, K, generator=g).cuda(), (torch.randn(K, N, generator=g) / 32).cuda()
+    b, gamma, beta = torch.randn(N, generator=g).cuda(), torch.rand(N, generator=g).cuda() + 0.5, \
+        torch.randn(N, generator=g).cuda()
+    decay = torch.full((1,), 0.9, device="cuda")
+    sm, sv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+    mean, var = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    tk = torch.zeros(L.cloudaae_fc_forward_tickets(N), dtype=torch.int32, device="cuda")
+
+    def run(tickets, y, out):
+        _lib.check(L.cloudaae_fc_forward(M, K, N, x.data_ptr(), K, W.data_ptr(), b.data_ptr(), gamma.data_ptr(),
+                                         beta.data_ptr(), 1, decay.data_ptr(), sm.data_ptr(), sv.data_ptr(),
+                                         mean.data_ptr(), var.data_ptr(), 1, y.data_ptr(), out.data_ptr(), 0,
+                                         tickets, _lib.stream()), "fc_forward")
+    y0, out0 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    run(None, y0, out0)
+    junk = torch.randn(1 << 22, device="cuda")
+    worst = 0.0
+    for it in range(200):
+        y, out = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        if it % 3 == 0:
+            junk.mul_(1.0001)                       # dirty lines in the L2s between launches
+        run(tk.data_ptr(), y, out)
+        worst = max(worst, _rel(out, out0), _rel(y, y0))
+    torch.cuda.synchronize()
+    assert worst < 1e-5 and int(tk.abs().sum()) == 0
