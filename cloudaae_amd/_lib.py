@@ -57,6 +57,8 @@ _SIGNATURES = {
     "cloudaae_pool_rows": [_I, _I, _I, _I, _P, _P, _P, _P],
     "cloudaae_pool_rows_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cloudaae_mean_f32": [_L, _P, _P, _P, _P],
+    "cloudaae_add_mean_f32": [_L, _P, _P, _P, _P, _P, _P],
+    "cloudaae_nn_distance_grad_uniform": [_I, _I, _P, _I, _P, _P, _F, _P, _P, _P, _P, _I, _P],
     "cloudaae_trans_error": [_I, _P, _P, _P, _P],
     "cloudaae_trans_error_grad": [_I, _P, _P, _P, _P, _P, _P],
     "cloudaae_rotation_error": [_I, _P, _P, _P, _P, _P, _P],

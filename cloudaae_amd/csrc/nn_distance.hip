@@ -442,7 +442,8 @@ __global__ __launch_bounds__(256) void nn_distance_grad_kernel(
     int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
     const float *__restrict__ grad_dist1, const int *__restrict__ idx1,
     const float *__restrict__ grad_dist2, const int *__restrict__ idx2,
-    float *__restrict__ grad_xyz1, float *__restrict__ grad_xyz2, int blocks1)
+    float *__restrict__ grad_xyz1, float *__restrict__ grad_xyz2, int blocks1,
+    const float *__restrict__ uniform, float uniform_scale)
 {
     const int cloud = blockIdx.y;
     const bool second = (int)blockIdx.x >= blocks1;
@@ -456,7 +457,9 @@ __global__ __launch_bounds__(256) void nn_distance_grad_kernel(
     float *gA = second ? grad_xyz2 : grad_xyz1;
     float *gB = second ? grad_xyz1 : grad_xyz2;
     const int t = (second ? idx2 : idx1)[(size_t)cloud * na + j];
-    const float g = (second ? grad_dist2 : grad_dist1)[(size_t)cloud * na + j] * 2;
+    // uniform: every distance has the same upstream gradient uniform[0] * uniform_scale (a mean over them)
+    const float g = (uniform != nullptr ? uniform[0] * uniform_scale
+                                        : (second ? grad_dist2 : grad_dist1)[(size_t)cloud * na + j]) * 2;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float v = g * (A[3 * j + a] - B[3 * (size_t)t + a]);
@@ -536,7 +539,31 @@ CLOUDAAE_API int cloudaae_nn_distance_grad(int b, int n, const float *xyz1, int 
         return 0;
     const int b1 = ceil_div(n, 256), b2 = ceil_div(m, 256);
     hipLaunchKernelGGL(nn_distance_grad_kernel, dim3(b1 + b2, b), dim3(256), 0, s, n, m, xyz1, xyz2,
-                       grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2, b1);
+                       grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2, b1, nullptr, 0.0f);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_nn_distance_grad_uniform(int b, int n, const float *xyz1, int m, const float *xyz2,
+                                                   const float *grad, float scale, const int *idx1,
+                                                   const int *idx2, float *grad_xyz1, float *grad_xyz2,
+                                                   int outputs_zeroed, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_nn_distance_grad_uniform";
+    CLOUDAAE_REQUIRE(b >= 0 && n >= 0 && m >= 0 && grad != nullptr, name, "bad argument");
+    CLOUDAAE_REQUIRE(b <= 65535, name, "batch > 65535");
+    hipStream_t s = (hipStream_t)stream;
+    if (!outputs_zeroed) {
+        if (grad_xyz1 && (size_t)b * n)
+            CLOUDAAE_CHECK_HIP(hipMemsetAsync(grad_xyz1, 0, sizeof(float) * (size_t)b * n * 3, s), name);
+        if (grad_xyz2 && (size_t)b * m)
+            CLOUDAAE_CHECK_HIP(hipMemsetAsync(grad_xyz2, 0, sizeof(float) * (size_t)b * m * 3, s), name);
+    }
+    if (b == 0 || n == 0 || m == 0)
+        return 0;
+    const int b1 = ceil_div(n, 256), b2 = ceil_div(m, 256);
+    hipLaunchKernelGGL(nn_distance_grad_kernel, dim3(b1 + b2, b), dim3(256), 0, s, n, m, xyz1, xyz2, nullptr, idx1,
+                       nullptr, idx2, grad_xyz1, grad_xyz2, b1, grad, scale);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }

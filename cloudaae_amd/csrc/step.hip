@@ -220,6 +220,26 @@ __global__ __launch_bounds__(256) void mean_stage1_kernel(long long n, const flo
     if (threadIdx.x == 0)
         partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+// per[i] = a[i] + b[i] and the first stage of its mean in one pass (losses/chamfer_loss.py:13-14:
+// loss_per_sample = dists_forward + dists_backward; loss = reduce_mean(loss_per_sample))
+__global__ __launch_bounds__(256) void add_mean_stage1_kernel(long long n, const float *__restrict__ a,
+                                                             const float *__restrict__ b, float *__restrict__ per,
+                                                             double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double s = 0.0;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) {
+        const float v = a[i] + b[i];
+        per[i] = v;
+        s += (double)v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
 __global__ __launch_bounds__(256) void mean_stage2_kernel(int parts, double n, const double *__restrict__ partial,
                                                          float *__restrict__ out)
 {
@@ -730,6 +750,22 @@ CLOUDAAE_API int cloudaae_mean_f32(long long n, const float *x, float *out, void
     if (parts > MEAN_BLOCKS)
         parts = MEAN_BLOCKS;
     hipLaunchKernelGGL(mean_stage1_kernel, dim3(parts), dim3(256), 0, s, n, x, (double *)workspace);
+    hipLaunchKernelGGL(mean_stage2_kernel, dim3(1), dim3(256), 0, s, parts, (double)n, (const double *)workspace,
+                       out);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_add_mean_f32(long long n, const float *a, const float *b, float *per, float *out,
+                                       void *workspace, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_add_mean_f32";
+    CLOUDAAE_REQUIRE(n > 0 && a && b && per && out && workspace, name, "empty input or null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int parts = stream_grid(n);
+    if (parts > MEAN_BLOCKS)
+        parts = MEAN_BLOCKS;
+    hipLaunchKernelGGL(add_mean_stage1_kernel, dim3(parts), dim3(256), 0, s, n, a, b, per, (double *)workspace);
     hipLaunchKernelGGL(mean_stage2_kernel, dim3(1), dim3(256), 0, s, parts, (double)n, (const double *)workspace,
                        out);
     CLOUDAAE_CHECK_LAUNCH(name);

@@ -9,7 +9,10 @@ def get_loss(pred, label):
     returns (loss, loss_per_sample) where loss_per_sample = dists_forward + dists_backward is
     [B,N] (elementwise, so both clouds must have the same number of points) and
     loss = reduce_mean(loss_per_sample). """
+    if pred.dim() == 3 and label.dim() == 3 and pred.shape[1] == label.shape[1]:
+        # one node: nn_distance, the sum of the two distance arrays and its mean
+        return F.ChamferLossFn.apply(pred, label)
     dists_forward, _, dists_backward, _ = tf_nndistance.nn_distance(pred, label)
-    loss_per_sample = F.AddFn.apply(dists_forward, dists_backward)
+    loss_per_sample = F.AddFn.apply(dists_forward, dists_backward)      # fails for n != m like the reference
     loss = F.MeanFn.apply(loss_per_sample)
     return loss, loss_per_sample

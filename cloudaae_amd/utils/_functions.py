@@ -708,6 +708,61 @@ class AddFn(torch.autograd.Function):
         return g, g
 
 
+class ChamferLossFn(torch.autograd.Function):
+    """losses/chamfer_loss.py:8-14 as one node: nn_distance both ways, loss_per_sample = forward + backward
+    distances, loss = their mean.  Returns (loss, loss_per_sample).  When only the loss is differentiated
+    (the training step) the backward pass needs no per-point gradient arrays: every distance has the upstream
+    gradient d(loss)/N (cloudaae_nn_distance_grad_uniform)."""
+
+    @staticmethod
+    def forward(ctx, pred, label):
+        ctx.set_materialize_grads(False)
+        require(pred.dim() == 3 and label.dim() == 3 and pred.shape[2] == 3 and label.shape[2] == 3,
+                "NnDistance requires clouds of shape (batch,#points,3)")
+        require(pred.shape[0] == label.shape[0], "NnDistance expects xyz1 and xyz2 have same batch size")
+        require(pred.shape[1] == label.shape[1], "chamfer_loss: dists_forward + dists_backward needs clouds of "
+                                                 "equal size (the reference fails the same way, chamfer_loss.py:12)")
+        pred, label = pred.contiguous(), label.contiguous()
+        b, n, _ = pred.shape
+        dev = pred.device
+        d1 = _lib.empty((b, n), dtype=torch.float32, device=dev)
+        d2 = _lib.empty((b, n), dtype=torch.float32, device=dev)
+        i1 = _lib.empty((b, n), dtype=torch.int32, device=dev)
+        i2 = _lib.empty((b, n), dtype=torch.int32, device=dev)
+        _lib.check(L().cloudaae_nn_distance(b, n, ptr(pred), n, ptr(label), ptr(d1), ptr(i1), ptr(d2), ptr(i2), stream()),
+                   "cloudaae_nn_distance")
+        per = _lib.empty((b, n), dtype=torch.float32, device=dev)
+        loss = _lib.empty((), dtype=torch.float32, device=dev)
+        ws = _ws(L().cloudaae_mean_workspace_bytes(), dev)
+        _lib.check(L().cloudaae_add_mean_f32(b * n, ptr(d1), ptr(d2), ptr(per), ptr(loss), ptr(ws), stream()),
+                   "cloudaae_add_mean_f32")
+        ctx.save_for_backward(pred, label, i1, i2)
+        return loss, per
+
+    @staticmethod
+    def backward(ctx, gloss, gper):
+        pred, label, i1, i2 = ctx.saved_tensors
+        b, n, _ = pred.shape
+        need1, need2 = ctx.needs_input_grad
+        if gloss is None and gper is None:
+            return None, None
+        if gper is None:
+            rec = _lib.recording() is not None
+            mk = (lambda t: _lib.zeros(t.shape, dtype=torch.float32, device=t.device)) if rec else _lib.empty_like
+            g1 = mk(pred) if need1 else None
+            g2 = mk(label) if need2 else None
+            _lib.check(L().cloudaae_nn_distance_grad_uniform(
+                b, n, ptr(pred), n, ptr(label), ptr(gloss.contiguous()), 1.0 / (b * n), ptr(i1), ptr(i2), ptr(g1),
+                ptr(g2), 1 if rec else 0, stream()), "cloudaae_nn_distance_grad_uniform")
+            return g1, g2
+        gd = gper.contiguous() if gloss is None else gper + gloss / (b * n)
+        g1 = _lib.empty_like(pred) if need1 else None
+        g2 = _lib.empty_like(label) if need2 else None
+        _lib.check(L().cloudaae_nn_distance_grad(b, n, ptr(pred), n, ptr(label), ptr(gd), ptr(i1), ptr(gd), ptr(i2),
+                                                 ptr(g1), ptr(g2), stream()), "cloudaae_nn_distance_grad")
+        return g1, g2
+
+
 class MeanFn(torch.autograd.Function):
     """tf.reduce_mean over all elements -> 0-dim fp32."""
 

@@ -59,6 +59,12 @@ int cloudaae_nn_distance_grad(int b, int n, const float *xyz1, int m, const floa
                               const float *grad_dist1, const int *idx1, const float *grad_dist2,
                               const int *idx2, float *grad_xyz1, float *grad_xyz2,
                               cloudaae_stream_t stream);
+/* The same when every distance has the SAME upstream gradient grad[0] * scale (the Chamfer loss is a mean
+ * over them, losses/chamfer_loss.py:13-14): no per-point gradient arrays.  outputs_zeroed != 0: the caller
+ * provides zero-filled outputs (otherwise the call clears them, as above). */
+int cloudaae_nn_distance_grad_uniform(int b, int n, const float *xyz1, int m, const float *xyz2, const float *grad,
+                                      float scale, const int *idx1, const int *idx2, float *grad_xyz1,
+                                      float *grad_xyz2, int outputs_zeroed, cloudaae_stream_t stream);
 
 /* ---- tf_ops/sampling ---------------------------------------------------- */
 
@@ -312,6 +318,9 @@ int cloudaae_fill_scaled(long long n, const float *scalar, float scale, const fl
                          cloudaae_stream_t stream);
 long long cloudaae_mean_workspace_bytes(void);
 int cloudaae_mean_f32(long long n, const float *x, float *out, void *workspace, cloudaae_stream_t stream);
+/* per[i] = a[i] + b[i] and out = mean(per) in one pass (chamfer_loss.py:13-14); workspace as for the mean. */
+int cloudaae_add_mean_f32(long long n, const float *a, const float *b, float *per, float *out, void *workspace,
+                          cloudaae_stream_t stream);
 /* losses/trans_distance.py:4-9 */
 int cloudaae_trans_error(int b, const float *pred, const float *label, float *per, cloudaae_stream_t stream);
 int cloudaae_trans_error_grad(int b, const float *pred, const float *label, const float *per,
