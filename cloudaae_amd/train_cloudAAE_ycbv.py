@@ -238,6 +238,7 @@ class TrainGraph(object):
         side = _lib.side_stream() if self.side_stream else None
         F.SIDE_STREAM = side
         F.SIDE_EDGE = os.environ.get("CLOUDAAE_SIDE_STREAM", "0") != "agg"
+        F.SIDE_AGG = os.environ.get("CLOUDAAE_SIDE_STREAM", "0") != "edge"
         try:
             out = self.forward(element, is_training=True)
             out['total_loss'].backward(self._one)

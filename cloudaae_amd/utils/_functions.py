@@ -87,6 +87,7 @@ def gemm_is_bf16():
 # -- before consuming gradients (TrainGraph does, around backward); None = everything on the current stream.
 SIDE_STREAM = None
 SIDE_EDGE = True      # edge-convolution layers use it too (else only the dgcnn_agg weight gradient)
+SIDE_AGG = True       # the dgcnn_agg weight gradient uses it
 
 
 def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, accumulate=0, site=None, bf16=False, on=None):
@@ -434,7 +435,7 @@ class ConcatLinearFn(torch.autograd.Function):
                 ctx.slot.dcat = dcat
         gw = _ParamGrad(w, ctx.needs_input_grad[1])
         if gw.needed:
-            side = SIDE_STREAM if gw.own is None else None          # (a returned gradient is consumed at once)
+            side = SIDE_STREAM if (gw.own is None and SIDE_AGG) else None   # (a returned gradient is consumed at once)
             if side is not None:
                 _lib.stream_wait(side, stream())                    # dy is complete
             gemm(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.gemm_acc, bf16=ctx.bf16, on=side)
