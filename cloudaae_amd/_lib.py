@@ -35,7 +35,7 @@ _SIGNATURES = {
     "cloudaae_colsum_f32": [_I, _I, _P, _I, _P, _I, _P, _P],
     "cloudaae_gemm_f32_colstats": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P],
     "cloudaae_bn_forward_colstats": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P,
-                                     _P, _I, _P],
+                                     _P, _P, _I, _P],
     "cloudaae_fc_forward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
     "cloudaae_fc_backward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P,
                              _P, _I, _P],

@@ -546,13 +546,13 @@ using namespace cloudaae;
 
 CLOUDAAE_API long long cloudaae_bn_workspace_bytes(int C) { return (long long)(bn_ws_doubles(C) * sizeof(double)); }
 
-// colstats_parts > 0: the first colstats_parts x 2 x C doubles of the workspace already hold the column
-// sums of y (written by cloudaae_gemm_f32_colstats): the statistics pass over y is skipped
+// colstats != NULL: colstats[colstats_parts][2][C] already holds the column sums of y (written by
+// cloudaae_gemm_f32_colstats): the statistics pass over y is skipped
 static int bn_forward_impl(const char *name, int M, int C, const float *y, int ldy, const float *gamma,
                            const float *beta, int training, const float *decay, float *ema_mean, float *ema_var,
                            float *save_mean, float *save_var, int relu, float *out, int ldo, int pool_rows,
                            int pool_mode, float *pooled, float *tie_count, double *pool_stats, void *workspace,
-                           int colstats_parts, cloudaae_stream_t stream)
+                           const double *colstats, int colstats_parts, cloudaae_stream_t stream)
 {
     CLOUDAAE_REQUIRE(M > 0 && C > 0 && ldy >= C, name, "bad size");
     CLOUDAAE_REQUIRE(workspace != nullptr && gamma && beta && save_mean && save_var, name, "null argument");
@@ -571,11 +571,12 @@ static int bn_forward_impl(const char *name, int M, int C, const float *y, int l
     }
     double *partial = (double *)workspace;
     float *scale_shift = (float *)(partial + (size_t)BN_MAX_PARTS * 4 * C);
-    const int parts = colstats_parts > 0 ? colstats_parts : bn_parts(M);
+    const int parts = colstats != nullptr ? colstats_parts : bn_parts(M);
     const int cb = ceil_div(C, 64);
-    if (training && colstats_parts <= 0)
+    if (training && colstats == nullptr)
         hipLaunchKernelGGL(bn_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, M, C, y, ldy, partial, parts);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C,
+                       colstats != nullptr ? colstats : partial, parts,
                        (double)M, training, decay, ema_mean, ema_var, gamma, beta, save_mean, save_var,
                        scale_shift);
     if (pool_mode == 0) {
@@ -609,7 +610,7 @@ CLOUDAAE_API int cloudaae_bn_forward(int M, int C, const float *y, int ldy, cons
 {
     return bn_forward_impl("cloudaae_bn_forward", M, C, y, ldy, gamma, beta, training, decay, ema_mean, ema_var,
                            save_mean, save_var, relu, out, ldo, pool_rows, pool_mode, pooled, tie_count, pool_stats,
-                           workspace, 0, stream);
+                           workspace, nullptr, 0, stream);
 }
 
 CLOUDAAE_API int cloudaae_bn_forward_colstats(int M, int C, const float *y, int ldy, const float *gamma,
@@ -617,13 +618,13 @@ CLOUDAAE_API int cloudaae_bn_forward_colstats(int M, int C, const float *y, int 
                                               float *ema_mean, float *ema_var, float *save_mean, float *save_var,
                                               int relu, float *out, int ldo, int pool_rows, int pool_mode,
                                               float *pooled, float *tie_count, double *pool_stats, void *workspace,
-                                              int colstats_parts, cloudaae_stream_t stream)
+                                              const double *colstats, int colstats_parts, cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_bn_forward_colstats";
-    CLOUDAAE_REQUIRE(colstats_parts > 0 && colstats_parts <= 2 * BN_MAX_PARTS, name, "bad number of column-sum rows");
+    CLOUDAAE_REQUIRE(colstats != nullptr && colstats_parts > 0, name, "no column sums given");
     CLOUDAAE_REQUIRE(M > BN_SMALL_M || pool_mode != 0, name, "small batches take cloudaae_bn_forward");
     return bn_forward_impl(name, M, C, y, ldy, gamma, beta, training, decay, ema_mean, ema_var, save_mean, save_var,
-                           relu, out, ldo, pool_rows, pool_mode, pooled, tie_count, pool_stats, workspace,
+                           relu, out, ldo, pool_rows, pool_mode, pooled, tie_count, pool_stats, workspace, colstats,
                            colstats_parts, stream);
 }
 

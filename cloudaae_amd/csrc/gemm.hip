@@ -484,10 +484,7 @@ CLOUDAAE_API int cloudaae_gemm_f32_colstats_parts(int M, int N, int K)
         return 0;
     int BM, BN, splits;
     gemm_plan(M, N, K, BM, BN, splits);
-    // one row of sums per tile row, and the batch norm's workspace holds 256 of them (2 * BN_MAX_PARTS):
-    // taller products (B = 256 per GPU) keep the separate statistics pass
-    const int parts = ceil_div(M, BM);
-    return (splits == 1 && parts <= 256) ? parts : 0;
+    return splits == 1 ? ceil_div(M, BM) : 0;      // one row of sums per tile row
 }
 
 CLOUDAAE_API int cloudaae_gemm_f32_colstats(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,

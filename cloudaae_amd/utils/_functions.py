@@ -401,7 +401,7 @@ class ConcatLinearFn(torch.autograd.Function):
         # sums of its tiles in the batch norm's workspace and the statistics pass over y is skipped
         parts = int(L().cloudaae_gemm_f32_colstats_parts(M, N, Ktot)) if (int(bias_grad_by_bn) & 2 and not ctx.bf16) else 0
         if parts > 0:
-            ws = _ws(L().cloudaae_bn_workspace_bytes(N), w.device)
+            ws = _lib.empty(parts * 2 * N, dtype=torch.float64, device=w.device)      # colstats[parts][2][N]
             rec = TIMED_SITES.get("agg_fwd")
             if rec is not None:
                 _lib.host(_mark, rec)
@@ -482,13 +482,13 @@ class BatchNormFn(torch.autograd.Function):
             pstats = _lib.empty((M // pool_rows) * 3 * C, dtype=torch.float64, device=dev)
         global _COLSTATS
         pre, _COLSTATS = _COLSTATS, None
+        ws = _ws(L().cloudaae_bn_workspace_bytes(C), dev)
         if pre is not None and pre[0] == yp and ldy == C and training:
             _lib.check(L().cloudaae_bn_forward_colstats(
                 M, C, yp, ldy, ptr(gamma), ptr(beta), int(training), ptr(decay), ptr(ema_mean), ptr(ema_var),
                 ptr(save_mean), ptr(save_var), int(relu), ptr(out), C, int(pool_rows), int(pool_mode), ptr(pooled),
-                ptr(ties), ptr(pstats), ptr(pre[1]), int(pre[2]), stream()), "cloudaae_bn_forward_colstats")
+                ptr(ties), ptr(pstats), ptr(ws), ptr(pre[1]), int(pre[2]), stream()), "cloudaae_bn_forward_colstats")
         else:
-            ws = _ws(L().cloudaae_bn_workspace_bytes(C), dev)
             _lib.check(L().cloudaae_bn_forward(
                 M, C, yp, ldy, ptr(gamma), ptr(beta), int(training), ptr(decay), ptr(ema_mean), ptr(ema_var),
                 ptr(save_mean), ptr(save_var), int(relu), ptr(out), C, int(pool_rows), int(pool_mode), ptr(pooled),

@@ -157,14 +157,14 @@ int cloudaae_bn_forward(int M, int C, const float *y, int ldy, const float *gamm
                         float *save_mean, float *save_var, int relu, float *out, int ldo, int pool_rows,
                         int pool_mode, float *pooled, float *tie_count, double *pool_stats, void *workspace,
                         cloudaae_stream_t stream);
-/* The same with the statistics pass skipped: the first colstats_parts x 2 x C doubles of `workspace`
- * already hold per-row-tile column sums / sums of squares of y, written by cloudaae_gemm_f32_colstats
- * (the product that made y had the tile in registers anyway: for dgcnn_agg this saves reading 134 MB). */
+/* The same with the statistics pass skipped: colstats[colstats_parts][2][C] already holds per-row-tile
+ * column sums / sums of squares of y, written by cloudaae_gemm_f32_colstats (the product that made y had
+ * the tile in registers anyway: for dgcnn_agg this saves reading 134 MB). */
 int cloudaae_bn_forward_colstats(int M, int C, const float *y, int ldy, const float *gamma, const float *beta,
                                  int training, const float *decay, float *ema_mean, float *ema_var,
                                  float *save_mean, float *save_var, int relu, float *out, int ldo, int pool_rows,
                                  int pool_mode, float *pooled, float *tie_count, double *pool_stats, void *workspace,
-                                 int colstats_parts, cloudaae_stream_t stream);
+                                 const double *colstats, int colstats_parts, cloudaae_stream_t stream);
 /* gradient of the above: upstream = dout[M,C] (may be NULL) and/or dpooled[M/pool_rows,C]
  * (mean: /pool_rows; max: shared among equal maxima, as tf.reduce_max does);
  * produces dy[M,C], dgamma[C], dbeta[C] (NULL = not wanted), and dbias[C] (NULL = not wanted): the

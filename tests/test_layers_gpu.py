@@ -491,8 +491,7 @@ def test_gemm_colstats_feed_batch_norm(hip, M, N, K):
     L = hip.lib()
     parts = L.cloudaae_gemm_f32_colstats_parts(M, N, K)
     assert parts > 0
-    # taller than the batch norm's workspace has rows for (B = 256 per GPU): no fused statistics
-    assert L.cloudaae_gemm_f32_colstats_parts(262144, 1024, 320) == 0
+    assert L.cloudaae_gemm_f32_colstats_parts(262144, 1024, 320) == 2048      # B = 256 per GPU
     g = torch.Generator().manual_seed(M + N)
     A = torch.randn(M, K, generator=g).cuda()
     B = (torch.randn(K, N, generator=g) / math.sqrt(K)).cuda()
@@ -504,6 +503,7 @@ def test_gemm_colstats_feed_batch_norm(hip, M, N, K):
     for fused in (False, True):
         C = torch.empty(M, N, device="cuda")
         ws = torch.zeros(int(L.cloudaae_bn_workspace_bytes(N)) // 8 + 1, dtype=torch.float64, device="cuda")
+        cs = torch.zeros(parts * 2 * N, dtype=torch.float64, device="cuda")
         sm, sv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
         mean, var = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
         out = torch.empty(M, N, device="cuda")
@@ -511,11 +511,11 @@ def test_gemm_colstats_feed_batch_norm(hip, M, N, K):
         P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         s = hip.stream()
         if fused:
-            hip.check(L.cloudaae_gemm_f32_colstats(0, 0, M, N, K, P(A), K, P(B), N, P(C), N, P(bias), P(ws), s), "g")
+            hip.check(L.cloudaae_gemm_f32_colstats(0, 0, M, N, K, P(A), K, P(B), N, P(C), N, P(bias), P(cs), s), "g")
             hip.check(L.cloudaae_bn_forward_colstats(M, N, P(C), N, P(gamma), P(beta), 1, P(decay), P(sm), P(sv), P(mean),
                                                      P(var), 1, P(out), N, rows, 1 if rows else 0, P(pooled), None,
-                                                     None, P(ws), parts, s), "bn")
-            stats = ws[:parts * 2 * N].reshape(parts, 2, N).sum(0)
+                                                     None, P(ws), P(cs), parts, s), "bn")
+            stats = cs.reshape(parts, 2, N).sum(0)
             Cd = C.double()
             assert _rel(stats[0], Cd.sum(0)) < 1e-9 and _rel(stats[1], (Cd * Cd).sum(0)) < 1e-9
         else:
