@@ -188,11 +188,14 @@ __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int 
         if (a.tickets == nullptr)
             return;
         // Batch norm needs the whole column.  Every slice adds its sums with agent-scope atomics (performed
-        // at the memory side, where all XCDs meet), waits until they are acknowledged (__syncthreads
-        // drains each wave's counters), then takes a ticket; the workgroup that draws the last one reads
-        // the column tile back with agent-scope loads and finishes it.  No cache write-back or
-        // invalidate is involved -- a __threadfence() here costs more than the whole product -- because
-        // no ordinary store takes part.  The counter returns to zero for the next launch.
+        // at the memory side, where all XCDs meet) and every WAVE waits until its own adds are acknowledged
+        // (s_waitcnt vmcnt(0): a returnless atomic counts in vmcnt until the memory side has performed it;
+        // s_barrier alone does NOT drain the counter) before the barrier; only then is a ticket taken; the
+        // workgroup that draws the last one reads the column tile back with agent-scope loads and finishes
+        // it.  No cache write-back or invalidate is involved -- a __threadfence() here costs more than the
+        // whole product -- because no ordinary store takes part.  The counter returns to zero for the next
+        // launch.  (tests/test_capi_symbols.py checks the emitted ISA for the wait in front of the barrier.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
             const int t = __hip_atomic_fetch_add(&a.tickets[tile_x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

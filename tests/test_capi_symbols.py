@@ -42,3 +42,31 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(root, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "liboracle" not in text, f
+
+
+def test_fc_ticket_is_taken_after_the_atomics_are_drained():
+    """csrc/fc.hip, batch norm over a K-cut product: every wave must wait for its float adds into y
+    (s_waitcnt vmcnt(0)) BEFORE the barrier that precedes the ticket -- s_barrier does not drain the
+    counter, and a ticket published early lets the last workgroup read incomplete column sums.
+    Checked on the emitted gfx950 ISA: between the last global_atomic_add_f32 and the ticket
+    (global_atomic_add ... sc0) there is an s_waitcnt vmcnt(0) in front of the s_barrier."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc on this machine")
+    src = os.path.join(ROOT, "cloudaae_amd", "csrc", "fc.hip")
+    asm = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                          "-munsafe-fp-atomics", "-S", "--cuda-device-only", src, "-o", "-"],
+                         check=True, capture_output=True, text=True).stdout.splitlines()
+    tickets = [i for i, l in enumerate(asm) if re.search(r"\bglobal_atomic_add\s.*\bsc0\b", l)]
+    assert tickets, "no returning integer atomic (the ticket) in fc.hip's ISA"
+    for t in tickets:
+        adds = [i for i in range(t) if "global_atomic_add_f32" in asm[i]]
+        assert adds, "ticket without preceding float adds"
+        window = [l.strip() for l in asm[adds[-1] + 1:t]]
+        bar = [i for i, l in enumerate(window) if l.startswith("s_barrier")]
+        assert bar, "no barrier between the adds and the ticket"
+        waits = [i for i, l in enumerate(window[:bar[0]]) if re.match(r"s_waitcnt\s+vmcnt\(0\)", l)]
+        assert waits, "the adds are not drained before the barrier:\n" + "\n".join(window)
