@@ -1,20 +1,30 @@
 """bench.py -- throughput of the CloudAAE training step on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+    (N > 1: one rank per GPU over RCCL -- either launched by torch.distributed.run, which sets
+    WORLD_SIZE/RANK/LOCAL_RANK, or by bench.py itself: with WORLD_SIZE unset it starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process before
+    anything here touches the GPU, relays rank 0's JSON line and exits with the child's code)
 
 A "step" is one pass of the hot path over one batch of synthetic input, i.e. one
 iteration of the reference's session loop (train_cloudAAE_ycbv.py:350-368): BN-decay
 schedule, input assembly, DGCNN encoder + decoder + pose heads, Chamfer / translation /
 SO(3) losses, backward, TF-Adam (+ gradient all-reduce for N > 1).  Workload at N=1 is
-BASELINE.json configs[1]: all 21 classes, batch 32, 1024 points, fp32.  For N > 1 the
-per-GPU batch stays 32 (weak scaling).  Inputs are resident in HBM before the timed region.
+BASELINE.json configs[1]: all 21 classes, batch 32, 1024 points, fp32.  For N > 1 the workload is
+BASELINE.json configs[3]'s per-GPU shape: 128 clouds per GPU (global batch 1024 on 8 GPUs), fixed as
+N grows ("weak"); `--per-gpu-batch` overrides either.  Because the N=1 line is a different (smaller)
+batch than the N>1 lines, every N>1 line also carries `one_rank_same_shape`: rank 0 alone, no
+collectives, the same 128-cloud batch -- the honest denominator for a scaling efficiency.
+Inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   roofline     : the dominant kernel (the dgcnn_agg forward GEMM on the matrix cores),
                  timed live with HIP events on the launch stream over the timed region
   cpu_baseline : the CPU oracle's train step timed on this box's host cores on a bounded
                  sample (rank 0, N=1 only)
+  comm (N > 1) : ranks_seen (an RCCL all-reduce of ones), allreduce_exposed_ms (HIP events on the
+                 compute stream around the end-of-backward exchange: the time the step waits for
+                 gradients, the early fully-connected piece having been reduced behind backward)
 """
 import argparse
 import json
@@ -105,27 +115,140 @@ def chamfer_kernel_rate(batch, n, m, iters=20):
             "clouds/s": round(batch / sec, 1), "frac_of_matrix_pipe_bound": round(pairs / sec / bound, 4)}
 
 
+def chamfer_train_rate(batch=32, n=16384, m=1024, iters=20):
+    """The reference's own micro-benchmark, as it runs it (tf_ops/nn_distance/tf_nndistance.py:45-66):
+    an SGD step on loss = sum(dist1) + sum(dist2) with xyz1 the variable, i.e. per iteration the forward
+    search both ways, the two reductions, NnDistanceGrad with unit upstream gradients and
+    xyz1 -= 0.05 * grad.  Same shapes and seed; everything through the C ABI."""
+    from cloudaae_amd import _lib
+    L, P, S = _lib.lib(), _lib.ptr, _lib.stream
+    g = torch.Generator(device="cuda").manual_seed(100)
+    a = torch.randn((batch, n, 3), generator=g, device="cuda")
+    c = torch.randn((batch, m, 3), generator=g, device="cuda")
+    d1, d2 = torch.empty((batch, n), device="cuda"), torch.empty((batch, m), device="cuda")
+    i1 = torch.empty((batch, n), dtype=torch.int32, device="cuda")
+    i2 = torch.empty((batch, m), dtype=torch.int32, device="cuda")
+    one1, one2 = torch.ones_like(d1), torch.ones_like(d2)
+    ga, gc = torch.empty_like(a), torch.empty_like(c)
+    s1, s2 = torch.empty((), device="cuda"), torch.empty((), device="cuda")
+    ws = torch.empty(int(L.cloudaae_mean_workspace_bytes()) // 8 + 1, dtype=torch.float64, device="cuda")
+
+    def step():
+        _lib.check(L.cloudaae_nn_distance(batch, n, P(a), m, P(c), P(d1), P(i1), P(d2), P(i2), S()), "nn_distance")
+        _lib.check(L.cloudaae_mean_f32(batch * n, P(d1), P(s1), P(ws), S()), "mean")        # tf.reduce_sum(reta)
+        _lib.check(L.cloudaae_mean_f32(batch * m, P(d2), P(s2), P(ws), S()), "mean")        # tf.reduce_sum(retc)
+        _lib.check(L.cloudaae_nn_distance_grad(batch, n, P(a), m, P(c), P(one1), P(i1), P(one2), P(i2), P(ga), P(gc),
+                                               S()), "nn_distance_grad")
+        _lib.check(L.cloudaae_sgd(batch * n * 3, P(a), P(ga), 0.05, 1.0, S()), "sgd")     # GradientDescentOptimizer(0.05)
+    for _ in range(3):
+        step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    return {"what": "tf_nndistance.py:45-66: forward + sums + NnDistanceGrad + SGD on xyz1",
+            "shape": "[%d,%d,3]x[%d,%d,3]" % (batch, n, batch, m), "us_per_iteration": round(sec * 1e6, 2),
+            "clouds/s": round(batch / sec, 1)}
+
+
+def git_blob_sha(path):
+    """`git hash-object` of a file, without git (the GPU box has no .git)."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def measured_traffic(B, N, kernel_key):
+    """HBM bytes per launch of a named kernel from the rocprofv3 PMC passes recorded in
+    profiles/roofline_traffic.json -- used ONLY if that file was collected on the very sources that are
+    running (git blob hashes of the kernel's source files match) and on this workload; else None."""
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    rec = json.load(open(tpath)).get(kernel_key)
+    if not rec or rec.get("workload") != "B=%d,N=%d" % (B, N):
+        return None
+    for rel, sha in rec.get("source_blobs", {}).items():
+        f = os.path.join(ROOT, rel)
+        if not os.path.exists(f) or git_blob_sha(f) != sha:
+            return None
+    return rec.get("traffic_bytes_per_launch")
+
+
+def launch_children(args):
+    """--gpus N without a launcher: run N ranks as children of THIS process (which has not touched the
+    GPU and will not), relay their output, return the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def timed_steps(graph, el, steps, warmup, world, sites):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+    from cloudaae_amd.utils import _functions as F
+    for _ in range(warmup):
+        graph.train_step(el)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    for k in sites:
+        F.TIMED_SITES[k].clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = graph.train_step(el)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=graph.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    return elapsed, out
+
+
+def site_ms(events):
+    ms = [events[i].elapsed_time(events[i + 1]) for i in range(0, len(events) - 1, 2)]
+    return (sum(ms) / len(ms) if ms else 0.0), len(ms)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--per-gpu-batch", type=int, default=32)
+    ap.add_argument("--per-gpu-batch", type=int, default=0, help="clouds per GPU (0 = 32 on one GPU: BASELINE "
+                    "configs[1]; 128 on several: the per-GPU shape of configs[3])")
     ap.add_argument("--num-point", type=int, default=1024)
-    ap.add_argument("--k", type=int, default=10, help="neighbours of the edge convolution (BASELINE config 4: 20)")
+    ap.add_argument("--k", type=int, default=10, help="neighbours of the edge convolution (BASELINE configs[4]: 20)")
     ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="train steps of the CPU-baseline sample")
-    ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "bf16"], help="bf16: BASELINE config 3's "
+    ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "bf16"], help="bf16: BASELINE configs[2]'s "
                     "arithmetic (dense-layer operands rounded to bf16, fp32 accumulate; everything else fp32)")
+    ap.add_argument("--sync-bn", action="store_true", help="batch-norm moments over the GLOBAL batch (all ranks)")
     ap.add_argument("--eager", action="store_true", help="step through Python/autograd every time instead of "
                     "replaying the recorded step (TrainGraph(replay=False))")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: become one.  Nothing in this process has initialised the GPU (importing torch does not).
+        sys.exit(launch_children(args))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs torch.distributed.run (WORLD_SIZE is unset)" % args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     force = os.environ.get("CLOUDAAE_FORCE_COLLECTIVES") == "1" and "MASTER_ADDR" in os.environ
@@ -135,52 +258,47 @@ def main():
     from cloudaae_amd import train_cloudAAE_ycbv as T
     from cloudaae_amd.utils import _functions as F
 
-    B = args.per_gpu_batch
+    B = args.per_gpu_batch or (32 if world == 1 else 128)
     N = args.num_point
-    # the dgcnn_agg forward GEMM records a HIP event before and after itself on its launch stream,
-    # live in every step of the timed region (host callbacks of the recorded step)
-    F.TIMED_SITES["agg_fwd"] = []
+    # live HIP events on the launch stream around: the dgcnn_agg forward GEMM, the three kNN launches over 64
+    # feature channels, and (N > 1) the end-of-backward gradient exchange -- host callbacks of the recorded step
+    sites = ["agg_fwd", "knn64"] + (["exchange"] if (world > 1 or force) else [])
+    for k in sites:
+        F.TIMED_SITES[k] = []
     graph = T.TrainGraph({"num_point": N, "gpu": local}, {"optimizer": "adam"},
                          {"batch_size": B * world, "learning_rate": 0.0008}, replay=not args.eager,
-                         gemm_dtype=args.gemm_dtype, k_neighbor=args.k)
+                         gemm_dtype=args.gemm_dtype, k_neighbor=args.k, sync_bn=args.sync_bn)
     el = T.synthetic_element(B, N, graph.device, seed=123456789, rank=rank)
     graph.reuse_staged_inputs = True     # one fixed batch, resident in HBM: do not re-copy it every step
 
-    for _ in range(args.warmup):
-        graph.train_step(el)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    ranks_seen = 1
+    if world > 1 or force:
+        ones = torch.ones(1, device=graph.device)
+        dist.all_reduce(ones)                                   # RCCL: every rank contributes 1
+        ranks_seen = int(round(float(ones)))
 
-    F.TIMED_SITES["agg_fwd"].clear()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = graph.train_step(el)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    events = F.TIMED_SITES.pop("agg_fwd")
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=graph.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    elapsed, out = timed_steps(graph, el, args.steps, args.warmup, world, sites)
+    events = {k: F.TIMED_SITES.pop(k) for k in sites}
     loss = float(out["total_loss"])
 
+    one_rank = None
+    if world > 1:
+        # the same per-GPU batch on rank 0 ALONE (no collectives, the others wait at the barrier)
+        if rank == 0:
+            solo = T.TrainGraph({"num_point": N, "gpu": local}, {"optimizer": "adam"},
+                                {"batch_size": B, "learning_rate": 0.0008}, replay=not args.eager,
+                                gemm_dtype=args.gemm_dtype, k_neighbor=args.k, process_group=False)
+            solo.reuse_staged_inputs = True
+            t1, _ = timed_steps(solo, el, args.steps, args.warmup, 1, [])
+            one_rank = {"per_gpu_batch": B, "clouds/s": round(B * args.steps / t1, 2),
+                        "ms_per_step": round(t1 / args.steps * 1e3, 4)}
+        dist.barrier()
+
     if rank == 0:
-        ms = [events[i].elapsed_time(events[i + 1]) for i in range(0, len(events) - 1, 2)]
-        k_ms = sum(ms) / max(1, len(ms))
+        k_ms, k_n = site_ms(events["agg_fwd"])
         M, Nn, K = B * N, 1024, 320
         flops = 2.0 * M * Nn * K                      # algorithmic flops of one dgcnn_agg forward launch
         achieved = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_roofline_traffic.json")
-        if os.path.exists(tpath) and B == 32 and N == 1024:
-            # HBM bytes per launch of the same kernel from rocprofv3 PMC passes (FETCH_SIZE x2
-            # corrected + WRITE_SIZE; collected separately, see profiles/ and DESIGN.md section 5)
-            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
         line = {
             "metric": "point-clouds/sec (train step, N=%d)" % N,
             "value": round(B * world * args.steps / elapsed, 2),
@@ -195,30 +313,56 @@ def main():
             "dtype": "f32" if args.gemm_dtype == "f32" else "bf16 dense-layer operands, f32 accumulate and everything else",
             "data": "synthetic",
             "config": {"workload": "CloudAAE train step: get_model_dgcnn_mean_6d, all 21 YCB classes, "
-                                   "batch %d/GPU, N=%d points, k=%d, 4N-point Chamfer target, TF-Adam" % (B, N, args.k),
-                       "global_batch": B * world, "num_point": N, "parallelism": "dp%d" % world,
+                                   "batch %d/GPU, N=%d points, k=%d, 4N-point Chamfer target, TF-Adam%s"
+                                   % (B, N, args.k, ", SyncBN" if args.sync_bn else ""),
+                       "baseline_config": ("configs[1]" if (world == 1 and B == 32 and args.gemm_dtype == "f32") else
+                                           "configs[2]" if (world == 1 and B == 256 and args.gemm_dtype == "bf16") else
+                                           "configs[3] (128 clouds per GPU)" if (B == 128 and world > 1) else "custom"),
+                       "global_batch": B * world, "per_gpu_batch": B, "num_point": N, "parallelism": "dp%d" % world,
                        "step_issue": "recorded step replay" if graph.replay else "eager",
                        "final_total_loss": round(loss, 4)},
             "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,2,2> dgcnn_agg forward "
                                                      "[%d x 320] x [320 x 1024]" % M,
                          "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "launch_ms": round(k_ms, 4), "launches_timed": len(ms)},
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": measured_traffic(B, N, "agg_fwd") if args.gemm_dtype == "f32" else None,
+                         "launch_ms": round(k_ms, 4), "launches_timed": k_n},
         }
         if args.gemm_dtype == "bf16":
             # with bf16 operands the same product leaves the matrix pipe (2.5 PFLOP/s dense) and is bound by
-            # HBM: fp32 activations in (M x 320), weights, fp32 output out (M x 1024)
+            # HBM: activations in (M x 320), weights, fp32 output out (M x 1024)
             nbytes = 4.0 * (M * K + K * Nn + Nn + M * Nn)
             gbs = nbytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
             line["roofline"] = {"bound": "hbm", "kernel": "gemm_bf16_kernel<128,128,2,2> dgcnn_agg forward "
                                                           "[%d x 320] x [320 x 1024]" % M,
-                                "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                                "frac": round(gbs / 8000.0, 4), "traffic": None, "launch_ms": round(k_ms, 4),
-                                "launches_timed": len(ms)}
+                                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(B, N, "agg_fwd_bf16"),
+                                "launch_ms": round(k_ms, 4), "launches_timed": k_n}
+        # second roofline entry: the kNN over 64 feature channels (layers 2-4), the kernel furthest below its
+        # bound.  Algorithmic flops = the N x N x 64 inner products of every cloud (2 N^2 C B), on the fp32
+        # matrix pipe (the selection that follows is what keeps it from that bound)
+        q_ms, q_n = site_ms(events["knn64"])
+        if q_n:
+            qf = 2.0 * B * N * N * 64 / (q_ms * 1e-3) / 1e12
+            line["roofline_knn64"] = {"bound": "mfma", "kernel": "knn64 (cloudaae_knn, C=64, k=%d) [%d x %d x %d]"
+                                                                   % (args.k, B, N, N),
+                                      "achieved": round(qf, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(qf / FP32_MFMA_PEAK_TFLOPS, 4),
+                                      "traffic": measured_traffic(B, N, "knn64"),
+                                      "launch_ms": round(q_ms, 4), "launches_timed": q_n}
+        if world > 1 or force:
+            x_ms, x_n = site_ms(events["exchange"])
+            line["comm"] = {"backend": "nccl (RCCL)", "ranks_seen": ranks_seen,
+                            "allreduce_exposed_ms": round(x_ms, 4), "exchanges_timed": x_n,
+                            "bytes_per_step": int(graph.store.flat_grads.numel()) * 4,
+                            "sync_bn": bool(args.sync_bn)}
+        if one_rank is not None:
+            line["one_rank_same_shape"] = one_rank
         if world == 1:
             # "Chamfer kernel GB/s": the train shape (n = m = 4N) and the reference's own
-            # micro-benchmark shape (tf_nndistance.py:48-49)
+            # micro-benchmark shape (tf_nndistance.py:48-49), forward alone and the whole iteration it times
             line["chamfer_kernel"] = [chamfer_kernel_rate(B, 4 * N, 4 * N), chamfer_kernel_rate(32, 16384, 1024)]
+            line["chamfer_reference_microbench"] = chamfer_train_rate()
             if args.cpu_batch > 0:
                 line["chamfer_kernel"][0]["cpu"] = chamfer_cpu_rate(4 * N, 4 * N)
         if world == 1 and args.cpu_batch > 0:

@@ -303,10 +303,13 @@ class PoseRecords(object):
         return len(self.class_id)
 
     def shard(self, rank, world):
+        """Rank-strided shard, truncated to len // world records so that EVERY rank yields the same number
+        of batches per epoch (one rank running an extra step would issue all-reduces nobody joins)."""
+        n = len(self) // world
         out = object.__new__(PoseRecords)
-        out.translation = self.translation[rank::world]
-        out.axisangle = self.axisangle[rank::world]
-        out.class_id = self.class_id[rank::world]
+        out.translation = self.translation[rank::world][:n]
+        out.axisangle = self.axisangle[rank::world][:n]
+        out.class_id = self.class_id[rank::world][:n]
         return out
 
     def epoch(self, batch_size, seed=None, shuffle=True):

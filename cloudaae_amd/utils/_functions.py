@@ -344,9 +344,10 @@ class FcGroupFn(torch.autograd.Function):
         return tuple(grads)
 
 
-# hand-off from a product that computed the column sums of its output to the batch norm that consumes it:
-# (data_ptr of y, workspace holding the sums, number of tile rows), taken once by BatchNormFn.forward
-_COLSTATS = None
+# Hand-off from a product that computed the column sums of its output to the batch norm that consumes it:
+# the product's output tensor y carries `_cloudaae_colstats` = (workspace holding the sums, number of tile
+# rows, M, N); BatchNormFn.forward uses it only for that very tensor (same object, same shape) in training
+# mode.  Nothing global: a batch norm that is skipped leaves nothing behind for a later one to pick up.
 
 
 class ConcatSlot(object):
@@ -410,8 +411,7 @@ class ConcatLinearFn(torch.autograd.Function):
                        "cloudaae_gemm_f32_colstats")
             if rec is not None:
                 _lib.host(_mark, rec)
-            global _COLSTATS
-            _COLSTATS = (y.data_ptr(), ws, parts)
+            y._cloudaae_colstats = (ws, parts, M, N)
         else:
             gemm(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, site="agg_fwd",
                  bf16=ctx.bf16)
@@ -480,14 +480,13 @@ class BatchNormFn(torch.autograd.Function):
         pstats = None
         if pool_mode == 1 and training and relu and not want_activation:
             pstats = _lib.empty((M // pool_rows) * 3 * C, dtype=torch.float64, device=dev)
-        global _COLSTATS
-        pre, _COLSTATS = _COLSTATS, None
+        pre = getattr(y, "_cloudaae_colstats", None)
         ws = _ws(L().cloudaae_bn_workspace_bytes(C), dev)
-        if pre is not None and pre[0] == yp and ldy == C and training:
+        if pre is not None and pre[2] == M and pre[3] == C and ldy == C and training:
             _lib.check(L().cloudaae_bn_forward_colstats(
                 M, C, yp, ldy, ptr(gamma), ptr(beta), int(training), ptr(decay), ptr(ema_mean), ptr(ema_var),
                 ptr(save_mean), ptr(save_var), int(relu), ptr(out), C, int(pool_rows), int(pool_mode), ptr(pooled),
-                ptr(ties), ptr(pstats), ptr(ws), ptr(pre[1]), int(pre[2]), stream()), "cloudaae_bn_forward_colstats")
+                ptr(ties), ptr(pstats), ptr(ws), ptr(pre[0]), int(pre[1]), stream()), "cloudaae_bn_forward_colstats")
         else:
             _lib.check(L().cloudaae_bn_forward(
                 M, C, yp, ldy, ptr(gamma), ptr(beta), int(training), ptr(decay), ptr(ema_mean), ptr(ema_var),

@@ -54,6 +54,11 @@ def test_epoch_semantics_and_sharding(golden_dir):
     assert len(list(ds.epoch(13, seed=0))) == 0
     a, b = ds.shard(0, 2), ds.shard(1, 2)
     assert len(a) == len(b) == 6
+    # every rank gets the same number of records (a longer shard would run a step nobody joins)
+    odd = [ds.shard(r, 5) for r in range(5)]
+    assert [len(x) for x in odd] == [2] * 5
+    ds7 = T.PoseRecords([path, path])                                       # 8 records over 3 ranks
+    assert [len(ds7.shard(r, 3)) for r in range(3)] == [2, 2, 2]
     seen = np.concatenate([x["translation"] for x in ds.epoch(4, seed=1)])
     assert seen.shape == (12, 3)                                            # a permutation of everything
     assert np.array_equal(np.sort(seen[:, 0]), np.sort(ds.translation[:, 0]))
