@@ -33,6 +33,16 @@ _SIGNATURES = {
     "cloudaae_bn_backward": [_I, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I,
                              _P, _P, _P, _I, _P, _P, _P],
     "cloudaae_colsum_f32": [_I, _I, _P, _I, _P, _I, _P, _P],
+    # SyncBN variants: the plain argument lists + (colstats, parts for the forward) + cloudaae_bn_sync* + stream(s)
+    "cloudaae_bn_forward_sync": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P,
+                                 _P, _P, _I, _P, _P],
+    "cloudaae_bn_backward_sync": [_I, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I,
+                                  _P, _P, _P, _I, _P, _P, _P, _P],
+    "cloudaae_edgeconv_forward_sync": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P,
+                                       _P, _P, _P, _I, _P, _P, _I, _P, _P, _P],
+    "cloudaae_edgeconv_backward_sync": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P,
+                                        _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P,
+                                        _P, _P],
     "cloudaae_gemm_f32_colstats": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P],
     "cloudaae_bn_forward_colstats": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P,
                                      _P, _P, _I, _P],
@@ -86,6 +96,15 @@ class FcLayer(ctypes.Structure):
                 ("ema_mean", _P), ("ema_var", _P), ("save_mean", _P), ("save_var", _P), ("relu", _I), ("y", _P),
                 ("out", _P), ("tickets", _P), ("dout", _P), ("lddo", _I), ("dx", _P), ("lddx", _I), ("dw", _P),
                 ("accumulate_dw", _I), ("dgamma", _P), ("dbeta", _P), ("dbias", _P), ("accumulate_param_grads", _I)]
+
+
+# int (*cloudaae_allreduce_fn)(void *ctx, double *buf, int count, cloudaae_stream_t stream)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(_I, _P, _P, _I, _P)
+
+
+class BnSyncStruct(ctypes.Structure):
+    """struct cloudaae_bn_sync (include/cloudaae_hip.h): the host's all-reduce for batch-norm sums."""
+    _fields_ = [("allreduce", ALLREDUCE_FN), ("ctx", _P), ("world", _I), ("buf", _P)]
 
 
 _LONGLONG_RESULTS = ["cloudaae_bn_workspace_bytes", "cloudaae_edgeconv_workspace_bytes",

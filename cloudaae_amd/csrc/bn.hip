@@ -552,7 +552,8 @@ static int bn_forward_impl(const char *name, int M, int C, const float *y, int l
                            const float *beta, int training, const float *decay, float *ema_mean, float *ema_var,
                            float *save_mean, float *save_var, int relu, float *out, int ldo, int pool_rows,
                            int pool_mode, float *pooled, float *tie_count, double *pool_stats, void *workspace,
-                           const double *colstats, int colstats_parts, cloudaae_stream_t stream)
+                           const double *colstats, int colstats_parts, const cloudaae_bn_sync *sync,
+                           cloudaae_stream_t stream)
 {
     CLOUDAAE_REQUIRE(M > 0 && C > 0 && ldy >= C, name, "bad size");
     CLOUDAAE_REQUIRE(workspace != nullptr && gamma && beta && save_mean && save_var, name, "null argument");
@@ -563,7 +564,9 @@ static int bn_forward_impl(const char *name, int M, int C, const float *y, int l
                      "pooling needs pool_rows | M and an output");
     CLOUDAAE_REQUIRE(pool_mode != 0 || out != nullptr, name, "no output requested");
     hipStream_t s = (hipStream_t)stream;
-    if (pool_mode == 0 && M <= BN_SMALL_M) {   // FC layers: one fused launch
+    if (!(training && sync != nullptr))
+        sync = nullptr;                        // inference: the moments are the EMA shadows, nothing to exchange
+    if (pool_mode == 0 && M <= BN_SMALL_M && sync == nullptr) {   // FC layers: one fused launch
         hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, M, C, y, ldy, gamma, beta,
                            training, decay, ema_mean, ema_var, save_mean, save_var, relu, out, ldo);
         CLOUDAAE_CHECK_LAUNCH(name);
@@ -575,10 +578,18 @@ static int bn_forward_impl(const char *name, int M, int C, const float *y, int l
     const int cb = ceil_div(C, 64);
     if (training && colstats == nullptr)
         hipLaunchKernelGGL(bn_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, M, C, y, ldy, partial, parts);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C,
-                       colstats != nullptr ? colstats : partial, parts,
-                       (double)M, training, decay, ema_mean, ema_var, gamma, beta, save_mean, save_var,
-                       scale_shift);
+    const double *sums = colstats != nullptr ? colstats : partial;
+    int fin_parts = parts;
+    double count = (double)M;
+    if (sync != nullptr) {      // SyncBN: this rank's sums -> the sums of the global batch
+        if (int rc = bn_sync_exchange(name, sync, C, sums, parts, s))
+            return rc;
+        sums = sync->buf;
+        fin_parts = 1;
+        count *= (double)sync->world;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C, sums, fin_parts,
+                       count, training, decay, ema_mean, ema_var, gamma, beta, save_mean, save_var, scale_shift);
     if (pool_mode == 0) {
         const int slab = 64;
         hipLaunchKernelGGL(bn_apply_kernel<0>, dim3(cb, ceil_div(M, slab)), dim3(256), 0, s, M, C, y, ldy,
@@ -610,7 +621,7 @@ CLOUDAAE_API int cloudaae_bn_forward(int M, int C, const float *y, int ldy, cons
 {
     return bn_forward_impl("cloudaae_bn_forward", M, C, y, ldy, gamma, beta, training, decay, ema_mean, ema_var,
                            save_mean, save_var, relu, out, ldo, pool_rows, pool_mode, pooled, tie_count, pool_stats,
-                           workspace, nullptr, 0, stream);
+                           workspace, nullptr, 0, nullptr, stream);
 }
 
 CLOUDAAE_API int cloudaae_bn_forward_colstats(int M, int C, const float *y, int ldy, const float *gamma,
@@ -625,18 +636,32 @@ CLOUDAAE_API int cloudaae_bn_forward_colstats(int M, int C, const float *y, int 
     CLOUDAAE_REQUIRE(M > BN_SMALL_M || pool_mode != 0, name, "small batches take cloudaae_bn_forward");
     return bn_forward_impl(name, M, C, y, ldy, gamma, beta, training, decay, ema_mean, ema_var, save_mean, save_var,
                            relu, out, ldo, pool_rows, pool_mode, pooled, tie_count, pool_stats, workspace, colstats,
-                           colstats_parts, stream);
+                           colstats_parts, nullptr, stream);
 }
 
-CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, const float *gamma,
-                                      const float *beta, const float *save_mean, const float *save_var,
-                                      int training, int relu, const float *dout, int lddo, int pool_rows,
-                                      int pool_mode, const float *dpooled, const float *pooled,
-                                      const float *tie_count, float *dy, int lddy, float *dgamma,
-                                      float *dbeta, float *dbias, int accumulate_param_grads,
-                                      const double *pool_stats, void *workspace, cloudaae_stream_t stream)
+CLOUDAAE_API int cloudaae_bn_forward_sync(int M, int C, const float *y, int ldy, const float *gamma,
+                                          const float *beta, int training, const float *decay, float *ema_mean,
+                                          float *ema_var, float *save_mean, float *save_var, int relu, float *out,
+                                          int ldo, int pool_rows, int pool_mode, float *pooled, float *tie_count,
+                                          double *pool_stats, void *workspace, const double *colstats,
+                                          int colstats_parts, const cloudaae_bn_sync *sync, cloudaae_stream_t stream)
 {
-    const char *name = "cloudaae_bn_backward";
+    const char *name = "cloudaae_bn_forward_sync";
+    CLOUDAAE_REQUIRE(colstats == nullptr || colstats_parts > 0, name, "column sums given without their part count");
+    return bn_forward_impl(name, M, C, y, ldy, gamma, beta, training, decay, ema_mean, ema_var, save_mean, save_var,
+                           relu, out, ldo, pool_rows, pool_mode, pooled, tie_count, pool_stats, workspace, colstats,
+                           colstats_parts, sync, stream);
+}
+
+static int bn_backward_impl(const char *name, int M, int C, const float *y, int ldy, const float *gamma,
+                            const float *beta, const float *save_mean, const float *save_var,
+                            int training, int relu, const float *dout, int lddo, int pool_rows,
+                            int pool_mode, const float *dpooled, const float *pooled,
+                            const float *tie_count, float *dy, int lddy, float *dgamma,
+                            float *dbeta, float *dbias, int accumulate_param_grads,
+                            const double *pool_stats, void *workspace, const cloudaae_bn_sync *sync,
+                            cloudaae_stream_t stream)
+{
     CLOUDAAE_REQUIRE(M > 0 && C > 0 && ldy >= C, name, "bad size");
     CLOUDAAE_REQUIRE(workspace && gamma && beta && save_mean && save_var && dy, name, "null argument");
     CLOUDAAE_REQUIRE(pool_mode >= 0 && pool_mode <= 2, name, "bad pool_mode");
@@ -645,7 +670,9 @@ CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, con
     CLOUDAAE_REQUIRE(pool_mode != 2 || (pooled && tie_count), name, "max pool backward needs max and tie count");
     CLOUDAAE_REQUIRE(dout != nullptr || pool_mode != 0, name, "no upstream gradient");
     hipStream_t s = (hipStream_t)stream;
-    if (pool_mode == 0 && M <= BN_SMALL_M) {
+    if (!(training && sync != nullptr))
+        sync = nullptr;                        // inference-mode statistics do not depend on the batch
+    if (pool_mode == 0 && M <= BN_SMALL_M && sync == nullptr) {
         hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, s, M, C, y, ldy, gamma, beta,
                            save_mean, save_var, training, relu, dout, lddo, dy, lddy, dgamma, dbeta, dbias,
                            accumulate_param_grads);
@@ -672,13 +699,49 @@ CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, con
     } else {
         hipLaunchKernelGGL(bn_bwd_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, a, partial, parts);
     }
+    const double *gsums = nullptr;
+    double gcount = 0.0;
+    if (sync != nullptr) {      // SyncBN: the means of dz and dz * x_hat are over the global batch
+        if (int rc = bn_sync_exchange(name, sync, C, partial, parts, s))
+            return rc;
+        gsums = sync->buf;
+        gcount = (double)M * (double)sync->world;
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts,
-                       (double)M, training, dgamma, dbeta, accumulate_param_grads, m12, dbias, gamma, save_var);
+                       (double)M, training, dgamma, dbeta, accumulate_param_grads, m12, dbias, gamma, save_var, gsums,
+                       gcount);
     const int slab = 64;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cb, ceil_div(M, slab)), dim3(256), 0, s, a, m12, dy, lddy,
                        slab);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
+}
+
+CLOUDAAE_API int cloudaae_bn_backward(int M, int C, const float *y, int ldy, const float *gamma,
+                                      const float *beta, const float *save_mean, const float *save_var,
+                                      int training, int relu, const float *dout, int lddo, int pool_rows,
+                                      int pool_mode, const float *dpooled, const float *pooled,
+                                      const float *tie_count, float *dy, int lddy, float *dgamma,
+                                      float *dbeta, float *dbias, int accumulate_param_grads,
+                                      const double *pool_stats, void *workspace, cloudaae_stream_t stream)
+{
+    return bn_backward_impl("cloudaae_bn_backward", M, C, y, ldy, gamma, beta, save_mean, save_var, training, relu, dout,
+                            lddo, pool_rows, pool_mode, dpooled, pooled, tie_count, dy, lddy, dgamma, dbeta, dbias,
+                            accumulate_param_grads, pool_stats, workspace, nullptr, stream);
+}
+
+CLOUDAAE_API int cloudaae_bn_backward_sync(int M, int C, const float *y, int ldy, const float *gamma,
+                                           const float *beta, const float *save_mean, const float *save_var,
+                                           int training, int relu, const float *dout, int lddo, int pool_rows,
+                                           int pool_mode, const float *dpooled, const float *pooled,
+                                           const float *tie_count, float *dy, int lddy, float *dgamma,
+                                           float *dbeta, float *dbias, int accumulate_param_grads,
+                                           const double *pool_stats, void *workspace, const cloudaae_bn_sync *sync,
+                                           cloudaae_stream_t stream)
+{
+    return bn_backward_impl("cloudaae_bn_backward_sync", M, C, y, ldy, gamma, beta, save_mean, save_var, training, relu,
+                            dout, lddo, pool_rows, pool_mode, dpooled, pooled, tie_count, dy, lddy, dgamma, dbeta, dbias,
+                            accumulate_param_grads, pool_stats, workspace, sync, stream);
 }
 
 CLOUDAAE_API int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, float *out, int accumulate,

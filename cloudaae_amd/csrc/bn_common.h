@@ -2,6 +2,7 @@
 // Partial-sum layout everywhere: double partial[parts][2][C].
 #pragma once
 #include "common.h"
+#include "../../include/cloudaae_hip.h"
 
 namespace cloudaae {
 
@@ -126,8 +127,11 @@ static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_kernel(
 static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_bwd_finalize_kernel(
     int C, const double *__restrict__ partial, int parts, double count, int training,
     float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate, float *__restrict__ m12,
-    float *__restrict__ dbias, const float *__restrict__ gamma, const float *__restrict__ save_var)
+    float *__restrict__ dbias, const float *__restrict__ gamma, const float *__restrict__ save_var,
+    const double *__restrict__ gsums = nullptr, double gcount = 0.0)
 {
+    // gsums != nullptr (SyncBN): gsums[2][C] = the two sums over ALL ranks' rows, gcount = their row count;
+    // the means the input gradient needs come from those, dgamma / dbeta / dbias stay this rank's sums
     const int c = bn_fin_channel(), pl = bn_fin_lane();
     double s, s2, s3 = 0.0;
     bn_reduce_partials(partial, parts, C, c, pl, s, s2,
@@ -138,8 +142,8 @@ static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_bwd_finalize_kernel(
         dbeta[c] = (accumulate ? dbeta[c] : 0.0f) + (float)s;
     if (dgamma != nullptr)
         dgamma[c] = (accumulate ? dgamma[c] : 0.0f) + (float)s2;
-    const float m1 = training ? (float)(s / count) : 0.0f;
-    const float m2 = training ? (float)(s2 / count) : 0.0f;
+    const float m1 = training ? (gsums != nullptr ? (float)(gsums[c] / gcount) : (float)(s / count)) : 0.0f;
+    const float m2 = training ? (gsums != nullptr ? (float)(gsums[C + c] / gcount) : (float)(s2 / count)) : 0.0f;
     m12[c] = m1;
     m12[C + c] = m2;
     if (dbias != nullptr) {
@@ -148,6 +152,38 @@ static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_bwd_finalize_kernel(
         const double gr = (double)gamma[c] * (double)bn_rsqrt(save_var[c] + BN_EPS);
         dbias[c] = (accumulate ? dbias[c] : 0.0f) + (float)(gr * ((s - count * (double)m1) - (double)m2 * s3));
     }
+}
+
+// ---- SyncBN: the sums of a layer leave for the other ranks between its statistics pass and its finalise ----
+// sums[2][C] = sum over the parts of partial[parts][2][C]  (grid = ceil(C/BN_FIN_CH) x BN_FIN_THREADS)
+static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_sum_partials_kernel(int C, const double *__restrict__ partial,
+                                                                              int parts, double *__restrict__ sums)
+{
+    const int c = bn_fin_channel(), pl = bn_fin_lane();
+    double s, s2;
+    bn_reduce_partials(partial, parts, C, c, pl, s, s2);
+    if (c >= C || pl != 0)
+        return;
+    sums[c] = s;
+    sums[C + c] = s2;
+}
+
+// partial[parts][2][C] -> sync->buf[2][C], summed over all ranks by the host's all-reduce.  Afterwards the
+// caller finalises from (sync->buf, 1 part, count * world).
+static inline int bn_sync_exchange(const char *name, const cloudaae_bn_sync *sync, int C, const double *partial, int parts,
+                                   hipStream_t s)
+{
+    CLOUDAAE_REQUIRE(sync->allreduce != nullptr && sync->buf != nullptr && sync->world >= 1, name,
+                     "bad cloudaae_bn_sync (allreduce, buf and world >= 1 are needed)");
+    hipLaunchKernelGGL(bn_sum_partials_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C, partial,
+                       parts, sync->buf);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    const int rc = sync->allreduce(sync->ctx, sync->buf, 2 * C, (cloudaae_stream_t)s);
+    if (rc != 0) {
+        set_error("%s: the host's all-reduce callback failed (%d)", name, rc);
+        return rc > 0 ? rc : (int)hipErrorUnknown;
+    }
+    return 0;
 }
 
 } // namespace cloudaae

@@ -440,8 +440,10 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_bwd_stats_pool_kernel(E
 static __global__ __launch_bounds__(BN_FIN_THREADS) void ec_bwd_finalize_kernel(
     int C, const double *__restrict__ partial, const double *__restrict__ partial3, int parts, double count,
     int training, const float *__restrict__ gamma, const float *__restrict__ save_var,
-    float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dbias, float *__restrict__ m12)
+    float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dbias, float *__restrict__ m12,
+    const double *__restrict__ gsums, double gcount)
 {
+    // gsums != nullptr (SyncBN): the two sums over all ranks' edges and their count; see bn_bwd_finalize_kernel
     const int c = bn_fin_channel(), pl = bn_fin_lane();
     double s, s2, s3;
     bn_reduce_partials(partial, parts, C, c, pl, s, s2, partial3, &s3);
@@ -451,8 +453,8 @@ static __global__ __launch_bounds__(BN_FIN_THREADS) void ec_bwd_finalize_kernel(
         dbeta[c] = (float)s;
     if (dgamma != nullptr)
         dgamma[c] = (float)s2;
-    const float m1 = training ? (float)(s / count) : 0.0f;
-    const float m2 = training ? (float)(s2 / count) : 0.0f;
+    const float m1 = training ? (gsums != nullptr ? (float)(gsums[c] / gcount) : (float)(s / count)) : 0.0f;
+    const float m2 = training ? (gsums != nullptr ? (float)(gsums[C + c] / gcount) : (float)(s2 / count)) : 0.0f;
     m12[c] = m1;
     m12[C + c] = m2;
     if (dbias != nullptr) {
@@ -750,15 +752,14 @@ static int ec_check(const char *name, int b, int n, int k, int cin, int cout, in
     return 0;
 }
 
-CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cout, const float *x, int ldx,
-                                           const int *nn_idx, const float *weights, const float *biases,
-                                           const float *gamma, const float *beta, int training,
-                                           const float *decay, float *ema_mean, float *ema_var,
-                                           int pool_mode, float *pq, float *save_mean, float *save_var,
-                                           float *out, int ldo, float *tie_count, float *edge_stats,
-                                           int gemm_bf16, void *workspace, cloudaae_stream_t stream)
+static int ec_forward_impl(const char *name, int b, int n, int k, int cin, int cout, const float *x, int ldx,
+                           const int *nn_idx, const float *weights, const float *biases,
+                           const float *gamma, const float *beta, int training,
+                           const float *decay, float *ema_mean, float *ema_var,
+                           int pool_mode, float *pq, float *save_mean, float *save_var,
+                           float *out, int ldo, float *tie_count, float *edge_stats,
+                           int gemm_bf16, void *workspace, const cloudaae_bn_sync *sync, cloudaae_stream_t stream)
 {
-    const char *name = "cloudaae_edgeconv_forward";
     if (int rc = ec_check(name, b, n, k, cin, cout, pool_mode))
         return rc;
     CLOUDAAE_REQUIRE(training || (ema_mean && ema_var), name, "inference needs the EMA statistics");
@@ -783,9 +784,18 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
         EC_DISPATCH(EC_STATS);
 #undef EC_STATS
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(cout, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, cout, partial, grid,
-                       (double)P * (double)k, training, decay, ema_mean, ema_var, gamma, beta, save_mean,
-                       save_var, scale_shift);
+    const double *sums = partial;
+    int fin_parts = grid;
+    double count = (double)P * (double)k;
+    if (training && sync != nullptr) {      // SyncBN: the edges of every rank's clouds
+        if (int rcs = bn_sync_exchange(name, sync, cout, partial, grid, s))
+            return rcs;
+        sums = sync->buf;
+        fin_parts = 1;
+        count *= (double)sync->world;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(cout, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, cout, sums, fin_parts,
+                       count, training, decay, ema_mean, ema_var, gamma, beta, save_mean, save_var, scale_shift);
     if (pool_mode == 1) {
 #define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, es, pq)
         EC_DISPATCH(EC_APPLY);
@@ -799,18 +809,44 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
     return 0;
 }
 
-CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int cout, const float *x, int ldx,
-                                            const int *nn_idx, const float *weights, const float *biases,
-                                            const float *gamma, const float *beta, int training,
-                                            int pool_mode, const float *pq, const float *save_mean,
-                                            const float *save_var, const float *out, int ldo,
-                                            const float *tie_count, const float *dout, int lddo, float *dpq,
-                                            int *rev_scratch, int rev_ready, float *dx, int lddx, int accumulate_dx,
-                                            float *dweights, int dweights_zeroed, float *dbiases, float *dgamma,
-                                            float *dbeta, const float *edge_stats, int gemm_bf16, void *workspace,
-                                            cloudaae_stream_t stream, cloudaae_stream_t side_stream)
+CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cout, const float *x, int ldx,
+                                           const int *nn_idx, const float *weights, const float *biases,
+                                           const float *gamma, const float *beta, int training,
+                                           const float *decay, float *ema_mean, float *ema_var,
+                                           int pool_mode, float *pq, float *save_mean, float *save_var,
+                                           float *out, int ldo, float *tie_count, float *edge_stats,
+                                           int gemm_bf16, void *workspace, cloudaae_stream_t stream)
 {
-    const char *name = "cloudaae_edgeconv_backward";
+    return ec_forward_impl("cloudaae_edgeconv_forward", b, n, k, cin, cout, x, ldx, nn_idx, weights, biases, gamma, beta,
+                           training, decay, ema_mean, ema_var, pool_mode, pq, save_mean, save_var, out, ldo, tie_count,
+                           edge_stats, gemm_bf16, workspace, nullptr, stream);
+}
+
+CLOUDAAE_API int cloudaae_edgeconv_forward_sync(int b, int n, int k, int cin, int cout, const float *x, int ldx,
+                                                const int *nn_idx, const float *weights, const float *biases,
+                                                const float *gamma, const float *beta, int training,
+                                                const float *decay, float *ema_mean, float *ema_var,
+                                                int pool_mode, float *pq, float *save_mean, float *save_var,
+                                                float *out, int ldo, float *tie_count, float *edge_stats,
+                                                int gemm_bf16, void *workspace, const cloudaae_bn_sync *sync,
+                                                cloudaae_stream_t stream)
+{
+    return ec_forward_impl("cloudaae_edgeconv_forward_sync", b, n, k, cin, cout, x, ldx, nn_idx, weights, biases, gamma,
+                           beta, training, decay, ema_mean, ema_var, pool_mode, pq, save_mean, save_var, out, ldo,
+                           tie_count, edge_stats, gemm_bf16, workspace, sync, stream);
+}
+
+static int ec_backward_impl(const char *name, int b, int n, int k, int cin, int cout, const float *x, int ldx,
+                            const int *nn_idx, const float *weights, const float *biases,
+                            const float *gamma, const float *beta, int training,
+                            int pool_mode, const float *pq, const float *save_mean,
+                            const float *save_var, const float *out, int ldo,
+                            const float *tie_count, const float *dout, int lddo, float *dpq,
+                            int *rev_scratch, int rev_ready, float *dx, int lddx, int accumulate_dx,
+                            float *dweights, int dweights_zeroed, float *dbiases, float *dgamma,
+                            float *dbeta, const float *edge_stats, int gemm_bf16, void *workspace,
+                            const cloudaae_bn_sync *sync, cloudaae_stream_t stream, cloudaae_stream_t side_stream)
+{
     if (int rc = ec_check(name, b, n, k, cin, cout, pool_mode))
         return rc;
     CLOUDAAE_REQUIRE(dpq && dout && workspace && rev_scratch, name, "null argument");
@@ -858,9 +894,17 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
         EC_DISPATCH(EC_BS);
 #undef EC_BS
     }
+    const double *gsums = nullptr;
+    double gcount = 0.0;
+    if (training && sync != nullptr) {      // SyncBN: means of dz and dz * x_hat over every rank's edges
+        if (int rcs = bn_sync_exchange(name, sync, cout, partial, grid, s))
+            return rcs;
+        gsums = sync->buf;
+        gcount = (double)P * (double)k * (double)sync->world;
+    }
     hipLaunchKernelGGL(ec_bwd_finalize_kernel, dim3(ceil_div(cout, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, cout, partial,
                        partial + (size_t)EC_MAX_PARTS * 2 * cout, grid, (double)P * (double)k, training, gamma,
-                       save_var, dgamma, dbeta, dbiases, m12);
+                       save_var, dgamma, dbeta, dbiases, m12, gsums, gcount);
     if (rev_ready) {
         // (built for all layers at once: cloudaae_edgeconv_revlists)
     } else if (two) {
@@ -898,4 +942,39 @@ CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int co
             return rc;
     }
     return 0;
+}
+
+CLOUDAAE_API int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int cout, const float *x, int ldx,
+                                            const int *nn_idx, const float *weights, const float *biases,
+                                            const float *gamma, const float *beta, int training,
+                                            int pool_mode, const float *pq, const float *save_mean,
+                                            const float *save_var, const float *out, int ldo,
+                                            const float *tie_count, const float *dout, int lddo, float *dpq,
+                                            int *rev_scratch, int rev_ready, float *dx, int lddx, int accumulate_dx,
+                                            float *dweights, int dweights_zeroed, float *dbiases, float *dgamma,
+                                            float *dbeta, const float *edge_stats, int gemm_bf16, void *workspace,
+                                            cloudaae_stream_t stream, cloudaae_stream_t side_stream)
+{
+    return ec_backward_impl("cloudaae_edgeconv_backward", b, n, k, cin, cout, x, ldx, nn_idx, weights, biases, gamma, beta,
+                            training, pool_mode, pq, save_mean, save_var, out, ldo, tie_count, dout, lddo, dpq,
+                            rev_scratch, rev_ready, dx, lddx, accumulate_dx, dweights, dweights_zeroed, dbiases, dgamma,
+                            dbeta, edge_stats, gemm_bf16, workspace, nullptr, stream, side_stream);
+}
+
+CLOUDAAE_API int cloudaae_edgeconv_backward_sync(int b, int n, int k, int cin, int cout, const float *x, int ldx,
+                                                 const int *nn_idx, const float *weights, const float *biases,
+                                                 const float *gamma, const float *beta, int training,
+                                                 int pool_mode, const float *pq, const float *save_mean,
+                                                 const float *save_var, const float *out, int ldo,
+                                                 const float *tie_count, const float *dout, int lddo, float *dpq,
+                                                 int *rev_scratch, int rev_ready, float *dx, int lddx,
+                                                 int accumulate_dx, float *dweights, int dweights_zeroed,
+                                                 float *dbiases, float *dgamma, float *dbeta, const float *edge_stats,
+                                                 int gemm_bf16, void *workspace, const cloudaae_bn_sync *sync,
+                                                 cloudaae_stream_t stream, cloudaae_stream_t side_stream)
+{
+    return ec_backward_impl("cloudaae_edgeconv_backward_sync", b, n, k, cin, cout, x, ldx, nn_idx, weights, biases, gamma,
+                            beta, training, pool_mode, pq, save_mean, save_var, out, ldo, tie_count, dout, lddo, dpq,
+                            rev_scratch, rev_ready, dx, lddx, accumulate_dx, dweights, dweights_zeroed, dbiases, dgamma,
+                            dbeta, edge_stats, gemm_bf16, workspace, sync, stream, side_stream);
 }

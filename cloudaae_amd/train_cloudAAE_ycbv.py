@@ -118,6 +118,10 @@ class TrainGraph(object):
         # reference computes (utils/tf_util.py:492: tf.nn.moments over the whole batch), so that an N-rank
         # run equals a 1-rank run of the global batch; default: per-rank moments (local BN)
         self.sync_bn = bool(sync_bn) and self.world > 1
+        self.bn_sync = None
+        if self.sync_bn:
+            from .utils.sync_bn import BnSync
+            self.bn_sync = BnSync(self.pg, self.world)
         # MODEL = importlib.import_module(general_opts['model'])   (:147) -- the plugin seam
         self.MODEL = importlib.import_module('cloudaae_amd.models.' +
                                              general_opts.get('model', 'pointnet_ycb_23_decoder_4'))
@@ -167,7 +171,8 @@ class TrainGraph(object):
             lo = min(self.store.offsets[v.name] for v in fc)
             early = (lo, n)
         self.exchange = GradExchange(self.store.flat_grads, early, self.pg, world=self.world, early_count=len(fc))
-        self._zero_limit = early[0] if (early is not None and F.fc_fits(self.local_batch)) else None
+        # (with SyncBN the fully connected stack runs as product + batch norm, whose split-K products ADD)
+        self._zero_limit = early[0] if (early is not None and F.fc_fits(self.local_batch) and not self.sync_bn) else None
         self.exchange.broadcast_params(self.store.flat_params)     # identical initial weights on every rank
         if early is not None and self.exchange.active:
             for v in fc:
@@ -176,6 +181,7 @@ class TrainGraph(object):
     def _call_model(self, pc, is_training):
         set_default_store(self.store)      # several graphs may live in one process (cf. tf.Graph.as_default)
         F.GEMM_DTYPE = self.gemm_dtype     # read by every dense layer's forward (its backward follows suit)
+        F.BN_SYNC = self.bn_sync           # ... and by every batch norm's
         if self.is_pn:
             return self.model_fn(pc, is_training, bn_decay=self.bn_decay)
         return self.model_fn(pc, is_training, is_training, self.k, bn_decay=self.bn_decay)
@@ -235,6 +241,8 @@ class TrainGraph(object):
         # gradients of the fully connected stack are stored whole by its grouped kernels (batch <= 32):
         # only the encoder's slots (split-K products add into them) are cleared
         self.store.begin_step(zero_grads=True, zero_limit=self._zero_limit)
+        if self.bn_sync is not None:
+            self.bn_sync.begin_step()
         # self.bn_decay holds min(0.99, 1 - 0.5 * 0.5^floor(batch*BATCH_SIZE/40)) (:194-202) for THIS step: the
         # previous step's optimiser kernel derived it when it advanced `batch` (refresh_bn_decay() after
         # setting `batch` by hand)

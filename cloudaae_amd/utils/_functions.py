@@ -76,6 +76,11 @@ def _mark(rec):
 GEMM_DTYPE = "f32"
 
 
+# SyncBN (utils/sync_bn.BnSync) or None: read when a batch-norm layer's FORWARD runs in training mode; its
+# backward follows suit.  With it set, moments and backward means are over the batch of ALL ranks.
+BN_SYNC = None
+
+
 def gemm_is_bf16():
     require(GEMM_DTYPE in ("f32", "bf16"), "GEMM_DTYPE must be 'f32' or 'bf16'")
     return GEMM_DTYPE == "bf16"
@@ -481,8 +486,17 @@ class BatchNormFn(torch.autograd.Function):
         if pool_mode == 1 and training and relu and not want_activation:
             pstats = _lib.empty((M // pool_rows) * 3 * C, dtype=torch.float64, device=dev)
         pre = getattr(y, "_cloudaae_colstats", None)
+        if not (pre is not None and pre[2] == M and pre[3] == C and ldy == C and training):
+            pre = None
         ws = _ws(L().cloudaae_bn_workspace_bytes(C), dev)
-        if pre is not None and pre[2] == M and pre[3] == C and ldy == C and training:
+        ctx.sync = BN_SYNC if training else None
+        if ctx.sync is not None:
+            _lib.check(L().cloudaae_bn_forward_sync(
+                M, C, yp, ldy, ptr(gamma), ptr(beta), int(training), ptr(decay), ptr(ema_mean), ptr(ema_var),
+                ptr(save_mean), ptr(save_var), int(relu), ptr(out), C, int(pool_rows), int(pool_mode), ptr(pooled),
+                ptr(ties), ptr(pstats), ptr(ws), ptr(pre[0]) if pre is not None else None,
+                int(pre[1]) if pre is not None else 0, ctx.sync.arg(C, dev), stream()), "cloudaae_bn_forward_sync")
+        elif pre is not None:
             _lib.check(L().cloudaae_bn_forward_colstats(
                 M, C, yp, ldy, ptr(gamma), ptr(beta), int(training), ptr(decay), ptr(ema_mean), ptr(ema_var),
                 ptr(save_mean), ptr(save_var), int(relu), ptr(out), C, int(pool_rows), int(pool_mode), ptr(pooled),
@@ -531,10 +545,17 @@ class BatchNormFn(torch.autograd.Function):
                 if not g.accumulate:
                     g.buf.zero_()
         ws = _ws(L().cloudaae_bn_workspace_bytes(C), y.device)
-        _lib.check(L().cloudaae_bn_backward(
-            M, C, yp, ldy, ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_var), training, relu, ptr(dout), C,
-            pool_rows, pool_mode, ptr(dpooled), ptr(pooled), ptr(ties), ptr(dy), C, ptr(gg.buf), ptr(gb.buf),
-            ptr(glb.buf), acc, ptr(ctx.pstats) if dout is None else None, ptr(ws), stream()), "cloudaae_bn_backward")
+        if ctx.sync is not None:
+            _lib.check(L().cloudaae_bn_backward_sync(
+                M, C, yp, ldy, ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_var), training, relu, ptr(dout), C,
+                pool_rows, pool_mode, ptr(dpooled), ptr(pooled), ptr(ties), ptr(dy), C, ptr(gg.buf), ptr(gb.buf),
+                ptr(glb.buf), acc, ptr(ctx.pstats) if dout is None else None, ptr(ws), ctx.sync.arg(C, y.device),
+                stream()), "cloudaae_bn_backward_sync")
+        else:
+            _lib.check(L().cloudaae_bn_backward(
+                M, C, yp, ldy, ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_var), training, relu, ptr(dout), C,
+                pool_rows, pool_mode, ptr(dpooled), ptr(pooled), ptr(ties), ptr(dy), C, ptr(gg.buf), ptr(gb.buf),
+                ptr(glb.buf), acc, ptr(ctx.pstats) if dout is None else None, ptr(ws), stream()), "cloudaae_bn_backward")
         return (dy, gg.done(), gb.done()) + (None,) * 8 + (glb.done() if glb.needed else None,)
 
 
@@ -574,11 +595,19 @@ class EdgeConvFn(torch.autograd.Function):
         ws = _ws(L().cloudaae_edgeconv_workspace_bytes(cout), dev)
         # mean pool, training: per point what backward's statistics need of its k edges (see the C header)
         estats = _lib.empty((B * N, 3, cout), dtype=torch.float32, device=dev) if (training and pool_mode == 1) else None
-        _lib.check(L().cloudaae_edgeconv_forward(
-            B, N, k, cin, cout, x.data_ptr(), ldx, ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
-            int(training), ptr(decay), ptr(ema_mean), ptr(ema_var), int(pool_mode), ptr(pq), ptr(save_mean),
-            ptr(save_var), out.data_ptr(), ldo, ptr(ties), ptr(estats), int(gemm_is_bf16()), ptr(ws), stream()),
-            "cloudaae_edgeconv_forward")
+        ctx.sync = BN_SYNC if training else None
+        if ctx.sync is not None:
+            _lib.check(L().cloudaae_edgeconv_forward_sync(
+                B, N, k, cin, cout, x.data_ptr(), ldx, ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
+                int(training), ptr(decay), ptr(ema_mean), ptr(ema_var), int(pool_mode), ptr(pq), ptr(save_mean),
+                ptr(save_var), out.data_ptr(), ldo, ptr(ties), ptr(estats), int(gemm_is_bf16()), ptr(ws),
+                ctx.sync.arg(cout, dev), stream()), "cloudaae_edgeconv_forward_sync")
+        else:
+            _lib.check(L().cloudaae_edgeconv_forward(
+                B, N, k, cin, cout, x.data_ptr(), ldx, ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
+                int(training), ptr(decay), ptr(ema_mean), ptr(ema_var), int(pool_mode), ptr(pq), ptr(save_mean),
+                ptr(save_var), out.data_ptr(), ldo, ptr(ties), ptr(estats), int(gemm_is_bf16()), ptr(ws), stream()),
+                "cloudaae_edgeconv_forward")
         ctx.bf16 = gemm_is_bf16()
         ctx.estats = estats
         ctx.rev, ctx.rev_slot = None, None
@@ -641,14 +670,18 @@ class EdgeConvFn(torch.autograd.Function):
             tmp[id(g)] = g.buf
             g.buf = _lib.empty_like(g.buf)
         ws = _ws(L().cloudaae_edgeconv_workspace_bytes(cout), dev)
-        _lib.check(L().cloudaae_edgeconv_backward(
-            B, N, k, cin, cout, x.data_ptr(), x.stride(1), ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
-            training, pool_mode, ptr(pq), ptr(save_mean), ptr(save_var),
-            fwd_out.data_ptr() if fwd_out is not None else None, fwd_out.stride(1) if fwd_out is not None else 0,
-            ptr(ties), dout.data_ptr(), dout.stride(1), ptr(dpq), ptr(rev), rev_ready, dx_ptr, lddx, acc_dx, ptr(gw.buf),
-            1 if (gw.needed and gw.gemm_acc == 2) else 0, ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), ptr(ctx.estats),
-            int(ctx.bf16), ptr(ws), stream(), SIDE_STREAM if (SIDE_EDGE and not shared and gw.needed and gw.own is None) else None),
-            "cloudaae_edgeconv_backward")
+        head = (B, N, k, cin, cout, x.data_ptr(), x.stride(1), ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
+                training, pool_mode, ptr(pq), ptr(save_mean), ptr(save_var),
+                fwd_out.data_ptr() if fwd_out is not None else None, fwd_out.stride(1) if fwd_out is not None else 0,
+                ptr(ties), dout.data_ptr(), dout.stride(1), ptr(dpq), ptr(rev), rev_ready, dx_ptr, lddx, acc_dx, ptr(gw.buf),
+                1 if (gw.needed and gw.gemm_acc == 2) else 0, ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), ptr(ctx.estats),
+                int(ctx.bf16), ptr(ws))
+        side = SIDE_STREAM if (SIDE_EDGE and not shared and gw.needed and gw.own is None) else None
+        if ctx.sync is not None:
+            _lib.check(L().cloudaae_edgeconv_backward_sync(*(head + (ctx.sync.arg(cout, dev), stream(), side))),
+                       "cloudaae_edgeconv_backward_sync")
+        else:
+            _lib.check(L().cloudaae_edgeconv_backward(*(head + (stream(), side))), "cloudaae_edgeconv_backward")
         for g in shared:
             L().cloudaae_add_f32(g.buf.numel(), ptr(tmp[id(g)]), ptr(g.buf), ptr(tmp[id(g)]), stream())
             g.buf = tmp[id(g)]

@@ -197,7 +197,9 @@ def fully_connected(inputs,
     weights, biases, gamma, beta, ema_mean, ema_var = _fc_variables(
         scope, inputs.shape[-1], num_outputs, bn, use_xavier=use_xavier, stddev=stddev, weight_decay=weight_decay,
         trainable=trainable)
-    if F.fc_fits(inputs.shape[0]):      # a batch of <= 32 clouds: the whole layer is one launch
+    # a batch of <= 32 clouds: the whole layer is one launch (not with SyncBN in training mode: the moments
+    # leave for the other ranks between the product and the normalisation)
+    if F.fc_fits(inputs.shape[0]) and not (bn and is_training and F.BN_SYNC is not None):
         require(bn or not act, "fully_connected: ReLU without batch norm does not occur in CloudAAE")
         outputs = F.FcFn.apply(inputs, weights, biases, gamma, beta, ema_mean, ema_var,
                                _decay_tensor(bn_decay) if bn else None, bool(is_training), act)
@@ -240,7 +242,7 @@ def fully_connected_chains(inputs, chains, bn_decay=None, is_training=None):
     (scope, num_outputs, bn) with ReLU exactly on the bn layers.  Variables are created chain by chain,
     i.e. in the order separate fully_connected() calls would create them.  Returns the chain outputs."""
     require(inputs.dim() == 2, "fully_connected_chains: inputs must be BxN")
-    if not F.fc_fits(inputs.shape[0]) or len(chains) > F.fc_max_group():
+    if not F.fc_fits(inputs.shape[0]) or len(chains) > F.fc_max_group() or (is_training and F.BN_SYNC is not None):
         outs = []
         branches = F.FanOutFn.apply(inputs, len(chains)) if len(chains) > 1 else (inputs,)
         for net, chain in zip(branches, chains):

@@ -176,6 +176,60 @@ int cloudaae_bn_backward(int M, int C, const float *y, int ldy, const float *gam
                          const float *pooled, const float *tie_count, float *dy, int lddy, float *dgamma,
                          float *dbeta, float *dbias, int accumulate_param_grads, const double *pool_stats,
                          void *workspace, cloudaae_stream_t stream);
+/* ---- batch norm over a batch that is sharded across ranks (SyncBN) -------------------
+ * The reference is single-GPU: tf.nn.moments (utils/tf_util.py:492) sees the WHOLE batch.  When the
+ * batch is sharded data-parallel, the `_sync` variants below reproduce that: every rank reduces its rows
+ * to per-channel fp64 sums, the HOST-SUPPLIED `allreduce` adds them across ranks (the library does not
+ * link a communication library; the host passes RCCL through torch.distributed, or anything else), and
+ * the moments / the backward means are taken over count x world rows.  dgamma, dbeta and the bias gradient
+ * stay LOCAL sums (the gradient exchange adds them across ranks like every other parameter gradient);
+ * the EMA shadows see the global moments, so they stay identical on every rank.
+ *   allreduce(ctx, buf, count, stream): sum `count` doubles at device pointer `buf` over all ranks, in
+ *     place, ordered after the work already enqueued on `stream` and before whatever is enqueued next;
+ *     returns 0 on success.  Called once per forward and once per backward of a layer.
+ *   buf: device scratch of at least 2*C doubles owned by the caller (the sums travel in it).
+ *   world: number of ranks (every rank contributes the same number of rows).
+ * sync == NULL: exactly the plain entry point. */
+typedef int (*cloudaae_allreduce_fn)(void *ctx, double *buf, int count, cloudaae_stream_t stream);
+typedef struct cloudaae_bn_sync {
+    cloudaae_allreduce_fn allreduce;
+    void *ctx;
+    int world;
+    double *buf;
+} cloudaae_bn_sync;
+/* cloudaae_bn_forward / _colstats (colstats may be NULL) with global moments */
+int cloudaae_bn_forward_sync(int M, int C, const float *y, int ldy, const float *gamma, const float *beta,
+                             int training, const float *decay, float *ema_mean, float *ema_var,
+                             float *save_mean, float *save_var, int relu, float *out, int ldo, int pool_rows,
+                             int pool_mode, float *pooled, float *tie_count, double *pool_stats, void *workspace,
+                             const double *colstats, int colstats_parts, const cloudaae_bn_sync *sync,
+                             cloudaae_stream_t stream);
+/* cloudaae_bn_backward with the means of (dz, dz*x_hat) over the global batch */
+int cloudaae_bn_backward_sync(int M, int C, const float *y, int ldy, const float *gamma, const float *beta,
+                              const float *save_mean, const float *save_var, int training, int relu,
+                              const float *dout, int lddo, int pool_rows, int pool_mode, const float *dpooled,
+                              const float *pooled, const float *tie_count, float *dy, int lddy, float *dgamma,
+                              float *dbeta, float *dbias, int accumulate_param_grads, const double *pool_stats,
+                              void *workspace, const cloudaae_bn_sync *sync, cloudaae_stream_t stream);
+/* cloudaae_edgeconv_forward / _backward (declared below) with the batch norm of the block over the edges of
+ * every rank's clouds: same arguments plus `sync` in front of the stream(s). */
+int cloudaae_edgeconv_forward_sync(int b, int n, int k, int cin, int cout, const float *x, int ldx,
+                                   const int *nn_idx, const float *weights, const float *biases,
+                                   const float *gamma, const float *beta, int training, const float *decay,
+                                   float *ema_mean, float *ema_var, int pool_mode, float *pq, float *save_mean,
+                                   float *save_var, float *out, int ldo, float *tie_count, float *edge_stats,
+                                   int gemm_bf16, void *workspace, const cloudaae_bn_sync *sync,
+                                   cloudaae_stream_t stream);
+int cloudaae_edgeconv_backward_sync(int b, int n, int k, int cin, int cout, const float *x, int ldx,
+                                    const int *nn_idx, const float *weights, const float *biases,
+                                    const float *gamma, const float *beta, int training, int pool_mode,
+                                    const float *pq, const float *save_mean, const float *save_var,
+                                    const float *out, int ldo, const float *tie_count, const float *dout, int lddo,
+                                    float *dpq, int *rev_scratch, int rev_ready, float *dx, int lddx,
+                                    int accumulate_dx, float *dweights, int dweights_zeroed, float *dbiases,
+                                    float *dgamma, float *dbeta, const float *edge_stats, int gemm_bf16,
+                                    void *workspace, const cloudaae_bn_sync *sync, cloudaae_stream_t stream,
+                                    cloudaae_stream_t side_stream);
 /* out[c] (+)= sum_r x[r][c] (bias gradients); workspace as for bn (same C). */
 int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, float *out, int accumulate, void *workspace,
                         cloudaae_stream_t stream);
