@@ -741,6 +741,418 @@ static hipError_t launch_knn_scan(int b, int n, int ld, int k, const float *x, i
     return hipSuccess;
 }
 
+// ---- C = 64, third generation: a BOUND on the k-th distance first, then one filtered scan ------------
+// What the scan kernel above still spends its time on is the start of every lane's stream: until a lane's
+// list has tightened, nearly every candidate passes its running threshold (k (1 + ln(n/k)) ~ 50 sorted inserts
+// per lane at n = 512 per lane, the wave paying the maximum over its lanes, six pops per round whether needed
+// or not).  Here the threshold is known BEFORE the scan:
+//   pass A : a quarter of the candidate tiles (every stride-th one).  Per lane and tile the minimum of every
+//            group of four candidate rows (a "unit") goes into a value-only sorted list; afterwards the K-th
+//            smallest unit minimum over the query's 2*CS lane lists is tau.  The K smallest unit minima belong
+//            to K DISTINCT candidates, so tau >= the true K-th smallest distance; with 64 units of four
+//            (n = 1024) about 40 of the 1024 candidates lie at or below it.
+//   pass B : every tile; a candidate is pushed on the lane's LDS queue iff d <= tau (one 8-byte write, branch
+//            free), ~10 per lane over the whole scan.  The queue goes through the sorted insert only when it
+//            could overflow (ties, duplicated points: correctness never depends on the bound being tight) and
+//            once at the end; then the 2*CS lists of a query are merged by (d, j) as before.
+// Both passes evaluate d with the SAME instructions on the same MFMA results, so "d <= tau" in pass B is exact
+// and the indices stay bit-identical to oracle_knn.  Matrix work: 1.25 x the N x N x 64 products.
+constexpr int KB_QCAP = 26;          // queue slots per lane (d and j, 4 bytes each)
+
+template <int K>
+struct MinK {                        // the K smallest values seen, ascending
+    float d[K];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int p = 0; p < K; ++p)
+            d[p] = __builtin_inff();
+    }
+    __device__ __forceinline__ void insert(float nd)
+    {
+        d[K - 1] = fminf(d[K - 1], nd);
+#pragma unroll
+        for (int p = K - 1; p > 0; --p) {
+            const float a = d[p - 1], b = d[p];
+            d[p - 1] = fminf(a, b);
+            d[p] = fmaxf(a, b);
+        }
+    }
+};
+
+template <int K, int QW, int CS>
+__global__ __launch_bounds__(64 * QW * CS) void knn64_bound_kernel(int n, int ld, int k,
+                                                                   const float *__restrict__ x,
+                                                                   int *__restrict__ nn_idx)
+{
+    constexpr int WAVES = QW * CS, THREADS = 64 * WAVES;
+    constexpr int KS_LD = 68;                              // staged row: [32 even channels | 32 odd | 4 pad]
+    constexpr int TILE_FLOATS = KM_TILE * KS_LD;
+    extern __shared__ __attribute__((aligned(16))) char kb_smem[];
+    // layout: tile[2][CS][TILE_FLOATS] | queue d[WAVES][QCAP][64] | queue j[WAVES][QCAP][64] | sq[ntiles * 32] | 1.0
+    float *tiles = reinterpret_cast<float *>(kb_smem);
+    float *qd_all = tiles + 2 * CS * TILE_FLOATS;
+    int *qj_all = reinterpret_cast<int *>(qd_all + WAVES * KB_QCAP * 64);
+    float *sq = reinterpret_cast<float *>(qj_all + WAVES * KB_QCAP * 64);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qt = wave / CS, cs = wave % CS;
+    int qgroup, cloud;
+    xcd_cloud_tile(qgroup, cloud);
+    const float *X = x + (size_t)cloud * n * ld;
+    const int ntiles = (n + KM_TILE - 1) / KM_TILE;
+
+    // |x_j|^2 of the whole cloud (oracle order: sequential un-fused sum of rounded squares); rows past the end
+    // hold +inf, so their distances come out +inf and never pass a finite threshold; sq[ntiles * 32] = 1.0
+    for (int j = tid; j <= ntiles * KM_TILE; j += THREADS) {
+        float acc = j == ntiles * KM_TILE ? 1.0f : __builtin_inff();
+        if (j < n) {
+            const float *row = X + (size_t)j * ld;
+            acc = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float4v v = *reinterpret_cast<const float4v *>(row + 4 * g);
+                const float a = v.x * v.x, b = v.y * v.y, c = v.z * v.z, d = v.w * v.w;
+                acc = acc + a;
+                acc = acc + b;
+                acc = acc + c;
+                acc = acc + d;
+            }
+        }
+        sq[j] = acc;
+    }
+
+    const int col = lane & 31, half = lane >> 5;
+    const int qi0 = (qgroup * QW + qt) * KM_TILE + col;   // this lane's query
+    const bool qvalid = qi0 < n;
+    const int qs = qvalid ? qi0 : 0;
+    // B operand: MINUS TWICE the query channels of parity `half` (scaling by -2 is exact and commutes with
+    // every rounding of the fma chain, so the 32 MFMA steps leave exactly -2 <x_q, x_c>); a 33rd step then adds
+    // |x_q|^2 (k = 0: candidate side 1, query side |x_q|^2) and |x_c|^2 (k = 1: candidate side |x_c|^2, query
+    // side 1) in the oracle's order: acc = ((-2 inner) + sq_q) + sq_c = D -- the matrix pipe delivers the
+    // finished distance, no vector arithmetic per candidate
+    float bq[32];
+    {
+        const float *row = X + (size_t)qs * ld;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float4v v = *reinterpret_cast<const float4v *>(row + 4 * g);
+            bq[2 * g] = -2.0f * (half ? v.y : v.x);
+            bq[2 * g + 1] = -2.0f * (half ? v.w : v.z);
+        }
+    }
+
+    // pass A's sample: S tiles, every stride-th one
+    const int S = min(ntiles, max((ntiles + 3) / 4, 4));
+    const int stride = ntiles / S;
+
+    // staging: a round = CS tiles of 32 rows x 16 float4; thread -> (row tid >> 4 of tile slot u, float4 tid & 15)
+    constexpr int VECS = CS * KM_TILE * 16, PER = VECS / THREADS;
+    static_assert(PER * THREADS == VECS && (THREADS / 16) * PER == CS * KM_TILE && THREADS / 16 <= KM_TILE,
+                  "a thread stages the same row of PER tile slots");
+    constexpr int ROWS_PER_U = THREADS / 16;               // rows covered per u
+    const int srow = tid >> 4, sq4 = tid & 15;
+    const float *gsrc = X + (size_t)srow * ld + 4 * sq4;
+    float4v stage[PER];
+    auto fetch = [&](bool passA, int r) {                  // global -> registers (nothing past the last round)
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int rowu = u * ROWS_PER_U + srow;         // row within the round's CS * 32 rows
+            const int slot = r * CS + (rowu >> 5);
+            const int c0 = passA ? (slot < S ? slot * stride * KM_TILE : n) : slot * KM_TILE;
+            const int g = c0 + (rowu & 31);
+            stage[u] = g < n ? *reinterpret_cast<const float4v *>(gsrc + (size_t)(g - srow) * ld)
+                             : float4v{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&](float *buf) {                        // registers -> LDS tile buffers
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int rowu = u * ROWS_PER_U + srow;
+            float *dst = buf + (rowu >> 5) * TILE_FLOATS + (rowu & 31) * KS_LD + 2 * sq4;
+            *reinterpret_cast<float2v *>(dst) = float2v{stage[u].x, stage[u].z};
+            *reinterpret_cast<float2v *>(dst + 32) = float2v{stage[u].y, stage[u].w};
+        }
+    };
+    const int lrow = cs * TILE_FLOATS + col * KS_LD + 32 * half;   // this lane's operand row in a round's buffer
+    // operands of the 33rd step: candidate side sq[c0 + col] for the k = 1 lanes, the 1.0 behind sq[] for k = 0
+    const int xoff = half ? col : ntiles * KM_TILE;
+    const int xmul = half;                                 // (+ c0 only for the k = 1 lanes)
+    // operands of one staged tile -> registers (8 ds_read_b128 + the 33rd step's)
+    auto operands = [&](const float *buf, int c0, float4v (&a4)[8], float &ax) {
+        const float4v *arow = reinterpret_cast<const float4v *>(buf + lrow);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            a4[s] = arow[s];
+        ax = sq[xoff + xmul * c0];
+    };
+
+    // The scan loop of both passes is software pipelined three deep: while the matrix pipe works on the operands
+    // of round r (in registers), the operands of round r+1 travel LDS -> registers and the rows of round r+2
+    // global -> registers -> LDS (they replace round r's, which every wave has had in registers since the
+    // barrier that ended round r-1).  One barrier per round.
+    float bx = 1.0f;                                       // query side of the 33rd step (set once sq[] is visible)
+    f32x16 acc;
+
+    // ---------------- pass A: tau ----------------
+    const int roundsA = (S + CS - 1) / CS;
+    auto c0A = [&](int r) {
+        const int slot = r * CS + cs;
+        return slot < S ? slot * stride * KM_TILE : ntiles * KM_TILE - KM_TILE;      // (idle slot: a tile again)
+    };
+    fetch(true, 0);
+    commit(tiles);
+    if (roundsA > 1) {
+        fetch(true, 1);
+        commit(tiles + CS * TILE_FLOATS);
+    }
+    __syncthreads();                                       // rounds 0 and 1 and sq[] visible
+    bx = half ? 1.0f : sq[qs];
+    MinK<K> um;
+    um.init();
+    {
+        float4v opA[8], opB[8];
+        float axA, axB = 0.0f;
+        operands(tiles, c0A(0), opA, axA);
+        auto roundA = [&](int r, float4v (&cur)[8], float axc, float4v (&nxt)[8], float &axn) {
+            if (r + 1 < roundsA)
+                operands(tiles + ((r + 1) & 1) * CS * TILE_FLOATS, c0A(r + 1), nxt, axn);
+            if (r + 2 < roundsA)
+                fetch(true, r + 2);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                acc[e] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 32; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s >> 2][s & 3], bq[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bx, acc, 0, 0, 0);
+            const bool live = r * CS + cs < S;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                  // units: the lane's rows 8 g + 4 half + (0..3)
+                const float m = fminf(fminf(acc[4 * g], acc[4 * g + 1]), fminf(acc[4 * g + 2], acc[4 * g + 3]));
+                um.insert(live ? m : __builtin_inff());
+            }
+            if (r + 2 < roundsA)
+                commit(tiles + (r & 1) * CS * TILE_FLOATS);
+            __syncthreads();
+        };
+        int r = 0;
+        for (; r + 1 < roundsA; r += 2) {
+            roundA(r, opA, axA, opB, axB);
+            roundA(r + 1, opB, axB, opA, axA);
+        }
+        if (r < roundsA)
+            roundA(r, opA, axA, opB, axB);
+    }
+    // K-th smallest unit minimum over the 2*CS lists of the query, through the queue area of the query
+    // tile's first wave: [list][p][query]
+    float *md = qd_all + (qt * CS) * KB_QCAP * 64;
+    int *mi = qj_all + (qt * CS) * KB_QCAP * 64;
+    static_assert(2 * CS * K * 32 <= CS * KB_QCAP * 64, "scratch lists must fit the queue area of one query tile");
+    const int list = cs * 2 + half;
+#pragma unroll
+    for (int p = 0; p < K; ++p)
+        md[(list * K + p) * 32 + col] = um.d[p];
+    const int roundsB = (ntiles + CS - 1) / CS;
+    fetch(false, 0);                                       // pass B's first rounds travel meanwhile
+    commit(tiles);
+    if (roundsB > 1) {
+        fetch(false, 1);
+        commit(tiles + CS * TILE_FLOATS);
+    }
+    __syncthreads();
+    float tau = __builtin_inff();
+    {
+        int head[2 * CS];
+#pragma unroll
+        for (int l = 0; l < 2 * CS; ++l)
+            head[l] = 0;
+        for (int p = 0; p < K; ++p) {
+            float bd = __builtin_inff();
+            int bl = 0;
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l) {
+                const float d = head[l] < K ? md[(l * K + head[l]) * 32 + col] : __builtin_inff();
+                const bool better = d < bd;
+                bd = better ? d : bd;
+                bl = better ? l : bl;
+            }
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l)
+                head[l] += (l == bl) ? 1 : 0;
+            tau = bd;                                      // after K picks: the K-th smallest
+        }
+    }
+    tau = fminf(tau, 3.4028234664e38f);                    // rows past the end (+inf) never pass
+    __syncthreads();                                       // scratch lists consumed (the queues start empty)
+
+    // ---------------- pass B: everything at or below tau ----------------
+    // this lane's queue is qd_all / qj_all[q0 + 64 t]; wo = its next free slot
+    const int q0 = wave * KB_QCAP * 64 + lane;
+    int wo = q0;
+    const int wlimit = q0 + (KB_QCAP - 4) * 64;           // room for one group of four candidates
+    // The scan only APPENDS: the sorted lists (20 registers of state) are built once, after it.  Any use of them
+    // inside the loop costs dearly twice over -- the waves of a workgroup meet at a barrier every round, so a wave
+    // that stops to insert makes the other seven wait (48 of 130 us), and every branch around code that changes
+    // the lists drags ~40 register copies along (the compiler's phi moves: 10 k instructions per wave).
+    // A queue that is nearly full (> 22 candidates at or below tau in one lane's share of the cloud: duplicated
+    // points, outliers) is SQUEEZED in place instead: with t' = the K-th smallest queued distance, only the
+    // entries below t' and the first ties at t' (in index order) can still reach the query's K best, and later
+    // candidates must be strictly below t'.  State touched: tau and the queue pointer.
+    auto squeeze = [&]() {
+        if (wo > wlimit) {
+            MinK<K> mk;
+            mk.init();
+            for (int ro = q0; ro < wo; ro += 64)
+                mk.insert(qd_all[ro]);
+            const float t1 = mk.d[K - 1];
+            int ties = K, w2 = q0;                         // ties at t1 that may stay: K - #(entries below t1)
+#pragma unroll
+            for (int p = 0; p < K; ++p)
+                ties -= mk.d[p] < t1 ? 1 : 0;
+            for (int ro = q0; ro < wo; ro += 64) {
+                const float d = qd_all[ro];
+                const int jj = qj_all[ro];
+                const bool tie = d == t1;
+                if (d < t1 || (tie && ties > 0)) {         // ascending index order: the first ties win
+                    qd_all[w2] = d;
+                    qj_all[w2] = jj;
+                    w2 += 64;
+                    ties -= tie ? 1 : 0;
+                }
+            }
+            wo = w2;                                       // at most K entries left
+            // from now on: strictly below t1 (the largest float below it; t1 is finite: it is <= tau)
+            const unsigned tb = __float_as_uint(t1);
+            tau = t1 > 0.0f ? __uint_as_float(tb - 1u) : (t1 < 0.0f ? __uint_as_float(tb + 1u) : -1.4e-45f);
+        }
+    };
+    // candidates 4 g .. 4 g + 3 of the previous tile: a pass is rare (a few per cent), lanes that pass append
+    // (d, j) to their queue
+    f32x16 prev;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        prev[e] = __builtin_inff();
+    int pj = 0;
+    auto push4 = [&](int g) {
+        if (__any(wo > wlimit))
+            squeeze();
+#pragma unroll
+        for (int e = 4 * g; e < 4 * g + 4; ++e)
+            if (prev[e] <= tau) {
+                qd_all[wo] = prev[e];
+                qj_all[wo] = pj + (e & 3) + 8 * (e >> 2);
+                wo += 64;
+            }
+    };
+    auto c0B = [&](int r) { return min(r * CS + cs, ntiles - 1) * KM_TILE; };   // (idle slot of the last round: the
+                                                                                //  last tile again, discarded below)
+    {
+        float4v opA[8], opB[8];
+        float axA, axB = 0.0f;
+        operands(tiles, c0B(0), opA, axA);
+        auto roundB = [&](int r, float4v (&cur)[8], float axc, float4v (&nxt)[8], float &axn) {
+            if (r + 1 < roundsB)
+                operands(tiles + ((r + 1) & 1) * CS * TILE_FLOATS, c0B(r + 1), nxt, axn);
+            if (r + 2 < roundsB)
+                fetch(false, r + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            // the filter of the PREVIOUS tile is issued between the MFMAs of this one (four candidates per
+            // eight MFMAs) and runs in their shadow
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                acc[e] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s >> 2][s & 3], bq[s], acc, 0, 0, 0);
+                if ((s & 7) == 7)
+                    push4(s >> 3);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bx, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool live = r * CS + cs < ntiles;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                prev[e] = live ? acc[e] : __builtin_inff();
+            pj = c0B(r) + 4 * half;
+            if (r + 2 < roundsB)
+                commit(tiles + (r & 1) * CS * TILE_FLOATS);
+            __syncthreads();
+        };
+        int r = 0;
+        for (; r + 1 < roundsB; r += 2) {
+            roundB(r, opA, axA, opB, axB);
+            roundB(r + 1, opB, axB, opA, axA);
+        }
+        if (r < roundsB)
+            roundB(r, opA, axA, opB, axB);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)                            // the last tile's filter
+        push4(g);
+    // the queue -> this lane's sorted list of its K best (candidates were appended in ascending index order and
+    // the insert is stable, so ties keep the lower index first)
+    TopK<K> top;
+    top.init();
+    for (int ro = q0; __any(ro < wo); ro += 64)
+        if (ro < wo)
+            top.insert(qd_all[ro], qj_all[ro]);
+
+    // merge the 2*CS lists of every query lexicographically by (d, j) (each is sorted that way: its candidates
+    // arrived in ascending j and the insert is stable), through the queue area of the query tile's first wave
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < K; ++p) {
+        md[(list * K + p) * 32 + col] = top.d[p];
+        mi[(list * K + p) * 32 + col] = top.i[p];
+    }
+    __syncthreads();
+    if (cs == 0 && half == 0 && qvalid) {
+        int head[2 * CS];
+#pragma unroll
+        for (int l = 0; l < 2 * CS; ++l)
+            head[l] = 0;
+        int *dst = nn_idx + ((size_t)cloud * n + qi0) * k;
+        for (int p = 0; p < k; ++p) {
+            float bd = __builtin_inff();
+            int bi = 0x7fffffff, bl = 0;
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l) {
+                const int h = head[l];
+                const float d = h < K ? md[(l * K + h) * 32 + col] : __builtin_inff();
+                const int i = h < K ? mi[(l * K + h) * 32 + col] : 0x7fffffff;
+                const bool better = d < bd || (d == bd && i < bi);
+                bd = better ? d : bd;
+                bi = better ? i : bi;
+                bl = better ? l : bl;
+            }
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l)
+                head[l] += (l == bl) ? 1 : 0;
+            dst[p] = bi == 0x7fffffff ? 0 : bi;
+        }
+    }
+}
+
+template <int K, int QW, int CS>
+static hipError_t launch_knn_bound(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
+{
+    const size_t lds = sizeof(float) * (2 * CS * KM_TILE * 68 + (size_t)ceil_div(n, KM_TILE) * KM_TILE + 4) +
+                       2 * sizeof(float) * QW * CS * KB_QCAP * 64;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn64_bound_kernel<K, QW, CS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess)
+            return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL((knn64_bound_kernel<K, QW, CS>), dim3(ceil_div(n, KM_TILE * QW), b), dim3(64 * QW * CS), lds, s,
+                       n, ld, k, x, nn_idx);
+    return hipSuccess;
+}
+
 // ---- C = 3, second generation: the selection split into filter + queued drain ------------------
 // knn3_kernel above runs the sorted insert for every candidate of every lane (a wave executes it
 // whenever ANY lane needs it, i.e. always): ~45 instructions per candidate against 8 for the
@@ -889,12 +1301,13 @@ static hipError_t launch_knn3_scan(int b, int n, int ld, int k, const float *x, 
 //    256 (B=8)      61            108                 82
 //   1024 (B=32)    138            134                113
 //   8192 (B=256)   808            645                833
-// 0 = knn64_mfma_kernel.  CLOUDAAE_KNN_SCAN=0/1/2 forces a choice (tests cover all three).
+// Return value / CLOUDAAE_KNN_SCAN (forces a choice; the tests cover all of them): 0 = knn64_mfma_kernel,
+// 1 / 2 = knn64_scan_kernel with one / two waves per query tile, 3 / 4 = knn64_bound_kernel with one / two.
 static int knn_scan_waves(long long tiles)
 {
     if (const char *e = getenv("CLOUDAAE_KNN_SCAN"))
         return atoi(e);
-    return tiles >= 4096 ? 1 : tiles >= 1024 ? 2 : 0;
+    return tiles >= 4096 ? 1 : tiles >= 1024 ? 2 : 0;      // (the bound kernel is not faster yet: DESIGN.md section 4)
 }
 
 template <int K>
@@ -916,7 +1329,13 @@ static void launch_knn(int b, int n, int c, int ld, int k, const float *x, int *
              knn_scan_waves((long long)ceil_div(n, KM_TILE) * b) > 0) {
         if constexpr (K <= 20) {
             const long long tiles = (long long)ceil_div(n, KM_TILE) * b;
-            if (knn_scan_waves(tiles) == 2)
+            const int mode = knn_scan_waves(tiles);
+            // (the bound kernel wants enough units for its bound: 8 per sampled tile, >= 4 sampled tiles)
+            if (mode == 4 && n >= 256)
+                (void)launch_knn_bound<K, 4, 2>(b, n, ld, k, x, nn_idx, s);
+            else if (mode == 3 && n >= 256)
+                (void)launch_knn_bound<K, 4, 1>(b, n, ld, k, x, nn_idx, s);
+            else if (mode == 2 || mode == 4)
                 (void)launch_knn_scan<K, 4, 2>(b, n, ld, k, x, nn_idx, s);
             else
                 (void)launch_knn_scan<K, 4, 1>(b, n, ld, k, x, nn_idx, s);

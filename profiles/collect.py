@@ -1,0 +1,99 @@
+"""Turns the three rocprofv3 runs of tools/profile_step.sh (kernel trace; --pmc FETCH_SIZE; --pmc WRITE_SIZE --
+separate passes, as MI355X_MICROARCH.md prescribes) into the summaries committed under profiles/:
+
+    <tag>_kernel_stats.csv        one row per (kernel, grid): calls, total/avg us, percent   (summarize.py)
+    <tag>_pmc_hbm_traffic.csv     per (kernel, grid): FETCH_SIZE raw, x2-corrected (gfx950 tallies 128-B requests
+                                  as 64 B), WRITE_SIZE, bytes per launch
+    roofline_traffic.json         the kernels bench.py prices, keyed by site, each with the git blob hashes of the
+                                  sources it was collected on (bench.py emits the number only when they match)
+
+usage: python profiles/collect.py <dir holding trace/ fetch/ write/> <tag> <workload e.g. B=32,N=1024>"""
+import csv
+import glob
+import hashlib
+import json
+import os
+import re
+import sqlite3
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import summarize  # noqa: E402
+
+
+def blob(path):
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def db_of(d):
+    hits = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+    assert hits, "no rocpd database under " + d
+    return hits[0]
+
+
+def per_kernel(db, counter):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute(
+        "select kernel_name, grid_size_x / workgroup_size_x, grid_size_y / workgroup_size_y, "
+        "grid_size_z / workgroup_size_z, count(*), avg(value) from counters_collection where counter_name = ? "
+        "group by kernel_name, grid_size_x, grid_size_y, grid_size_z, workgroup_size_x", (counter,))
+    return {(summarize.short(n), "%dx%dx%d" % (gx, gy, gz)): (c, v * 1024.0) for n, gx, gy, gz, c, v in rows}   # KB -> B
+
+
+# sites bench.py prices: (key, regex on the short kernel name, grid predicate, source files)
+SITES = [
+    ("agg_fwd", r"^gemm_f32_kernel<128, ?128, ?2, ?2, ?false, ?false, ?true", None,
+     ["cloudaae_amd/csrc/gemm.hip", "cloudaae_amd/csrc/gemm.h"]),
+    ("agg_fwd_bf16", r"^gemm_bf16_kernel<128, ?128", "largest", ["cloudaae_amd/csrc/gemm_bf16.hip", "cloudaae_amd/csrc/gemm.h"]),
+    ("agg_dw", r"^gemm_f32_kernel<64, ?128, ?2, ?2, ?true, ?false", "largest", ["cloudaae_amd/csrc/gemm.hip", "cloudaae_amd/csrc/gemm.h"]),
+    ("knn64", r"^knn64_", "largest", ["cloudaae_amd/csrc/knn.hip"]),
+]
+
+
+def main(d, tag, workload):
+    out = os.path.join(d, "summary")
+    os.makedirs(out, exist_ok=True)
+    summarize.main(db_of(os.path.join(d, "trace")), os.path.join(out, tag + "_kernel_stats.csv"))
+    fetch = per_kernel(db_of(os.path.join(d, "fetch")), "FETCH_SIZE")
+    write = per_kernel(db_of(os.path.join(d, "write")), "WRITE_SIZE")
+    times = {}
+    with open(os.path.join(out, tag + "_kernel_stats.csv")) as f:
+        for r in csv.DictReader(f):
+            times[(r["kernel"], r["grid_workgroups"])] = r
+    rows = []
+    for key in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, (0, 0))[1] * 2 + write.get(k, (0, 0))[1])):
+        fc, fb = fetch.get(key, (0, 0.0))
+        wc, wb = write.get(key, (0, 0.0))
+        t = times.get(key, {})
+        avg_us = float(t.get("avg_us", 0) or 0)
+        total = 2 * fb + wb
+        rows.append([key[0], key[1], fc or wc, round(fb), round(2 * fb), round(wb), round(total),
+                     avg_us, round(total / (avg_us * 1e-6) / 1e9, 1) if avg_us else ""])
+    with open(os.path.join(out, tag + "_pmc_hbm_traffic.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "grid_workgroups", "launches", "FETCH_SIZE_raw_bytes", "fetch_bytes_x2_corrected",
+                    "WRITE_SIZE_bytes", "hbm_bytes_per_launch", "avg_us(kernel trace run)", "GB/s"])
+        w.writerows(rows)
+    traffic = {}
+    for site, pat, pick, srcs in SITES:
+        cands = [r for r in rows if re.search(pat, r[0])]
+        if not cands:
+            continue
+        r = max(cands, key=lambda x: x[6])
+        traffic[site] = {"kernel": r[0], "grid_workgroups": r[1], "workload": workload,
+                         "fetch_bytes_raw": r[3], "fetch_bytes_corrected_x2": r[4], "write_bytes": r[5],
+                         "traffic_bytes_per_launch": r[6],
+                         "source_blobs": {s: blob(os.path.join(ROOT, s)) for s in srcs},
+                         "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes "
+                                "(tools/profile_step.sh), per-launch averages; FETCH_SIZE doubled per "
+                                "MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)"}
+    with open(os.path.join(out, "roofline_traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
+    print("wrote", out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "B=32,N=1024")

@@ -178,10 +178,13 @@ def test_knn_vs_oracle(hip, oracle, b, n, c, ld, k):
 
 
 @pytest.mark.parametrize("b,n,k,mode", [(2, 333, 10, 1), (40, 1024, 10, 1), (3, 1500, 20, 2), (33, 1024, 10, 2),
-                                          (2, 700, 20, 0), (140, 1024, 10, None)])
+                                          (2, 700, 20, 0), (140, 1024, 10, None), (2, 333, 10, 3), (40, 1024, 10, 3),
+                                          (3, 1500, 20, 4), (33, 1024, 10, 4), (2, 257, 20, 3), (5, 1000, 5, 4),
+                                          (32, 1024, 10, None), (2, 4096, 20, 4), (2, 260, 10, 4)])
 def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, monkeypatch, b, n, k, mode):
-    """All three C = 64 kernels (CLOUDAAE_KNN_SCAN = 0: knn64_mfma, 1 / 2: whole-cloud scan with one /
-    two waves per query tile; None: the launcher's own choice) keep the same bit-exact contract."""
+    """All C = 64 kernels (CLOUDAAE_KNN_SCAN = 0: knn64_mfma, 1 / 2: whole-cloud scan with one / two waves
+    per query tile, 3 / 4: bound pass + filtered scan with one / two; None: the launcher's own choice) keep
+    the same bit-exact contract."""
     from cloudaae_amd import _lib
     if mode is None:
         monkeypatch.delenv("CLOUDAAE_KNN_SCAN", raising=False)
@@ -193,6 +196,37 @@ def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, monkeypatch, b, n, k, mod
     want = oracle.knn(x, k, channels=64, threads=8)
     xd = _dev(x)
     got = torch.empty((b, n, k), dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().cloudaae_knn(b, n, 64, 64, k, _lib.ptr(xd), _lib.ptr(got), _lib.stream()), "knn")
+    assert np.array_equal(want, got.cpu().numpy())
+
+
+@pytest.mark.parametrize("mode", [3, 4])
+@pytest.mark.parametrize("case", ["all_equal", "few_distinct", "lattice", "large_finite", "far_cluster"])
+def test_knn_c64_bound_kernel_adversarial(hip, oracle, monkeypatch, mode, case):
+    """The bound kernel's correctness must not depend on its bound being tight: clouds where (nearly) every
+    candidate ties with the k-th distance (the queue overflows and is drained over and over), where the sampled
+    tiles are unrepresentative, and where distances are huge."""
+    from cloudaae_amd import _lib
+    monkeypatch.setenv("CLOUDAAE_KNN_SCAN", str(mode))
+    rng = np.random.default_rng(7)
+    b, n, k = 3, 1024, 10
+    if case == "all_equal":
+        x = np.tile(rng.standard_normal((b, 1, 64)), (1, n, 1))
+    elif case == "few_distinct":
+        x = rng.standard_normal((b, 5, 64))[:, rng.integers(0, 5, n)]
+    elif case == "lattice":
+        x = rng.integers(0, 2, (b, n, 64)).astype(np.float64)        # exact small-integer distances: ties everywhere
+    elif case == "large_finite":
+        x = rng.standard_normal((b, n, 64)) * 1e15                   # |x|^2 ~ 6e31: finite, heavy cancellation
+        # (non-finite distances are outside the contract: tf.nn.top_k over NaN is unspecified)
+    else:
+        x = rng.standard_normal((b, n, 64)) * 0.01
+        x[:, ::128] += 50.0                                          # every sampled tile starts with an outlier
+        x[:, 32:64] += 100.0                                         # and a whole unsampled tile sits far away
+    x = x.astype(np.float32)
+    want = oracle.knn(x, k, channels=64, threads=8)
+    xd = _dev(x)
+    got = torch.full((b, n, k), -1, dtype=torch.int32, device="cuda")
     _lib.check(_lib.lib().cloudaae_knn(b, n, 64, 64, k, _lib.ptr(xd), _lib.ptr(got), _lib.stream()), "knn")
     assert np.array_equal(want, got.cpu().numpy())
 

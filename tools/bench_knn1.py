@@ -1,0 +1,17 @@
+"""Dev: one kNN shape, many launches (for rocprofv3 PMC passes): python tools/bench_knn1.py B N C LD K [iters]"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cloudaae_amd import _lib
+L = _lib.lib()
+b, n, c, ld, k = (int(a) for a in sys.argv[1:6])
+iters = int(sys.argv[6]) if len(sys.argv) > 6 else 10
+g = torch.Generator(device="cuda").manual_seed(1)
+x = torch.relu(torch.randn((b, n, ld), device="cuda", generator=g))     # post-ReLU features, like net1..net3
+out = torch.empty((b, n, k), dtype=torch.int32, device="cuda")
+go = lambda: _lib.check(L.cloudaae_knn(b, n, c, ld, k, x.data_ptr(), out.data_ptr(), _lib.stream()), "knn")
+for _ in range(3): go()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters): go()
+e1.record(); torch.cuda.synchronize()
+print((b, n, c, ld, k), "mode", os.environ.get("CLOUDAAE_KNN_SCAN"), "%.1f us" % (e0.elapsed_time(e1) * 1e3 / iters))
