@@ -238,6 +238,8 @@ def main():
     ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "bf16"], help="bf16: BASELINE configs[2]'s "
                     "arithmetic (dense-layer operands rounded to bf16, fp32 accumulate; everything else fp32)")
     ap.add_argument("--sync-bn", action="store_true", help="batch-norm moments over the GLOBAL batch (all ranks)")
+    ap.add_argument("--step-only", action="store_true", help="skip the Chamfer kernel micro-benchmarks and the CPU "
+                    "baseline (profiling runs: only the train step's kernels in the trace)")
     ap.add_argument("--eager", action="store_true", help="step through Python/autograd every time instead of "
                     "replaying the recorded step (TrainGraph(replay=False))")
     args = ap.parse_args()
@@ -358,14 +360,14 @@ def main():
                             "sync_bn": bool(args.sync_bn)}
         if one_rank is not None:
             line["one_rank_same_shape"] = one_rank
-        if world == 1:
+        if world == 1 and not args.step_only:
             # "Chamfer kernel GB/s": the train shape (n = m = 4N) and the reference's own
             # micro-benchmark shape (tf_nndistance.py:48-49), forward alone and the whole iteration it times
             line["chamfer_kernel"] = [chamfer_kernel_rate(B, 4 * N, 4 * N), chamfer_kernel_rate(32, 16384, 1024)]
             line["chamfer_reference_microbench"] = chamfer_train_rate()
             if args.cpu_batch > 0:
                 line["chamfer_kernel"][0]["cpu"] = chamfer_cpu_rate(4 * N, 4 * N)
-        if world == 1 and args.cpu_batch > 0:
+        if world == 1 and args.cpu_batch > 0 and not args.step_only:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_batch, args.cpu_steps)
         print(json.dumps(line))
     if dist.is_initialized():

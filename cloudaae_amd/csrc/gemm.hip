@@ -166,9 +166,23 @@ __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
     // consecutive virtual ids inside one XCD, so the panel is fetched from HBM once per XCD
     // pass instead of once per column tile (PMC: 8x over-fetch of A without this)
     const int tiles = gridDim.x * gridDim.y;
-    const int vid = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, tiles);
+    int vid, slice;
+    if (gridDim.z > 1 && (gridDim.z & 7) == 0) {
+        // split K, slices a multiple of 8: ALL tiles of a K slice go to ONE XCD (slice s -> XCD s % 8), in
+        // dispatch order, so the slice's A and B panels (1.3 + 4 MB for the dgcnn_agg weight gradient) are
+        // fetched from HBM once by the tiles that walk them in step instead of once per tile row / column:
+        // the transposed product of dgcnn_agg fetched 784 MB against 176 MB algorithmic with the per-slice
+        // tile order below (each XCD saw 5 of the 40 tiles of EVERY slice)
+        const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int u = lin >> 3;
+        slice = (lin & 7) + 8 * (u / tiles);
+        vid = u % tiles;
+    } else {
+        vid = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, tiles);
+        slice = blockIdx.z;
+    }
     const int m0 = (vid / (int)gridDim.x) * BM, n0 = (vid % (int)gridDim.x) * BN;
-    const int kbeg = blockIdx.z * kchunk;
+    const int kbeg = slice * kchunk;
     const int kend = min(K, kbeg + kchunk);
 
     f32x16 acc[TM][TN];
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
     }
 
     // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool add_bias = bias != nullptr && (epilogue != EPI_ATOMIC || blockIdx.z == 0);
+    const bool add_bias = bias != nullptr && (epilogue != EPI_ATOMIC || slice == 0);
     if (colstats != nullptr) {
         // Column sums of this tile (values as stored, bias included) for the batch norm that consumes C:
         // colstats[tile row][0][col] = sum, [1][col] = sum of squares, in fp64 -- what bn_colsum_kernel
@@ -380,6 +394,8 @@ static void gemm_plan(int M, int N, int K, int &BM, int &BN, int &splits)
             splits = 1024;
         if (splits < 1)
             splits = 1;
+        if (splits > 8)
+            splits = splits / 8 * 8;      // whole slices per XCD (the kernel then keeps a slice's tiles on one XCD)
         if (const char *e = getenv("CLOUDAAE_GEMM_SPLITS"))
             splits = atoi(e);
     }

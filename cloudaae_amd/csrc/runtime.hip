@@ -15,7 +15,69 @@ void set_error(const char *fmt, ...)
 }
 } // namespace cloudaae
 
-CLOUDAAE_API int cloudaae_version(void) { return 100; }
+CLOUDAAE_API int cloudaae_version(void) { return 200; }
+
+// ---- CRC-32C (Castagnoli) on the HOST: the checksum of the TFRecord framing (train_cloudAAE_ycbv.py:80-135
+// reads such files) and of TensorFlow checkpoints (tf.train.Saver, :276 / :418-430), which TensorFlow computes
+// with the SSE4.2 crc32 instruction; a byte-at-a-time Python loop needs minutes for the 262 MB of a checkpoint.
+namespace cloudaae {
+static unsigned crc32c_table(const unsigned char *p, unsigned long long n, unsigned c)
+{
+    static unsigned tab[8][256];
+    static bool ready = false;
+    if (!ready) {
+        for (unsigned i = 0; i < 256; ++i) {
+            unsigned v = i;
+            for (int k = 0; k < 8; ++k)
+                v = (v >> 1) ^ ((v & 1) ? 0x82F63B78u : 0u);
+            tab[0][i] = v;
+        }
+        for (unsigned i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t)
+                tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 0xFF];
+        ready = true;
+    }
+    while (n >= 8) {            // slicing by eight
+        const unsigned lo = ((unsigned)p[0] | (unsigned)p[1] << 8 | (unsigned)p[2] << 16 | (unsigned)p[3] << 24) ^ c;
+        c = tab[7][lo & 0xFF] ^ tab[6][(lo >> 8) & 0xFF] ^ tab[5][(lo >> 16) & 0xFF] ^ tab[4][lo >> 24] ^
+            tab[3][p[4]] ^ tab[2][p[5]] ^ tab[1][p[6]] ^ tab[0][p[7]];
+        p += 8;
+        n -= 8;
+    }
+    while (n--)
+        c = tab[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c;
+}
+#if defined(__x86_64__)
+__attribute__((target("sse4.2"))) static unsigned crc32c_hw(const unsigned char *p, unsigned long long n, unsigned c)
+{
+    unsigned long long c64 = c;
+    while (n >= 8) {
+        unsigned long long v;
+        __builtin_memcpy(&v, p, 8);
+        c64 = __builtin_ia32_crc32di(c64, v);
+        p += 8;
+        n -= 8;
+    }
+    c = (unsigned)c64;
+    while (n--)
+        c = __builtin_ia32_crc32qi(c, *p++);
+    return c;
+}
+#endif
+} // namespace cloudaae
+
+// crc = cloudaae_crc32c(data, n, 0) for a whole buffer; pass the previous result to continue over a next piece
+CLOUDAAE_API unsigned cloudaae_crc32c(const void *data, unsigned long long n, unsigned crc)
+{
+    const unsigned char *p = (const unsigned char *)data;
+    unsigned c = ~crc;
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("sse4.2"))
+        return ~cloudaae::crc32c_hw(p, n, c);
+#endif
+    return ~cloudaae::crc32c_table(p, n, c);
+}
 CLOUDAAE_API const char *cloudaae_last_error(void) { return cloudaae::g_err; }
 
 // ---- a second stream for work off the critical path ------------------------------------------

@@ -18,6 +18,7 @@ import argparse
 import importlib
 import math
 import os
+import re
 import time
 
 import torch
@@ -39,6 +40,7 @@ BN_DECAY_CLIP = 0.99
 NOISE_STDDEV = 0.004 / 3.           # :217
 LOSS_WEIGHTS = (1000.0, 10.0, 1.0)  # :268
 K_NEIGHBOR = 10                     # :230
+EMA_NAME_SCOPE = 'decoder'          # tf.name_scope the model is built under (:223)
 
 
 def get_training_argparser():
@@ -67,7 +69,8 @@ def get_training_argparser():
                        help='batches per epoch (0 = the whole epoch); synthetic steps without --data_dir (0 = 100)')
     extra.add_argument('--data_dir', default='', help='directory holding object_model_tfrecord/ and '
                        'ycb_video_data_tfRecords/train_syn/ (:31-39); empty = synthetic batches')
-    extra.add_argument('--restore', default='', help='checkpoint (.npz) to resume from')
+    extra.add_argument('--restore', default='', help='checkpoint to resume from: a TensorFlow V2 prefix (model.ckpt) or an .npz')
+    extra.add_argument('--ckpt_format', default='npz', choices=['npz', 'tf'], help="format of the epoch checkpoints")
     extra.add_argument('--gemm_dtype', default='f32', help="f32, or bf16 = bf16 operands for the dense layers")
     extra.add_argument('--print_every', type=int, default=1, help='print the losses every n batches (each print syncs)')
     return parser
@@ -367,11 +370,13 @@ class TrainGraph(object):
             return self.forward(element, is_training=False)
 
     # -- tf.train.Saver (:276, :418-424): every variable under its TF name ---------------------
-    def checkpoint(self):
-        """name -> numpy array, with the names tf.train.Saver would write for this graph: the
-        model variables and BN moving averages (store names), the Adam slots `<var>/Adam`,
+    def checkpoint(self, name_scope=EMA_NAME_SCOPE):
+        """name -> numpy array, with the names tf.train.Saver writes for this graph: the model variables, the BN
+        moving averages (`<scope>/bn/<name_scope>/<scope>/bn/moments/Squeeze[_1]/ExponentialMovingAverage`: TF names
+        an EMA shadow after the op it shadows, and the model is built under tf.name_scope('decoder'), :223 -- the
+        shipped snapshot and evaluate_cloudAAE_ycbv.py:436 use '6d_pose'), the Adam slots `<var>/Adam`,
         `<var>/Adam_1`, `beta1_power`, `beta2_power`, and the step counter `Variable` (:192)."""
-        ck = {n: t.cpu().numpy() for n, t in self.store.state_dict().items()}
+        ck = {tf_variable_name(n, name_scope): t.cpu().numpy() for n, t in self.store.state_dict().items()}
         for v in self.store.trainable_variables():
             o = self.store.offsets[v.name]
             n = v.data.numel()
@@ -382,21 +387,35 @@ class TrainGraph(object):
         ck['Variable'] = self.batch.cpu().numpy().reshape(())
         return ck
 
-    def save(self, path):
-        """saver.save(sess, path) (:424).  Written as a NumPy archive (`path` + '.npz') by rank 0."""
+    def save(self, path, fmt='npz', name_scope=EMA_NAME_SCOPE):
+        """saver.save(sess, path) (:424), by rank 0.  fmt 'npz': a NumPy archive `path`.npz; fmt 'tf': a TensorFlow
+        V2 checkpoint `path`.index + `path`.data-00000-of-00001 (tf_checkpoint.py) that tf.train.Saver restores."""
         import numpy as np
+        require(fmt in ('npz', 'tf'), "fmt must be 'npz' or 'tf'")
+        if fmt == 'tf':
+            if self.rank == 0:
+                from . import tf_checkpoint
+                tf_checkpoint.write_checkpoint(path, self.checkpoint(name_scope))
+            return path
         if self.rank == 0:
             tmp = path + '.tmp.npz'
-            np.savez(tmp, **self.checkpoint())
+            np.savez(tmp, **self.checkpoint(name_scope))
             os.replace(tmp, path + '.npz')
         return path + '.npz'
 
     def restore(self, path, strict=True):
-        """saver.restore(sess, path): accepts what save() wrote, or any name -> array archive with
-        the reference's variable names (e.g. a converted TF checkpoint; optimizer slots optional)."""
+        """saver.restore(sess, path) (:425-430; evaluate_cloudAAE_ycbv.py:495-499): a TensorFlow V2 checkpoint
+        prefix (`path`.index exists -- e.g. the reference's trained_network/<run>/model.ckpt), or what save() wrote,
+        or any name -> array archive with the reference's variable names (optimizer slots optional).  BN moving
+        averages are accepted under any name scope ('decoder', '6d_pose', none)."""
         import numpy as np
-        with np.load(path if path.endswith('.npz') else path + '.npz') as z:
-            ck = {k: z[k] for k in z.files}
+        if os.path.exists(path + '.index') or path.endswith('.index'):
+            from . import tf_checkpoint
+            ck = tf_checkpoint.load_checkpoint(path)
+        else:
+            with np.load(path if path.endswith('.npz') else path + '.npz') as z:
+                ck = {k: z[k] for k in z.files}
+        ck = {store_variable_name(k): v for k, v in ck.items()}
         names = set(self.store.vars)
         self.store.load_state_dict({k: v for k, v in ck.items() if k in names}, strict=strict)
         with torch.no_grad():
@@ -410,6 +429,28 @@ class TrainGraph(object):
                 if key in ck:
                     t.fill_(float(ck[key]))
         self.refresh_bn_decay()      # the decay of the next step follows the restored global_step
+
+
+_EMA_STORE = re.compile(r'^(.*)/bn/moments/(Squeeze(?:_1)?)/ExponentialMovingAverage$')
+_EMA_TF = re.compile(r'^(.*)/bn/(?:[^/]+/)?\1/bn/moments/(Squeeze(?:_1)?)/ExponentialMovingAverage$')
+
+
+def tf_variable_name(name, name_scope=EMA_NAME_SCOPE):
+    """The name tf.train.Saver gives a variable of the store: only the BN moving averages differ -- TF names an
+    EMA shadow `<variable scope>/<full name of the shadowed op>/ExponentialMovingAverage` and that op lives in the
+    name scope the model was built under."""
+    m = _EMA_STORE.match(name)
+    if m is None or not name_scope:
+        return name
+    return '%s/bn/%s/%s/bn/moments/%s/ExponentialMovingAverage' % (m.group(1), name_scope, m.group(1), m.group(2))
+
+
+def store_variable_name(name):
+    """Inverse of tf_variable_name for any name scope."""
+    m = _EMA_TF.match(name)
+    if m is None:
+        return name
+    return '%s/bn/moments/%s/ExponentialMovingAverage' % (m.group(1), m.group(2))
 
 
 # ---- the data pipeline of train_cloudAAE_ycbv.py:42-117, batched on the GPU --------------------

@@ -27,6 +27,10 @@ typedef void *cloudaae_stream_t; /* hipStream_t */
 
 int cloudaae_version(void);
 const char *cloudaae_last_error(void);
+/* HOST helper: CRC-32C (Castagnoli, reflected, init/final xor 0xffffffff) of n bytes of host memory -- the
+ * checksum of the TFRecord framing (train_cloudAAE_ycbv.py:80-135) and of tf.train.Saver checkpoints
+ * (:276, :418-430).  crc = 0 for a whole buffer, or the previous result to continue over the next piece. */
+unsigned cloudaae_crc32c(const void *data, unsigned long long n, unsigned crc);
 
 /* Two-stream plumbing.  cloudaae_side_stream(): a low-priority stream owned by the library (one per
  * process), for work off the critical path; NULL on failure.  cloudaae_stream_wait(waiter, signaller):
@@ -180,7 +184,7 @@ int cloudaae_bn_backward(int M, int C, const float *y, int ldy, const float *gam
  * The reference is single-GPU: tf.nn.moments (utils/tf_util.py:492) sees the WHOLE batch.  When the
  * batch is sharded data-parallel, the `_sync` variants below reproduce that: every rank reduces its rows
  * to per-channel fp64 sums, the HOST-SUPPLIED `allreduce` adds them across ranks (the library does not
- * link a communication library; the host passes RCCL through torch.distributed, or anything else), and
+ * link a communication library; the host passes RCCL, or anything else, through its own runtime), and
  * the moments / the backward means are taken over count x world rows.  dgamma, dbeta and the bias gradient
  * stay LOCAL sums (the gradient exchange adds them across ranks like every other parameter gradient);
  * the EMA shadows see the global moments, so they stay identical on every rank.

@@ -165,3 +165,71 @@ def test_prob_sample_golden_and_semantics(oracle, golden_dir):
 
 def test_golden_files_present(golden_dir):
     assert len(glob.glob(os.path.join(golden_dir, "*.npz"))) >= 10
+
+
+# ---- independent cross-pins of oracle pieces the reference itself cannot pin (TensorFlow is absent).
+# They stay labelled "parity unpinned by the reference": these checks only show that the restatement implements the
+# documented formula, via a second, independently written implementation.
+def test_oracle_batch_norm_equals_torch_functional():
+    import torch
+    from oracle import model_oracle as MO
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(6, 50, 1, 16, generator=g) * 3 + 1
+    V = MO.Vars(seed=0)
+    V.p["s/gamma"] = (torch.rand(16, generator=g) + 0.5).requires_grad_(True)
+    V.p["s/beta"] = torch.randn(16, generator=g).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    y = MO.batch_norm(xr, "s", V, True, 0.9)
+    y.square().sum().backward()
+    x2 = x.clone().requires_grad_(True)
+    w, b = V.p["s/gamma"].detach().clone().requires_grad_(True), V.p["s/beta"].detach().clone().requires_grad_(True)
+    rm, rv = torch.zeros(16), torch.zeros(16)
+    # torch's momentum is (1 - decay); its running_var update uses the UNBIASED variance, TF's EMA the biased one
+    y2 = torch.nn.functional.batch_norm(x2.reshape(-1, 16), rm, rv, w, b, True, 0.1, MO.BN_EPS).reshape(x.shape)
+    y2.square().sum().backward()
+    assert torch.allclose(y, y2, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(xr.grad, x2.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(V.p["s/gamma"].grad, w.grad, rtol=1e-4, atol=1e-3)
+    flat = x.reshape(-1, 16)
+    assert torch.allclose(V.s["s/moments/Squeeze/ExponentialMovingAverage"], 0.1 * flat.mean(0), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(V.s["s/moments/Squeeze_1/ExponentialMovingAverage"], 0.1 * flat.var(0, unbiased=False), rtol=1e-5)
+    ye = MO.batch_norm(x, "s", V, False, None)                        # inference: the shadows
+    want = (x - V.s["s/moments/Squeeze/ExponentialMovingAverage"]) / torch.sqrt(
+        V.s["s/moments/Squeeze_1/ExponentialMovingAverage"] + 1e-3) * V.p["s/gamma"] + V.p["s/beta"]
+    assert torch.allclose(ye, want, rtol=1e-5, atol=1e-5)
+
+
+def test_oracle_adam_equals_the_closed_form_of_tf_apply_adam():
+    import torch
+    from oracle import model_oracle as MO
+    rng = np.random.default_rng(5)
+    p0 = rng.standard_normal(1000)
+    params = {"w": torch.tensor(p0, dtype=torch.float32)}
+    opt = MO.AdamTF()
+    p, m, v = p0.astype(np.float64), np.zeros(1000), np.zeros(1000)
+    for t in range(1, 6):
+        g = rng.standard_normal(1000) * 10.0 ** (t - 3)
+        opt.apply(params, {"w": torch.tensor(g, dtype=torch.float32)})
+        # tf.train.AdamOptimizer: lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); m, v EMAs; var -= lr_t m / (sqrt(v) + eps)
+        gf = g.astype(np.float32).astype(np.float64)
+        m = 0.9 * m + 0.1 * gf
+        v = 0.999 * v + 0.001 * gf * gf
+        p = p - 0.0008 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (np.sqrt(v) + 1e-8)
+        assert np.abs(params["w"].numpy() - p).max() < 5e-6, t
+    assert abs(float(opt.b1p) - 0.9 ** 6) < 1e-6 and abs(float(opt.b2p) - 0.999 ** 6) < 1e-6
+
+
+def test_oracle_fps_equals_naive_argmax_on_tie_free_clouds(oracle):
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((3, 500, 3)).astype(np.float32)          # continuous coordinates: no distance ties
+    got = oracle.farthest_point_sample(40, x)
+    for b in range(3):
+        d = np.full(500, 1e38, np.float32)
+        idx, last = [0], 0
+        for _ in range(39):
+            diff = x[b] - x[b, last]
+            dist = (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]
+            d = np.minimum(d, dist.astype(np.float32))
+            last = int(np.argmax(d))
+            idx.append(last)
+        assert np.array_equal(got[b], np.array(idx, np.int32)), b

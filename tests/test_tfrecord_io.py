@@ -110,3 +110,15 @@ def test_fast_pose_decode_equals_record_by_record(golden_dir, tmp_path):
     odd.write_bytes(raw + rec)
     assert R._decode_pose_file_fast(str(odd)) is None
     assert sum(1 for _ in R.tf_record_iterator(str(odd), verify=True)) == 5
+
+
+def test_native_crc32c_equals_the_table_loop():
+    """cloudaae_crc32c (host code of libcloudaae_hip.so, SSE4.2) against the byte-at-a-time definition and the
+    standard check value of CRC-32C."""
+    import os as _os
+    assert T.crc32c(b"123456789", native=False) == 0xE3069283
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 7, 8, 9, 63, 64, 65, 255, 4096, 100003):
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert T.crc32c(d) == T.crc32c(d, native=False), n
+    assert T._native(), "libcloudaae_hip.so is built in this tree: the native checksum must load"

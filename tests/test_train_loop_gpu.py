@@ -106,3 +106,29 @@ def test_checkpoint_round_trip(hip, dataset, tmp_path):
     diff = (g1.store.flat_params - g2.store.flat_params).abs()
     assert float(diff.max()) <= 2.1 * 0.0008
     assert float((diff > 1e-5).float().mean()) < 0.01
+
+
+def test_tf_checkpoint_save_restore(hip, tmp_path):
+    """saver.save / saver.restore in the reference's own format (train...:418-430): TrainGraph.save(fmt='tf') writes a
+    TensorFlow V2 checkpoint whose names are what tf.train.Saver uses (BN moving averages under the 'decoder' name
+    scope of train...:223), restore() brings another graph to the identical state -- also from the '6d_pose' naming of
+    the shipped snapshot / evaluate_cloudAAE_ycbv.py:436."""
+    from cloudaae_amd import tf_checkpoint as C
+    from cloudaae_amd import train_cloudAAE_ycbv as T
+    g = T.TrainGraph({"num_point": 128, "gpu": 0}, {}, {"batch_size": 4})
+    el = T.synthetic_element(4, 128, g.device, seed=2)
+    for _ in range(3):
+        g.train_step(el)
+    for scope in ("decoder", "6d_pose"):
+        prefix = str(tmp_path / ("model_%s.ckpt" % scope))
+        assert g.save(prefix, fmt="tf", name_scope=scope) == prefix
+        idx = C.read_index(prefix)
+        assert "dgcnn1/bn/%s/dgcnn1/bn/moments/Squeeze/ExponentialMovingAverage" % scope in idx
+        assert "dgcnn_output/weights/Adam_1" in idx and idx["Variable"]["shape"] == ()
+        h = T.TrainGraph({"num_point": 128, "gpu": 0}, {}, {"batch_size": 4}, seed=99)
+        assert not torch.equal(h.store.flat_params, g.store.flat_params)
+        h.restore(prefix)
+        for a, b in ((h.store.flat_params, g.store.flat_params), (h.store.flat_state, g.store.flat_state),
+                     (h.adam_m, g.adam_m), (h.adam_v, g.adam_v), (h.batch, g.batch), (h.beta1_power, g.beta1_power),
+                     (h.beta2_power, g.beta2_power), (h.bn_decay, g.bn_decay)):
+            assert torch.equal(a, b)

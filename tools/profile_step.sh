@@ -9,9 +9,9 @@ TAG=$1; WORKLOAD=$2; shift 2
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" --steps 50 --warmup 5 --cpu-batch 0 "$@" > "$OUT/trace.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o f -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --cpu-batch 0 "$@" > "$OUT/fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o w -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --cpu-batch 0 "$@" > "$OUT/write.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t -- python3 "$ROOT/bench.py" --steps 50 --warmup 5 --step-only "$@" > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o f -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --step-only "$@" > "$OUT/fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o w -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --step-only "$@" > "$OUT/write.log" 2>&1
 grep -h '^{"metric"' "$OUT/trace.log" > "$OUT/summary_bench_line.json" || true
 python3 "$ROOT/profiles/collect.py" "$OUT" "$TAG" "$WORKLOAD"
 # keep the merged-back payload small: the databases stay on the box
