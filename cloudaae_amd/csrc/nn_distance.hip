@@ -238,8 +238,15 @@ struct NfTop {
 __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
     int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
     float *__restrict__ dist1, int *__restrict__ idx1, float *__restrict__ dist2,
-    int *__restrict__ idx2, int blocks1)
+    int *__restrict__ idx2, int blocks1, int split1, int split2, unsigned long long *__restrict__ keys1,
+    unsigned long long *__restrict__ keys2)
 {
+    // split > 1: the candidates of that direction are cut into `split` ranges (multiples of NF_CHUNK), one
+    // workgroup per (query block, range); every range delivers its exact first-index minimum and the ranges meet
+    // in keys[] = min over (distance bits << 32 | index) -- squared distances are >= +0, so their bit patterns
+    // order like the values, and equal distances resolve to the lower index, the reference's first-wins rule.
+    // A cloud pair of very unequal sizes (the reference's own benchmark: 16384 x 1024 points) otherwise leaves
+    // the few workgroups that own the short side's queries scanning the whole long side alone.
     __shared__ float2v cand[NF_CHUNK / 32 + 1][64];     // (+1: the pipeline reads one tile ahead)
     __shared__ float bmax_s[NF_WAVES];
 
@@ -247,12 +254,20 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
     const int c32 = lane & 31, half = lane >> 5;
     const int cloud = blockIdx.y;
     const bool second = (int)blockIdx.x >= blocks1;
-    const int blk = second ? (int)blockIdx.x - blocks1 : (int)blockIdx.x;
+    const int split = second ? split2 : split1;
+    const int lin = second ? (int)blockIdx.x - blocks1 : (int)blockIdx.x;
+    const int blk = lin / split, part = lin % split;
     const int nq = second ? m : n, nc = second ? n : m;
     const float *from = (second ? xyz2 : xyz1) + (size_t)cloud * nq * 3;
     const float *to = (second ? xyz1 : xyz2) + (size_t)cloud * nc * 3;
     float *dist = (second ? dist2 : dist1) + (size_t)cloud * nq;
     int *idx = (second ? idx2 : idx1) + (size_t)cloud * nq;
+    unsigned long long *keys = (second ? keys2 : keys1) + (size_t)cloud * nq;
+    // this workgroup's candidate range
+    const int range = ((nc + split - 1) / split + NF_CHUNK - 1) / NF_CHUNK * NF_CHUNK;
+    const int cbeg = min(part * range, nc), cend = min(cbeg + range, nc);
+    if (cbeg >= cend)
+        return;                                         // (an empty trailing range)
 
     const float cx = to[0], cy = to[1], cz = to[2];
     float qx[NF_QT], qy[NF_QT], qz[NF_QT], b0[NF_QT], b1[NF_QT], a2[NF_QT];
@@ -291,8 +306,8 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
     // hand, left to two waves per SIMD, or both -- so the VALU work is what gets minimised.
     float run[NF_QT];
     float bmax2 = 0.0f;
-    for (int c0 = 0; c0 < nc; c0 += NF_CHUNK) {
-        const int cnt = min(NF_CHUNK, nc - c0);
+    for (int c0 = cbeg; c0 < cend; c0 += NF_CHUNK) {
+        const int cnt = min(NF_CHUNK, cend - c0);
         const int padded = (cnt + 31) & ~31;
         __syncthreads();
         for (int k = tid; k < padded + 32; k += NF_WAVES * 64) {
@@ -366,7 +381,7 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
 #pragma unroll 4
         for (int s = 0; s < 32; ++s) {
             const int k = base + (s & 3) + 8 * (s >> 2);
-            if (k < nc) {
+            if (k < cend) {
                 const float d = sqdist(to[3 * (size_t)k], to[3 * (size_t)k + 1], to[3 * (size_t)k + 2], qx[q],
                                        qy[q], qz[q]);
                 const unsigned u = __float_as_uint(d);
@@ -393,11 +408,11 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
             unsigned sb = 0xffffffffu;
             int si = 0x7fffffff;
             constexpr int RU = 4;       // loads of four candidates in flight per lane
-            for (int k0 = lane; k0 < nc; k0 += 64 * RU) {
+            for (int k0 = cbeg + lane; k0 < cend; k0 += 64 * RU) {
                 float px[RU], py[RU], pz[RU];
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
-                    const int k = min(k0 + 64 * u, nc - 1);
+                    const int k = min(k0 + 64 * u, cend - 1);
                     px[u] = to[3 * (size_t)k];
                     py[u] = to[3 * (size_t)k + 1];
                     pz[u] = to[3 * (size_t)k + 2];
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
                 for (int u = 0; u < RU; ++u) {
                     const int k = k0 + 64 * u;
                     const unsigned v = __float_as_uint(sqdist(px[u], py[u], pz[u], fx, fy, fz));
-                    if (k < nc && v < sb) {     // ascending k within the lane: the first minimum stays
+                    if (k < cend && v < sb) {   // ascending k within the lane: the first minimum stays
                         sb = v;
                         si = k;
                     }
@@ -427,9 +442,25 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
             }
         }
         if (half == 0 && j < nq) {
-            dist[j] = __uint_as_float(kb);
-            idx[j] = ki;
+            if (split > 1) {
+                atomicMin(&keys[j], ((unsigned long long)kb << 32) | (unsigned)ki);
+            } else {
+                dist[j] = __uint_as_float(kb);
+                idx[j] = ki;
+            }
         }
+    }
+}
+
+// keys[] of a direction whose candidates were split -> the two output arrays
+__global__ __launch_bounds__(256) void nn_distance_unpack_kernel(long long total, const unsigned long long *__restrict__ keys,
+                                                                float *__restrict__ dist, int *__restrict__ idx)
+{
+    const long long i = blockIdx.x * 256LL + threadIdx.x;
+    if (i < total) {
+        const unsigned long long k = keys[i];
+        dist[i] = __uint_as_float((unsigned)(k >> 32));
+        idx[i] = (int)(unsigned)k;
     }
 }
 
@@ -491,9 +522,43 @@ CLOUDAAE_API int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, co
         filter = atoi(env) != 0 && n > 0 && m > 0;
     if (filter) {
         const int t1 = ceil_div(n, NF_QBLOCK), t2 = ceil_div(m, NF_QBLOCK);
-        hipLaunchKernelGGL(nn_distance_filter_kernel, dim3(t1 + t2, b), dim3(NF_WAVES * 64), 0, s, n, m, xyz1,
-                           xyz2, dist1, idx1, dist2, idx2, t1);
+        // A direction with fewer query blocks than the chip has CUs and many candidates (clouds of unequal size) is
+        // cut over its candidates until it has ~4 workgroups per CU, ranges no shorter than one LDS chunk.
+        // (Measured at [32,4096]^2, 256 query blocks per direction: two ranges 152 us, one 117 us -- the fixed
+        // cost per workgroup, 64 exact evaluations per query, doubles; [32,16384]x[32,1024]: 365 -> 199 us.)
+        auto splits_of = [&](int tq, int nc) {
+            int sp = 1;
+            if ((long long)tq * b < 256 && nc >= 2 * NF_CHUNK) {
+                sp = (int)(1024 / ((long long)tq * b));
+                if (sp > nc / NF_CHUNK)
+                    sp = nc / NF_CHUNK;
+                if (sp < 1)
+                    sp = 1;
+            }
+            if (const char *e = getenv("CLOUDAAE_NN_SPLIT"))
+                sp = atoi(e) > 0 ? atoi(e) : 1;
+            return sp;
+        };
+        const int s1 = splits_of(t1, m), s2 = splits_of(t2, n);
+        unsigned long long *keys = nullptr, *k1 = nullptr, *k2 = nullptr;
+        const size_t c1 = s1 > 1 ? (size_t)b * n : 0, c2 = s2 > 1 ? (size_t)b * m : 0;
+        if (c1 + c2 > 0) {      // scratch of the call, stream ordered: no state outlives it
+            CLOUDAAE_CHECK_HIP(hipMallocAsync((void **)&keys, (c1 + c2) * sizeof(unsigned long long), s), name);
+            CLOUDAAE_CHECK_HIP(hipMemsetAsync(keys, 0xff, (c1 + c2) * sizeof(unsigned long long), s), name);
+            k1 = keys;
+            k2 = keys + c1;
+        }
+        hipLaunchKernelGGL(nn_distance_filter_kernel, dim3(t1 * s1 + t2 * s2, b), dim3(NF_WAVES * 64), 0, s, n, m, xyz1,
+                           xyz2, dist1, idx1, dist2, idx2, t1 * s1, s1, s2, k1, k2);
+        if (c1)
+            hipLaunchKernelGGL(nn_distance_unpack_kernel, dim3(ceil_div((long long)c1, 256)), dim3(256), 0, s,
+                               (long long)c1, k1, dist1, idx1);
+        if (c2)
+            hipLaunchKernelGGL(nn_distance_unpack_kernel, dim3(ceil_div((long long)c2, 256)), dim3(256), 0, s,
+                               (long long)c2, k2, dist2, idx2);
         CLOUDAAE_CHECK_LAUNCH(name);
+        if (keys != nullptr)
+            CLOUDAAE_CHECK_HIP(hipFreeAsync(keys, s), name);
         return 0;
     }
     // queries per lane: enough workgroups to fill 256 CUs first, then amortise

@@ -260,6 +260,29 @@ def test_prob_sample_vs_oracle(hip, oracle, b, n, m):
         assert np.abs(freq - p.sum(0) / p.sum()).max() < 0.05
 
 
+@pytest.mark.parametrize("b,n,m,split", [(2, 16384, 1024, None), (3, 700, 9000, None), (2, 5000, 4100, "3"),
+                                         (1, 4096, 4096, "2"), (2, 1000, 20000, "7"), (33, 600, 4096, None)])
+def test_nn_distance_split_candidates_vs_oracle(hip, oracle, b, n, m, split, monkeypatch):
+    """Clouds of unequal size (the reference's own benchmark is 16384 x 1024 points, tf_nndistance.py:48-49): the
+    direction with few queries and many candidates is cut over its candidates, the ranges meet in a 64-bit
+    (distance, index) minimum.  Bit-exact incl. the first-index rule ACROSS ranges (duplicated candidates sit in
+    different ranges).  split: CLOUDAAE_NN_SPLIT forces a range count on both directions."""
+    from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
+    monkeypatch.setenv("CLOUDAAE_NN_FILTER", "1")
+    if split is not None:
+        monkeypatch.setenv("CLOUDAAE_NN_SPLIT", split)
+    rng = np.random.default_rng(n + m)
+    a = (rng.standard_normal((b, n, 3)) * 0.05 + [0.1, -0.2, 0.9]).astype(np.float32)
+    c = (rng.standard_normal((b, m, 3)) * 0.05 + [0.1, -0.2, 0.9]).astype(np.float32)
+    c[:, m - 50:m - 10] = c[:, :40]            # exact duplicates far apart: the lower index must win
+    a[:, n - 50:n - 10] = a[:, 5:45]
+    a[:, :8] = c[:, 100:108]                   # zero distances
+    want = oracle.nn_distance(a, c, threads=8)
+    got = tf_nndistance.nn_distance(_dev(a), _dev(c))
+    for w, g_ in zip(want, got):
+        assert np.array_equal(w, g_.cpu().numpy())
+
+
 @pytest.mark.parametrize("case", ["lattice", "far_from_origin", "huge", "tiny_scale", "one_candidate", "ragged"])
 def test_nn_distance_filter_kernel_adversarial(hip, oracle, case, monkeypatch):
     """The matrix-core search + exact verification (nn_distance_filter_kernel) on inputs built to defeat a
