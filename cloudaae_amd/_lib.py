@@ -44,6 +44,7 @@ _SIGNATURES = {
                                         _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P,
                                         _P, _P],
     "cloudaae_gemm_f32_colstats": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P],
+    "cloudaae_gemm_bf16_colstats": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P],
     "cloudaae_bn_forward_colstats": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P,
                                      _P, _P, _I, _P],
     "cloudaae_fc_forward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
@@ -277,6 +278,8 @@ def lib():
         cdll.cloudaae_bn_workspace_bytes.argtypes = [_I]
         cdll.cloudaae_gemm_f32_colstats_parts.argtypes = [_I, _I, _I]
         cdll.cloudaae_gemm_f32_colstats_parts.restype = ctypes.c_int
+        cdll.cloudaae_gemm_bf16_colstats_parts.argtypes = [_I, _I, _I]
+        cdll.cloudaae_gemm_bf16_colstats_parts.restype = ctypes.c_int
         for q in ("cloudaae_fc_max_rows", "cloudaae_fc_max_group"):
             getattr(cdll, q).argtypes = []
             getattr(cdll, q).restype = ctypes.c_int

@@ -322,16 +322,24 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_partials_kernel(int C, int gr
                                                                   const double *__restrict__ pool_stats,
                                                                   double *__restrict__ partial)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    // grid.y = parts <= BN_MAX_PARTS partial-sum rows; part p takes the groups p, p + parts, ... (a batch of more
+    // than 128 clouds per GPU: BASELINE configs[2] runs 256)
+    const int c = blockIdx.x * 256 + threadIdx.x, parts = gridDim.y;
     if (c >= C)
         return;
-    const double gv = (double)(dpooled[(size_t)g * C + c] / (float)rows);
-    const double *ps = pool_stats + (size_t)g * 3 * C + c;
-    partial[((size_t)g * 2 + 0) * C + c] = gv * ps[0];
-    partial[((size_t)g * 2 + 1) * C + c] = gv * ps[C];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int g = blockIdx.y; g < groups; g += parts) {
+        const double gv = (double)(dpooled[(size_t)g * C + c] / (float)rows);
+        const double *ps = pool_stats + (size_t)g * 3 * C + c;
+        s0 += gv * ps[0];
+        s1 += gv * ps[C];
+        s2 += ps[2 * (size_t)C];
+    }
+    partial[((size_t)blockIdx.y * 2 + 0) * C + c] = s0;
+    partial[((size_t)blockIdx.y * 2 + 1) * C + c] = s1;
     double *p3 = partial + (size_t)BN_MAX_PARTS * 2 * C;
-    p3[((size_t)g * 2 + 0) * C + c] = ps[2 * (size_t)C];
-    p3[((size_t)g * 2 + 1) * C + c] = 0.0;
+    p3[((size_t)blockIdx.y * 2 + 0) * C + c] = s2;
+    p3[((size_t)blockIdx.y * 2 + 1) * C + c] = 0.0;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const float *__restrict__ m12,
@@ -692,9 +700,9 @@ static int bn_backward_impl(const char *name, int M, int C, const float *y, int 
     int parts = bn_parts(M);
     const int cb = ceil_div(C, 64);
     const int groups = pool_mode == 1 ? M / pool_rows : 0;
-    if (pool_stats != nullptr && pool_mode == 1 && dout == nullptr && relu && training && groups <= BN_MAX_PARTS) {
-        parts = groups;     // one partial-sum row per group, from what the forward pass counted
-        hipLaunchKernelGGL(bn_bwd_pool_partials_kernel, dim3(ceil_div(C, 256), groups), dim3(256), 0, s, C, groups,
+    if (pool_stats != nullptr && pool_mode == 1 && dout == nullptr && relu && training) {
+        parts = groups < BN_MAX_PARTS ? groups : BN_MAX_PARTS;     // partial-sum rows from what the forward pass counted
+        hipLaunchKernelGGL(bn_bwd_pool_partials_kernel, dim3(ceil_div(C, 256), parts), dim3(256), 0, s, C, groups,
                            pool_rows, dpooled, pool_stats, partial);
     } else {
         hipLaunchKernelGGL(bn_bwd_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, a, partial, parts);

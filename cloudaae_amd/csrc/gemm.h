@@ -10,12 +10,12 @@ namespace cloudaae {
 // storage fold into stacked row blocks: logical (r, c) -> physical row (c / width) * rows + r, column
 // c % width, leading dimension == width.  With width = cout the edge convolution's [2*cin, cout]
 // kernel IS the [cin, 2*cout] matrix [W_centre | W_neighbour].
-// colstats (fp32 launcher only, optional): per row tile the column sums and sums of squares of C.
+// colstats (optional): per row tile the column sums and sums of squares of C.
 int gemm_f32_launch(const char *name, int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                     const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate, int fold_b,
                     int fold_c, hipStream_t stream, double *colstats = nullptr);
 int gemm_bf16_launch(const char *name, int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                      const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate, int fold_b,
-                     int fold_c, hipStream_t stream);
+                     int fold_c, hipStream_t stream, double *colstats = nullptr);
 
 } // namespace cloudaae

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
                                                                float *__restrict__ C, int ldc,
                                                                const float *__restrict__ bias, int epilogue,
                                                                int kchunk, int vecA, int vecB, FoldB foldB,
-                                                               FoldB foldC)
+                                                               FoldB foldC, double *__restrict__ colstats)
 {
     static_assert(WM * WN * 64 == GB_THREADS, "4 waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -141,9 +141,20 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int tiles = gridDim.x * gridDim.y;
-    const int vid = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, tiles);
+    int vid, slice;
+    if (gridDim.z > 1 && (gridDim.z & 7) == 0) {
+        // split K, slices a multiple of 8: all tiles of a slice on ONE XCD (see gemm_f32_kernel: the transposed
+        // product of dgcnn_agg fetched 4.4 x its algorithmic bytes with the per-slice tile order)
+        const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int u = lin >> 3;
+        slice = (lin & 7) + 8 * (u / tiles);
+        vid = u % tiles;
+    } else {
+        vid = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, tiles);
+        slice = blockIdx.z;
+    }
     const int m0 = (vid / (int)gridDim.x) * BM, n0 = (vid % (int)gridDim.x) * BN;
-    const int kbeg = blockIdx.z * kchunk;
+    const int kbeg = slice * kchunk;
     const int kend = min(K, kbeg + kchunk);
 
     f32x16 acc[TM][TN];
@@ -189,7 +200,46 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
     }
 
     // epilogue: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool add_bias = bias != nullptr && (epilogue != GB_ATOMIC || blockIdx.z == 0);
+    const bool add_bias = bias != nullptr && (epilogue != GB_ATOMIC || slice == 0);
+    if (colstats != nullptr) {
+        // column sums / sums of squares of this tile in fp64 for the batch norm that consumes C (as in
+        // gemm_f32_kernel: colstats[tile row][0 | 1][col]; fixed order of summation)
+        __shared__ double cs[2][WM][BN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cl = (wn * TN + j) * 32 + fr;
+            const float bv = (add_bias && n0 + cl < N) ? bias[n0 + cl] : 0.0f;
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    if (row < M) {
+                        const double v = (double)(acc[i][j][r] + bv);
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (fk == 0) {
+                cs[0][wm][cl] = s1;
+                cs[1][wm][cl] = s2;
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * BN; t += GB_THREADS) {
+            const int which = t / BN, cl = t % BN;
+            if (n0 + cl < N) {
+                double v = cs[which][0][cl];
+#pragma unroll
+                for (int w = 1; w < WM; ++w)
+                    v += cs[which][w][cl];
+                colstats[((size_t)(m0 / BM) * 2 + which) * N + n0 + cl] = v;
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wn * TN + j) * 32 + fr;
@@ -219,21 +269,21 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
 template <int BM, int BN, int WM, int WN>
 static void launch_bf16(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A, int lda,
                         const float *B, int ldb, float *C, int ldc, const float *bias, int epi, int kchunk,
-                        int vecA, int vecB, FoldB fb, FoldB fc)
+                        int vecA, int vecB, FoldB fb, FoldB fc, double *cs)
 {
     dim3 block(GB_THREADS);
     if (!ta && !tb)
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
     else if (!ta && tb)
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
     else if (ta && !tb)
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
     else
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc);
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
 }
 
 // tile shape and K slices (same policy as gemm.hip's gemm_plan, slabs of 32)
@@ -262,6 +312,8 @@ static void gemm_bf16_plan(int M, int N, int K, int &BM, int &BN, int &splits)
             splits = max_splits;
         if (splits < 1)
             splits = 1;
+        if (splits > 8)
+            splits = splits / 8 * 8;      // whole slices per XCD
     }
 }
 
@@ -281,7 +333,7 @@ CLOUDAAE_API int cloudaae_gemm_bf16_splits(int M, int N, int K)
 
 int cloudaae::gemm_bf16_launch(const char *name, int trans_a, int trans_b, int M, int N, int K, const float *A,
                                int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
-                               int fold_b, int fold_c, hipStream_t s)
+                               int fold_b, int fold_c, hipStream_t s, double *colstats)
 {
     CLOUDAAE_REQUIRE(M >= 0 && N >= 0 && K >= 0, name, "negative size");
     if (M == 0 || N == 0)
@@ -304,6 +356,8 @@ int cloudaae::gemm_bf16_launch(const char *name, int trans_a, int trans_b, int M
     gemm_bf16_plan(M, N, K, BM, BN, splits);
     const int tm = ceil_div(M, BM), tn = ceil_div(N, BN);
     CLOUDAAE_REQUIRE(tm <= 65535, name, "M too large");
+    CLOUDAAE_REQUIRE(colstats == nullptr || (splits == 1 && accumulate == 0 && !fold_c), name,
+                     "column statistics need an unsplit, overwriting product");
     int kchunk = K > 0 ? ceil_div(ceil_div(K, splits), GB_BK) * GB_BK : GB_BK;
     splits = K > 0 ? ceil_div(K, kchunk) : 1;
     int epi = accumulate == 1 ? GB_ACCUM : GB_STORE;
@@ -323,16 +377,16 @@ int cloudaae::gemm_bf16_launch(const char *name, int trans_a, int trans_b, int M
     const bool ta = trans_a != 0, tb = trans_b != 0;
     if (BM == 32)
         launch_bf16<32, 128, 1, 4>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
-                                   fc);
+                                   fc, colstats);
     else if (BN == 64)
         launch_bf16<128, 64, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
-                                   fc);
+                                   fc, colstats);
     else if (BM == 64)
         launch_bf16<64, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
-                                   fc);
+                                   fc, colstats);
     else
         launch_bf16<128, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB,
-                                    fb, fc);
+                                    fb, fc, colstats);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }
@@ -343,4 +397,23 @@ CLOUDAAE_API int cloudaae_gemm_bf16(int trans_a, int trans_b, int M, int N, int 
 {
     return gemm_bf16_launch("cloudaae_gemm_bf16", trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate,
                             0, 0, (hipStream_t)stream);
+}
+
+CLOUDAAE_API int cloudaae_gemm_bf16_colstats_parts(int M, int N, int K)
+{
+    if (M <= 0 || N <= 0 || K <= 0)
+        return 0;
+    int BM, BN, splits;
+    gemm_bf16_plan(M, N, K, BM, BN, splits);
+    return splits == 1 ? ceil_div(M, BM) : 0;      // one row of sums per tile row
+}
+
+CLOUDAAE_API int cloudaae_gemm_bf16_colstats(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                                             const float *B, int ldb, float *C, int ldc, const float *bias,
+                                             double *colstats, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_gemm_bf16_colstats";
+    CLOUDAAE_REQUIRE(colstats != nullptr, name, "null argument");
+    return gemm_bf16_launch(name, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, 0, 0, 0,
+                            (hipStream_t)stream, colstats);
 }

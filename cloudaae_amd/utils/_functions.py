@@ -411,15 +411,16 @@ class ConcatLinearFn(torch.autograd.Function):
         ctx.bf16 = gemm_is_bf16()
         # bias_grad_by_bn & 2: a training-mode batch norm consumes y next -- the product leaves the column
         # sums of its tiles in the batch norm's workspace and the statistics pass over y is skipped
-        parts = int(L().cloudaae_gemm_f32_colstats_parts(M, N, Ktot)) if (int(bias_grad_by_bn) & 2 and not ctx.bf16) else 0
+        parts_fn = L().cloudaae_gemm_bf16_colstats_parts if ctx.bf16 else L().cloudaae_gemm_f32_colstats_parts
+        parts = int(parts_fn(M, N, Ktot)) if int(bias_grad_by_bn) & 2 else 0
         if parts > 0:
             ws = _lib.empty(parts * 2 * N, dtype=torch.float64, device=w.device)      # colstats[parts][2][N]
             rec = TIMED_SITES.get("agg_fwd")
             if rec is not None:
                 _lib.host(_mark, rec)
-            _lib.check(L().cloudaae_gemm_f32_colstats(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N,
-                                                      ptr(b) if b is not None else None, ptr(ws), stream()),
-                       "cloudaae_gemm_f32_colstats")
+            fn = L().cloudaae_gemm_bf16_colstats if ctx.bf16 else L().cloudaae_gemm_f32_colstats
+            _lib.check(fn(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, ptr(ws),
+                          stream()), "cloudaae_gemm_colstats")
             if rec is not None:
                 _lib.host(_mark, rec)
             y._cloudaae_colstats = (ws, parts, M, N)

@@ -144,6 +144,11 @@ int cloudaae_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, const floa
                        const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
                        cloudaae_stream_t stream);
 int cloudaae_gemm_bf16_splits(int M, int N, int K);
+/* cloudaae_gemm_f32_colstats_parts / _colstats for the bf16-operand product. */
+int cloudaae_gemm_bf16_colstats_parts(int M, int N, int K);
+int cloudaae_gemm_bf16_colstats(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                                const float *B, int ldb, float *C, int ldc, const float *bias, double *colstats,
+                                cloudaae_stream_t stream);
 
 /* batch_norm_template (utils/tf_util.py:473-511) on rows y[M,C] (+ ReLU), writing the
  * activation out[M,C] and/or its pool over groups of pool_rows consecutive rows

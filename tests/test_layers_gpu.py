@@ -528,3 +528,25 @@ def test_gemm_colstats_feed_batch_norm(hip, M, N, K):
     for a, b in zip(res[0][1:], res[1][1:]):
         if a is not None:
             assert _rel(a, b) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1024, 320), (1000, 130, 70), (32768, 1024, 320)])
+def test_gemm_bf16_colstats(hip, M, N, K):
+    """cloudaae_gemm_bf16_colstats: the same C as cloudaae_gemm_bf16, and per tile row the fp64 column sums / sums of
+    squares of exactly those stored values (what cloudaae_bn_forward_colstats starts from)."""
+    L = hip.lib()
+    parts = L.cloudaae_gemm_bf16_colstats_parts(M, N, K)
+    assert parts > 0
+    g = torch.Generator().manual_seed(M + N + 1)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (torch.randn(K, N, generator=g) / math.sqrt(K)).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    C0, C1 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    cs = torch.zeros(parts * 2 * N, dtype=torch.float64, device="cuda")
+    P = lambda t: t.data_ptr()  # noqa: E731
+    hip.check(L.cloudaae_gemm_bf16(0, 0, M, N, K, P(A), K, P(B), N, P(C0), N, P(bias), 0, hip.stream()), "g")
+    hip.check(L.cloudaae_gemm_bf16_colstats(0, 0, M, N, K, P(A), K, P(B), N, P(C1), N, P(bias), P(cs), hip.stream()), "g")
+    assert torch.equal(C0, C1)
+    stats = cs.reshape(parts, 2, N).sum(0)
+    Cd = C1.double()
+    assert _rel(stats[0], Cd.sum(0)) < 1e-9 and _rel(stats[1], (Cd * Cd).sum(0)) < 1e-9
