@@ -36,6 +36,24 @@ struct TopK {
             i[p] = 0;
         }
     }
+    // insert_bf: the same without a branch (a divergent `if` around 2K registers of state drags ~4K register copies
+    // along in the compiled code); (+inf, _) is a no-op
+    __device__ __forceinline__ void insert_bf(float nd, int ni)
+    {
+        const bool in = nd < d[K - 1];
+        d[K - 1] = in ? nd : d[K - 1];
+        i[K - 1] = in ? ni : i[K - 1];
+#pragma unroll
+        for (int p = K - 1; p > 0; --p) {
+            const bool sw = d[p] < d[p - 1];
+            const float a = d[p - 1], b = d[p];
+            const int ia = i[p - 1], ib = i[p];
+            d[p - 1] = sw ? b : a;
+            d[p] = sw ? a : b;
+            i[p - 1] = sw ? ib : ia;
+            i[p] = sw ? ia : ib;
+        }
+    }
     // stable: the newcomer only passes entries that are strictly larger
     __device__ __forceinline__ void insert(float nd, int ni)
     {
@@ -1095,9 +1113,20 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_bound_kernel(int n, int ld
     // the insert is stable, so ties keep the lower index first)
     TopK<K> top;
     top.init();
-    for (int ro = q0; __any(ro < wo); ro += 64)
-        if (ro < wo)
-            top.insert(qd_all[ro], qj_all[ro]);
+    {
+        // (entries past a lane's end read as +inf: no branch around the insert; the next entry is in flight while
+        //  the current one bubbles down)
+        float nd = q0 < wo ? qd_all[q0] : __builtin_inff();
+        int ni = qj_all[q0];
+        for (int ro = q0; __any(ro < wo); ro += 64) {
+            const float cd = nd;
+            const int ci = ni;
+            const int rn = ro + 64;
+            nd = rn < wo ? qd_all[min(rn, q0 + (KB_QCAP - 1) * 64)] : __builtin_inff();
+            ni = qj_all[min(rn, q0 + (KB_QCAP - 1) * 64)];
+            top.insert_bf(cd, ci);
+        }
+    }
 
     // merge the 2*CS lists of every query lexicographically by (d, j) (each is sorted that way: its candidates
     // arrived in ascending j and the insert is stable), through the queue area of the query tile's first wave
