@@ -1,7 +1,7 @@
 // gemm_bf16.hip -- the dense layers with bf16 operands on the gfx950 matrix cores
 // (v_mfma_f32_32x32x16_bf16), fp32 accumulate, fp32 in and out.
 //
-// BASELINE config 3 ("bf16 MLPs + fp32 Chamfer"): every conv1x1 / fully connected product of the
+// BASELINE configs[2] ("bf16 MLPs + fp32 Chamfer"): every conv1x1 / fully connected product of the
 // CloudAAE path (reference utils/tf_util.py:161-166, :349-352) and both of its gradient products
 //     y  = x W + b,   dx = dy W^T,   dW = x^T dy
 // with the operands rounded to bfloat16 (round to nearest even, v_cvt_pk_bf16_f32) as they are

@@ -146,7 +146,7 @@ class TrainGraph(object):
         # to the launches themselves, which is what keeps a batch-32 step GPU-bound.
         # gemm_dtype='bf16': the per-point conv1x1 products (and their gradient products) round their operands
         # to bfloat16 on the way to the matrix cores, fp32 accumulate; everything else -- tensors in
-        # HBM, batch norm, kNN, Chamfer, pose losses, Adam -- stays fp32 (BASELINE config 3)
+        # HBM, batch norm, kNN, Chamfer, pose losses, Adam -- stays fp32 (BASELINE configs[2])
         require(gemm_dtype in ('f32', 'bf16'), "gemm_dtype must be 'f32' or 'bf16'")
         self.gemm_dtype = gemm_dtype
         self.replay = bool(replay)

@@ -76,7 +76,7 @@ def _mark(rec):
 
 # Operand type of the per-point dense layers (conv2d 1x1, the edge convolution, dgcnn_agg): "f32", or
 # "bf16" = operands rounded to bfloat16 on their way to the matrix cores, fp32 accumulate (BASELINE
-# config 3).  The fully connected stack (rows = batch size) stays fp32: it is bound by reading its
+# configs[2]).  The fully connected stack (rows = batch size) stays fp32: it is bound by reading its
 # fp32 weights, not by the matrix pipe, and bf16 staging only adds work there (measured: 12.9 vs
 # 7.9 us per 32 x 1024 x 1024 product).  Read when a layer's FORWARD runs; its backward follows suit.
 GEMM_DTYPE = "f32"

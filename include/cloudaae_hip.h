@@ -139,7 +139,7 @@ int cloudaae_gemm_f32_colstats(int trans_a, int trans_b, int M, int N, int K, co
 int cloudaae_gemm_f32_splits(int M, int N, int K);
 /* The same product with both operands rounded to bfloat16 (round to nearest even) on their way
  * to the matrix cores (v_mfma_f32_32x32x16_bf16), fp32 accumulate; A, B, C, bias stay fp32 in
- * memory, so the call is interchangeable with cloudaae_gemm_f32 (BASELINE config 3: bf16 MLPs). */
+ * memory, so the call is interchangeable with cloudaae_gemm_f32 (BASELINE configs[2]: bf16 MLPs). */
 int cloudaae_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                        const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
                        cloudaae_stream_t stream);

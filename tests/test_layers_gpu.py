@@ -361,7 +361,7 @@ def test_train_step_vs_oracle(hip, B, N, model_fn):
 
 @pytest.mark.parametrize("B,N,k", [(4, 256, 20), (4, 4096, 20)])
 def test_train_step_k20_vs_oracle(hip, B, N, k):
-    """BASELINE config 4's shape: DGCNN with k=20 edge-conv, up to N=4096 points (LDS-tiled kNN
+    """BASELINE configs[4]'s shape (the fifth configuration): DGCNN with k=20 edge-conv, up to N=4096 points (LDS-tiled kNN
     stress), one full step vs the CPU restatement.
 
     The kNN op itself is bit-exact on identical inputs (test_ops_gpu.py).  Inside the network the
@@ -410,7 +410,7 @@ def test_train_step_k20_vs_oracle(hip, B, N, k):
 
 @pytest.mark.parametrize("B,N", [(8, 256), (4, 1024)])
 def test_train_step_bf16_gemms_vs_oracle(hip, B, N):
-    """BASELINE config 3's arithmetic: the per-point conv1x1 products and their gradient products with bf16
+    """BASELINE configs[2]'s arithmetic: the per-point conv1x1 products and their gradient products with bf16
     operands (round to nearest even) and fp32 accumulate, everything else fp32 -- against the
     restatement with the same rounding (oracle/model_oracle.py: GEMM_BF16), grouped on the GPU's
     neighbour indices.  A value on a bf16 rounding boundary rounds differently when the two
