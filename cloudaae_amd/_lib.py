@@ -28,6 +28,7 @@ _SIGNATURES = {
     "cloudaae_knn": [_I, _I, _I, _I, _I, _P, _P, _P],
     "cloudaae_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "cloudaae_gemm_bf16": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
+    "cloudaae_gemm_f32_tn_group": [_I, _P, _P],
     "cloudaae_bn_forward": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P,
                             _P, _P, _P],
     "cloudaae_bn_backward": [_I, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I,
@@ -89,6 +90,12 @@ _SIGNATURES = {
     "cloudaae_spherical_flip": [_I, _I, _P, _I, _P, _P, _F, _P, _P, _P],
     "cloudaae_hidden_point_removal": [_I, _I, _P, _P, _U, _P, _P, _P, _P, _P],
 }
+
+
+class GemmTnJob(ctypes.Structure):
+    """struct cloudaae_gemm_tn_job (include/cloudaae_hip.h): one product of a grouped weight-gradient launch."""
+    _fields_ = [("M", _I), ("N", _I), ("K", _I), ("A", _P), ("lda", _I), ("B", _P), ("ldb", _I), ("C", _P), ("ldc", _I),
+                ("fold_c", _I), ("zeroed", _I)]
 
 
 class FcLayer(ctypes.Structure):

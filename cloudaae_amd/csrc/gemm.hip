@@ -147,11 +147,12 @@ struct Panel {
 
 // C[M,N] (+)= op(A)[M,K] * op(B)[K,N] (+ bias[N])
 // TA: A is stored [K][M] (lda >= M); else [M][K].  TB: B is stored [N][K]; else [K][N].
+// The tile (m0, n0) of K slice `slice` (what one workgroup computes).
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool FAST>
-__global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
+__device__ __forceinline__ void gemm_f32_tile(
     int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
     float *__restrict__ C, int ldc, const float *__restrict__ bias, int epilogue, int kchunk,
-    int vecA, int vecB, Fold foldB, Fold foldC, double *__restrict__ colstats)
+    int vecA, int vecB, Fold foldB, Fold foldC, double *__restrict__ colstats, int m0, int n0, int slice)
 {
     static_assert(WM * WN * 64 == GEMM_THREADS, "4 waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;   // 32x32 tiles per wave
@@ -162,26 +163,6 @@ __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    // XCD-aware tile order: workgroups that share an A row-panel (same tile row) get
-    // consecutive virtual ids inside one XCD, so the panel is fetched from HBM once per XCD
-    // pass instead of once per column tile (PMC: 8x over-fetch of A without this)
-    const int tiles = gridDim.x * gridDim.y;
-    int vid, slice;
-    if (gridDim.z > 1 && (gridDim.z & 7) == 0) {
-        // split K, slices a multiple of 8: ALL tiles of a K slice go to ONE XCD (slice s -> XCD s % 8), in
-        // dispatch order, so the slice's A and B panels (1.3 + 4 MB for the dgcnn_agg weight gradient) are
-        // fetched from HBM once by the tiles that walk them in step instead of once per tile row / column:
-        // the transposed product of dgcnn_agg fetched 784 MB against 176 MB algorithmic with the per-slice
-        // tile order below (each XCD saw 5 of the 40 tiles of EVERY slice)
-        const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        const int u = lin >> 3;
-        slice = (lin & 7) + 8 * (u / tiles);
-        vid = u % tiles;
-    } else {
-        vid = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, tiles);
-        slice = blockIdx.z;
-    }
-    const int m0 = (vid / (int)gridDim.x) * BM, n0 = (vid % (int)gridDim.x) * BN;
     const int kbeg = slice * kchunk;
     const int kend = min(K, kbeg + kchunk);
 
@@ -308,6 +289,80 @@ __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
             }
         }
     }
+}
+
+// C[M,N] (+)= op(A)[M,K] * op(B)[K,N] (+ bias[N])
+// TA: A is stored [K][M] (lda >= M); else [M][K].  TB: B is stored [N][K]; else [K][N].
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool FAST>
+__global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
+    int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+    float *__restrict__ C, int ldc, const float *__restrict__ bias, int epilogue, int kchunk,
+    int vecA, int vecB, Fold foldB, Fold foldC, double *__restrict__ colstats)
+{
+    // XCD-aware tile order: workgroups that share an A row-panel (same tile row) get
+    // consecutive virtual ids inside one XCD, so the panel is fetched from HBM once per XCD
+    // pass instead of once per column tile (PMC: 8x over-fetch of A without this)
+    const int tiles = gridDim.x * gridDim.y;
+    int vid, slice;
+    if (gridDim.z > 1 && (gridDim.z & 7) == 0) {
+        // split K, slices a multiple of 8: ALL tiles of a K slice go to ONE XCD (slice s -> XCD s % 8), in
+        // dispatch order, so the slice's A and B panels (1.3 + 4 MB for the dgcnn_agg weight gradient) are
+        // fetched from HBM once by the tiles that walk them in step instead of once per tile row / column:
+        // the transposed product of dgcnn_agg fetched 784 MB against 176 MB algorithmic with the per-slice
+        // tile order below (each XCD saw 5 of the 40 tiles of EVERY slice)
+        const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int u = lin >> 3;
+        slice = (lin & 7) + 8 * (u / tiles);
+        vid = u % tiles;
+    } else {
+        vid = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, tiles);
+        slice = blockIdx.z;
+    }
+    gemm_f32_tile<BM, BN, WM, WN, TA, TB, FAST>(M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, kchunk, vecA, vecB, foldB,
+                                                foldC, colstats, (vid / (int)gridDim.x) * BM, (vid % (int)gridDim.x) * BN,
+                                                slice);
+}
+
+// ---- several independent weight-gradient products C_j = A_j^T B_j in ONE launch ------------------------------
+// The four edge-convolution layers each end their backward pass with dW = X^T [dP' | dQ]: 32768 rows reduced
+// into a 24..64 x 128..256 output, split over K into ~256 slices of one 64 x 128 tile.  Alone, such a launch
+// is a single wave of short workgroups -- 17-22 us of mostly latency for 4-7 us of memory traffic -- and nothing
+// waits for the result before the optimiser, so the four run as one launch at the end of backward.
+constexpr int GEMM_GROUP_MAX = 8;
+struct GemmGroupJob {
+    int M, N, K, lda, ldb, ldc, kchunk, vecA, vecB, block0, tiles_x, tiles, splits;
+    const float *A, *B;
+    float *C;
+    Fold foldC;
+};
+struct GemmGroup {
+    int count;
+    GemmGroupJob job[GEMM_GROUP_MAX];
+};
+
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_tn_group_kernel(GemmGroup g)
+{
+    int p = 0;
+    for (int i = 1; i < g.count; ++i)
+        if ((int)blockIdx.x >= g.job[i].block0)
+            p = i;
+    const GemmGroupJob &j = g.job[p];
+    const int local = (int)blockIdx.x - j.block0;
+    if (local >= j.tiles * j.splits)
+        return;                         // (padding up to the next multiple of 8)
+    int vid, slice;
+    if ((j.splits & 7) == 0) {          // (block0 is a multiple of 8: local & 7 is the XCD the workgroup runs on)
+        const int u = local >> 3;
+        slice = (local & 7) + 8 * (u / j.tiles);
+        vid = u % j.tiles;
+    } else {
+        slice = local / j.tiles;
+        vid = local % j.tiles;
+    }
+    const Fold nofold = {-1, 0};
+    gemm_f32_tile<64, 128, 2, 2, true, false, false>(j.M, j.N, j.K, j.A, j.lda, j.B, j.ldb, j.C, j.ldc, nullptr, EPI_ATOMIC,
+                                                     j.kchunk, j.vecA, j.vecB, nofold, j.foldC, nullptr,
+                                                     (vid / j.tiles_x) * 64, (vid % j.tiles_x) * 128, slice);
 }
 
 template <int BM, int BN, int WM, int WN, bool FAST>
@@ -511,4 +566,54 @@ CLOUDAAE_API int cloudaae_gemm_f32_colstats(int trans_a, int trans_b, int M, int
     CLOUDAAE_REQUIRE(colstats != nullptr, name, "null argument");
     return gemm_f32_launch(name, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, 0, 0, 0,
                            (hipStream_t)stream, colstats);
+}
+
+// Several weight-gradient products C_j (+)= A_j^T B_j in one launch (struct cloudaae_gemm_tn_job).  Every C_j is
+// added to with atomics: it must hold zeros (zeroed != 0: the caller cleared it; else this call clears it first).
+CLOUDAAE_API int cloudaae_gemm_f32_tn_group(int count, const cloudaae_gemm_tn_job *jobs, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_gemm_f32_tn_group";
+    CLOUDAAE_REQUIRE(count >= 1 && count <= GEMM_GROUP_MAX && jobs != nullptr, name, "1 to 8 products per launch");
+    hipStream_t s = (hipStream_t)stream;
+    GemmGroup g = {};
+    g.count = count;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        const cloudaae_gemm_tn_job &q = jobs[i];
+        CLOUDAAE_REQUIRE(q.M > 0 && q.N > 0 && q.K > 0 && q.A && q.B && q.C, name, "bad product");
+        CLOUDAAE_REQUIRE(q.lda >= q.M && q.ldb >= q.N, name, "leading dimension too small");
+        CLOUDAAE_REQUIRE(q.fold_c ? (q.ldc == q.fold_c && (q.fold_c & (q.fold_c - 1)) == 0 && q.fold_c % 4 == 0)
+                                  : q.ldc >= q.N, name, "bad output layout");
+        GemmGroupJob &j = g.job[i];
+        j.M = q.M; j.N = q.N; j.K = q.K; j.lda = q.lda; j.ldb = q.ldb; j.ldc = q.ldc;
+        j.A = q.A; j.B = q.B; j.C = q.C;
+        j.foldC.shift = q.fold_c ? __builtin_ctz((unsigned)q.fold_c) : -1;
+        j.foldC.rows = q.M;
+        j.tiles_x = ceil_div(q.N, 128);
+        j.tiles = j.tiles_x * ceil_div(q.M, 64);
+        // K slices: one wave of workgroups for the whole group (5 resident per CU), >= 64 k each, whole slices per XCD
+        int splits = (256 * 5 / count) / j.tiles;
+        if (splits > q.K / 64)
+            splits = q.K / 64;
+        if (splits > 8)
+            splits = splits / 8 * 8;
+        if (splits < 1)
+            splits = 1;
+        j.kchunk = ceil_div(ceil_div(q.K, splits), GEMM_BK) * GEMM_BK;
+        j.splits = ceil_div(q.K, j.kchunk);
+        j.vecA = (((uintptr_t)q.A & 15) == 0 && q.lda % 4 == 0) ? 1 : 0;
+        j.vecB = (((uintptr_t)q.B & 15) == 0 && q.ldb % 4 == 0) ? 1 : 0;
+        j.block0 = blocks;
+        blocks += ceil_div(j.tiles * j.splits, 8) * 8;      // (jobs start on a multiple of 8: see the kernel)
+        if (!q.zeroed) {
+            if (q.fold_c)
+                CLOUDAAE_CHECK_HIP(hipMemsetAsync(q.C, 0, sizeof(float) * (size_t)q.M * (size_t)q.N, s), name);
+            else
+                CLOUDAAE_CHECK_HIP(hipMemset2DAsync(q.C, sizeof(float) * (size_t)q.ldc, 0, sizeof(float) * (size_t)q.N,
+                                                    (size_t)q.M, s), name);
+        }
+    }
+    hipLaunchKernelGGL(gemm_f32_tn_group_kernel, dim3(blocks), dim3(GEMM_THREADS), 0, s, g);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
 }

@@ -258,6 +258,7 @@ class TrainGraph(object):
         try:
             out = self.forward(element, is_training=True)
             out['total_loss'].backward(self._one)
+            F.flush_deferred_dw()          # (deferred weight-gradient products of layers whose group stayed incomplete)
         finally:
             F.SIDE_STREAM = None
         if side is not None:

@@ -375,6 +375,30 @@ class ConcatSlot(object):
         # call builds all their reverse neighbour lists with one launch
         self.revs = []
         self.revs_built = False
+        # weight-gradient products of those layers, deferred to ONE grouped launch (cloudaae_gemm_f32_tn_group) when the
+        # last of them has run its backward pass: (job fields, tensors kept alive, the parameter's _ParamGrad)
+        self.dw_jobs = []
+
+
+_PENDING_DW = []        # ConcatSlots holding deferred weight-gradient products
+
+
+def flush_deferred_dw(slot=None):
+    """Launch the deferred weight-gradient products of `slot` (or of every slot that still holds some: the end of a
+    backward pass in which not every layer took part) as one grouped launch."""
+    slots = [slot] if slot is not None else list(_PENDING_DW)
+    for sl in slots:
+        if sl in _PENDING_DW:
+            _PENDING_DW.remove(sl)
+        jobs, sl.dw_jobs = sl.dw_jobs, []
+        if not jobs:
+            continue
+        arr = (_lib.GemmTnJob * len(jobs))()
+        for a, (f, _, _) in zip(arr, jobs):
+            a.M, a.N, a.K, a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.fold_c, a.zeroed = f
+        _lib.check(L().cloudaae_gemm_f32_tn_group(len(jobs), arr, stream()), "cloudaae_gemm_f32_tn_group")
+        for _, _, gw in jobs:
+            gw.done()
 
 
 class ConcatLinearFn(torch.autograd.Function):
@@ -677,13 +701,17 @@ class EdgeConvFn(torch.autograd.Function):
             tmp[id(g)] = g.buf
             g.buf = _lib.empty_like(g.buf)
         ws = _ws(L().cloudaae_edgeconv_workspace_bytes(cout), dev)
+        side = SIDE_STREAM if (SIDE_EDGE and not shared and gw.needed and gw.own is None) else None
+        # the weight gradient (nothing reads it before the optimiser) joins the other layers' in ONE grouped launch
+        # at the end of the encoder's backward pass: alone it is a single wave of short split-K workgroups
+        defer = (slot_r is not None and rev_ready and gw.needed and gw.own is None and not gw.accumulate and side is None
+                 and not ctx.bf16)
         head = (B, N, k, cin, cout, x.data_ptr(), x.stride(1), ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
                 training, pool_mode, ptr(pq), ptr(save_mean), ptr(save_var),
                 fwd_out.data_ptr() if fwd_out is not None else None, fwd_out.stride(1) if fwd_out is not None else 0,
-                ptr(ties), dout.data_ptr(), dout.stride(1), ptr(dpq), ptr(rev), rev_ready, dx_ptr, lddx, acc_dx, ptr(gw.buf),
-                1 if (gw.needed and gw.gemm_acc == 2) else 0, ptr(gb.buf), ptr(gg.buf), ptr(gbe.buf), ptr(ctx.estats),
-                int(ctx.bf16), ptr(ws))
-        side = SIDE_STREAM if (SIDE_EDGE and not shared and gw.needed and gw.own is None) else None
+                ptr(ties), dout.data_ptr(), dout.stride(1), ptr(dpq), ptr(rev), rev_ready, dx_ptr, lddx, acc_dx,
+                None if defer else ptr(gw.buf), 1 if (gw.needed and gw.gemm_acc == 2) else 0, ptr(gb.buf), ptr(gg.buf),
+                ptr(gbe.buf), ptr(ctx.estats), int(ctx.bf16), ptr(ws))
         if ctx.sync is not None:
             _lib.check(L().cloudaae_edgeconv_backward_sync(*(head + (ctx.sync.arg(cout, dev), stream(), side))),
                        "cloudaae_edgeconv_backward_sync")
@@ -692,6 +720,15 @@ class EdgeConvFn(torch.autograd.Function):
         for g in shared:
             L().cloudaae_add_f32(g.buf.numel(), ptr(tmp[id(g)]), ptr(g.buf), ptr(tmp[id(g)]), stream())
             g.buf = tmp[id(g)]
+        if defer:
+            # [dW_c | dW_n] = X^T [dP' | dQ] over the folded kernel (as cloudaae_edgeconv_backward would issue it)
+            slot_r.dw_jobs.append(((cin, 2 * cout, B * N, x.data_ptr(), x.stride(1), ptr(dpq), 2 * cout, ptr(gw.buf), cout,
+                                    cout, 1 if gw.gemm_acc == 2 else 0), (x, dpq), gw))
+            if slot_r not in _PENDING_DW:
+                _PENDING_DW.append(slot_r)
+            if len(slot_r.dw_jobs) == len(slot_r.revs):
+                flush_deferred_dw(slot_r)
+            return (dx, None, None, gb.done(), gg.done(), gbe.done()) + (None,) * 7
         return (dx, None, gw.done(), gb.done(), gg.done(), gbe.done()) + (None,) * 7
 
 

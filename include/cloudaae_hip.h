@@ -137,6 +137,23 @@ int cloudaae_gemm_f32_colstats(int trans_a, int trans_b, int M, int N, int K, co
 /* K slices cloudaae_gemm_f32 will use for this shape (> 1: the output is combined with atomics and
  * must hold zeros first -- the call clears it itself unless accumulate is 1 or 2). */
 int cloudaae_gemm_f32_splits(int M, int N, int K);
+/* Several independent weight-gradient products C_j += A_j^T B_j (A_j stored [K][M], B_j [K][N]: dW = x^T dy of
+ * utils/tf_util.py:161-166 for several layers) in ONE launch: each is a single wave of short split-K workgroups on its
+ * own, and nothing waits for them before the optimiser.  C_j is added to with atomics and must hold zeros: zeroed != 0
+ * says the caller cleared it, else the call does.  fold_c: 0, or the power-of-two width at which C's logical columns
+ * fold into stacked row blocks (the edge convolution's [2*cin, cout] kernel used as [cin, 2*cout]); then ldc == fold_c. */
+typedef struct cloudaae_gemm_tn_job {
+    int M, N, K;
+    const float *A;
+    int lda;
+    const float *B;
+    int ldb;
+    float *C;
+    int ldc;
+    int fold_c;
+    int zeroed;
+} cloudaae_gemm_tn_job;
+int cloudaae_gemm_f32_tn_group(int count, const cloudaae_gemm_tn_job *jobs, cloudaae_stream_t stream);
 /* The same product with both operands rounded to bfloat16 (round to nearest even) on their way
  * to the matrix cores (v_mfma_f32_32x32x16_bf16), fp32 accumulate; A, B, C, bias stay fp32 in
  * memory, so the call is interchangeable with cloudaae_gemm_f32 (BASELINE configs[2]: bf16 MLPs). */
