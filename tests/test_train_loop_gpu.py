@@ -80,7 +80,8 @@ def test_checkpoint_round_trip(hip, dataset, tmp_path):
     ck = np.load(path)
     names = set(ck.files)
     # the names tf.train.Saver would write for this graph
-    for n in ("dgcnn1/weights", "dgcnn1/bn/beta", "dgcnn1/bn/moments/Squeeze/ExponentialMovingAverage",
+    # (BN moving averages carry the tf.name_scope the model is built under, train...:223: see tf_variable_name)
+    for n in ("dgcnn1/weights", "dgcnn1/bn/beta", "dgcnn1/bn/decoder/dgcnn1/bn/moments/Squeeze/ExponentialMovingAverage",
               "dgcnn1/weights/Adam", "dgcnn1/weights/Adam_1", "beta1_power", "beta2_power", "Variable"):
         assert n in names, n
     assert float(ck["Variable"]) == 3.0
