@@ -54,6 +54,23 @@ struct TopK {
             i[p] = sw ? ia : ib;
         }
     }
+    // insert_lex: branch free, for newcomers that arrive in ANY order: (d, index) compared lexicographically
+    __device__ __forceinline__ void insert_lex(float nd, int ni)
+    {
+        const bool in = nd < d[K - 1] || (nd == d[K - 1] && ni < i[K - 1]);
+        d[K - 1] = in ? nd : d[K - 1];
+        i[K - 1] = in ? ni : i[K - 1];
+#pragma unroll
+        for (int p = K - 1; p > 0; --p) {
+            const bool sw = d[p] < d[p - 1] || (d[p] == d[p - 1] && i[p] < i[p - 1]);
+            const float a = d[p - 1], b = d[p];
+            const int ia = i[p - 1], ib = i[p];
+            d[p - 1] = sw ? b : a;
+            d[p] = sw ? a : b;
+            i[p - 1] = sw ? ib : ia;
+            i[p] = sw ? ia : ib;
+        }
+    }
     // stable: the newcomer only passes entries that are strictly larger
     __device__ __forceinline__ void insert(float nd, int ni)
     {
@@ -769,13 +786,15 @@ static hipError_t launch_knn_scan(int b, int n, int ld, int k, const float *x, i
 //            smallest unit minimum over the query's 2*CS lane lists is tau.  The K smallest unit minima belong
 //            to K DISTINCT candidates, so tau >= the true K-th smallest distance; with 64 units of four
 //            (n = 1024) about 40 of the 1024 candidates lie at or below it.
-//   pass B : every tile; a candidate is pushed on the lane's LDS queue iff d <= tau (one 8-byte write, branch
-//            free), ~10 per lane over the whole scan.  The queue goes through the sorted insert only when it
-//            could overflow (ties, duplicated points: correctness never depends on the bound being tight) and
-//            once at the end; then the 2*CS lists of a query are merged by (d, j) as before.
+//   pass B : every tile; a candidate with d <= tau is APPENDED to its query's LDS queue (shared by the query's
+//            2*CS lanes, slots handed out by an LDS atomic; ~46 of 1024 candidates).  The sorted lists are built
+//            once, after the scan: each of the query's lanes takes every (2*CS)-th queue entry through a
+//            branch-free lexicographic insert, then the 2*CS lists are merged by (d, j) as before.  A query whose
+//            queue is full (duplicated points, adversarial clouds) raises the workgroup's flag and the workgroup
+//            repeats the scan the plain way (sorted insert per candidate): correctness never depends on the bound.
 // Both passes evaluate d with the SAME instructions on the same MFMA results, so "d <= tau" in pass B is exact
 // and the indices stay bit-identical to oracle_knn.  Matrix work: 1.25 x the N x N x 64 products.
-constexpr int KB_QCAP = 26;          // queue slots per lane (d and j, 4 bytes each)
+constexpr int KB_QCAP = 36;          // queue slots per lane-list; a query owns 2*CS*KB_QCAP (fp32 distance + 16-bit index)
 
 template <int K>
 struct MinK {                        // the K smallest values seen, ascending
@@ -807,11 +826,14 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_bound_kernel(int n, int ld
     constexpr int KS_LD = 68;                              // staged row: [32 even channels | 32 odd | 4 pad]
     constexpr int TILE_FLOATS = KM_TILE * KS_LD;
     extern __shared__ __attribute__((aligned(16))) char kb_smem[];
-    // layout: tile[2][CS][TILE_FLOATS] | queue d[WAVES][QCAP][64] | queue j[WAVES][QCAP][64] | sq[ntiles * 32] | 1.0
+    // layout: tile[2][CS][TILE_FLOATS] | queue d[QW * 32 queries][QPQ] (fp32) | queue j, same shape (u16: n <= 65536) |
+    //         queue lengths [QW * 32] | sq[ntiles * 32] | 1.0 | overflow flag
+    constexpr int QPQ = 2 * CS * KB_QCAP;                  // queue slots per QUERY (its 2 * CS lanes share them)
     float *tiles = reinterpret_cast<float *>(kb_smem);
     float *qd_all = tiles + 2 * CS * TILE_FLOATS;
-    int *qj_all = reinterpret_cast<int *>(qd_all + WAVES * KB_QCAP * 64);
-    float *sq = reinterpret_cast<float *>(qj_all + WAVES * KB_QCAP * 64);
+    unsigned short *qj_all = reinterpret_cast<unsigned short *>(qd_all + QW * 32 * QPQ);
+    int *qn_all = reinterpret_cast<int *>(qj_all + QW * 32 * QPQ);
+    float *sq = reinterpret_cast<float *>(qn_all + QW * 32);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qt = wave / CS, cs = wave % CS;
@@ -822,8 +844,11 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_bound_kernel(int n, int ld
 
     // |x_j|^2 of the whole cloud (oracle order: sequential un-fused sum of rounded squares); rows past the end
     // hold +inf, so their distances come out +inf and never pass a finite threshold; sq[ntiles * 32] = 1.0
-    for (int j = tid; j <= ntiles * KM_TILE; j += THREADS) {
-        float acc = j == ntiles * KM_TILE ? 1.0f : __builtin_inff();
+    for (int j = tid; j < QW * 32; j += THREADS)
+        qn_all[j] = 0;
+    for (int j = tid; j <= ntiles * KM_TILE + 1; j += THREADS) {
+        // (sq[ntiles * 32] = 1.0 for the 33rd step; the word behind it = 0: the workgroup's "a queue overflowed" flag)
+        float acc = j == ntiles * KM_TILE ? 1.0f : (j > ntiles * KM_TILE ? 0.0f : __builtin_inff());
         if (j < n) {
             const float *row = X + (size_t)j * ld;
             acc = 0.0f;
@@ -965,9 +990,9 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_bound_kernel(int n, int ld
     }
     // K-th smallest unit minimum over the 2*CS lists of the query, through the queue area of the query
     // tile's first wave: [list][p][query]
-    float *md = qd_all + (qt * CS) * KB_QCAP * 64;
-    int *mi = qj_all + (qt * CS) * KB_QCAP * 64;
-    static_assert(2 * CS * K * 32 <= CS * KB_QCAP * 64, "scratch lists must fit the queue area of one query tile");
+    float *md = qd_all + qt * 32 * QPQ;
+    unsigned short *mi = qj_all + qt * 32 * QPQ;               // (indices of the merge lists: 16 bits)
+    static_assert(2 * CS * K * 32 <= 32 * QPQ, "scratch lists must fit the queue area of one query tile");
     const int list = cs * 2 + half;
 #pragma unroll
     for (int p = 0; p < K; ++p)
@@ -1006,46 +1031,22 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_bound_kernel(int n, int ld
     __syncthreads();                                       // scratch lists consumed (the queues start empty)
 
     // ---------------- pass B: everything at or below tau ----------------
-    // this lane's queue is qd_all / qj_all[q0 + 64 t]; wo = its next free slot
-    const int q0 = wave * KB_QCAP * 64 + lane;
-    int wo = q0;
-    const int wlimit = q0 + (KB_QCAP - 4) * 64;           // room for one group of four candidates
+    // The queue of a QUERY is shared by its 2 * CS lanes (the lane halves of CS waves): slots are handed out by an
+    // LDS atomic on the query's length -- a pass is rare, and one lane's share of the cloud can hold three times its
+    // fair share of a query's candidates (a per-lane queue of 36 slots overflowed in most workgroups although the
+    // average lane uses 12).
+    const int qq = qt * 32 + col;                          // this lane's query within the workgroup
+    float *qd = qd_all + qq * QPQ;
+    unsigned short *qj = qj_all + qq * QPQ;
     // The scan only APPENDS: the sorted lists (20 registers of state) are built once, after it.  Any use of them
     // inside the loop costs dearly twice over -- the waves of a workgroup meet at a barrier every round, so a wave
     // that stops to insert makes the other seven wait (48 of 130 us), and every branch around code that changes
-    // the lists drags ~40 register copies along (the compiler's phi moves: 10 k instructions per wave).
-    // A queue that is nearly full (> 22 candidates at or below tau in one lane's share of the cloud: duplicated
-    // points, outliers) is SQUEEZED in place instead: with t' = the K-th smallest queued distance, only the
-    // entries below t' and the first ties at t' (in index order) can still reach the query's K best, and later
-    // candidates must be strictly below t'.  State touched: tau and the queue pointer.
-    auto squeeze = [&]() {
-        if (wo > wlimit) {
-            MinK<K> mk;
-            mk.init();
-            for (int ro = q0; ro < wo; ro += 64)
-                mk.insert(qd_all[ro]);
-            const float t1 = mk.d[K - 1];
-            int ties = K, w2 = q0;                         // ties at t1 that may stay: K - #(entries below t1)
-#pragma unroll
-            for (int p = 0; p < K; ++p)
-                ties -= mk.d[p] < t1 ? 1 : 0;
-            for (int ro = q0; ro < wo; ro += 64) {
-                const float d = qd_all[ro];
-                const int jj = qj_all[ro];
-                const bool tie = d == t1;
-                if (d < t1 || (tie && ties > 0)) {         // ascending index order: the first ties win
-                    qd_all[w2] = d;
-                    qj_all[w2] = jj;
-                    w2 += 64;
-                    ties -= tie ? 1 : 0;
-                }
-            }
-            wo = w2;                                       // at most K entries left
-            // from now on: strictly below t1 (the largest float below it; t1 is finite: it is <= tau)
-            const unsigned tb = __float_as_uint(t1);
-            tau = t1 > 0.0f ? __uint_as_float(tb - 1u) : (t1 < 0.0f ? __uint_as_float(tb + 1u) : -1.4e-45f);
-        }
-    };
+    // the lists drags ~40 register copies along (the compiler's phi moves: 10 k instructions per wave); even an
+    // overflow handler that is merely PRESENT in the loop (inlined or called) cost 19-35 us.  So when a query's
+    // queue is full (> 144 candidates at or below tau: duplicated points, adversarial clouds) the candidate is
+    // dropped and the workgroup's flag raised; a flagged workgroup then repeats the scan the slow, plain way (sorted
+    // insert per candidate, no bound) -- correctness never depends on the bound being tight.
+    bool lost = false;
     // candidates 4 g .. 4 g + 3 of the previous tile: a pass is rare (a few per cent), lanes that pass append
     // (d, j) to their queue
     f32x16 prev;
@@ -1054,14 +1055,16 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_bound_kernel(int n, int ld
         prev[e] = __builtin_inff();
     int pj = 0;
     auto push4 = [&](int g) {
-        if (__any(wo > wlimit))
-            squeeze();
 #pragma unroll
         for (int e = 4 * g; e < 4 * g + 4; ++e)
             if (prev[e] <= tau) {
-                qd_all[wo] = prev[e];
-                qj_all[wo] = pj + (e & 3) + 8 * (e >> 2);
-                wo += 64;
+                const int slot = atomicAdd(&qn_all[qq], 1);
+                if (slot < QPQ) {
+                    qd[slot] = prev[e];
+                    qj[slot] = (unsigned short)(pj + (e & 3) + 8 * (e >> 2));
+                } else {
+                    lost = true;
+                }
             }
     };
     auto c0B = [&](int r) { return min(r * CS + cs, ntiles - 1) * KM_TILE; };   // (idle slot of the last round: the
@@ -1109,22 +1112,54 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_bound_kernel(int n, int ld
 #pragma unroll
     for (int g = 0; g < 4; ++g)                            // the last tile's filter
         push4(g);
+    int *flag = reinterpret_cast<int *>(sq + ntiles * KM_TILE + 1);
+    if (lost)
+        *flag = 1;
+    __syncthreads();
     // the queue -> this lane's sorted list of its K best (candidates were appended in ascending index order and
     // the insert is stable, so ties keep the lower index first)
     TopK<K> top;
     top.init();
-    {
-        // (entries past a lane's end read as +inf: no branch around the insert; the next entry is in flight while
-        //  the current one bubbles down)
-        float nd = q0 < wo ? qd_all[q0] : __builtin_inff();
-        int ni = qj_all[q0];
-        for (int ro = q0; __any(ro < wo); ro += 64) {
+    if (*flag == 0) {
+        // The query's 2 * CS lanes take every (2 * CS)-th entry of its queue.  Slots were handed out in arrival
+        // order, not index order, so the insert compares (d, j) lexicographically (the tie rule: lower index first).
+        // Entries past the end read as (+inf, _): no branch around the insert; the next entry is in flight while the
+        // current one bubbles down.
+        const int nq_ = min(qn_all[qq], QPQ);
+        int ro = list;
+        float nd = ro < nq_ ? qd[ro] : __builtin_inff();
+        int ni = (int)qj[min(ro, QPQ - 1)];
+        for (; __any(ro < nq_); ro += 2 * CS) {
             const float cd = nd;
             const int ci = ni;
-            const int rn = ro + 64;
-            nd = rn < wo ? qd_all[min(rn, q0 + (KB_QCAP - 1) * 64)] : __builtin_inff();
-            ni = qj_all[min(rn, q0 + (KB_QCAP - 1) * 64)];
-            top.insert_bf(cd, ci);
+            const int rn = ro + 2 * CS;
+            nd = rn < nq_ ? qd[min(rn, QPQ - 1)] : __builtin_inff();
+            ni = (int)qj[min(rn, QPQ - 1)];
+            top.insert_lex(cd, ci);
+        }
+    } else {
+        // a queue overflowed somewhere in this workgroup: the plain scan (every candidate through the sorted insert)
+        for (int r = 0; r < roundsB; ++r) {
+            __syncthreads();                               // the tile buffer is free
+            fetch(false, r);
+            commit(tiles);
+            __syncthreads();
+            float4v op[8];
+            float axp;
+            const int c0 = c0B(r);
+            operands(tiles, c0, op, axp);
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                acc[e] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 32; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[s >> 2][s & 3], bq[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bx, acc, 0, 0, 0);
+            if (r * CS + cs < ntiles) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    top.insert(acc[e], c0 + 4 * half + (e & 3) + 8 * (e >> 2));     // (+inf rows past the end: rejected)
+            }
         }
     }
 
@@ -1134,7 +1169,7 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_bound_kernel(int n, int ld
 #pragma unroll
     for (int p = 0; p < K; ++p) {
         md[(list * K + p) * 32 + col] = top.d[p];
-        mi[(list * K + p) * 32 + col] = top.i[p];
+        mi[(list * K + p) * 32 + col] = (unsigned short)top.i[p];
     }
     __syncthreads();
     if (cs == 0 && half == 0 && qvalid) {
@@ -1150,7 +1185,7 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_bound_kernel(int n, int ld
             for (int l = 0; l < 2 * CS; ++l) {
                 const int h = head[l];
                 const float d = h < K ? md[(l * K + h) * 32 + col] : __builtin_inff();
-                const int i = h < K ? mi[(l * K + h) * 32 + col] : 0x7fffffff;
+                const int i = h < K ? (int)mi[(l * K + h) * 32 + col] : 0x7fffffff;
                 const bool better = d < bd || (d == bd && i < bi);
                 bd = better ? d : bd;
                 bi = better ? i : bi;
@@ -1168,7 +1203,7 @@ template <int K, int QW, int CS>
 static hipError_t launch_knn_bound(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
     const size_t lds = sizeof(float) * (2 * CS * KM_TILE * 68 + (size_t)ceil_div(n, KM_TILE) * KM_TILE + 4) +
-                       2 * sizeof(float) * QW * CS * KB_QCAP * 64;
+                       (sizeof(float) + sizeof(unsigned short)) * QW * 32 * (2 * CS * KB_QCAP) + sizeof(int) * QW * 32;
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn64_bound_kernel<K, QW, CS>),
