@@ -289,8 +289,20 @@ static void launch_bf16(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N
 // tile shape and K slices (same policy as gemm.hip's gemm_plan, slabs of 32)
 static void gemm_bf16_plan(int M, int N, int K, int &BM, int &BN, int &splits)
 {
+    // With bf16 operands these products are bound by what the CUs pull out of L2, so the side that is a multiple of
+    // 160 but not of 128 (the 320 concat channels of dgcnn_agg: N of dX, M of dW) takes 160-wide tiles of five 32 x 32
+    // accumulators per wave: the big operand (dY, 1.07 GB at B=256) is then re-read twice instead of five times
+    // (measured, dW / dX: B=256 987 -> 716 / 563 -> 542 us, B=128 494 -> 372 / 288 -> 276 us, B=32 139 -> 152 / 79 -> 64 us:
+    // the transposed product keeps 64-row tiles below 65536 rows of K).  CLOUDAAE_BF16_TILE160=0 switches the rule off.
+    const bool t160 = !(getenv("CLOUDAAE_BF16_TILE160") && atoi(getenv("CLOUDAAE_BF16_TILE160")) == 0);
     if (M <= 32) {
         BM = 32;
+        BN = 128;
+    } else if (t160 && N % 160 == 0 && N % 128 != 0 && M >= 1024) {
+        BM = 128;
+        BN = 160;
+    } else if (t160 && M % 160 == 0 && M % 128 != 0 && N % 128 == 0 && K >= 65536) {
+        BM = 160;
         BN = 128;
     } else if (N <= 64 || (N % 128 != 0 && N % 64 == 0)) {
         BM = 128;
@@ -378,6 +390,12 @@ int cloudaae::gemm_bf16_launch(const char *name, int trans_a, int trans_b, int M
     if (BM == 32)
         launch_bf16<32, 128, 1, 4>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
                                    fc, colstats);
+    else if (BN == 160)
+        launch_bf16<128, 160, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
+                                    fc, colstats);
+    else if (BM == 160)
+        launch_bf16<160, 128, 1, 4>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
+                                    fc, colstats);
     else if (BN == 64)
         launch_bf16<128, 64, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
                                    fc, colstats);
