@@ -253,6 +253,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CLOUDAAE_BENCH_DRYRUN") == "1":      # (CPU test of the launch path: no GPU is touched)
+        print(json.dumps({"dryrun": True, "rank": rank, "world": world, "local_rank": local,
+                          "per_gpu_batch": args.per_gpu_batch or (32 if world == 1 else 128)}), flush=True)
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     force = os.environ.get("CLOUDAAE_FORCE_COLLECTIVES") == "1" and "MASTER_ADDR" in os.environ

@@ -413,6 +413,11 @@ static void gemm_plan(int M, int N, int K, int &BM, int &BN, int &splits)
     if (M <= 32) {
         BM = 32;
         BN = 128;
+    } else if (N % 160 == 0 && N % 128 != 0 && M >= 1024 && K >= 512 && !getenv("CLOUDAAE_F32_TILE64")) {
+        // dX of dgcnn_agg (N = 320): 160-wide tiles, five 32 x 32 accumulators per wave -- 1.2 LDS fragment reads per
+        // MFMA instead of 1.5 and 512 workgroups instead of 1280: 214 -> 208 us (B=32), 830 -> 807 us (B=128)
+        BM = 128;
+        BN = 160;
     } else if (N <= 64 || (N % 128 != 0 && N % 64 == 0)) {
         BM = 128;
         BN = 64;
@@ -527,6 +532,9 @@ int cloudaae::gemm_f32_launch(const char *name, int trans_a, int trans_b, int M,
     if (BM == 32)
         launch_cfg<32, 128, 1, 4>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
                                   vecA, vecB, fb, fc, colstats);
+    else if (BN == 160)
+        launch_cfg<128, 160, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
+                                   vecA, vecB, fb, fc, colstats);
     else if (BM == 64 && BN == 64)
         launch_cfg<64, 64, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
                                  vecA, vecB, fb, fc, colstats);

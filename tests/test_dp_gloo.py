@@ -127,3 +127,32 @@ def test_variable_store_flat_layout_cpu():
     sd["dgcnn1/biases"] = torch.full((64,), 3.0)
     st.load_state_dict(sd)
     assert float(st.flat_params[48 * 64]) == 3.0
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) must start N ranks itself, as children of a
+    parent that never touches the GPU, and exit with their code.  Checked on CPU with CLOUDAAE_BENCH_DRYRUN=1 (every
+    rank reports who it is and stops before any GPU call)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["CLOUDAAE_BENCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert sorted(l["rank"] for l in lines) == [0, 1] and all(l["world"] == 2 for l in lines), r.stdout[-2000:]
+    assert all(l["per_gpu_batch"] == 128 for l in lines)            # the per-GPU shape of BASELINE configs[3]
+    # one GPU: no children, BASELINE configs[1]'s batch
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py")], env=env, capture_output=True, text=True,
+                        timeout=300)
+    l1 = [json.loads(l) for l in r1.stdout.splitlines() if l.startswith("{")]
+    assert r1.returncode == 0 and len(l1) == 1 and l1[0]["world"] == 1 and l1[0]["per_gpu_batch"] == 32
+    # under a launcher it is a rank itself: no second level of children
+    env2 = dict(env, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2,
+                        capture_output=True, text=True, timeout=300)
+    l2 = [json.loads(l) for l in r2.stdout.splitlines() if l.startswith("{")]
+    assert r2.returncode == 0 and len(l2) == 1 and l2[0]["rank"] == 1
