@@ -120,7 +120,9 @@ class TrainGraph(object):
         # sync_bn: batch-norm moments (and their gradients) over the GLOBAL batch -- what the single-GPU
         # reference computes (utils/tf_util.py:492: tf.nn.moments over the whole batch), so that an N-rank
         # run equals a 1-rank run of the global batch; default: per-rank moments (local BN)
-        self.sync_bn = bool(sync_bn) and self.world > 1
+        # (CLOUDAAE_FORCE_COLLECTIVES=1: also with one rank, to exercise the RCCL path on a single-GPU box)
+        forced = not solo and os.environ.get("CLOUDAAE_FORCE_COLLECTIVES") == "1"
+        self.sync_bn = bool(sync_bn) and (self.world > 1 or forced)
         self.bn_sync = None
         if self.sync_bn:
             from .utils.sync_bn import BnSync
