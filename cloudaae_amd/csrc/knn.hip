@@ -36,25 +36,8 @@ struct TopK {
             i[p] = 0;
         }
     }
-    // insert_bf: the same without a branch (a divergent `if` around 2K registers of state drags ~4K register copies
-    // along in the compiled code); (+inf, _) is a no-op
-    __device__ __forceinline__ void insert_bf(float nd, int ni)
-    {
-        const bool in = nd < d[K - 1];
-        d[K - 1] = in ? nd : d[K - 1];
-        i[K - 1] = in ? ni : i[K - 1];
-#pragma unroll
-        for (int p = K - 1; p > 0; --p) {
-            const bool sw = d[p] < d[p - 1];
-            const float a = d[p - 1], b = d[p];
-            const int ia = i[p - 1], ib = i[p];
-            d[p - 1] = sw ? b : a;
-            d[p] = sw ? a : b;
-            i[p - 1] = sw ? ib : ia;
-            i[p] = sw ? ia : ib;
-        }
-    }
-    // insert_lex: branch free, for newcomers that arrive in ANY order: (d, index) compared lexicographically
+    // insert_lex: branch free (a divergent `if` around 2K registers of state drags ~4K register copies along in the
+    // compiled code), for newcomers that arrive in ANY order: (d, index) compared lexicographically; (+inf, _) is a no-op
     __device__ __forceinline__ void insert_lex(float nd, int ni)
     {
         const bool in = nd < d[K - 1] || (nd == d[K - 1] && ni < i[K - 1]);
