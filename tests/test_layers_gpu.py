@@ -550,3 +550,37 @@ def test_gemm_bf16_colstats(hip, M, N, K):
     stats = cs.reshape(parts, 2, N).sum(0)
     Cd = C1.double()
     assert _rel(stats[0], Cd.sum(0)) < 1e-9 and _rel(stats[1], (Cd * Cd).sum(0)) < 1e-9
+
+
+def test_gemm_tn_group(hip):
+    """cloudaae_gemm_f32_tn_group: several weight-gradient products C_j += A_j^T B_j in one launch -- partial tiles
+    (M = 24), a folded output ([2*cin, cout] kernel addressed as [cin, 2*cout]), outputs cleared by the call or by the
+    caller -- against float64 products."""
+    import ctypes
+    L = hip.lib()
+    rng = np.random.default_rng(4)
+    shapes = [(24, 128, 5000, 64, 1), (64, 128, 4096, 64, 0), (64, 256, 32768, 128, 1), (130, 70, 777, 0, 0)]   # M, N, K, fold_c, zeroed
+    jobs = (hip.GemmTnJob * len(shapes))()
+    keep, want = [], []
+    for j, (M, N, K, fold, zeroed) in zip(jobs, shapes):
+        lda, ldb = M + 8, N
+        A = torch.from_numpy(rng.standard_normal((K, lda)).astype(np.float32)).cuda()
+        B = torch.from_numpy(rng.standard_normal((K, ldb)).astype(np.float32)).cuda()
+        if fold:
+            C = torch.zeros((N // fold) * M, fold, device="cuda") if zeroed else torch.full(((N // fold) * M, fold), 7.0, device="cuda")
+            ldc = fold
+        else:
+            C = torch.zeros(M, N, device="cuda") if zeroed else torch.full((M, N), 7.0, device="cuda")
+            ldc = N
+        j.M, j.N, j.K, j.A, j.lda, j.B, j.ldb, j.C, j.ldc, j.fold_c, j.zeroed = M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc, fold, zeroed
+        keep.append((A, B, C))
+        want.append(A[:, :M].double().t().cpu() @ B.double().cpu())
+    hip.check(L.cloudaae_gemm_f32_tn_group(len(shapes), jobs, hip.stream()), "group")
+    torch.cuda.synchronize()
+    for (M, N, K, fold, _), (_, _, C), w in zip(shapes, keep, want):
+        got = C.cpu().double()
+        if fold:      # logical (r, c) lives at row (c // fold) * M + r, column c % fold
+            got = got.reshape(N // fold, M, fold).permute(1, 0, 2).reshape(M, N)
+        assert float((got - w).abs().max()) / (math.sqrt(K) + 1) < 2e-5, (M, N, K)
+    # more than eight products per launch is refused
+    assert L.cloudaae_gemm_f32_tn_group(9, jobs, hip.stream()) != 0
