@@ -74,6 +74,47 @@ struct TopK {
     }
 };
 
+// A (distance, index) pair as ONE positive double that orders the way the pair does lexicographically: the float's
+// bits made monotone (sign folded) times 2^16, plus the index (< 65536); 48 bits, exact.  A sorted insert is then K
+// min/max pairs (20 instructions for K = 10, against ~90 for the compare-and-select network on (float, int) pairs).
+__device__ __forceinline__ double knn_key(float d, int j)
+{
+    d = d + 0.0f;                                           // -0 -> +0: they compare equal as floats
+    const unsigned b = __float_as_uint(d);
+    const unsigned u = b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+    return __builtin_fma((double)u, 65536.0, (double)j);
+}
+__device__ __forceinline__ int knn_key_index(double key)   // an empty slot (+inf) reads as index 0
+{
+    const double hi = __builtin_trunc(__builtin_ldexp(key, -16));
+    const int j = (int)__builtin_fma(-hi, 65536.0, key);
+    return key < __builtin_inf() ? j : 0;
+}
+
+template <int K>
+struct TopKey {                      // the K smallest keys, ascending
+    double key[K];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int p = 0; p < K; ++p)
+            key[p] = __builtin_inf();
+    }
+    __device__ __forceinline__ void insert(double x)
+    {
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            // (v_min_f64 / v_max_f64 spelled out: __builtin_fmin would first canonicalize the loop-carried key,
+            // a third instruction per slot; keys are never NaN)
+            double lo, hi;
+            asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(key[p]), "v"(x));
+            asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(key[p]), "v"(x));
+            key[p] = lo;
+            x = hi;
+        }
+    }
+};
+
 template <int K>
 __device__ __forceinline__ void merge_and_store(TopK<K> &top, float *mbuf_d, int *mbuf_i, int wave,
                                                 int lane, bool valid, int k, int *dst)
@@ -1200,6 +1241,350 @@ static hipError_t launch_knn_bound(int b, int n, int ld, int k, const float *x, 
     return hipSuccess;
 }
 
+static size_t knn_wide_lds_bytes(int n)
+{
+    return sizeof(float) * (4 * KM_TILE * 68 + (size_t)ceil_div(n, KM_TILE) * KM_TILE + 4) +
+           (sizeof(float) + sizeof(unsigned short)) * 128 * 144 + sizeof(int) * 128;
+}
+
+// ---- C = 64, bound pass + filtered scan with FOUR waves per SIMD (16-wave workgroups) ---------------------------
+// knn64_bound_kernel above leaves the matrix pipe idle two thirds of the time: with one 8-wave workgroup per CU
+// (256 workgroups for 256 CUs at B = 32) two lock-stepped waves share a SIMD, and each wave's own serial chain --
+// its dependent MFMAs, its vector instructions, its LDS and barrier waits -- sets the kernel time.  Here a query
+// tile is scanned by CS = 4 waves (a quarter of the candidate tiles each), a workgroup is QW x CS = 16 waves, so
+// every SIMD has four waves to overlap and each wave's chain is half as long.  What that costs: 128 registers per
+// lane (no operand double-buffering, the filter runs right after its tile's MFMAs) and one LDS tile buffer per wave
+// slot (two barriers per round: operands read, next tiles committed).  Same arithmetic, same queues, same fallback.
+template <int K>
+__global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, const float *__restrict__ x,
+                                                          const float *__restrict__ sqnorm,
+                                                          int *__restrict__ nn_idx, int dbg)
+{
+    constexpr int QW = 4, CS = 4, THREADS = 1024;
+    constexpr int KS_LD = 68;                              // staged row: [32 even channels | 32 odd | 4 pad]
+    constexpr int TILE_FLOATS = KM_TILE * KS_LD;
+    constexpr int QPQ = 144;                               // queue slots per query (its 8 lanes share them)
+    extern __shared__ __attribute__((aligned(16))) char kw_smem[];
+    // layout: tile[CS][TILE_FLOATS] | queue d[128 queries][QPQ] (fp32) | queue j, same shape (u16) | queue lengths [128] |
+    //         sq[ntiles * 32] | 1.0 | overflow flag
+    float *tiles = reinterpret_cast<float *>(kw_smem);
+    float *qd_all = tiles + CS * TILE_FLOATS;
+    unsigned short *qj_all = reinterpret_cast<unsigned short *>(qd_all + QW * 32 * QPQ);
+    int *qn_all = reinterpret_cast<int *>(qj_all + QW * 32 * QPQ);
+    float *sq = reinterpret_cast<float *>(qn_all + QW * 32);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qt = wave / CS, cs = wave % CS;
+    int qgroup, cloud;
+    xcd_cloud_tile(qgroup, cloud);
+    const float *X = x + (size_t)cloud * n * ld;
+    const int ntiles = (n + KM_TILE - 1) / KM_TILE;
+
+    for (int j = tid; j < QW * 32; j += THREADS)
+        qn_all[j] = 0;
+    for (int j = tid; j <= ntiles * KM_TILE + 1; j += THREADS)   // |x_j|^2; +inf past the end; 1.0 (33rd step); 0 = the overflow flag
+        sq[j] = j < n ? sqnorm[(size_t)cloud * n + j]
+                      : (j == ntiles * KM_TILE ? 1.0f : (j > ntiles * KM_TILE ? 0.0f : __builtin_inff()));
+
+    const int col = lane & 31, half = lane >> 5;
+    const int qi0 = (qgroup * QW + qt) * KM_TILE + col;   // this lane's query
+    const bool qvalid = qi0 < n;
+    const int qs = qvalid ? qi0 : 0;
+    const int S = min(ntiles, max((ntiles + 3) / 4, 4));   // pass A's sample: S tiles, every stride-th one
+    const int stride = ntiles / S;
+
+    // staging: a round = CS tiles of 32 rows x 16 float4 = 2048 float4, two per thread (rows srow and srow + 64)
+    const int srow = tid >> 4, sq4 = tid & 15;
+    const float *gsrc = X + (size_t)srow * ld + 4 * sq4;
+    float4v stage[2];
+    auto fetch = [&](int what, int r) {                    // what: 0 = pass B's tiles, 1 = pass A's sample, 2 = the query tiles
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rowu = u * 64 + srow;                // row within the round's 128 rows
+            const int slot = r * CS + (rowu >> 5);
+            const int c0 = what == 1 ? (slot < S ? slot * stride * KM_TILE : n)
+                                     : (what == 2 ? qgroup * QW + slot : slot) * KM_TILE;
+            const int g = c0 + (rowu & 31);
+            stage[u] = g < n ? *reinterpret_cast<const float4v *>(gsrc + (size_t)(g - srow) * ld)
+                             : float4v{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rowu = u * 64 + srow;
+            float *dst = tiles + (rowu >> 5) * TILE_FLOATS + (rowu & 31) * KS_LD + 2 * sq4;
+            *reinterpret_cast<float2v *>(dst) = float2v{stage[u].x, stage[u].z};
+            *reinterpret_cast<float2v *>(dst + 32) = float2v{stage[u].y, stage[u].w};
+        }
+    };
+    const float4v *arow = reinterpret_cast<const float4v *>(tiles + cs * TILE_FLOATS + col * KS_LD + 32 * half);
+    const int xoff = half ? col : ntiles * KM_TILE;        // 33rd step, candidate side: sq[c0 + col] (k = 1) or 1.0 (k = 0)
+    const int xmul = half;
+
+    f32x16 acc;
+    float bq[32];                                         // B operand: -2 x the query's channels of parity `half`
+    float bx = 1.0f;
+    // one round: operands of this wave's tile -> registers, next round's tiles -> LDS, the 33 MFMA steps
+    auto round = [&](int what, int r, int rounds, int c0) {
+        __syncthreads();                                   // this round's tiles are in LDS
+        float4v a4[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            a4[s] = arow[s];
+        const float ax = sq[xoff + xmul * c0];
+        __syncthreads();                                   // every wave holds its operands: the buffer is free
+        if (r + 1 < rounds)
+            commit();
+        if (r + 2 < rounds)
+            fetch(what, r + 2);
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            acc[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s >> 2][s & 3], bq[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, acc, 0, 0, 0);
+    };
+
+    // ---------------- pass A: tau ----------------
+    const int roundsA = (S + CS - 1) / CS;
+    fetch(2, 0);                                           // the workgroup's 4 query tiles, staged like candidate tiles
+    commit();
+    fetch(1, 0);
+    __syncthreads();
+    {
+        const float4v *qrow = reinterpret_cast<const float4v *>(tiles + qt * TILE_FLOATS + col * KS_LD + 32 * half);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float4v v = qrow[s];
+            bq[4 * s] = -2.0f * v.x;
+            bq[4 * s + 1] = -2.0f * v.y;
+            bq[4 * s + 2] = -2.0f * v.z;
+            bq[4 * s + 3] = -2.0f * v.w;
+        }
+    }
+    bx = half ? 1.0f : sq[qs];
+    __syncthreads();                                       // every wave holds its query operands: the buffer is free
+    commit();
+    if (roundsA > 1)
+        fetch(1, 1);
+    if (dbg == 1) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) t += bq[g];
+        __syncthreads();
+        if (qvalid && cs == 0 && half == 0) nn_idx[((size_t)cloud * n + qi0) * k] = (int)(t + sq[qs]);
+        return;
+    }
+    MinK<K> um;
+    um.init();
+    for (int r = 0; r < roundsA; ++r) {
+        const int slot = r * CS + cs;
+        round(1, r, roundsA, slot < S ? slot * stride * KM_TILE : ntiles * KM_TILE - KM_TILE);
+        const bool live = slot < S;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                      // units: the lane's rows 8 g + 4 half + (0..3)
+            const float m = fminf(fminf(acc[4 * g], acc[4 * g + 1]), fminf(acc[4 * g + 2], acc[4 * g + 3]));
+            um.insert(live ? m : __builtin_inff());
+        }
+    }
+    // K-th smallest unit minimum over the query's 2*CS lists, through the query tile's queue area
+    float *md = qd_all + qt * 32 * QPQ;
+    static_assert(2 * CS * K * 32 <= 32 * QPQ, "scratch lists must fit the queue area of one query tile");
+    const int list = cs * 2 + half;
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < K; ++p)
+        md[(list * K + p) * 32 + col] = um.d[p];
+    const int roundsB = (ntiles + CS - 1) / CS;
+    fetch(0, 0);                                       // pass B's first tiles travel during the merge below
+    __syncthreads();
+    float tau = __builtin_inff();
+    {
+        // K steps of "smallest head, advance it" over the 2*CS sorted lists.  Equal heads advance together, which can
+        // only make tau larger (the bound stays valid); every lane of the query computes the same value.
+        int head[2 * CS];
+#pragma unroll
+        for (int l = 0; l < 2 * CS; ++l)
+            head[l] = (l * K) * 32 + col;
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            float hv[2 * CS];
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l)
+                hv[l] = md[head[l]];                       // (a head moves at most once per step: never past its list)
+            float m = hv[0];
+#pragma unroll
+            for (int l = 1; l < 2 * CS; ++l)
+                m = fminf(m, hv[l]);
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l)
+                head[l] += hv[l] == m ? 32 : 0;
+            tau = m;
+        }
+    }
+    commit();
+    if (roundsB > 1)
+        fetch(0, 1);
+    if (dbg == 2) {
+        if (qvalid && cs == 0 && half == 0) nn_idx[((size_t)cloud * n + qi0) * k] = (int)tau;
+        return;
+    }
+    tau = fminf(tau, 3.4028234664e38f);                    // rows past the end (+inf) never pass
+    // (the scratch lists are consumed before the first round's second barrier; the queues are only appended to after it)
+
+    // ---------------- pass B: everything at or below tau goes to the query's queue ----------------
+    const int qq = qt * 32 + col;
+    float *qd = qd_all + qq * QPQ;
+    unsigned short *qj = qj_all + qq * QPQ;
+    for (int r = 0; r < roundsB; ++r) {
+        const int slot = r * CS + cs;
+        const int c0 = min(slot, ntiles - 1) * KM_TILE;
+        round(0, r, roundsB, c0);
+        if (slot < ntiles) {
+            const int jb = c0 + 4 * half;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (acc[e] <= tau) {
+                    // past the end of a full queue the last slot is overwritten: the count still says "overflowed"
+                    const int sl = min(atomicAdd(&qn_all[qq], 1), QPQ - 1);
+                    qd[sl] = acc[e];
+                    qj[sl] = (unsigned short)(jb + (e & 3) + 8 * (e >> 2));
+                }
+        }
+    }
+    int *flag = reinterpret_cast<int *>(sq + ntiles * KM_TILE + 1);
+    __syncthreads();
+    if (qn_all[qq] > QPQ)
+        *flag = 1;
+    __syncthreads();
+    if (dbg == 3) {
+        if (qvalid && cs == 0 && half == 0) nn_idx[((size_t)cloud * n + qi0) * k] = qn_all[qq] + *flag;
+        return;
+    }
+    TopKey<K> top;
+    top.init();
+    if (dbg == 4) {
+    } else if (*flag == 0) {
+        // the query's 8 lanes take every 8th entry of its queue (they arrive in any order: keyed insert)
+        const int nq_ = min(qn_all[qq], QPQ);
+        int ro = list;
+        float nd = qd[min(ro, QPQ - 1)];
+        int ni = (int)qj[min(ro, QPQ - 1)];
+        for (; __any(ro < nq_); ro += 2 * CS) {
+            const double key = ro < nq_ ? knn_key(nd, ni) : __builtin_inf();
+            const int rn = min(ro + 2 * CS, QPQ - 1);
+            nd = qd[rn];
+            ni = (int)qj[rn];
+            top.insert(key);
+        }
+    } else {
+        // a queue overflowed somewhere in this workgroup: the plain scan (every candidate through the sorted insert)
+        fetch(0, 0);
+        __syncthreads();
+        commit();
+        if (roundsB > 1)
+            fetch(0, 1);
+        for (int r = 0; r < roundsB; ++r) {
+            const int slot = r * CS + cs;
+            const int c0 = min(slot, ntiles - 1) * KM_TILE;
+            round(0, r, roundsB, c0);
+            if (slot < ntiles) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    top.insert(knn_key(acc[e], c0 + 4 * half + (e & 3) + 8 * (e >> 2)));   // (rows past n are +inf)
+            }
+        }
+    }
+
+    // merge the 2*CS sorted key lists of every query, through the query tile's share of the queue area; the merging
+    // lanes of the four query tiles sit in waves 0, 5, 10, 15: one per SIMD
+    __syncthreads();
+    double *mk = reinterpret_cast<double *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6));
+    static_assert(2 * CS * K * 32 * 8 <= 32 * QPQ * 6 && (32 * QPQ * 6) % 8 == 0, "key lists must fit a query tile's queues");
+#pragma unroll
+    for (int p = 0; p < K; ++p)
+        mk[(list * K + p) * 32 + col] = top.key[p];
+    __syncthreads();
+    if (cs == qt && half == 0 && qvalid) {
+        int head[2 * CS];
+#pragma unroll
+        for (int l = 0; l < 2 * CS; ++l)
+            head[l] = 0;
+        int *dst = nn_idx + ((size_t)cloud * n + qi0) * k;
+        for (int p = 0; p < k; ++p) {
+            double hk[2 * CS];
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l)
+                hk[l] = mk[(l * K + min(head[l], K - 1)) * 32 + col];
+            double best = __builtin_inf();
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l) {
+                hk[l] = head[l] < K ? hk[l] : __builtin_inf();
+                best = __builtin_fmin(best, hk[l]);
+            }
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l)
+                head[l] += (hk[l] == best) ? 1 : 0;      // keys are unique (a candidate is in one list) except +inf
+            dst[p] = knn_key_index(best);
+        }
+    }
+}
+
+// |x_j|^2 of every row, the un-fused sequential sum the oracle defines.  Rows are read coalesced into LDS (row stride
+// 68 floats keeps 16-byte accesses of consecutive rows on distinct banks); one thread per row does the 64 dependent adds.
+__global__ __launch_bounds__(64) void knn64_sqnorm_kernel(long long rows, int ld, const float *__restrict__ x,
+                                                          float *__restrict__ sqnorm)
+{
+    __shared__ __attribute__((aligned(16))) float t[64 * 68];
+    const long long r0 = (long long)blockIdx.x * 64;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int v = u * 64 + threadIdx.x, row = v >> 4, q4 = v & 15;
+        *reinterpret_cast<float4v *>(t + row * 68 + 4 * q4) =
+            r0 + row < rows ? *reinterpret_cast<const float4v *>(x + (size_t)(r0 + row) * ld + 4 * q4)
+                            : float4v{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    const float4v *row = reinterpret_cast<const float4v *>(t + threadIdx.x * 68);
+    float acc = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const float4v v = row[g];
+        const float a = v.x * v.x, b = v.y * v.y, c = v.z * v.z, d = v.w * v.w;
+        acc = acc + a;
+        acc = acc + b;
+        acc = acc + c;
+        acc = acc + d;
+    }
+    if (r0 + threadIdx.x < rows)
+        sqnorm[r0 + threadIdx.x] = acc;
+}
+
+template <int K>
+static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
+{
+    const size_t lds = knn_wide_lds_bytes(n);
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn64_wide_kernel<K>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess)
+            return e;
+        raised = true;
+    }
+    float *sqnorm = nullptr;          // scratch of the call, stream ordered: no state outlives it
+    const long long rows = (long long)b * n;
+    hipError_t e = hipMallocAsync((void **)&sqnorm, sizeof(float) * rows, s);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(knn64_sqnorm_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, rows, ld, x, sqnorm);
+    hipLaunchKernelGGL((knn64_wide_kernel<K>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s, n, ld, k, x, sqnorm,
+                       nn_idx, getenv("CLOUDAAE_KNN_DBG") ? atoi(getenv("CLOUDAAE_KNN_DBG")) : 0);
+    return hipFreeAsync(sqnorm, s);
+}
+
 // ---- C = 3, second generation: the selection split into filter + queued drain ------------------
 // knn3_kernel above runs the sorted insert for every candidate of every lane (a wave executes it
 // whenever ANY lane needs it, i.e. always): ~45 instructions per candidate against 8 for the
@@ -1378,7 +1763,10 @@ static void launch_knn(int b, int n, int c, int ld, int k, const float *x, int *
             const long long tiles = (long long)ceil_div(n, KM_TILE) * b;
             const int mode = knn_scan_waves(tiles);
             // (the bound kernel wants enough units for its bound: 8 per sampled tile, >= 4 sampled tiles)
-            if (mode == 4 && n >= 256)
+            if (mode == 5 && n >= 256 && K <= 10 && knn_wide_lds_bytes(n) <= 160 * 1024) {
+                if constexpr (K <= 10)
+                    (void)launch_knn_wide<K>(b, n, ld, k, x, nn_idx, s);
+            } else if (mode == 4 && n >= 256)
                 (void)launch_knn_bound<K, 4, 2>(b, n, ld, k, x, nn_idx, s);
             else if (mode == 3 && n >= 256)
                 (void)launch_knn_bound<K, 4, 1>(b, n, ld, k, x, nn_idx, s);

@@ -180,10 +180,12 @@ def test_knn_vs_oracle(hip, oracle, b, n, c, ld, k):
 @pytest.mark.parametrize("b,n,k,mode", [(2, 333, 10, 1), (40, 1024, 10, 1), (3, 1500, 20, 2), (33, 1024, 10, 2),
                                           (2, 700, 20, 0), (140, 1024, 10, None), (2, 333, 10, 3), (40, 1024, 10, 3),
                                           (3, 1500, 20, 4), (33, 1024, 10, 4), (2, 257, 20, 3), (5, 1000, 5, 4),
-                                          (32, 1024, 10, None), (2, 4096, 20, 4), (2, 260, 10, 4)])
+                                          (32, 1024, 10, None), (2, 4096, 20, 4), (2, 260, 10, 4),
+                                          (40, 1024, 10, 5), (3, 1500, 10, 5), (2, 260, 5, 5), (2, 2048, 10, 5)])
 def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, monkeypatch, b, n, k, mode):
     """All C = 64 kernels (CLOUDAAE_KNN_SCAN = 0: knn64_mfma, 1 / 2: whole-cloud scan with one / two waves
-    per query tile, 3 / 4: bound pass + filtered scan with one / two; None: the launcher's own choice) keep
+    per query tile, 3 / 4: bound pass + filtered scan with one / two, 5: the same with four
+    waves per query tile in 16-wave workgroups; None: the launcher's own choice) keep
     the same bit-exact contract."""
     from cloudaae_amd import _lib
     if mode is None:
@@ -200,7 +202,7 @@ def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, monkeypatch, b, n, k, mod
     assert np.array_equal(want, got.cpu().numpy())
 
 
-@pytest.mark.parametrize("mode", [3, 4])
+@pytest.mark.parametrize("mode", [3, 4, 5])
 @pytest.mark.parametrize("case", ["all_equal", "few_distinct", "lattice", "large_finite", "far_cluster"])
 def test_knn_c64_bound_kernel_adversarial(hip, oracle, monkeypatch, mode, case):
     """The bound kernel's correctness must not depend on its bound being tight: clouds where (nearly) every
