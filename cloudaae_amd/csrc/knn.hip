@@ -1258,7 +1258,7 @@ static size_t knn_wide_lds_bytes(int n)
 template <int K>
 __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, const float *__restrict__ x,
                                                           const float *__restrict__ sqnorm,
-                                                          int *__restrict__ nn_idx, int dbg)
+                                                          int *__restrict__ nn_idx)
 {
     constexpr int QW = 4, CS = 4, THREADS = 1024;
     constexpr int KS_LD = 68;                              // staged row: [32 even channels | 32 odd | 4 pad]
@@ -1369,14 +1369,6 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     commit();
     if (roundsA > 1)
         fetch(1, 1);
-    if (dbg == 1) {
-        float t = 0.f;
-#pragma unroll
-        for (int g = 0; g < 32; ++g) t += bq[g];
-        __syncthreads();
-        if (qvalid && cs == 0 && half == 0) nn_idx[((size_t)cloud * n + qi0) * k] = (int)(t + sq[qs]);
-        return;
-    }
     MinK<K> um;
     um.init();
     for (int r = 0; r < roundsA; ++r) {
@@ -1427,10 +1419,6 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     commit();
     if (roundsB > 1)
         fetch(0, 1);
-    if (dbg == 2) {
-        if (qvalid && cs == 0 && half == 0) nn_idx[((size_t)cloud * n + qi0) * k] = (int)tau;
-        return;
-    }
     tau = fminf(tau, 3.4028234664e38f);                    // rows past the end (+inf) never pass
     // (the scratch lists are consumed before the first round's second barrier; the queues are only appended to after it)
 
@@ -1459,14 +1447,9 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     if (qn_all[qq] > QPQ)
         *flag = 1;
     __syncthreads();
-    if (dbg == 3) {
-        if (qvalid && cs == 0 && half == 0) nn_idx[((size_t)cloud * n + qi0) * k] = qn_all[qq] + *flag;
-        return;
-    }
     TopKey<K> top;
     top.init();
-    if (dbg == 4) {
-    } else if (*flag == 0) {
+    if (*flag == 0) {
         // the query's 8 lanes take every 8th entry of its queue (they arrive in any order: keyed insert)
         const int nq_ = min(qn_all[qq], QPQ);
         int ro = list;
@@ -1581,7 +1564,7 @@ static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, i
         return e;
     hipLaunchKernelGGL(knn64_sqnorm_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, rows, ld, x, sqnorm);
     hipLaunchKernelGGL((knn64_wide_kernel<K>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s, n, ld, k, x, sqnorm,
-                       nn_idx, getenv("CLOUDAAE_KNN_DBG") ? atoi(getenv("CLOUDAAE_KNN_DBG")) : 0);
+                       nn_idx);
     return hipFreeAsync(sqnorm, s);
 }
 
@@ -1729,17 +1712,22 @@ static hipError_t launch_knn3_scan(int b, int n, int ld, int k, const float *x, 
 }
 
 // Which C = 64 kernel for `tiles` 32-query tiles (measured, B x N = 1024 points, k = 10, us):
-//   tiles      knn64_mfma   scan, 1 wave/tile   scan, 2 waves/tile
-//    256 (B=8)      61            108                 82
-//   1024 (B=32)    138            134                113
-//   8192 (B=256)   808            645                833
+//   tiles      knn64_mfma   scan, 1 wave/tile   scan, 2 waves/tile   wide (bound pass, 16 waves)
+//    256 (B=8)      56            152                100                  80
+//    768 (B=24)     87            153                102                  83
+//   1024 (B=32)    138            134                102                  87
+//   4096 (B=128)                  414                397                 305
+//   8192 (B=256)   780            631                788                 601
 // Return value / CLOUDAAE_KNN_SCAN (forces a choice; the tests cover all of them): 0 = knn64_mfma_kernel,
-// 1 / 2 = knn64_scan_kernel with one / two waves per query tile, 3 / 4 = knn64_bound_kernel with one / two.
-static int knn_scan_waves(long long tiles)
+// 1 / 2 = knn64_scan_kernel with one / two waves per query tile, 3 / 4 = knn64_bound_kernel with one / two,
+// 5 = knn64_wide_kernel (k <= 10 and a cloud whose norms fit its LDS: n <= ~2400; otherwise 5 means 1).
+static int knn_scan_waves(long long tiles, int n, int k)
 {
     if (const char *e = getenv("CLOUDAAE_KNN_SCAN"))
         return atoi(e);
-    return tiles >= 4096 ? 1 : tiles >= 1024 ? 2 : 0;      // (the bound kernel is not faster yet: DESIGN.md section 4)
+    if (tiles >= 768 && k <= 10 && n >= 256 && knn_wide_lds_bytes(n) <= 160 * 1024)
+        return 5;
+    return tiles >= 4096 ? 1 : tiles >= 1024 ? 2 : 0;
 }
 
 template <int K>
@@ -1758,10 +1746,10 @@ static void launch_knn(int b, int n, int c, int ld, int k, const float *x, int *
         hipLaunchKernelGGL(knn3_kernel<K>, dim3(ceil_div(n, 64), b), dim3(KNN_THREADS), 0, s, n, ld,
                            k, x, nn_idx);
     else if (c == 64 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && K <= 20 && n <= 16384 &&
-             knn_scan_waves((long long)ceil_div(n, KM_TILE) * b) > 0) {
+             knn_scan_waves((long long)ceil_div(n, KM_TILE) * b, n, K) > 0) {
         if constexpr (K <= 20) {
             const long long tiles = (long long)ceil_div(n, KM_TILE) * b;
-            const int mode = knn_scan_waves(tiles);
+            const int mode = knn_scan_waves(tiles, n, K);
             // (the bound kernel wants enough units for its bound: 8 per sampled tile, >= 4 sampled tiles)
             if (mode == 5 && n >= 256 && K <= 10 && knn_wide_lds_bytes(n) <= 160 * 1024) {
                 if constexpr (K <= 10)
