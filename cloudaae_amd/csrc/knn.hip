@@ -1293,30 +1293,27 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     const int S = min(ntiles, max((ntiles + 3) / 4, 4));   // pass A's sample: S tiles, every stride-th one
     const int stride = ntiles / S;
 
-    // staging: a round = CS tiles of 32 rows x 16 float4 = 2048 float4, two per thread (rows srow and srow + 64)
-    const int srow = tid >> 4, sq4 = tid & 15;
-    const float *gsrc = X + (size_t)srow * ld + 4 * sq4;
-    float4v stage[2];
-    auto fetch = [&](int what, int r) {                    // what: 0 = pass B's tiles, 1 = pass A's sample, 2 = the query tiles
+    // staging: a round = CS tiles of 32 rows; a wave brings 8 rows, each with ONE global_load_lds_dword: lane l fetches
+    // the channel that belongs at position l of the staged row ([32 even | 32 odd]), the 256 bytes land in LDS without
+    // passing through registers (a register-staged copy cost 8 VGPRs for the whole round and spilled).  Rows past the
+    // end repeat row n - 1: their |x|^2 reads +inf, so their distances are +inf.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int chan = 2 * col + half;
+    auto stage_rows = [&](int what, int r) {               // what: 0 = pass B's tiles, 1 = pass A's sample, 2 = the query tiles
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int rowu = u * 64 + srow;                // row within the round's 128 rows
+        for (int u = 0; u < 8; ++u) {
+            const int rowu = wave_u * 8 + u;               // row within the round's 128 rows
             const int slot = r * CS + (rowu >> 5);
             const int c0 = what == 1 ? (slot < S ? slot * stride * KM_TILE : n)
                                      : (what == 2 ? qgroup * QW + slot : slot) * KM_TILE;
-            const int g = c0 + (rowu & 31);
-            stage[u] = g < n ? *reinterpret_cast<const float4v *>(gsrc + (size_t)(g - srow) * ld)
-                             : float4v{0.f, 0.f, 0.f, 0.f};
+            const int g = min(c0 + (rowu & 31), n - 1);
+            __builtin_amdgcn_global_load_lds(X + (size_t)g * ld + chan,
+                                             tiles + (rowu >> 5) * TILE_FLOATS + (rowu & 31) * KS_LD, 4, 0, 0);
         }
     };
-    auto commit = [&]() {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int rowu = u * 64 + srow;
-            float *dst = tiles + (rowu >> 5) * TILE_FLOATS + (rowu & 31) * KS_LD + 2 * sq4;
-            *reinterpret_cast<float2v *>(dst) = float2v{stage[u].x, stage[u].z};
-            *reinterpret_cast<float2v *>(dst + 32) = float2v{stage[u].y, stage[u].w};
-        }
+    auto staged = [&]() {                                  // this wave's rows have landed; then the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     };
     const float4v *arow = reinterpret_cast<const float4v *>(tiles + cs * TILE_FLOATS + col * KS_LD + 32 * half);
     const int xoff = half ? col : ntiles * KM_TILE;        // 33rd step, candidate side: sq[c0 + col] (k = 1) or 1.0 (k = 0)
@@ -1327,7 +1324,7 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     float bx = 1.0f;
     // one round: operands of this wave's tile -> registers, next round's tiles -> LDS, the 33 MFMA steps
     auto round = [&](int what, int r, int rounds, int c0) {
-        __syncthreads();                                   // this round's tiles are in LDS
+        staged();                                          // this round's tiles are in LDS
         float4v a4[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s)
@@ -1335,9 +1332,7 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
         const float ax = sq[xoff + xmul * c0];
         __syncthreads();                                   // every wave holds its operands: the buffer is free
         if (r + 1 < rounds)
-            commit();
-        if (r + 2 < rounds)
-            fetch(what, r + 2);
+            stage_rows(what, r + 1);                       // travels behind the MFMAs
 #pragma unroll
         for (int e = 0; e < 16; ++e)
             acc[e] = 0.0f;
@@ -1349,10 +1344,8 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
 
     // ---------------- pass A: tau ----------------
     const int roundsA = (S + CS - 1) / CS;
-    fetch(2, 0);                                           // the workgroup's 4 query tiles, staged like candidate tiles
-    commit();
-    fetch(1, 0);
-    __syncthreads();
+    stage_rows(2, 0);                                      // the workgroup's 4 query tiles, staged like candidate tiles
+    staged();
     {
         const float4v *qrow = reinterpret_cast<const float4v *>(tiles + qt * TILE_FLOATS + col * KS_LD + 32 * half);
 #pragma unroll
@@ -1366,9 +1359,7 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     }
     bx = half ? 1.0f : sq[qs];
     __syncthreads();                                       // every wave holds its query operands: the buffer is free
-    commit();
-    if (roundsA > 1)
-        fetch(1, 1);
+    stage_rows(1, 0);
     MinK<K> um;
     um.init();
     for (int r = 0; r < roundsA; ++r) {
@@ -1390,7 +1381,7 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     for (int p = 0; p < K; ++p)
         md[(list * K + p) * 32 + col] = um.d[p];
     const int roundsB = (ntiles + CS - 1) / CS;
-    fetch(0, 0);                                       // pass B's first tiles travel during the merge below
+    stage_rows(0, 0);                                      // pass B's first tiles travel during the merge below
     __syncthreads();
     float tau = __builtin_inff();
     {
@@ -1416,9 +1407,6 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
             tau = m;
         }
     }
-    commit();
-    if (roundsB > 1)
-        fetch(0, 1);
     tau = fminf(tau, 3.4028234664e38f);                    // rows past the end (+inf) never pass
     // (the scratch lists are consumed before the first round's second barrier; the queues are only appended to after it)
 
@@ -1464,11 +1452,7 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
         }
     } else {
         // a queue overflowed somewhere in this workgroup: the plain scan (every candidate through the sorted insert)
-        fetch(0, 0);
-        __syncthreads();
-        commit();
-        if (roundsB > 1)
-            fetch(0, 1);
+        stage_rows(0, 0);
         for (int r = 0; r < roundsB; ++r) {
             const int slot = r * CS + cs;
             const int c0 = min(slot, ntiles - 1) * KM_TILE;
