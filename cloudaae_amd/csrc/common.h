@@ -40,6 +40,25 @@ inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
         }                                                                        \
     } while (0)
 
+// Scratch of ONE call, stream ordered (hipMallocAsync / hipFreeAsync on the caller's stream: no state outlives the
+// call, nothing synchronises).  The device's default pool is told once to keep what it is given back: with the
+// default release threshold of 0 every stream synchronisation returns the memory to the driver and the next call
+// pays a real allocation.
+inline hipError_t scratch_alloc(void **p, size_t bytes, hipStream_t s)
+{
+    static bool tuned[64] = {};
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !tuned[dev]) {
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+            uint64_t keep = UINT64_MAX;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        tuned[dev] = true;
+    }
+    return hipMallocAsync(p, bytes, s);
+}
+
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 

@@ -756,7 +756,8 @@ __global__ __launch_bounds__(64 * QW * CS) void knn64_scan_kernel(int n, int ld,
         mi[(list * K + p) * 32 + col] = top.i[p];
     }
     __syncthreads();
-    if (cs == 0 && half == 0 && qvalid) {
+    // (the merging lanes of the query tiles sit in different SIMDs: wave qt * CS + cs, SIMD = wave % 4)
+    if (cs == ((qt * CS) >> 2) % CS && half == 0 && qvalid) {
         int head[2 * CS];
 #pragma unroll
         for (int l = 0; l < 2 * CS; ++l)
@@ -1543,7 +1544,7 @@ static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, i
     }
     float *sqnorm = nullptr;          // scratch of the call, stream ordered: no state outlives it
     const long long rows = (long long)b * n;
-    hipError_t e = hipMallocAsync((void **)&sqnorm, sizeof(float) * rows, s);
+    hipError_t e = scratch_alloc((void **)&sqnorm, sizeof(float) * rows, s);
     if (e != hipSuccess)
         return e;
     hipLaunchKernelGGL(knn64_sqnorm_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, rows, ld, x, sqnorm);

@@ -543,7 +543,7 @@ CLOUDAAE_API int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, co
         unsigned long long *keys = nullptr, *k1 = nullptr, *k2 = nullptr;
         const size_t c1 = s1 > 1 ? (size_t)b * n : 0, c2 = s2 > 1 ? (size_t)b * m : 0;
         if (c1 + c2 > 0) {      // scratch of the call, stream ordered: no state outlives it
-            CLOUDAAE_CHECK_HIP(hipMallocAsync((void **)&keys, (c1 + c2) * sizeof(unsigned long long), s), name);
+            CLOUDAAE_CHECK_HIP(scratch_alloc((void **)&keys, (c1 + c2) * sizeof(unsigned long long), s), name);
             CLOUDAAE_CHECK_HIP(hipMemsetAsync(keys, 0xff, (c1 + c2) * sizeof(unsigned long long), s), name);
             k1 = keys;
             k2 = keys + c1;
