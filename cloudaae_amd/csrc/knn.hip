@@ -1258,7 +1258,6 @@ static size_t knn_wide_lds_bytes(int n)
 // slot (two barriers per round: operands read, next tiles committed).  Same arithmetic, same queues, same fallback.
 template <int K>
 __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, const float *__restrict__ x,
-                                                          const float *__restrict__ sqnorm,
                                                           int *__restrict__ nn_idx)
 {
     constexpr int QW = 4, CS = 4, THREADS = 1024;
@@ -1283,14 +1282,15 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
 
     for (int j = tid; j < QW * 32; j += THREADS)
         qn_all[j] = 0;
-    for (int j = tid; j <= ntiles * KM_TILE + 1; j += THREADS)   // |x_j|^2; +inf past the end; 1.0 (33rd step); 0 = the overflow flag
-        sq[j] = j < n ? sqnorm[(size_t)cloud * n + j]
-                      : (j == ntiles * KM_TILE ? 1.0f : (j > ntiles * KM_TILE ? 0.0f : __builtin_inff()));
+    // sq[j] = |x_j|^2, filled in as tiles are staged (norms() below); +inf until then and past the end; behind it 1.0
+    // (the 33rd step's other operand) and 0 = the workgroup's "a queue overflowed" flag
+    for (int j = tid; j <= ntiles * KM_TILE + 1; j += THREADS)
+        sq[j] = j == ntiles * KM_TILE ? 1.0f : (j > ntiles * KM_TILE ? 0.0f : __builtin_inff());
 
     const int col = lane & 31, half = lane >> 5;
     const int qi0 = (qgroup * QW + qt) * KM_TILE + col;   // this lane's query
     const bool qvalid = qi0 < n;
-    const int qs = qvalid ? qi0 : 0;
+    const int qs = qvalid ? qi0 : qgroup * QW * KM_TILE;   // (a row whose norm the prologue computes)
     const int S = min(ntiles, max((ntiles + 3) / 4, 4));   // pass A's sample: S tiles, every stride-th one
     const int stride = ntiles / S;
 
@@ -1316,6 +1316,37 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
+    // |x|^2 of the 128 staged rows, the un-fused sequential sum the oracle defines: waves 0 and 1, one row per lane,
+    // between the round's two barriers (the 33rd step's operand is read after the second one)
+    auto norms = [&](int what, int r) {
+        if (wave_u < 2) {
+            const int rowu = wave_u * 64 + lane;
+            const int slot = r * CS + (rowu >> 5);
+            const int c0 = what == 1 ? (slot < S ? slot * stride * KM_TILE : n)
+                                     : (what == 2 ? qgroup * QW + slot : slot) * KM_TILE;
+            const int g = c0 + (rowu & 31);
+            const float4v *ev = reinterpret_cast<const float4v *>(tiles + (rowu >> 5) * TILE_FLOATS + (rowu & 31) * KS_LD);
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {                  // channels 8 q .. 8 q + 7 = even[4q..4q+3] interleaved with odd[..]
+                if (q == 4)
+                    __builtin_amdgcn_sched_barrier(0);     // (two batches of eight 16-byte reads: 32 registers, not 64)
+                const float4v e = ev[q], o = ev[8 + q];
+                const float a0 = e.x * e.x, a1 = o.x * o.x, a2 = e.y * e.y, a3 = o.y * o.y;
+                const float a4_ = e.z * e.z, a5 = o.z * o.z, a6 = e.w * e.w, a7 = o.w * o.w;
+                acc = acc + a0;
+                acc = acc + a1;
+                acc = acc + a2;
+                acc = acc + a3;
+                acc = acc + a4_;
+                acc = acc + a5;
+                acc = acc + a6;
+                acc = acc + a7;
+            }
+            if (g < n)
+                sq[g] = acc;
+        }
+    };
     const float4v *arow = reinterpret_cast<const float4v *>(tiles + cs * TILE_FLOATS + col * KS_LD + 32 * half);
     const int xoff = half ? col : ntiles * KM_TILE;        // 33rd step, candidate side: sq[c0 + col] (k = 1) or 1.0 (k = 0)
     const int xmul = half;
@@ -1326,12 +1357,13 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     // one round: operands of this wave's tile -> registers, next round's tiles -> LDS, the 33 MFMA steps
     auto round = [&](int what, int r, int rounds, int c0) {
         staged();                                          // this round's tiles are in LDS
+        norms(what, r);                                    // (waves 0 and 1; before their operand reads: registers)
         float4v a4[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s)
             a4[s] = arow[s];
-        const float ax = sq[xoff + xmul * c0];
         __syncthreads();                                   // every wave holds its operands: the buffer is free
+        const float ax = sq[xoff + xmul * c0];
         if (r + 1 < rounds)
             stage_rows(what, r + 1);                       // travels behind the MFMAs
 #pragma unroll
@@ -1347,6 +1379,7 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     const int roundsA = (S + CS - 1) / CS;
     stage_rows(2, 0);                                      // the workgroup's 4 query tiles, staged like candidate tiles
     staged();
+    norms(2, 0);
     {
         const float4v *qrow = reinterpret_cast<const float4v *>(tiles + qt * TILE_FLOATS + col * KS_LD + 32 * half);
 #pragma unroll
@@ -1358,8 +1391,8 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
             bq[4 * s + 3] = -2.0f * v.w;
         }
     }
-    bx = half ? 1.0f : sq[qs];
     __syncthreads();                                       // every wave holds its query operands: the buffer is free
+    bx = half ? 1.0f : sq[qs];
     stage_rows(1, 0);
     MinK<K> um;
     um.init();
@@ -1378,9 +1411,11 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     static_assert(2 * CS * K * 32 <= 32 * QPQ, "scratch lists must fit the queue area of one query tile");
     const int list = cs * 2 + half;
     __syncthreads();
+    int slot0 = list * K * 32 + col;                       // (opaque: keeps the compiler from deriving these K addresses
+    asm volatile("" : "+v"(slot0));                        //  before the scan loop and spilling them across it)
 #pragma unroll
     for (int p = 0; p < K; ++p)
-        md[(list * K + p) * 32 + col] = um.d[p];
+        md[slot0 + p * 32] = um.d[p];
     const int roundsB = (ntiles + CS - 1) / CS;
     stage_rows(0, 0);                                      // pass B's first tiles travel during the merge below
     __syncthreads();
@@ -1471,9 +1506,11 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     __syncthreads();
     double *mk = reinterpret_cast<double *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6));
     static_assert(2 * CS * K * 32 * 8 <= 32 * QPQ * 6 && (32 * QPQ * 6) % 8 == 0, "key lists must fit a query tile's queues");
+    int slot1 = list * K * 32 + col;
+    asm volatile("" : "+v"(slot1));
 #pragma unroll
     for (int p = 0; p < K; ++p)
-        mk[(list * K + p) * 32 + col] = top.key[p];
+        mk[slot1 + p * 32] = top.key[p];
     __syncthreads();
     if (cs == qt && half == 0 && qvalid) {
         int head[2 * CS];
@@ -1500,36 +1537,6 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     }
 }
 
-// |x_j|^2 of every row, the un-fused sequential sum the oracle defines.  Rows are read coalesced into LDS (row stride
-// 68 floats keeps 16-byte accesses of consecutive rows on distinct banks); one thread per row does the 64 dependent adds.
-__global__ __launch_bounds__(64) void knn64_sqnorm_kernel(long long rows, int ld, const float *__restrict__ x,
-                                                          float *__restrict__ sqnorm)
-{
-    __shared__ __attribute__((aligned(16))) float t[64 * 68];
-    const long long r0 = (long long)blockIdx.x * 64;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int v = u * 64 + threadIdx.x, row = v >> 4, q4 = v & 15;
-        *reinterpret_cast<float4v *>(t + row * 68 + 4 * q4) =
-            r0 + row < rows ? *reinterpret_cast<const float4v *>(x + (size_t)(r0 + row) * ld + 4 * q4)
-                            : float4v{0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
-    const float4v *row = reinterpret_cast<const float4v *>(t + threadIdx.x * 68);
-    float acc = 0.0f;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const float4v v = row[g];
-        const float a = v.x * v.x, b = v.y * v.y, c = v.z * v.z, d = v.w * v.w;
-        acc = acc + a;
-        acc = acc + b;
-        acc = acc + c;
-        acc = acc + d;
-    }
-    if (r0 + threadIdx.x < rows)
-        sqnorm[r0 + threadIdx.x] = acc;
-}
-
 template <int K>
 static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
@@ -1542,15 +1549,8 @@ static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, i
             return e;
         raised = true;
     }
-    float *sqnorm = nullptr;          // scratch of the call, stream ordered: no state outlives it
-    const long long rows = (long long)b * n;
-    hipError_t e = scratch_alloc((void **)&sqnorm, sizeof(float) * rows, s);
-    if (e != hipSuccess)
-        return e;
-    hipLaunchKernelGGL(knn64_sqnorm_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, rows, ld, x, sqnorm);
-    hipLaunchKernelGGL((knn64_wide_kernel<K>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s, n, ld, k, x, sqnorm,
-                       nn_idx);
-    return hipFreeAsync(sqnorm, s);
+    hipLaunchKernelGGL((knn64_wide_kernel<K>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s, n, ld, k, x, nn_idx);
+    return hipSuccess;
 }
 
 // ---- C = 3, second generation: the selection split into filter + queued drain ------------------
