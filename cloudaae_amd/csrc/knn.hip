@@ -1255,7 +1255,14 @@ static size_t knn_wide_lds_bytes(int n)
 // tile is scanned by CS = 4 waves (a quarter of the candidate tiles each), a workgroup is QW x CS = 16 waves, so
 // every SIMD has four waves to overlap and each wave's chain is half as long.  What that costs: 128 registers per
 // lane (no operand double-buffering, the filter runs right after its tile's MFMAs) and one LDS tile buffer per wave
-// slot (two barriers per round: operands read, next tiles committed).  Same arithmetic, same queues, same fallback.
+// slot (two barriers per round: tiles landed / operands read).  What else differs from the kernel above:
+//   * tiles go global -> LDS without passing through registers (global_load_lds_dword, one staged row per instruction);
+//   * |x_j|^2 is computed from the staged tiles (waves 0 and 1, one row per lane, between the two barriers), so the
+//     workgroup never reads the cloud a second time;
+//   * sorted inserts and merges run on ONE orderable double per (distance, index) pair (knn_key / TopKey): 10 pairs of
+//     v_min_f64 / v_max_f64 per insert;
+//   * the merging lanes of the four query tiles sit in waves 0, 5, 10, 15: one per SIMD.
+// Same arithmetic, same bound, same queues (144 six-byte entries per query), same flagged fallback.
 template <int K>
 __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, const float *__restrict__ x,
                                                           int *__restrict__ nn_idx)
@@ -1698,11 +1705,12 @@ static hipError_t launch_knn3_scan(int b, int n, int ld, int k, const float *x, 
 
 // Which C = 64 kernel for `tiles` 32-query tiles (measured, B x N = 1024 points, k = 10, us):
 //   tiles      knn64_mfma   scan, 1 wave/tile   scan, 2 waves/tile   wide (bound pass, 16 waves)
-//    256 (B=8)      56            152                100                  80
-//    768 (B=24)     87            153                102                  83
-//   1024 (B=32)    138            134                102                  87
-//   4096 (B=128)                  414                397                 305
-//   8192 (B=256)   780            631                788                 601
+//    256 (B=8)      55            152                100                  73
+//    512 (B=16)     66            152                101                  74
+//    640 (B=20)     85                                                    75
+//   1024 (B=32)    138            134                102                  76
+//   4096 (B=128)                  414                397                 289
+//   8192 (B=256)   780            631                788                 571
 // Return value / CLOUDAAE_KNN_SCAN (forces a choice; the tests cover all of them): 0 = knn64_mfma_kernel,
 // 1 / 2 = knn64_scan_kernel with one / two waves per query tile, 3 / 4 = knn64_bound_kernel with one / two,
 // 5 = knn64_wide_kernel (k <= 10 and a cloud whose norms fit its LDS: n <= ~2400; otherwise 5 means 1).
@@ -1710,7 +1718,7 @@ static int knn_scan_waves(long long tiles, int n, int k)
 {
     if (const char *e = getenv("CLOUDAAE_KNN_SCAN"))
         return atoi(e);
-    if (tiles >= 768 && k <= 10 && n >= 256 && knn_wide_lds_bytes(n) <= 160 * 1024)
+    if (tiles > 512 && k <= 10 && n >= 256 && knn_wide_lds_bytes(n) <= 160 * 1024)
         return 5;
     return tiles >= 4096 ? 1 : tiles >= 1024 ? 2 : 0;
 }
