@@ -1,0 +1,59 @@
+"""How far the ORACLE's own losses move when every input coordinate moves by one fp32 ulp -- the yardstick for the
+tolerances the parity tests use (north_star: losses within 1e-5).
+
+Two facts the GPU tests lean on are demonstrated here on the CPU restatement alone, no GPU involved:
+  * BASELINE configs[0] is a batch of TWO: its batch norms normalise over two samples (x_hat = +-d / sqrt(d^2 + eps)),
+    and with the neighbour sets held fixed a 1-ulp input change already moves trans_loss / axag_loss by ~1e-5 relative,
+    30 x what a batch of four does.  Hence 5e-5 for the B = 2 cases (tests/test_layers_gpu.py, __graft_entry__.smoke)
+    and 1e-5 everywhere else.
+  * Free-running, the same 1-ulp change flips k-th / (k+1)-th near-ties of the kNN grouping in a few rows and the losses
+    move by up to ~1e-4: two correct implementations can only be compared to 1e-5 on the SAME neighbour sets, which is why
+    the step tests feed the GPU's indices to the oracle (`nn_override`) and report the free-running mismatch separately.
+"""
+import numpy as np
+import torch
+
+from oracle import model_oracle as MO
+
+KEYS = ("xyz_loss", "trans_loss", "axag_loss")
+
+
+def _losses(batch, N, idx=None):
+    V = MO.Vars(seed=11)
+    with torch.no_grad():
+        out = MO.forward_losses(batch, V, N, is_training=True, bn_decay=0.5, nn_override=idx)
+    return {k: float(out[k]) for k in KEYS}, [out["end_points"]["nn_idx%d" % i] for i in (1, 2, 3, 4)]
+
+
+def _shift(B, N, seeds=(5, 6)):
+    """(largest relative move with pinned neighbour sets, the same free-running, rows whose neighbour set changed)."""
+    pinned, free, flips = 0.0, 0.0, 0
+    for seed in seeds:
+        batch = MO.synthetic_batch(B, N, seed=seed, single_class=0 if B == 2 else None)
+        base, idx = _losses(batch, N)
+        for sign in (1.0, -1.0):
+            moved = dict(batch)
+            v = batch["visiblePoints"].numpy()
+            moved["visiblePoints"] = torch.from_numpy(np.nextafter(v, np.float32(sign * np.inf)))
+            a, idx2 = _losses(moved, N)
+            b, _ = _losses(moved, N, idx)
+            flips += sum(int((x != y).any(-1).sum()) for x, y in zip(idx, idx2))
+            for k in KEYS:
+                free = max(free, abs(a[k] - base[k]) / max(1.0, abs(base[k])))
+                pinned = max(pinned, abs(b[k] - base[k]) / max(1.0, abs(base[k])))
+    return pinned, free, flips
+
+
+def test_batch_of_two_is_ill_conditioned():
+    p2, _, _ = _shift(2, 256)
+    p4, _, _ = _shift(4, 128)
+    assert p4 < 2e-6, p4                      # round-off level: the 1e-5 tolerance has room
+    assert p2 > 3e-6 and p2 > 8 * p4, (p2, p4)   # one ulp of input already costs a third of the 1e-5 budget
+    assert p2 < 5e-5, p2                      # ... and stays inside the 5e-5 the B = 2 tests allow
+
+
+def test_free_running_neighbour_sets_move_the_losses():
+    pinned, free, flips = _shift(4, 256)
+    assert flips > 0                          # a 1-ulp change flips near-ties of the grouping
+    assert pinned < 2e-6, pinned
+    assert free > 1e-5, free                  # more than the north-star tolerance: compare on the same neighbour sets
