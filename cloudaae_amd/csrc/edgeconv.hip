@@ -668,6 +668,96 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
     });
 }
 
+// The same pass for mean pooling in training (S from the forward pass's edge statistics), with the reverse list
+// gathered SEVERAL SOURCE ROWS PER LOAD INSTRUCTION: a lane owns four consecutive channels (16-byte loads), so the
+// 64 lanes cover 64 / (COUT / 4) = 4 (COUT = 64) or 2 (COUT = 128) source rows at once, and a batch of four such
+// loads per array keeps 16 (8) rows = 8 KB of U and dOut in flight per wave.  ec_bwd_apply_kernel moves 256 bytes
+// per load instruction (one row, four bytes per lane) and is bound by the latency of its dependent gathers.  The
+// partial sums of the row groups meet in two (one) cross-lane steps; S is evaluated exactly as above.
+template <int COUT>
+__global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_mean4_kernel(
+    EcArgs a, const float *__restrict__ m12, const int *__restrict__ rev_off, const int *__restrict__ rev_src,
+    float *__restrict__ dpq, const float *__restrict__ edge_stats)
+{
+    constexpr int LPR = COUT / 4;          // lanes per row
+    constexpr int SPI = 64 / LPR;          // source rows per load instruction
+    constexpr int RU = 4;                  // load instructions per array in flight
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / LPR, c0 = 4 * (lane % LPR);
+    float sc[4], sh[4], mean[4], rstd[4], gr[4], m1[4], m2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e;
+        bn_scale_shift_of(a.gamma, a.beta, a.save_mean, a.save_var, c, sc[e], sh[e]);
+        mean[e] = a.save_mean[c];
+        rstd[e] = bn_rsqrt(a.save_var[c] + BN_EPS);
+        gr[e] = a.gamma[c] * rstd[e];
+        m1[e] = m12[c];
+        m2[e] = m12[COUT + c];
+    }
+    const float fk = (float)a.k;
+    ec_for_each_point<EC_WAVES>(a, wave, [&](int pt) {
+        const int cloud = pt / a.N, m = pt - cloud * a.N;
+        const int *off = rev_off + (size_t)cloud * (a.N + 1);
+        const int *src = rev_src + (size_t)cloud * a.N * a.k;
+        const int beg = off[m], end = off[m + 1];
+        int mine = (beg + lane < end) ? src[beg + lane] : 0;
+        // own edges: S_i = sum_j gr ((dz_ij - m1) - x_hat_ij m2), dz_ij = mask_ij dout_i / k, from the edge statistics
+        const float4v es0 = *reinterpret_cast<const float4v *>(edge_stats + (size_t)pt * 3 * COUT + c0);
+        const float4v es2 = *reinterpret_cast<const float4v *>(edge_stats + (size_t)pt * 3 * COUT + 2 * COUT + c0);
+        const float4v go = *reinterpret_cast<const float4v *>(a.dout + (size_t)pt * a.lddo + c0);
+        const float4v qm = *reinterpret_cast<const float4v *>(a.pq + (size_t)pt * a.ldpq + COUT + c0);
+        float S[4], T[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gk = go[e] / fk;
+            S[e] = gr[e] * ((gk * es0[e] - fk * m1[e]) - es2[e] * m2[e]);
+            T[e] = 0.0f;
+        }
+        for (int s0 = beg; s0 < end; s0 += 64) {
+            const int cntc = min(64, end - s0);
+            if (s0 != beg)
+                mine = lane < cntc ? src[s0 + lane] : 0;
+            for (int q0 = 0; q0 < cntc; q0 += SPI * RU) {
+                float4v ui[RU], gi[RU];
+                bool on[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int t = q0 + u * SPI + grp;       // this lane group's source of load u
+                    on[u] = t < cntc;
+                    const int i = cloud * a.N + __shfl(mine, on[u] ? t : q0, 64);
+                    ui[u] = *reinterpret_cast<const float4v *>(a.pq + (size_t)i * a.ldpq + c0);
+                    gi[u] = *reinterpret_cast<const float4v *>(a.dout + (size_t)i * a.lddo + c0);
+                }
+#pragma unroll
+                for (int u = 0; u < RU; ++u)
+                    if (on[u]) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float y = ui[u][e] + qm[e];   // U of the source point + Q of this one
+                            const float z = fmaxf(y * sc[e] + sh[e], 0.0f);
+                            float d = gi[u][e] / fk;
+                            if (!(z > 0.0f))
+                                d = 0.0f;
+                            const float xh = (y - mean[e]) * rstd[e];
+                            T[e] = T[e] + gr[e] * ((d - m1[e]) - xh * m2[e]);
+                        }
+                    }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1)
+                T[e] += __shfl_xor(T[e], o, 64);
+        if (grp == 0) {
+            float *mineo = dpq + (size_t)pt * a.ldpq + c0;
+            *reinterpret_cast<float4v *>(mineo) = float4v{S[0], S[1], S[2], S[3]};
+            *reinterpret_cast<float4v *>(mineo + COUT) = float4v{T[0] - S[0], T[1] - S[1], T[2] - S[2], T[3] - S[3]};
+        }
+    });
+}
+
 static int ec_stat_grid(int P)
 {
     int g = ceil_div(ceil_div(P, EC_STAT_WAVES * 2), 8) * 8;   // multiple of 8: one share per XCD
@@ -913,7 +1003,16 @@ static int ec_backward_impl(const char *name, int b, int n, int k, int cin, int 
     } else if (int rc = ec_launch_revlists(name, 1, b, n, k, idx1, rev1, s)) {
         return rc;
     }
-    if (pool_mode == 1) {
+    const bool quads = pool_mode == 1 && training && edge_stats != nullptr && (cout == 64 || cout == 128) && lddo % 4 == 0 &&
+                       (((uintptr_t)a.pq | (uintptr_t)a.dout | (uintptr_t)dpq | (uintptr_t)edge_stats) & 15) == 0 &&
+                       !(getenv("CLOUDAAE_EC_BWD_QUADS") && atoi(getenv("CLOUDAAE_EC_BWD_QUADS")) == 0);
+    if (quads && cout == 64) {
+        hipLaunchKernelGGL(ec_bwd_apply_mean4_kernel<64>, dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src,
+                           dpq, edge_stats);
+    } else if (quads) {
+        hipLaunchKernelGGL(ec_bwd_apply_mean4_kernel<128>, dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src,
+                           dpq, edge_stats);
+    } else if (pool_mode == 1) {
 #define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src, out, ldo, tie_count, dpq, training ? edge_stats : nullptr)
         EC_DISPATCH(EC_BA);
 #undef EC_BA
