@@ -6,4 +6,4 @@ cd "$ROOT"
 timeout 300 bash tools/pmc_kernel.sh r02_knn64_wide knn64_wide -- python3 "$ROOT/tools/bench_knn1.py" 32 1024 64 320 10
 timeout 400 bash tools/profile_step.sh r02_trainstep_b32_n1024 "B=32,N=1024"
 timeout 400 bash tools/profile_step.sh r02_trainstep_b128_n1024 "B=128,N=1024" --per-gpu-batch 128
-timeout 500 bash tools/profile_step.sh r02_trainstep_b256_n1024_bf16 "B=256,N=1024,bf16" --per-gpu-batch 256 --gemm-dtype bf16
+timeout 500 bash tools/profile_step.sh r02_trainstep_b256_n1024_bf16 "B=256,N=1024" --per-gpu-batch 256 --gemm-dtype bf16
