@@ -49,7 +49,10 @@ int cloudaae_stream_wait(cloudaae_stream_t waiter, cloudaae_stream_t signaller);
  *   (tf_ops/nn_distance/tf_nndistance.cpp:168, tf_nndistance_g.cu:128-131);
  * numerics of the CPU op (tf_nndistance.cpp:21-43): squared L2, un-fused fp32,
  * first minimum wins; m == 0 gives dist 0 / idx 0.
- * xyz1 [b,n,3], xyz2 [b,m,3] -> dist1 [b,n], idx1 [b,n], dist2 [b,m], idx2 [b,m]. */
+ * xyz1 [b,n,3], xyz2 [b,m,3] -> dist1 [b,n], idx1 [b,n], dist2 [b,m], idx2 [b,m].
+ * Clouds of very unequal size take stream-ordered scratch (hipMallocAsync / hipFreeAsync on `stream`, nothing
+ * outlives the call); the first such call raises the release threshold of the device's default memory pool so
+ * that later calls reuse the memory instead of returning it to the driver at every synchronisation. */
 int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2, float *dist1,
                          int *idx1, float *dist2, int *idx2, cloudaae_stream_t stream);
 
