@@ -1713,12 +1713,12 @@ static hipError_t launch_knn3_scan(int b, int n, int ld, int k, const float *x, 
 //   8192 (B=256)   780            631                788                 571
 // Return value / CLOUDAAE_KNN_SCAN (forces a choice; the tests cover all of them): 0 = knn64_mfma_kernel,
 // 1 / 2 = knn64_scan_kernel with one / two waves per query tile, 3 / 4 = knn64_bound_kernel with one / two,
-// 5 = knn64_wide_kernel (k <= 10 and a cloud whose norms fit its LDS: n <= ~2400; otherwise 5 means 1).
+// 5 = knn64_wide_kernel (k <= 10 and a cloud whose norms fit its LDS: n <= ~3200; otherwise 5 means 1).
 static int knn_scan_waves(long long tiles, int n, int k)
 {
     if (const char *e = getenv("CLOUDAAE_KNN_SCAN"))
         return atoi(e);
-    if (tiles > 512 && k <= 10 && n >= 256 && knn_wide_lds_bytes(n) <= 160 * 1024)
+    if (tiles > 512 && k <= 10 && n >= 256 && knn_wide_lds_bytes(n) <= 158 * 1024)
         return 5;
     return tiles >= 4096 ? 1 : tiles >= 1024 ? 2 : 0;
 }
@@ -1744,7 +1744,7 @@ static void launch_knn(int b, int n, int c, int ld, int k, const float *x, int *
             const long long tiles = (long long)ceil_div(n, KM_TILE) * b;
             const int mode = knn_scan_waves(tiles, n, K);
             // (the bound kernel wants enough units for its bound: 8 per sampled tile, >= 4 sampled tiles)
-            if (mode == 5 && n >= 256 && K <= 10 && knn_wide_lds_bytes(n) <= 160 * 1024) {
+            if (mode == 5 && n >= 256 && K <= 10 && knn_wide_lds_bytes(n) <= 158 * 1024) {
                 if constexpr (K <= 10)
                     (void)launch_knn_wide<K>(b, n, ld, k, x, nn_idx, s);
             } else if (mode == 4 && n >= 256)

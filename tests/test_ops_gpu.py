@@ -181,7 +181,8 @@ def test_knn_vs_oracle(hip, oracle, b, n, c, ld, k):
                                           (2, 700, 20, 0), (140, 1024, 10, None), (2, 333, 10, 3), (40, 1024, 10, 3),
                                           (3, 1500, 20, 4), (33, 1024, 10, 4), (2, 257, 20, 3), (5, 1000, 5, 4),
                                           (32, 1024, 10, None), (2, 4096, 20, 4), (2, 260, 10, 4),
-                                          (40, 1024, 10, 5), (3, 1500, 10, 5), (2, 260, 5, 5), (2, 2048, 10, 5)])
+                                          (40, 1024, 10, 5), (3, 1500, 10, 5), (2, 260, 5, 5), (2, 2048, 10, 5), (9, 3000, 10, None),
+                                          (1, 3300, 7, 5)])
 def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, monkeypatch, b, n, k, mode):
     """All C = 64 kernels (CLOUDAAE_KNN_SCAN = 0: knn64_mfma, 1 / 2: whole-cloud scan with one / two waves
     per query tile, 3 / 4: bound pass + filtered scan with one / two, 5: the same with four
