@@ -174,7 +174,8 @@ __global__ __launch_bounds__(NN_THREADS) void nn_distance_kernel(
 // ~140.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int NF_QT = 4;            // query tiles (32 queries each) per wave
+constexpr int NF_QT = 2;            // query tiles (32 queries each) per wave (4: 208 VGPRs, two waves per SIMD, 116 us at
+                                    // [32,4096]^2 and 186 us at [32,16384]x[32,1024]; 2: 109 VGPRs, four waves: 111 / 149 us; 1: 115 us)
 constexpr int NF_WAVES = 4;
 constexpr int NF_QBLOCK = NF_WAVES * NF_QT * 32;   // queries per workgroup
 constexpr int NF_CHUNK = 2048;      // candidates per LDS chunk: 64 tiles x 64 lanes x 8 bytes = 32 KiB
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
         top[q].init();
     }
 
-    // scores of one candidate tile for the wave's four query tiles: 8 MFMAs
+    // scores of one candidate tile for the wave's NF_QT query tiles: 2 MFMAs each
     auto issue = [&](f32x16 (&acc)[NF_QT], int t) {
         const float2v A = cand[t][lane];
 #pragma unroll
