@@ -1729,8 +1729,12 @@ static void launch_knn(int b, int n, int c, int ld, int k, const float *x, int *
 {
     if (c == 3 && K <= 20 && n <= 6144 && !(getenv("CLOUDAAE_KNN_SCAN") && atoi(getenv("CLOUDAAE_KNN_SCAN")) == 0)) {
         if constexpr (K <= 20) {
-            // candidate ranges per query tile: 2 when that still gives every SIMD a wave, else 4
-            if ((long long)ceil_div(n, 64) * b * 2 >= 4096)
+            // candidate ranges per query tile: as few as still give every SIMD two waves (fewer ranges = fewer lists to
+            // fill: measured, n = 1024, k = 10, ranges 4 / 2 / 1: B = 32 47 / 55 / - us, B = 64 89 / 67 / - us,
+            // B = 128 170 / 127 / 105 us, B = 256 - / 243 / 202 us)
+            if ((long long)ceil_div(n, 64) * b >= 2048)
+                (void)launch_knn3_scan<K, 1>(b, n, ld, k, x, nn_idx, s);
+            else if ((long long)ceil_div(n, 64) * b * 2 >= 2048)
                 (void)launch_knn3_scan<K, 2>(b, n, ld, k, x, nn_idx, s);
             else
                 (void)launch_knn3_scan<K, 4>(b, n, ld, k, x, nn_idx, s);

@@ -164,7 +164,7 @@ def test_knn_golden_bit_exact(hip, golden_dir, name):
 @pytest.mark.parametrize("b,n,c,ld,k", [(2, 256, 3, 24, 10), (3, 1024, 3, 24, 10), (2, 1000, 3, 3, 20),
                                         (2, 256, 64, 64, 10), (4, 1024, 64, 64, 10), (2, 777, 64, 64, 20),
                                         (1, 4096, 64, 64, 20), (2, 130, 64, 64, 5), (2, 100, 16, 16, 7),
-                                        (1, 64, 3, 24, 32)])
+                                        (1, 64, 3, 24, 32), (70, 1000, 3, 24, 10), (130, 1024, 3, 3, 10), (40, 4096, 3, 24, 20)])
 def test_knn_vs_oracle(hip, oracle, b, n, c, ld, k):
     from cloudaae_amd import _lib
     rng = np.random.default_rng(n * 7 + c + k)
