@@ -118,9 +118,13 @@ def test_side_stream_step_matches(hip):
         el["noise"] = torch.randn((B, N, 3), device="cuda") * 0.001
         o1, o2 = one.train_step(el), two.train_step(el)
         torch.cuda.synchronize()
+        # Two runs of the SAME configuration already differ by the order of their fp32 atomics (split-K products, the
+        # fully connected dX); at B = 8 the batch norms of the heads amplify that round-off about tenfold (see
+        # tests/test_oracle_conditioning.py), so: the north-star 1e-5 on the losses, 5e-3 of the largest gradient.
+        # (1e-6 / 2e-3 failed once in six full-suite runs.)
         for k in ("xyz_loss", "trans_loss", "axag_loss", "total_loss"):
             a, b = float(o1[k]), float(o2[k])
-            assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (step, k, a, b)
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (step, k, a, b)
         g1, g2 = one.store.flat_grads, two.store.flat_grads
-        assert float((g1 - g2).abs().max()) <= 2e-3 * float(g1.abs().max()), step
+        assert float((g1 - g2).abs().max()) <= 5e-3 * float(g1.abs().max()), step
     assert not two._plan.foreign_ops
