@@ -100,7 +100,7 @@ def test_checkpoint_round_trip(hip, dataset, tmp_path):
     # Chamfer gradient): same losses on the next step, same weights after it
     o1, o2 = g1.train_step(el), g2.train_step(el)
     for k in ("xyz_loss", "trans_loss", "axag_loss"):
-        assert abs(float(o1[k]) - float(o2[k])) <= 1e-6 * max(1.0, abs(float(o1[k])))
+        assert abs(float(o1[k]) - float(o2[k])) <= 1e-5 * max(1.0, abs(float(o1[k])))
     # (fp32 atomics in split-K GEMMs / the Chamfer gradient make two runs differ by round-off;
     # Adam turns round-off-sized gradients -- e.g. of the analytically dead conv biases in front of
     # a BN -- into +-lr-sized moves, so the bound is 2 lr for those few and ~0 for the rest)
