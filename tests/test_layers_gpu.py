@@ -28,7 +28,7 @@ def _rel(got, want):
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (32, 1024, 1024), (2, 3, 256), (200, 130, 70), (4096, 64, 24),
                                    (4096, 128, 64), (320, 1024, 8192), (64, 64, 20000), (129, 257, 33),
-                                   (2, 12288, 1024)])
+                                   (2, 12288, 1024), (128, 1024, 1024), (100, 300, 500), (128, 12288, 1024)])
 def test_gemm(hip, ta, tb, M, N, K):
     rng = np.random.default_rng(M * 7 + N * 3 + K + ta * 2 + tb)
     A = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
