@@ -28,6 +28,8 @@ _SIGNATURES = {
     "cloudaae_knn": [_I, _I, _I, _I, _I, _P, _P, _P],
     "cloudaae_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "cloudaae_gemm_bf16": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
+    "cloudaae_gemm_f32_ordered": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P],
+    "cloudaae_gemm_bf16_ordered": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P],
     "cloudaae_gemm_f32_tn_group": [_I, _P, _P],
     "cloudaae_bn_forward": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P,
                             _P, _P, _P],
@@ -48,7 +50,7 @@ _SIGNATURES = {
     "cloudaae_gemm_bf16_colstats": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P],
     "cloudaae_bn_forward_colstats": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P,
                                      _P, _P, _I, _P],
-    "cloudaae_fc_forward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
+    "cloudaae_fc_forward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P],
     "cloudaae_fc_backward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P,
                              _P, _I, _P],
     "cloudaae_stream_wait": [_P, _P],
@@ -103,7 +105,8 @@ class FcLayer(ctypes.Structure):
     _fields_ = [("K", _I), ("N", _I), ("x", _P), ("ldx", _I), ("w", _P), ("bias", _P), ("gamma", _P), ("beta", _P),
                 ("ema_mean", _P), ("ema_var", _P), ("save_mean", _P), ("save_var", _P), ("relu", _I), ("y", _P),
                 ("out", _P), ("tickets", _P), ("dout", _P), ("lddo", _I), ("dx", _P), ("lddx", _I), ("dw", _P),
-                ("accumulate_dw", _I), ("dgamma", _P), ("dbeta", _P), ("dbias", _P), ("accumulate_param_grads", _I)]
+                ("accumulate_dw", _I), ("dgamma", _P), ("dbeta", _P), ("dbias", _P), ("accumulate_param_grads", _I),
+                ("partials", _P)]
 
 
 # int (*cloudaae_allreduce_fn)(void *ctx, double *buf, int count, cloudaae_stream_t stream)
@@ -116,7 +119,8 @@ class BnSyncStruct(ctypes.Structure):
 
 
 _LONGLONG_RESULTS = ["cloudaae_bn_workspace_bytes", "cloudaae_edgeconv_workspace_bytes",
-                     "cloudaae_mean_workspace_bytes"]
+                     "cloudaae_mean_workspace_bytes", "cloudaae_gemm_f32_ordered_workspace",
+                     "cloudaae_gemm_bf16_ordered_workspace"]
 
 
 class HipLibraryError(RuntimeError):
@@ -282,6 +286,8 @@ def lib():
         cdll.cloudaae_gemm_f32_splits.restype = ctypes.c_int
         cdll.cloudaae_gemm_bf16_splits.argtypes = [_I, _I, _I]
         cdll.cloudaae_gemm_bf16_splits.restype = ctypes.c_int
+        cdll.cloudaae_gemm_f32_ordered_workspace.argtypes = [_I, _I, _I]
+        cdll.cloudaae_gemm_bf16_ordered_workspace.argtypes = [_I, _I, _I]
         cdll.cloudaae_bn_workspace_bytes.argtypes = [_I]
         cdll.cloudaae_gemm_f32_colstats_parts.argtypes = [_I, _I, _I]
         cdll.cloudaae_gemm_f32_colstats_parts.restype = ctypes.c_int
@@ -294,6 +300,8 @@ def lib():
         cdll.cloudaae_side_stream.restype = ctypes.c_void_p
         cdll.cloudaae_fc_forward_tickets.argtypes = [_I]
         cdll.cloudaae_fc_forward_tickets.restype = ctypes.c_int
+        cdll.cloudaae_fc_forward_partials.argtypes = [_I, _I, _I]
+        cdll.cloudaae_fc_forward_partials.restype = ctypes.c_longlong
         cdll.cloudaae_edgeconv_workspace_bytes.argtypes = [_I]
         _lib = _Library(cdll)
     return _lib

@@ -61,7 +61,8 @@ struct FcFwdArgs {
     const float *gamma, *beta, *decay;      // gamma == nullptr: no batch norm
     float *ema_mean, *ema_var, *save_mean, *save_var;
     float *y, *out;
-    int *tickets;       // batch norm over a product cut over K: one arrival counter per column tile
+    int *tickets;       // a product cut over K that is finished by its last slice: one arrival counter per column tile
+    float *partials;    // [tiles][splits][FC_M][FC_TN]: the slices' partial tiles, summed in slice order by the last to arrive
 };
 
 struct FcGroup {        // operands of eight k: lane half h holds k + 4h .. k + 4h + 3
@@ -167,7 +168,7 @@ __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int 
     // the bias joins once: with the only slice, with slice 0 of a plain cut product, or (batch norm
     // over a cut product) when the last slice to arrive reads the finished sums back
     const float bias = (a.bias != nullptr && ok) ? a.bias[c] : 0.0f;
-    const float bv = (!a.atomic || (a.tickets == nullptr && slice == 0)) ? bias : 0.0f;
+    const float bv = (!a.atomic || (a.tickets == nullptr && a.partials == nullptr && slice == 0)) ? bias : 0.0f;
     float v[RP];
 #pragma unroll
     for (int i = 0; i < RP; ++i) {
@@ -178,7 +179,73 @@ __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int 
             s += tile[((size_t)w * FC_M + row) * FC_LD + col];
         v[i] = s + bv;
     }
-    if (a.atomic) {     // one K slice of several: the output was cleared by the caller
+    if (a.atomic && a.partials != nullptr) {
+        // One K slice of several, combined in a FIXED order (bit-reproducible from run to run, whatever order the
+        // slices finish in): every slice publishes its partial tile with agent-scope stores (write-through to
+        // where all XCDs meet), every WAVE waits until its stores are acknowledged (s_waitcnt vmcnt(0); s_barrier
+        // alone does not drain the counter), then a ticket is taken; the workgroup that draws the last one reads
+        // all partial tiles back with agent-scope loads and sums them in slice order 0, 1, 2, ...  No cache
+        // write-back or invalidate is involved (a __threadfence() here costs more than the whole product)
+        // because no ordinary store takes part.  The counter returns to zero for the next launch.
+        // (tests/test_capi_symbols.py checks the emitted ISA for the wait in front of the barrier.)
+        float *slot = a.partials + (size_t)(tile_x * a.splits + slice) * (FC_M * FC_TN);
+#pragma unroll
+        for (int i = 0; i < RP; ++i)
+            if (rg + RG * i < a.M)
+                __hip_atomic_store(&slot[(rg + RG * i) * FC_TN + col], v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int t = __hip_atomic_fetch_add(&a.tickets[tile_x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *last_flag = t == a.splits - 1;
+            if (t == a.splits - 1)
+                __hip_atomic_store(&a.tickets[tile_x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!*last_flag)
+            return;
+        // thread t sums element pairs t, t + 256, ... of the 32 x 128 tile (8-byte loads, a row per wave and
+        // instruction); four slices' loads are in flight together; the sums meet the column threads in LDS
+        constexpr int PAIRS = FC_M * FC_TN / 2 / (NW * 64);
+        const unsigned long long *base =
+            reinterpret_cast<const unsigned long long *>(a.partials + (size_t)tile_x * a.splits * (FC_M * FC_TN));
+        float2v sum[PAIRS];
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q)
+            sum[q] = float2v{0.0f, 0.0f};
+        for (int s0 = 0; s0 < a.splits; s0 += 4) {
+            unsigned long long raw[4][PAIRS];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = min(s0 + u, a.splits - 1);        // (past the end: the last slice again, not added)
+#pragma unroll
+                for (int q = 0; q < PAIRS; ++q) {
+                    const int e = (int)threadIdx.x + NW * 64 * q;
+                    const int row = min(e / (FC_TN / 2), a.M - 1);      // rows >= M were never published
+                    raw[u][q] = __hip_atomic_load(&base[((size_t)s * FC_M + row) * (FC_TN / 2) + e % (FC_TN / 2)],
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (s0 + u < a.splits)
+#pragma unroll
+                    for (int q = 0; q < PAIRS; ++q) {
+                        sum[q].x += __uint_as_float((unsigned)raw[u][q]);
+                        sum[q].y += __uint_as_float((unsigned)(raw[u][q] >> 32));
+                    }
+        }
+        __syncthreads();        // (the waves' partial tiles in LDS have been consumed)
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) {
+            const int e = (int)threadIdx.x + NW * 64 * q;
+            *reinterpret_cast<float2v *>(tile + (e / (FC_TN / 2)) * FC_LD + 2 * (e % (FC_TN / 2))) = sum[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RP; ++i)
+            v[i] = tile[(rg + RG * i) * FC_LD + col] + bias;
+    } else if (a.atomic) {     // one K slice of several, added with fp32 atomics: the output was cleared by the caller
         if (ok)
 #pragma unroll
             for (int i = 0; i < RP; ++i)
@@ -187,14 +254,9 @@ __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int 
                                            __HIP_MEMORY_SCOPE_AGENT);
         if (a.tickets == nullptr)
             return;
-        // Batch norm needs the whole column.  Every slice adds its sums with agent-scope atomics (performed
-        // at the memory side, where all XCDs meet) and every WAVE waits until its own adds are acknowledged
-        // (s_waitcnt vmcnt(0): a returnless atomic counts in vmcnt until the memory side has performed it;
-        // s_barrier alone does NOT drain the counter) before the barrier; only then is a ticket taken; the
-        // workgroup that draws the last one reads the column tile back with agent-scope loads and finishes
-        // it.  No cache write-back or invalidate is involved -- a __threadfence() here costs more than the
-        // whole product -- because no ordinary store takes part.  The counter returns to zero for the next
-        // launch.  (tests/test_capi_symbols.py checks the emitted ISA for the wait in front of the barrier.)
+        // Batch norm needs the whole column: the same ticket protocol as above, with the sums added in arrival
+        // order by agent-scope atomics (performed at the memory side, where all XCDs meet) and read back by the
+        // last slice to arrive.  (Callers that pass no `partials` workspace.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -624,6 +686,26 @@ static int env_int(const char *name, int fallback)
     return (e && *e) ? atoi(e) : fallback;
 }
 
+// Column tiles and K slices of one forward layer.  Four waves per workgroup, each with at least sixteen k; K is
+// cut into slices until the chip is covered.  These products are short chains of load -> MFMA: what they need
+// is every load of the layer in flight at once, i.e. many workgroups.  (Development knobs read once.)
+static void fc_fwd_plan(int K, int N, bool bn, bool whole_k, int &tiles, int &splits, int &kslice)
+{
+    static const int want_bn = env_int("CLOUDAAE_FC_FWD_BLOCKS", 128), want_plain = env_int("CLOUDAAE_FC_FWD_BLOCKS", 192);
+    static const int forced = env_int("CLOUDAAE_FC_FWD_SPLITS", 0);
+    tiles = ceil_div(N, FC_TN);
+    splits = (bn ? want_bn : want_plain) / tiles;
+    const int most = K / (16 * FC_NW);
+    splits = splits > most ? most : splits;
+    splits = splits < 1 ? 1 : splits;
+    if (forced)
+        splits = forced;
+    if (whole_k)
+        splits = 1;
+    kslice = ceil_div(ceil_div(K, splits), 8) * 8;
+    splits = ceil_div(K, kslice);
+}
+
 } // namespace cloudaae
 
 using namespace cloudaae;
@@ -631,6 +713,14 @@ using namespace cloudaae;
 CLOUDAAE_API int cloudaae_fc_max_rows(void) { return FC_M; }
 CLOUDAAE_API int cloudaae_fc_max_group(void) { return FC_MAX_GROUP; }
 CLOUDAAE_API int cloudaae_fc_forward_tickets(int N) { return N > 0 ? ceil_div(N, FC_TN) : 0; }
+CLOUDAAE_API long long cloudaae_fc_forward_partials(int K, int N, int batch_norm)
+{
+    if (K <= 0 || N <= 0)
+        return 0;
+    int tiles, splits, kslice;
+    fc_fwd_plan(K, N, batch_norm != 0, false, tiles, splits, kslice);
+    return splits > 1 ? (long long)tiles * splits * FC_M * FC_TN : 0;
+}
 
 CLOUDAAE_API int cloudaae_fc_forward_group(int M, int count, const cloudaae_fc_layer *layers, int training,
                                            const float *decay, int y_zeroed, cloudaae_stream_t stream)
@@ -652,22 +742,9 @@ CLOUDAAE_API int cloudaae_fc_forward_group(int M, int count, const cloudaae_fc_l
             CLOUDAAE_REQUIRE(training || (l.ema_mean && l.ema_var), name, "inference needs the EMA statistics");
             CLOUDAAE_REQUIRE(!training || !l.ema_mean || decay, name, "EMA update needs the decay scalar");
         }
-        const int tiles = ceil_div(l.N, FC_TN);
-        // Four waves per workgroup, each with at least sixteen k; K is cut into slices until the chip
-        // is covered.  These products are short chains of load -> MFMA: what they need is every load
-        // of the layer in flight at once, i.e. many workgroups.  A layer with batch norm can only be
-        // cut when the caller provides the arrival counters.
-        const int want = env_int("CLOUDAAE_FC_FWD_BLOCKS", bn ? 128 : 192);
-        int splits = want / tiles;
-        const int most = l.K / (16 * FC_NW);
-        splits = splits > most ? most : splits;
-        splits = splits < 1 ? 1 : splits;
-        if (const int f = env_int("CLOUDAAE_FC_FWD_SPLITS", 0))
-            splits = f;
-        if (bn && l.tickets == nullptr)
-            splits = 1;
-        const int kslice = ceil_div(ceil_div(l.K, splits), 8) * 8;
-        splits = ceil_div(l.K, kslice);
+        // a layer with batch norm can only be cut over K when the caller provides the arrival counters
+        int tiles, splits, kslice;
+        fc_fwd_plan(l.K, l.N, bn, bn && l.tickets == nullptr, tiles, splits, kslice);
         FcFwdArgs &a = g.p[i];
         a.M = M; a.K = l.K; a.N = l.N; a.ldx = l.ldx; a.kslice = kslice; a.atomic = splits > 1;
         a.training = training; a.relu = l.relu;
@@ -676,8 +753,11 @@ CLOUDAAE_API int cloudaae_fc_forward_group(int M, int count, const cloudaae_fc_l
         a.x = l.x; a.w = l.w; a.bias = l.bias; a.gamma = l.gamma; a.beta = l.beta; a.decay = decay;
         a.ema_mean = l.ema_mean; a.ema_var = l.ema_var; a.save_mean = l.save_mean; a.save_var = l.save_var;
         a.y = l.y; a.out = l.out;
-        a.tickets = (bn && a.atomic) ? l.tickets : nullptr;
-        if (a.atomic && !y_zeroed)
+        // cut over K: with the partial-tile workspace the slices are summed in a fixed order by the last one to
+        // arrive (y is plainly stored); without it they add into y with atomics (y cleared first)
+        a.partials = (a.atomic && l.tickets != nullptr) ? l.partials : nullptr;
+        a.tickets = (a.atomic && (bn || a.partials != nullptr)) ? l.tickets : nullptr;
+        if (a.atomic && a.partials == nullptr && !y_zeroed)
             CLOUDAAE_CHECK_HIP(hipMemsetAsync(l.y, 0, sizeof(float) * (size_t)M * l.N, s), name);
         blocks += tiles * splits;
     }
@@ -739,12 +819,12 @@ CLOUDAAE_API int cloudaae_fc_forward(int M, int K, int N, const float *x, int ld
                                      const float *bias, const float *gamma, const float *beta, int training,
                                      const float *decay, float *ema_mean, float *ema_var, float *save_mean,
                                      float *save_var, int relu, float *y, float *out, int y_zeroed, int *tickets,
-                                     cloudaae_stream_t stream)
+                                     float *partials, cloudaae_stream_t stream)
 {
     cloudaae_fc_layer l = {};
     l.K = K; l.N = N; l.x = x; l.ldx = ldx; l.w = w; l.bias = bias; l.gamma = gamma; l.beta = beta;
     l.ema_mean = ema_mean; l.ema_var = ema_var; l.save_mean = save_mean; l.save_var = save_var; l.relu = relu;
-    l.y = y; l.out = out; l.tickets = tickets;
+    l.y = y; l.out = out; l.tickets = tickets; l.partials = partials;
     return cloudaae_fc_forward_group(M, 1, &l, training, decay, y_zeroed, stream);
 }
 

@@ -13,9 +13,13 @@ namespace cloudaae {
 // colstats (optional): per row tile the column sums and sums of squares of C.
 int gemm_f32_launch(const char *name, int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                     const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate, int fold_b,
-                    int fold_c, hipStream_t stream, double *colstats = nullptr);
+                    int fold_c, hipStream_t stream, double *colstats = nullptr, float *ordered_ws = nullptr);
 int gemm_bf16_launch(const char *name, int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                      const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate, int fold_b,
-                     int fold_c, hipStream_t stream, double *colstats = nullptr);
+                     int fold_c, hipStream_t stream, double *colstats = nullptr, float *ordered_ws = nullptr);
+// ordered_ws (optional): room for splits * M * N floats; a product cut over K then keeps its slices apart and sums
+// them in slice order (bit-reproducible) instead of adding them with atomics.
+int gemm_slices_sum(const char *name, int M, int N, int splits, const float *ws, float *C, int ldc, const float *bias,
+                    hipStream_t stream);
 
 } // namespace cloudaae

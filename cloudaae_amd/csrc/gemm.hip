@@ -297,7 +297,7 @@ template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool FAST>
 __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
     int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
     float *__restrict__ C, int ldc, const float *__restrict__ bias, int epilogue, int kchunk,
-    int vecA, int vecB, Fold foldB, Fold foldC, double *__restrict__ colstats)
+    int vecA, int vecB, Fold foldB, Fold foldC, double *__restrict__ colstats, long long cslice)
 {
     // XCD-aware tile order: workgroups that share an A row-panel (same tile row) get
     // consecutive virtual ids inside one XCD, so the panel is fetched from HBM once per XCD
@@ -318,7 +318,8 @@ __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
         vid = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, tiles);
         slice = blockIdx.z;
     }
-    gemm_f32_tile<BM, BN, WM, WN, TA, TB, FAST>(M, N, K, A, lda, B, ldb, C, ldc, bias, epilogue, kchunk, vecA, vecB, foldB,
+    // cslice != 0: every K slice stores its own copy of C (summed in slice order by gemm_slices_sum_kernel)
+    gemm_f32_tile<BM, BN, WM, WN, TA, TB, FAST>(M, N, K, A, lda, B, ldb, C + (size_t)slice * (size_t)cslice, ldc, bias, epilogue, kchunk, vecA, vecB, foldB,
                                                 foldC, colstats, (vid / (int)gridDim.x) * BM, (vid % (int)gridDim.x) * BN,
                                                 slice);
 }
@@ -368,41 +369,67 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_f32_tn_group_kernel(GemmGro
 template <int BM, int BN, int WM, int WN, bool FAST>
 static void launch_fast(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A,
                         int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int epi,
-                        int kchunk, int vecA, int vecB, Fold fb, Fold fc, double *cs)
+                        int kchunk, int vecA, int vecB, Fold fb, Fold fc, double *cs, long long cslice)
 {
     dim3 block(GEMM_THREADS);
     if (!ta && !tb)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false, FAST>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
     else if (!ta && tb)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true, FAST>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
     else if (ta && !tb)
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false, FAST>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
     else
         hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, FAST>), grid, block, 0, s, M, N, K,
-                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
+                           A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
 }
 
 template <int BM, int BN, int WM, int WN>
 static void launch_cfg(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A,
                        int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int epi,
-                       int kchunk, int vecA, int vecB, Fold fb, Fold fc, double *cs)
+                       int kchunk, int vecA, int vecB, Fold fb, Fold fc, double *cs, long long cslice)
 {
     // every tile and every K-slab whole, both operands float4-loadable: the predicate-free kernel
     const bool fast = M % BM == 0 && N % BN == 0 && K % kchunk == 0 && kchunk % GEMM_BK == 0 && vecA && vecB;
     if (fast)
         launch_fast<BM, BN, WM, WN, true>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                          vecA, vecB, fb, fc, cs);
+                                          vecA, vecB, fb, fc, cs, cslice);
     else
         launch_fast<BM, BN, WM, WN, false>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                           vecA, vecB, fb, fc, cs);
+                                           vecA, vecB, fb, fc, cs, cslice);
 }
 
 } // namespace cloudaae
 
 namespace cloudaae {
+
+// C[r][c] = ((ws[0][r][c] + ws[1][r][c]) + ... ) + bias[c]: the slices of a product cut over K, in slice order.
+__global__ __launch_bounds__(256) void gemm_slices_sum_kernel(long long total, int N, int splits, const float *__restrict__ ws,
+                                                              float *__restrict__ C, int ldc, const float *__restrict__ bias)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total)
+        return;
+    float v = ws[i];
+    for (int s = 1; s < splits; ++s)
+        v += ws[(size_t)s * total + i];
+    const int r = (int)(i / N), c = (int)(i % N);
+    if (bias != nullptr)
+        v += bias[c];
+    C[(size_t)r * ldc + c] = v;
+}
+
+int gemm_slices_sum(const char *name, int M, int N, int splits, const float *ws, float *C, int ldc, const float *bias,
+                    hipStream_t s)
+{
+    const long long total = (long long)M * N;
+    hipLaunchKernelGGL(gemm_slices_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, N, splits, ws,
+                       C, ldc, bias);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
 
 // Tile shape and split-K slice count of a product (shared by the launcher and the query below).
 static void gemm_plan(int M, int N, int K, int &BM, int &BN, int &splits)
@@ -488,7 +515,7 @@ CLOUDAAE_API int cloudaae_gemm_f32_splits(int M, int N, int K)
 // row blocks (see Fold); the folded matrix has leading dimension == width.
 int cloudaae::gemm_f32_launch(const char *name, int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                               const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
-                              int fold_b, int fold_c, hipStream_t s, double *colstats)
+                              int fold_b, int fold_c, hipStream_t s, double *colstats, float *ordered_ws)
 {
     CLOUDAAE_REQUIRE(M >= 0 && N >= 0 && K >= 0, name, "negative size");
     if (M == 0 || N == 0)
@@ -520,7 +547,21 @@ int cloudaae::gemm_f32_launch(const char *name, int trans_a, int trans_b, int M,
     // a whole gradient buffer once): plain stores when K is not split, atomics WITHOUT the clear
     // pass when it is
     int epi = accumulate == 1 ? EPI_ACCUM : EPI_STORE;
-    if (splits > 1) {
+    // ordered_ws: a product cut over K keeps its slices apart -- slice s stores its [M, N] result at
+    // ordered_ws + s M N -- and a second kernel sums them in slice order (bit-reproducible, unlike the atomics)
+    const bool ordered = ordered_ws != nullptr && splits > 1;
+    CLOUDAAE_REQUIRE(ordered_ws == nullptr || (accumulate == 0 && !fold_c && colstats == nullptr), name,
+                     "slice-ordered products overwrite an unfolded output");
+    float *const Cout = C;
+    const int ldc_out = ldc;
+    const float *const bias_out = bias;
+    long long cslice = 0;
+    if (ordered) {
+        C = ordered_ws;
+        ldc = N;
+        bias = nullptr;
+        cslice = (long long)M * N;
+    } else if (splits > 1) {
         epi = EPI_ATOMIC;
         if (!accumulate) {  // slices add into a zeroed output
             if (fold_c)     // the folded output is one contiguous [N/width * M][width] block
@@ -537,23 +578,28 @@ int cloudaae::gemm_f32_launch(const char *name, int trans_a, int trans_b, int M,
     const bool ta = trans_a != 0, tb = trans_b != 0;
     if (BM == 32)
         launch_cfg<32, 128, 1, 4>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                  vecA, vecB, fb, fc, colstats);
+                                  vecA, vecB, fb, fc, colstats, cslice);
     else if (BN == 160)
         launch_cfg<128, 160, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                   vecA, vecB, fb, fc, colstats);
+                                   vecA, vecB, fb, fc, colstats, cslice);
     else if (BM == 64 && BN == 64)
         launch_cfg<64, 64, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                 vecA, vecB, fb, fc, colstats);
+                                 vecA, vecB, fb, fc, colstats, cslice);
     else if (BN == 64)
         launch_cfg<128, 64, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                  vecA, vecB, fb, fc, colstats);
+                                  vecA, vecB, fb, fc, colstats, cslice);
     else if (BM == 64)
         launch_cfg<64, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                  vecA, vecB, fb, fc, colstats);
+                                  vecA, vecB, fb, fc, colstats, cslice);
     else
         launch_cfg<128, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk,
-                                   vecA, vecB, fb, fc, colstats);
+                                   vecA, vecB, fb, fc, colstats, cslice);
     CLOUDAAE_CHECK_LAUNCH(name);
+    if (ordered) {
+        const int rc = gemm_slices_sum(name, M, N, splits, ordered_ws, Cout, ldc_out, bias_out, s);
+        if (rc != 0)
+            return rc;
+    }
     return 0;
 }
 
@@ -563,6 +609,23 @@ CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K
 {
     return gemm_f32_launch("cloudaae_gemm_f32", trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate,
                            0, 0, (hipStream_t)stream);
+}
+
+CLOUDAAE_API long long cloudaae_gemm_f32_ordered_workspace(int M, int N, int K)
+{
+    const int splits = cloudaae_gemm_f32_splits(M, N, K);
+    return splits > 1 ? (long long)splits * M * N : 0;
+}
+
+CLOUDAAE_API int cloudaae_gemm_f32_ordered(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                                           const float *B, int ldb, float *C, int ldc, const float *bias,
+                                           float *workspace, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_gemm_f32_ordered";
+    CLOUDAAE_REQUIRE(workspace != nullptr || cloudaae_gemm_f32_ordered_workspace(M, N, K) == 0, name,
+                     "this product is cut over K: workspace needed");
+    return gemm_f32_launch(name, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, 0, 0, 0, (hipStream_t)stream,
+                           nullptr, workspace);
 }
 
 CLOUDAAE_API int cloudaae_gemm_f32_colstats_parts(int M, int N, int K)

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
                                                                float *__restrict__ C, int ldc,
                                                                const float *__restrict__ bias, int epilogue,
                                                                int kchunk, int vecA, int vecB, FoldB foldB,
-                                                               FoldB foldC, double *__restrict__ colstats)
+                                                               FoldB foldC, double *__restrict__ colstats,
+                                                               long long cslice)
 {
     static_assert(WM * WN * 64 == GB_THREADS, "4 waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
     const int m0 = (vid / (int)gridDim.x) * BM, n0 = (vid % (int)gridDim.x) * BN;
     const int kbeg = slice * kchunk;
     const int kend = min(K, kbeg + kchunk);
+    C += (size_t)slice * (size_t)cslice;        // != 0: every K slice stores its own copy (summed in slice order afterwards)
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -269,21 +271,21 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
 template <int BM, int BN, int WM, int WN>
 static void launch_bf16(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A, int lda,
                         const float *B, int ldb, float *C, int ldc, const float *bias, int epi, int kchunk,
-                        int vecA, int vecB, FoldB fb, FoldB fc, double *cs)
+                        int vecA, int vecB, FoldB fb, FoldB fc, double *cs, long long cslice)
 {
     dim3 block(GB_THREADS);
     if (!ta && !tb)
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
     else if (!ta && tb)
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
     else if (ta && !tb)
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
     else
         hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs);
+                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
 }
 
 // tile shape and K slices (same policy as gemm.hip's gemm_plan, slabs of 32)
@@ -345,7 +347,7 @@ CLOUDAAE_API int cloudaae_gemm_bf16_splits(int M, int N, int K)
 
 int cloudaae::gemm_bf16_launch(const char *name, int trans_a, int trans_b, int M, int N, int K, const float *A,
                                int lda, const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
-                               int fold_b, int fold_c, hipStream_t s, double *colstats)
+                               int fold_b, int fold_c, hipStream_t s, double *colstats, float *ordered_ws)
 {
     CLOUDAAE_REQUIRE(M >= 0 && N >= 0 && K >= 0, name, "negative size");
     if (M == 0 || N == 0)
@@ -373,7 +375,20 @@ int cloudaae::gemm_bf16_launch(const char *name, int trans_a, int trans_b, int M
     int kchunk = K > 0 ? ceil_div(ceil_div(K, splits), GB_BK) * GB_BK : GB_BK;
     splits = K > 0 ? ceil_div(K, kchunk) : 1;
     int epi = accumulate == 1 ? GB_ACCUM : GB_STORE;
-    if (splits > 1) {
+    // ordered_ws: slices kept apart and summed in slice order by a second kernel (see gemm_f32_launch)
+    const bool ordered = ordered_ws != nullptr && splits > 1;
+    CLOUDAAE_REQUIRE(ordered_ws == nullptr || (accumulate == 0 && !fold_c && colstats == nullptr), name,
+                     "slice-ordered products overwrite an unfolded output");
+    float *const Cout = C;
+    const int ldc_out = ldc;
+    const float *const bias_out = bias;
+    long long cslice = 0;
+    if (ordered) {
+        C = ordered_ws;
+        ldc = N;
+        bias = nullptr;
+        cslice = (long long)M * N;
+    } else if (splits > 1) {
         epi = GB_ATOMIC;
         if (!accumulate) {
             if (fold_c)
@@ -389,23 +404,28 @@ int cloudaae::gemm_bf16_launch(const char *name, int trans_a, int trans_b, int M
     const bool ta = trans_a != 0, tb = trans_b != 0;
     if (BM == 32)
         launch_bf16<32, 128, 1, 4>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
-                                   fc, colstats);
+                                   fc, colstats, cslice);
     else if (BN == 160)
         launch_bf16<128, 160, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
-                                    fc, colstats);
+                                    fc, colstats, cslice);
     else if (BM == 160)
         launch_bf16<160, 128, 1, 4>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
-                                    fc, colstats);
+                                    fc, colstats, cslice);
     else if (BN == 64)
         launch_bf16<128, 64, 4, 1>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
-                                   fc, colstats);
+                                   fc, colstats, cslice);
     else if (BM == 64)
         launch_bf16<64, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb,
-                                   fc, colstats);
+                                   fc, colstats, cslice);
     else
         launch_bf16<128, 128, 2, 2>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB,
-                                    fb, fc, colstats);
+                                    fb, fc, colstats, cslice);
     CLOUDAAE_CHECK_LAUNCH(name);
+    if (ordered) {
+        const int rc = gemm_slices_sum(name, M, N, splits, ordered_ws, Cout, ldc_out, bias_out, s);
+        if (rc != 0)
+            return rc;
+    }
     return 0;
 }
 
@@ -415,6 +435,23 @@ CLOUDAAE_API int cloudaae_gemm_bf16(int trans_a, int trans_b, int M, int N, int 
 {
     return gemm_bf16_launch("cloudaae_gemm_bf16", trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate,
                             0, 0, (hipStream_t)stream);
+}
+
+CLOUDAAE_API long long cloudaae_gemm_bf16_ordered_workspace(int M, int N, int K)
+{
+    const int splits = cloudaae_gemm_bf16_splits(M, N, K);
+    return splits > 1 ? (long long)splits * M * N : 0;
+}
+
+CLOUDAAE_API int cloudaae_gemm_bf16_ordered(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                                            const float *B, int ldb, float *C, int ldc, const float *bias,
+                                            float *workspace, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_gemm_bf16_ordered";
+    CLOUDAAE_REQUIRE(workspace != nullptr || cloudaae_gemm_bf16_ordered_workspace(M, N, K) == 0, name,
+                     "this product is cut over K: workspace needed");
+    return gemm_bf16_launch(name, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, 0, 0, 0, (hipStream_t)stream,
+                            nullptr, workspace);
 }
 
 CLOUDAAE_API int cloudaae_gemm_bf16_colstats_parts(int M, int N, int K)

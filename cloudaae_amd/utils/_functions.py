@@ -113,6 +113,22 @@ def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, accumulate=0, site=
         _lib.host(_mark, rec)
 
 
+def gemm_forward(M, N, K, A, lda, B, ldb, C, ldc, bias, device, site=None, bf16=False):
+    """C = A B + bias for a FORWARD product: bit-reproducible from run to run (cloudaae_gemm_*_ordered: a product
+    cut over K keeps its slices apart and sums them in slice order instead of adding them with atomics)."""
+    rec = TIMED_SITES.get(site) if site is not None else None
+    if rec is not None:
+        _lib.host(_mark, rec)
+    wsq = L().cloudaae_gemm_bf16_ordered_workspace if bf16 else L().cloudaae_gemm_f32_ordered_workspace
+    n = int(wsq(M, N, K))
+    ws = _lib.empty(n, dtype=torch.float32, device=device) if n else None
+    fn = L().cloudaae_gemm_bf16_ordered if bf16 else L().cloudaae_gemm_f32_ordered
+    _lib.check(fn(0, 0, M, N, K, A, lda, B, ldb, C, ldc, bias, ptr(ws), stream()),
+               "cloudaae_gemm_bf16_ordered" if bf16 else "cloudaae_gemm_f32_ordered")
+    if rec is not None:
+        _lib.host(_mark, rec)
+
+
 def _gemm_out(shape, K, device, bf16=False):
     """Output buffer of a product and the accumulate flag to pass: when the product is split over K
     while a step is being recorded, the buffer comes from the plan's zero zone (cleared by one fill
@@ -134,8 +150,8 @@ class LinearFn(torch.autograd.Function):
         M, K = x.shape
         N = w.shape[1]
         ctx.bf16 = gemm_is_bf16() and bool(allow_bf16)
-        y, acc = _gemm_out((M, N), K, x.device, ctx.bf16)
-        gemm(0, 0, M, N, K, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, acc, bf16=ctx.bf16)
+        y = _lib.empty((M, N), dtype=torch.float32, device=x.device)
+        gemm_forward(M, N, K, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, x.device, bf16=ctx.bf16)
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None and not bias_grad_by_bn
         ctx.bvar = b
@@ -175,6 +191,17 @@ def fc_max_group():
     return int(L().cloudaae_fc_max_group())
 
 
+def _fc_scratch(K, N, bn, dev):
+    """(tickets, partials) of one forward layer of csrc/fc.hip: arrival counters of its column tiles (zero before
+    and after every launch) and room for the partial tiles of its K slices, which the last slice to arrive sums
+    in slice order -- the forward pass is bit-reproducible from run to run.  (None, None) when K stays whole."""
+    n = int(L().cloudaae_fc_forward_partials(int(K), int(N), int(bool(bn))))
+    if n == 0:
+        return None, None
+    return (_lib.zeros(L().cloudaae_fc_forward_tickets(int(N)), dtype=torch.int32, device=dev),
+            _lib.empty(n, dtype=torch.float32, device=dev))
+
+
 class FcFn(torch.autograd.Function):
     """tf_util.fully_connected as a whole (utils/tf_util.py:321-365): matmul + bias [+ batch norm + ReLU]
     for a batch of at most 32 rows, one launch forward and one backward (csrc/fc.hip)."""
@@ -188,23 +215,19 @@ class FcFn(torch.autograd.Function):
         N = w.shape[1]
         dev = x.device
         bn = gamma is not None
-        save_mean = save_var = out = tickets = None
+        save_mean = save_var = out = None
         if bn:
             out = _lib.empty((M, N), dtype=torch.float32, device=dev)
             save_mean = _lib.empty(N, dtype=torch.float32, device=dev)
             save_var = _lib.empty(N, dtype=torch.float32, device=dev)
-            # arrival counters of the column tiles (zero before and after every launch)
-            tickets = _lib.zeros(L().cloudaae_fc_forward_tickets(N), dtype=torch.int32, device=dev)
-        # the product is cut over K and its slices add into y: while a step is recorded y comes from the
-        # plan's zero zone (one clear per replay), otherwise the call clears it
-        if _lib.recording() is not None:
-            y, zeroed = _lib.zeros((M, N), dtype=torch.float32, device=dev), 1
-        else:
-            y, zeroed = _lib.empty((M, N), dtype=torch.float32, device=dev), 0
+        # a product cut over K is summed in slice order by its last slice (bit-reproducible forward pass):
+        # arrival counters of the column tiles (zero before and after every launch) + the slices' partial tiles
+        tickets, partials = _fc_scratch(K, N, bn, dev)
+        y = _lib.empty((M, N), dtype=torch.float32, device=dev)
         _lib.check(L().cloudaae_fc_forward(
             M, K, N, xp, ldx, ptr(w), ptr(b), ptr(gamma), ptr(beta), int(bool(training)), ptr(decay), ptr(ema_mean),
-            ptr(ema_var), ptr(save_mean), ptr(save_var), int(bool(relu)), ptr(y), ptr(out), zeroed, ptr(tickets), stream()),
-            "cloudaae_fc_forward")
+            ptr(ema_var), ptr(save_mean), ptr(save_var), int(bool(relu)), ptr(y), ptr(out), 0, ptr(tickets),
+            ptr(partials), stream()), "cloudaae_fc_forward")
         ctx.save_for_backward(x, w, y if bn else None, gamma, beta, save_mean, save_var)
         ctx.cfg = (int(bool(training)), int(bool(relu)))
         ctx.bvar = b
@@ -259,7 +282,6 @@ class FcGroupFn(torch.autograd.Function):
         per = [tensors[n_in + 6 * i:n_in + 6 * i + 6] for i in range(len(x_index))]
         dev = xs[0].device
         M = xs[0].shape[0]
-        rec = _lib.recording() is not None
         layers = (_lib.FcLayer * len(per))()
         outs, keep = [], []
         for i, (w, b, gamma, beta, ema_mean, ema_var) in enumerate(per):
@@ -268,26 +290,23 @@ class FcGroupFn(torch.autograd.Function):
             xp, ldx = rows_ptr(x)
             K, N = w.shape
             bn = gamma is not None
-            # a product cut over K adds its slices into y: while a step is recorded y comes from the
-            # plan's zero zone (one clear per replay), otherwise the call clears it
-            y = _lib.zeros((M, N), dtype=torch.float32, device=dev) if rec else \
-                _lib.empty((M, N), dtype=torch.float32, device=dev)
-            out = save_mean = save_var = tickets = None
+            y = _lib.empty((M, N), dtype=torch.float32, device=dev)
+            out = save_mean = save_var = None
             if bn:
                 out = _lib.empty((M, N), dtype=torch.float32, device=dev)
                 save_mean = _lib.empty(N, dtype=torch.float32, device=dev)
                 save_var = _lib.empty(N, dtype=torch.float32, device=dev)
-                # arrival counters of the column tiles (zero before and after every launch)
-                tickets = _lib.zeros(L().cloudaae_fc_forward_tickets(N), dtype=torch.int32, device=dev)
+            # a product cut over K is summed in slice order by its last slice (see _fc_scratch)
+            tickets, partials = _fc_scratch(K, N, bn, dev)
             l = layers[i]
             l.K, l.N, l.x, l.ldx, l.w, l.bias = K, N, xp, ldx, ptr(w), ptr(b)
             l.gamma, l.beta, l.ema_mean, l.ema_var = ptr(gamma), ptr(beta), ptr(ema_mean), ptr(ema_var)
             l.save_mean, l.save_var, l.relu = ptr(save_mean), ptr(save_var), int(bool(relus[i]))
-            l.y, l.out, l.tickets = ptr(y), ptr(out), ptr(tickets)
+            l.y, l.out, l.tickets, l.partials = ptr(y), ptr(out), ptr(tickets), ptr(partials)
             outs.append(out if bn else y)
-            keep.append((y if bn else None, save_mean, save_var, tickets))
-        _lib.check(L().cloudaae_fc_forward_group(M, len(per), layers, int(bool(training)), ptr(decay),
-                                                 1 if rec else 0, stream()), "cloudaae_fc_forward_group")
+            keep.append((y if bn else None, save_mean, save_var, tickets, partials))
+        _lib.check(L().cloudaae_fc_forward_group(M, len(per), layers, int(bool(training)), ptr(decay), 0, stream()),
+                   "cloudaae_fc_forward_group")
         ctx.cfg, ctx.xs, ctx.per, ctx.keep, ctx.fwd_layers = cfg, xs, per, keep, layers
         return tuple(outs)
 
@@ -316,7 +335,7 @@ class FcGroupFn(torch.autograd.Function):
         hold, done = [], []
         for n, i in enumerate(live):
             w, b, gamma, beta, _, _ = per[i]
-            y, save_mean, save_var, _ = keep[i]
+            y, save_mean, save_var = keep[i][:3]
             x = xs[x_index[i]]
             dout = douts[i]
             dout = dout.contiguous() if dout.stride(-1) != 1 else dout
@@ -449,8 +468,8 @@ class ConcatLinearFn(torch.autograd.Function):
                 _lib.host(_mark, rec)
             y._cloudaae_colstats = (ws, parts, M, N)
         else:
-            gemm(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, site="agg_fwd",
-                 bf16=ctx.bf16)
+            gemm_forward(M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None, w.device,
+                         site="agg_fwd", bf16=ctx.bf16)
         ctx.save_for_backward(w, *nets)
         ctx.widths, ctx.xp, ctx.bvar = widths, xp, b
         return y

@@ -140,6 +140,15 @@ int cloudaae_gemm_f32_colstats(int trans_a, int trans_b, int M, int N, int K, co
 /* K slices cloudaae_gemm_f32 will use for this shape (> 1: the output is combined with atomics and
  * must hold zeros first -- the call clears it itself unless accumulate is 1 or 2). */
 int cloudaae_gemm_f32_splits(int M, int N, int K);
+/* cloudaae_gemm_f32 (overwrite mode) whose result is BIT-REPRODUCIBLE from run to run: a product cut over K keeps
+ * its slices apart in workspace (cloudaae_gemm_f32_ordered_workspace(M, N, K) floats; 0 = K stays whole and
+ * workspace may be NULL) and a second kernel sums them in slice order, then adds the bias.  C need not be
+ * cleared.  Used for every FORWARD product (the reference's CPU path is sequential and deterministic;
+ * evaluate_cloudAAE_ycbv.py:421-477 returns the same reconstruction for the same frame). */
+long long cloudaae_gemm_f32_ordered_workspace(int M, int N, int K);
+int cloudaae_gemm_f32_ordered(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                              const float *B, int ldb, float *C, int ldc, const float *bias, float *workspace,
+                              cloudaae_stream_t stream);
 /* Several independent weight-gradient products C_j += A_j^T B_j (A_j stored [K][M], B_j [K][N]: dW = x^T dy of
  * utils/tf_util.py:161-166 for several layers) in ONE launch: each is a single wave of short split-K workgroups on its
  * own, and nothing waits for them before the optimiser.  C_j is added to with atomics and must hold zeros: zeroed != 0
@@ -164,6 +173,11 @@ int cloudaae_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, const floa
                        const float *B, int ldb, float *C, int ldc, const float *bias, int accumulate,
                        cloudaae_stream_t stream);
 int cloudaae_gemm_bf16_splits(int M, int N, int K);
+/* cloudaae_gemm_f32_ordered_workspace / _ordered for the bf16-operand product. */
+long long cloudaae_gemm_bf16_ordered_workspace(int M, int N, int K);
+int cloudaae_gemm_bf16_ordered(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                               const float *B, int ldb, float *C, int ldc, const float *bias, float *workspace,
+                               cloudaae_stream_t stream);
 /* cloudaae_gemm_f32_colstats_parts / _colstats for the bf16-operand product. */
 int cloudaae_gemm_bf16_colstats_parts(int M, int N, int K);
 int cloudaae_gemm_bf16_colstats(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
@@ -276,14 +290,20 @@ int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, float *out, int a
  * zeros (a product cut over K adds its slices into it; otherwise the call clears it first).
  * tickets: cloudaae_fc_forward_tickets(N) ints holding ZERO, left zero by the call (arrival counters
  * that let a layer WITH batch norm be cut over K: the last slice to arrive normalises the column tile);
- * NULL = such a layer keeps K whole in one workgroup per 128 columns (slower).  Two calls in flight at
- * the same time (different streams) need separate counters. */
+ * NULL = such a layer keeps K whole in one workgroup per 128 columns (slower).
+ * partials: cloudaae_fc_forward_partials(K, N, gamma != NULL) floats of scratch (any contents), or NULL.
+ * With tickets AND partials a product cut over K is summed in a FIXED slice order by the last slice to
+ * arrive: the layer is bit-reproducible from run to run (and y need not be cleared).  Without partials
+ * the slices add into y with fp32 atomics: results then differ by round-off between runs.
+ * Two calls in flight at the same time (different streams) need separate counters and scratch. */
 int cloudaae_fc_max_rows(void);
 int cloudaae_fc_forward_tickets(int N);
+long long cloudaae_fc_forward_partials(int K, int N, int batch_norm);
 int cloudaae_fc_forward(int M, int K, int N, const float *x, int ldx, const float *w, const float *bias,
                         const float *gamma, const float *beta, int training, const float *decay,
                         float *ema_mean, float *ema_var, float *save_mean, float *save_var, int relu,
-                        float *y, float *out, int y_zeroed, int *tickets, cloudaae_stream_t stream);
+                        float *y, float *out, int y_zeroed, int *tickets, float *partials,
+                        cloudaae_stream_t stream);
 /* backward of the same layer from dout[M,N] (gradient of `out`, or of y when gamma == NULL):
  *   dx[M,K] += d(y) w^T      (ADDED with fp32 atomics: pass zeros, or a buffer that other consumers
  *                             of x add their gradients to as well; NULL = not wanted)
@@ -321,6 +341,8 @@ typedef struct cloudaae_fc_layer {
     int accumulate_dw;
     float *dgamma, *dbeta, *dbias;
     int accumulate_param_grads;
+    /* forward */
+    float *partials;
 } cloudaae_fc_layer;
 int cloudaae_fc_max_group(void);
 int cloudaae_fc_forward_group(int M, int count, const cloudaae_fc_layer *layers, int training,

@@ -2,7 +2,7 @@
 against the CPU oracle (oracle/model_oracle.py) on the same seeded inputs.
 Tolerances: these are fp32 computations whose summation ORDER differs from the oracle's
 (MFMA k-order vs BLAS, fp64 two-level column sums vs torch), so they are compared to
-fp32 round-off, not bitwise; index-producing ops are bit-exact (test_ops_gpu.py)."""
+fp32 round-off, not bitwise; index-producing ops are bit-exact (test_00_ops_gpu.py)."""
 import math
 
 import numpy as np
@@ -364,7 +364,7 @@ def test_train_step_k20_vs_oracle(hip, B, N, k):
     """BASELINE configs[4]'s shape (the fifth configuration): DGCNN with k=20 edge-conv, up to N=4096 points (LDS-tiled kNN
     stress), one full step vs the CPU restatement.
 
-    The kNN op itself is bit-exact on identical inputs (test_ops_gpu.py).  Inside the network the
+    The kNN op itself is bit-exact on identical inputs (test_00_ops_gpu.py).  Inside the network the
     grouping inputs of the two implementations agree to ~1e-7 relative only (layer 1: the centroid
     subtracted at train...:226 is a sum over N points; layers 2-4: features), so a k-th/(k+1)-th
     near-tie can pick a different neighbour (measured: 0.05-0.7 % of the entries at k=20), and every

@@ -10,7 +10,7 @@ slots non-zero): the three losses, the reconstruction, the gradient of every var
 averages, and what the optimiser leaves behind -- weights, both Adam slots, beta powers, step counter
 and the next step's bn_decay.  The compared pass is the REPLAYED one (the recording pass is compared
 with it too).  The oracle groups on the GPU's neighbour indices (the kNN op itself is bit-exact on
-identical inputs, test_ops_gpu.py); how often free-running grouping differs is measured per layer,
+identical inputs, test_00_ops_gpu.py); how often free-running grouping differs is measured per layer,
 printed, written to gpurun_out/ and bounded.
 
 Size-dependent kernel choices these shapes reach and the small cases do not: knn64_scan by grid

@@ -63,16 +63,17 @@ def test_evaluate_batch_vs_oracle(hip, oracle, B, N):
     al, per = MO.rotation_error(out["rot_pred"].cpu().double(), el["axisangle"])
     assert abs(float(out["axag_loss"]) - float(al)) <= 1e-5
     assert out["xyz_recon_FPS"].shape == (B, N, 3) and out["xyz_loss_per_sample"].shape == (B, N)
-    # the recorded pass gives the same numbers, also on a second, different batch
+    # the recorded pass gives the same BITS, also on a second, different batch: every forward product is summed
+    # in a fixed order (fc.hip's slice-ordered tiles, cloudaae_gemm_*_ordered), as the reference's sequential CPU
+    # path is (tf_nndistance.cpp:21-43); evaluate_cloudAAE_ycbv.py:421-477 gives one answer per frame
     dev = {k: v.cuda() for k, v in el.items()}
     r1 = E.evaluate_batch(graph, dev, replay=True)
-    # (split-K products add their slices with fp32 atomics: two runs agree to round-off, not bitwise)
-    assert torch.allclose(r1["xyz_recon"], out["xyz_recon"], rtol=1e-5, atol=1e-6)
-    assert abs(float(r1["xyz_loss"]) - float(out["xyz_loss"])) <= 1e-5 * max(1.0, float(out["xyz_loss"]))
+    for k in ("xyz_recon", "xyz_recon_FPS", "trans_pred", "rot_pred", "xyz_loss", "trans_loss", "axag_loss"):
+        assert torch.equal(r1[k], out[k]), k
     el2 = _element(B, N, seed=999)
     dev2 = {k: v.cuda() for k, v in el2.items()}
     want2 = E.evaluate_batch(graph, dev2)
-    got2 = E.evaluate_batch(graph, dev2, replay=True)          # a replay
-    assert torch.allclose(got2["xyz_recon"], want2["xyz_recon"], rtol=1e-5, atol=1e-6)
-    # (the two passes differ by the order of fp32 atomics in the split-K products of the pose head)
-    assert abs(float(got2["axag_loss"]) - float(want2["axag_loss"])) <= 5e-6
+    for _ in range(3):
+        got2 = E.evaluate_batch(graph, dev2, replay=True)          # replays
+        for k in ("xyz_recon", "xyz_recon_FPS", "trans_pred", "rot_pred", "xyz_loss", "trans_loss", "axag_loss"):
+            assert torch.equal(got2[k], want2[k]), k

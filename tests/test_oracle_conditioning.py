@@ -4,7 +4,7 @@ tolerances the parity tests use (north_star: losses within 1e-5).
 Two facts the GPU tests lean on are demonstrated here on the CPU restatement alone, no GPU involved:
   * BASELINE configs[0] is a batch of TWO: its batch norms normalise over two samples (x_hat = +-d / sqrt(d^2 + eps)),
     and with the neighbour sets held fixed a 1-ulp input change already moves trans_loss / axag_loss by ~1e-5 relative,
-    30 x what a batch of four does.  Hence 5e-5 for the B = 2 cases (tests/test_layers_gpu.py, __graft_entry__.smoke)
+    30 x what a batch of four does.  Hence 5e-5 for the B = 2 cases (tests/test_01_layers_gpu.py, __graft_entry__.smoke)
     and 1e-5 everywhere else.
   * Free-running, the same 1-ulp change flips k-th / (k+1)-th near-ties of the kNN grouping in a few rows and the losses
     move by up to ~1e-4: two correct implementations can only be compared to 1e-5 on the SAME neighbour sets, which is why

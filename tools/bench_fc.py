@@ -49,9 +49,16 @@ def main():
         P = lambda t: t.data_ptr()  # noqa: E731
         gp, bp = (P(gamma), P(beta)) if bn else (None, None)
 
-        def fused_fwd():
+        nparts = int(L.cloudaae_fc_forward_partials(K, N, int(bn)))
+        parts = torch.empty(max(nparts, 1), device="cuda")
+
+        def fused_fwd():        # slices summed in a fixed order by the last one to arrive (what the package uses)
             L.cloudaae_fc_forward(M, K, N, P(x), K, P(W), P(b), gp, bp, 1, P(decay), P(sm), P(sv), P(mean), P(var), 1,
-                                  P(y), P(out), 1, P(tk), s)     # (y counted as cleared: kernel time only)
+                                  P(y), P(out), 1, P(tk), P(parts) if nparts else None, s)
+
+        def atomic_fwd():       # slices added with fp32 atomics (y counted as cleared: kernel time only)
+            L.cloudaae_fc_forward(M, K, N, P(x), K, P(W), P(b), gp, bp, 1, P(decay), P(sm), P(sv), P(mean), P(var), 1,
+                                  P(y), P(out), 1, P(tk), None, s)
 
         def old_fwd():
             L.cloudaae_gemm_f32(0, 0, M, N, K, P(x), K, P(W), N, P(y), N, P(b), 0, s)
@@ -77,9 +84,9 @@ def main():
 
         old_fwd()
         mb = K * N * 4 / 1e6
-        t = [timeit(f, args.iters) for f in (fused_fwd, old_fwd, fused_bwd, old_bwd)]
-        print("K=%5d N=%5d bn=%d  W=%.1f MB | fwd %6.1f us (was %6.1f) %.2f TB/s | bwd %6.1f us (was %6.1f) %.2f TB/s"
-              % (K, N, bn, mb, t[0], t[1], mb / t[0], t[2], t[3], 2 * mb / t[2]))
+        t = [timeit(f, args.iters) for f in (fused_fwd, old_fwd, fused_bwd, old_bwd, atomic_fwd)]
+        print("K=%5d N=%5d bn=%d  W=%.1f MB | fwd %6.1f us (atomics %6.1f, gemm+bn %6.1f) %.2f TB/s | bwd %6.1f us (was %6.1f) %.2f TB/s"
+              % (K, N, bn, mb, t[0], t[4], t[1], mb / t[0], t[2], t[3], 2 * mb / t[2]))
 
 
 if __name__ == "__main__":
