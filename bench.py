@@ -87,6 +87,63 @@ def chamfer_cpu_rate(n, m, clouds=4):
             "kind": kind, "sample": "%d clouds of %dx%d, %.2f s" % (clouds, n, m, dt)}
 
 
+def cpu_table(num_point):
+    """BASELINE.md section 2's CPU legs that are not a train step (rank 0, N=1, bounded samples of ~1 s each):
+      C1  Chamfer forward AND backward on the reference's own loops (tf_nndistance.cpp:21-43 / :126-163, compiled from
+          the reference's lines into oracle/_ref: kind "reference"; the oracle's restatement, kind "port", when that
+          library did not travel), single-threaded as the reference op runs them (:79-80), and on all host cores
+          with the clouds of the batch spread over threads (clouds are independent: one call per cloud; ctypes
+          releases the GIL) -- at the train shape [B,4N]x[B,4N] and the reference's benchmark shape
+          [32,16384]x[32,1024] (tf_nndistance.py:48-49), randn, seed 100;
+      C3  farthest point sampling 4N -> N, the restatement of tf_sampling_g.cu:105-170 (the reference has no CPU
+          kernel for it: kind "port"), 1 thread and all cores (OpenMP over the batch)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import native as O
+    cores = min(os.cpu_count() or 1, 64)
+    have_ref = O.have_ref()
+    fwd = O.ref_nn_distance if have_ref else (lambda x, y: O.nn_distance(x, y, threads=1))
+    bwd = O.ref_nn_distance_grad if have_ref else (lambda *a: O.nn_distance_grad(*a, threads=1))
+    kind = "reference" if have_ref else "port"
+    rng = np.random.default_rng(100)
+    rows = []
+
+    def timed(fn, reps=1):
+        fn()
+        t0 = time.time()
+        for _ in range(reps):
+            fn()
+        return (time.time() - t0) / reps
+
+    for n, m, c1 in ((4 * num_point, 4 * num_point, 2), (16384, 1024, 2)):
+        clouds = max(cores, c1)
+        a = rng.standard_normal((clouds, n, 3)).astype(np.float32)
+        c = rng.standard_normal((clouds, m, 3)).astype(np.float32)
+        d1, i1, d2, i2 = fwd(a[:c1], c[:c1])
+        g1, g2 = np.ones_like(d1), np.ones_like(d2)
+        t_f = timed(lambda: fwd(a[:c1], c[:c1]))
+        t_b = timed(lambda: bwd(a[:c1], c[:c1], g1, i1, g2, i2), reps=20)
+        with ThreadPoolExecutor(cores) as pool:
+            t_fa = timed(lambda: list(pool.map(lambda j: fwd(a[j:j + 1], c[j:j + 1]), range(clouds))))
+        shape = "[B,%d,3]x[B,%d,3]" % (n, m)
+        rows.append({"leg": "C1 chamfer forward", "shape": shape, "clouds/s": round(c1 / t_f, 2), "cores": 1, "kind": kind,
+                     "Gpairs/s": round(2.0 * c1 * n * m / t_f / 1e9, 3), "sample": "%d clouds" % c1})
+        rows.append({"leg": "C1 chamfer forward, all cores", "shape": shape, "clouds/s": round(clouds / t_fa, 2),
+                     "cores": cores, "kind": kind, "Gpairs/s": round(2.0 * clouds * n * m / t_fa / 1e9, 3),
+                     "sample": "%d clouds, one per thread" % clouds})
+        rows.append({"leg": "C1b chamfer backward (tf_nndistance.cpp:126-163)", "shape": shape,
+                     "clouds/s": round(c1 / t_b, 1), "cores": 1, "kind": kind, "sample": "%d clouds x 20" % c1})
+    n = 4 * num_point
+    x = rng.standard_normal((cores, n, 3)).astype(np.float32)
+    t1 = timed(lambda: O.farthest_point_sample(num_point, x[:2], threads=1))
+    ta = timed(lambda: O.farthest_point_sample(num_point, x, threads=cores))
+    rows.append({"leg": "C3 farthest point sampling", "shape": "[B,%d,3] -> %d" % (n, num_point),
+                 "clouds/s": round(2 / t1, 2), "cores": 1, "kind": "port", "sample": "2 clouds"})
+    rows.append({"leg": "C3 farthest point sampling, all cores", "shape": "[B,%d,3] -> %d" % (n, num_point),
+                 "clouds/s": round(cores / ta, 2), "cores": cores, "kind": "port", "sample": "%d clouds" % cores})
+    return rows
+
+
 def chamfer_kernel_rate(batch, n, m, iters=20):
     """The second half of BASELINE's metric: Chamfer nn_distance forward kernel rate.
     Algorithmic bytes = B*(n+m)*20 (12 B read + 4 B dist + 4 B idx per point): arithmetic-bound
@@ -374,6 +431,7 @@ def main():
             if args.cpu_batch > 0:
                 line["chamfer_kernel"][0]["cpu"] = chamfer_cpu_rate(4 * N, 4 * N)
         if world == 1 and args.cpu_batch > 0 and not args.step_only:
+            line["cpu_table"] = cpu_table(N)
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_batch, args.cpu_steps)
         print(json.dumps(line))
     if dist.is_initialized():

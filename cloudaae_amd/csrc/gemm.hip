@@ -465,7 +465,9 @@ static void gemm_plan(int M, int N, int K, int &BM, int &BN, int &splits)
     // bound by streaming A and C, not by the matrix pipe: with 128-row tiles they make one workgroup per
     // CU, each a handful of slabs long, and nothing hides the load latency (0.9-1.8 TB/s measured).
     // Halve the tile height until there are two workgroups per CU.
-    if (BM == 128 && M >= 1024 && K <= 512 && (long long)ceil_div(M, 128) * ceil_div(N, BN) < 512 &&
+    // (not the 160-wide tiles: they exist as 128 x 160 only -- a 64-row grid over them would start half the
+    //  workgroups past the end of the matrix)
+    if (BM == 128 && BN != 160 && M >= 1024 && K <= 512 && (long long)ceil_div(M, 128) * ceil_div(N, BN) < 512 &&
         !getenv("CLOUDAAE_GEMM_TALL128"))
         BM = 64;
     // (32-row tiles for these shapes, four workgroups per CU: 11.5 vs 11.9 us at [32768 x 64] x [64 x 128] -- not worth a

@@ -79,6 +79,62 @@ def test_gemm_bf16(hip, ta, tb, M, N, K):
         assert float((want - bias.cuda().double() - full).abs().max()) / scale > 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 320, 512), (16384, 320, 512), (1024, 160, 512), (4096, 320, 1024)])
+def test_gemm_160_wide_tiles_stay_inside(hip, M, N, K):
+    """N a multiple of 160 but not of 128 takes 128 x 160 tiles; the tall / short-K rule (64-row tiles below K = 512) must
+    not apply to them (it once launched a 64-row grid over 128-row tiles: half the workgroups started past the end of A
+    and C).  Guard rows before and after C must survive; result against float64."""
+    rng = np.random.default_rng(M + N + K)
+    A = _dev(rng.standard_normal((M, K)).astype(np.float32))
+    B = _dev(rng.standard_normal((K, N)).astype(np.float32))
+    guard = 64
+    buf = torch.full((guard + M + guard, N), 777.0, device="cuda")
+    C = buf[guard:guard + M]
+    L = hip.lib()
+    hip.check(L.cloudaae_gemm_f32(0, 0, M, N, K, hip.ptr(A), K, hip.ptr(B), N, C.data_ptr(), N, None, 0, hip.stream()),
+              "gemm")
+    torch.cuda.synchronize()
+    assert float((buf[:guard] - 777.0).abs().max()) == 0.0 and float((buf[guard + M:] - 777.0).abs().max()) == 0.0
+    assert _rel(C, A.double() @ B.double()) < 1e-5
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("M,N,K", [(128, 1024, 1024), (1024, 1024, 320), (256, 12288, 1024), (100, 300, 500), (4096, 64, 24),
+                                   (33, 3, 256)])
+def test_gemm_ordered_is_bit_reproducible(hip, M, N, K, bf16):
+    """cloudaae_gemm_*_ordered: a product cut over K keeps its slices apart and sums them in slice order -- the same
+    bits launch after launch (the plain call adds the slices with fp32 atomics), equal to the plain call to round-off,
+    C not cleared beforehand, bias added once."""
+    rng = np.random.default_rng(M + N + K)
+    A = _dev(rng.standard_normal((M, K)).astype(np.float32))
+    B = _dev(rng.standard_normal((K, N)).astype(np.float32))
+    bias = _dev(rng.standard_normal(N).astype(np.float32))
+    L = hip.lib()
+    nm = "bf16" if bf16 else "f32"
+    n = int(getattr(L, "cloudaae_gemm_%s_ordered_workspace" % nm)(M, N, K))
+    splits = int(getattr(L, "cloudaae_gemm_%s_splits" % nm)(M, N, K))
+    assert (n > 0) == (splits > 1) and n == (splits * M * N if splits > 1 else 0)
+    ws = torch.full((max(n, 1),), float("nan"), device="cuda")
+    runs = []
+    for _ in range(8):
+        C = torch.full((M, N), float("nan"), device="cuda")
+        hip.check(getattr(L, "cloudaae_gemm_%s_ordered" % nm)(0, 0, M, N, K, hip.ptr(A), K, hip.ptr(B), N, hip.ptr(C), N,
+                                                               hip.ptr(bias), ws.data_ptr() if n else None, hip.stream()),
+                  "gemm_ordered")
+        runs.append(C)
+    torch.cuda.synchronize()
+    for C in runs[1:]:
+        assert torch.equal(C, runs[0])
+    plain = torch.empty((M, N), device="cuda")
+    hip.check(getattr(L, "cloudaae_gemm_%s" % nm)(0, 0, M, N, K, hip.ptr(A), K, hip.ptr(B), N, hip.ptr(plain), N,
+                                                   hip.ptr(bias), 0, hip.stream()), "gemm")
+    assert _rel(runs[0], plain) < 1e-5
+    if n:       # a cut product without its workspace is refused
+        rc = getattr(L, "cloudaae_gemm_%s_ordered" % nm)(0, 0, M, N, K, hip.ptr(A), K, hip.ptr(B), N, hip.ptr(plain), N,
+                                                          None, None, hip.stream())
+        assert rc != 0 and "workspace" in L.cloudaae_last_error().decode()
+
+
 def test_gemm_strided_views(hip):
     # column slices of wider buffers as A and C (what the fused encoder uses)
     rng = np.random.default_rng(0)

@@ -120,9 +120,11 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype):
     assert graph.replay and graph._plan is not None and not graph._plan.foreign_ops, "step not replayable"
     _restore(graph, start)
     rep = run()                                   # the replayed pass: what bench.py times
-    # the two passes ran the same kernels on the same data (fp32 atomics reorder: round-off only)
+    # the two passes ran the same kernels on the same data: the forward pass is bit-reproducible (fixed-order
+    # sums everywhere), the backward pass reorders fp32 atomics (round-off only)
     for k in keys:
-        assert abs(rec["losses"][k] - rep["losses"][k]) <= 2e-6 * max(1.0, abs(rec["losses"][k])), k
+        assert rec["losses"][k] == rep["losses"][k], (k, rec["losses"][k], rep["losses"][k])
+    assert torch.equal(rec["recon"], rep["recon"])
     assert all(torch.equal(a, b) for a, b in zip(rec["idx"], rep["idx"]))
     assert _nrm(rec["grads"], rep["grads"]) < 1e-3      # (a Chamfer near-tie may flip between the passes)
 
@@ -150,9 +152,12 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype):
                        "mismatch_fraction_of_points_per_layer": mismatch}, f)
     except OSError:
         pass
-    # layer 1 groups on xyz (inputs differ by the round-off of the centroid only); layers 2-4 on features
-    # that went through one more batch norm each.  bf16 operands: a feature on a rounding boundary flips.
-    assert mismatch[0] < 0.01 and max(mismatch) < (0.25 if bf16 else 0.05), mismatch
+    # layer 1 groups on xyz (inputs differ by the round-off of the centroid only: measured 0); layers 2-4 on
+    # features that went through one more batch norm each (measured, profiles/r02_knn_free_running_mismatch_*:
+    # at most 0.95 % of the points at B=32, 1.14 % at B=128, 1.40 % at B=256 with bf16 operands, where a feature
+    # on a rounding boundary flips).  The bounds are what was measured plus headroom for another seed, so a
+    # regression of the kNN numerics cannot hide: 2 % (fp32), 3 % (bf16).
+    assert mismatch[0] < 0.001 and max(mismatch) < (0.03 if bf16 else 0.02), mismatch
 
     # ---- the oracle's iteration, grouped on the GPU's indices ----
     p0 = {n: p.detach().clone() for n, p in V.p.items()}
