@@ -303,6 +303,10 @@ def lib():
         cdll.cloudaae_fc_forward_partials.argtypes = [_I, _I, _I]
         cdll.cloudaae_fc_forward_partials.restype = ctypes.c_longlong
         cdll.cloudaae_edgeconv_workspace_bytes.argtypes = [_I]
+        for q in ("cloudaae_set_knob", "cloudaae_unset_knob"):
+            getattr(cdll, q).restype = ctypes.c_int
+        cdll.cloudaae_set_knob.argtypes = [ctypes.c_char_p, _I]
+        cdll.cloudaae_unset_knob.argtypes = [ctypes.c_char_p]
         _lib = _Library(cdll)
     return _lib
 
@@ -390,6 +394,14 @@ class _ForeignOps(TorchDispatchMode):
         if not self.plan.internal and not name.startswith(_HARMLESS) and any(isinstance(a, torch.Tensor) and a.is_cuda for a in args):
             self.plan.foreign_ops.append(name)      # a kernel (or a sync) the plan would not replay
         return func(*args, **(kwargs or {}))
+
+
+def set_knob(name, value):
+    """A development knob of the library (include/cloudaae_hip.h: cloudaae_set_knob); value None = unset."""
+    if value is None:
+        check(lib()._cdll.cloudaae_unset_knob(name.encode()), "cloudaae_unset_knob")
+    else:
+        check(lib()._cdll.cloudaae_set_knob(name.encode(), int(value)), "cloudaae_set_knob")
 
 
 def check(rc, what):

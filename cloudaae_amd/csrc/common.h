@@ -12,6 +12,26 @@ void set_error(const char *fmt, ...);
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Development knobs (kernel A/B choices, launch shapes): an integer per name, read from the environment variable
+// of that name ONCE, when the first call site asks for it; cloudaae_set_knob / cloudaae_unset_knob change it
+// afterwards (tests, sweeps).  None is needed in normal use.  A call site keeps its slot in a static pointer.
+struct Knob {
+    const char *name;
+    int value;
+    bool set;
+};
+Knob *knob_slot(const char *name);
+#define CLOUDAAE_KNOB(NAME, FALLBACK)                                 \
+    ([&]() -> int {                                                   \
+        static cloudaae::Knob *k__ = cloudaae::knob_slot(NAME);       \
+        return k__->set ? k__->value : (FALLBACK);                    \
+    }())
+#define CLOUDAAE_KNOB_SET(NAME)                                       \
+    ([&]() -> bool {                                                  \
+        static cloudaae::Knob *k__ = cloudaae::knob_slot(NAME);       \
+        return k__->set;                                              \
+    }())
+
 // Every C-ABI entry point returns 0 or a hipError_t value; kernels are launched
 // on the caller's stream and never synchronise.
 #define CLOUDAAE_CHECK_LAUNCH(name)                                              \

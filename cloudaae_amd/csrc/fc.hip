@@ -680,19 +680,14 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdGroup g)
 
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
-static int env_int(const char *name, int fallback)
-{
-    const char *e = getenv(name);
-    return (e && *e) ? atoi(e) : fallback;
-}
 
 // Column tiles and K slices of one forward layer.  Four waves per workgroup, each with at least sixteen k; K is
 // cut into slices until the chip is covered.  These products are short chains of load -> MFMA: what they need
-// is every load of the layer in flight at once, i.e. many workgroups.  (Development knobs read once.)
+// is every load of the layer in flight at once, i.e. many workgroups.  
 static void fc_fwd_plan(int K, int N, bool bn, bool whole_k, int &tiles, int &splits, int &kslice)
 {
-    static const int want_bn = env_int("CLOUDAAE_FC_FWD_BLOCKS", 128), want_plain = env_int("CLOUDAAE_FC_FWD_BLOCKS", 192);
-    static const int forced = env_int("CLOUDAAE_FC_FWD_SPLITS", 0);
+    const int want_bn = CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_BLOCKS", 128), want_plain = CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_BLOCKS", 192);
+    const int forced = CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_SPLITS", 0);
     tiles = ceil_div(N, FC_TN);
     splits = (bn ? want_bn : want_plain) / tiles;
     const int most = K / (16 * FC_NW);
@@ -787,12 +782,12 @@ CLOUDAAE_API int cloudaae_fc_backward_group(int M, int count, const cloudaae_fc_
         const int slices = ceil_div(l.N, FC_TN), ktiles = ceil_div(l.K, 32);
         // Few tiles (every layer but the wide output one): one tile per workgroup, its four waves share
         // it, everything resident at once.  Many tiles: a wave per tile, workgroups for the resident set.
-        const bool fine = (long long)slices * ktiles <= env_int("CLOUDAAE_FC_BWD_FINE", 1024);
+        const bool fine = (long long)slices * ktiles <= CLOUDAAE_KNOB("CLOUDAAE_FC_BWD_FINE", 1024);
         int by;
         if (fine) {
             by = ktiles;
         } else {
-            const int want = env_int("CLOUDAAE_FC_BWD_BLOCKS", 384);
+            const int want = CLOUDAAE_KNOB("CLOUDAAE_FC_BWD_BLOCKS", 384);
             by = ceil_div(want, slices);
             const int most = ceil_div(ktiles, 4);
             by = by > most ? most : by;

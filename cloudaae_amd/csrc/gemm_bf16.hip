@@ -296,7 +296,7 @@ static void gemm_bf16_plan(int M, int N, int K, int &BM, int &BN, int &splits)
     // accumulators per wave: the big operand (dY, 1.07 GB at B=256) is then re-read twice instead of five times
     // (measured, dW / dX: B=256 987 -> 716 / 563 -> 542 us, B=128 494 -> 372 / 288 -> 276 us, B=32 139 -> 152 / 79 -> 64 us:
     // the transposed product keeps 64-row tiles below 65536 rows of K).  CLOUDAAE_BF16_TILE160=0 switches the rule off.
-    const bool t160 = !(getenv("CLOUDAAE_BF16_TILE160") && atoi(getenv("CLOUDAAE_BF16_TILE160")) == 0);
+    const bool t160 = CLOUDAAE_KNOB("CLOUDAAE_BF16_TILE160", 1) != 0;
     if (M <= 32) {
         BM = 32;
         BN = 128;

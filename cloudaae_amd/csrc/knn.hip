@@ -24,6 +24,24 @@ namespace cloudaae {
 constexpr int KNN_WAVES = 4;
 constexpr int KNN_THREADS = 64 * KNN_WAVES;
 
+// Dynamic LDS above the default limit must be requested once per kernel AND device.
+template <typename F>
+static hipError_t raise_lds_limit(F kernel, bool (&raised)[64])
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        dev = 0;
+    if (!raised[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess)
+            return e;
+        raised[dev] = true;
+    }
+    return hipSuccess;
+}
+
+
 template <int K>
 struct TopK {
     float d[K];
@@ -204,116 +222,6 @@ __global__ __launch_bounds__(KNN_THREADS) void knn3_kernel(int n, int ld, int k,
             const float m2 = -2.0f * inner;
             const float t = sqi + m2;
             const float d = t + c.w;
-            top.insert(d, c0 + s);
-        }
-    }
-    merge_and_store<K>(top, mbuf_d, mbuf_i, wave, lane, valid, k,
-                       nn_idx + ((size_t)cloud * n + ii) * k);
-}
-
-// ---- C = 64 ---------------------------------------------------------------
-constexpr int KNN64_CHUNK = 32;  // candidates per wave per LDS refill (8 KiB)
-
-template <int K>
-__global__ __launch_bounds__(KNN_THREADS) void knn64_kernel(int n, int ld, int k,
-                                                            const float *__restrict__ x,
-                                                            int *__restrict__ nn_idx)
-{
-    // scan buffers (candidate rows + their |.|^2) and merge buffer share LDS
-    constexpr int ROW_BYTES = KNN_WAVES * KNN64_CHUNK * 16 * 16;
-    constexpr int SCAN_BYTES = ROW_BYTES + KNN_WAVES * KNN64_CHUNK * 4;
-    constexpr int MERGE_BYTES = (KNN_WAVES - 1) * K * 64 * 8;
-    __shared__ __attribute__((aligned(16))) char smem[SCAN_BYTES > MERGE_BYTES ? SCAN_BYTES : MERGE_BYTES];
-    float4v(*cand)[KNN64_CHUNK * 16] = reinterpret_cast<float4v(*)[KNN64_CHUNK * 16]>(smem);
-    float(*csq)[KNN64_CHUNK] = reinterpret_cast<float(*)[KNN64_CHUNK]>(smem + ROW_BYTES);
-    float *mbuf_d = reinterpret_cast<float *>(smem);
-    int *mbuf_i = reinterpret_cast<int *>(smem) + (KNN_WAVES - 1) * K * 64;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int tile, cloud;
-    xcd_cloud_tile(tile, cloud);   // a cloud's candidate rows stay in ONE XCD's L2
-    const float *X = x + (size_t)cloud * n * ld;
-    const int i = tile * 64 + lane;
-    const bool valid = i < n;
-    const int ii = valid ? i : 0;
-
-    float4v q[16];
-    float sqi = 0.0f;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        q[g] = *reinterpret_cast<const float4v *>(X + (size_t)ii * ld + 4 * g);
-        const float a = q[g].x * q[g].x, b = q[g].y * q[g].y, c = q[g].z * q[g].z,
-                    d = q[g].w * q[g].w;
-        sqi = sqi + a;
-        sqi = sqi + b;
-        sqi = sqi + c;
-        sqi = sqi + d;
-    }
-    TopK<K> top;
-    top.init();
-
-    const int per = (n + KNN_WAVES - 1) / KNN_WAVES;
-    const int j_begin = min(wave * per, n), j_end = min(j_begin + per, n);
-    const int rounds = (per + KNN64_CHUNK - 1) / KNN64_CHUNK;
-    const int half = lane & 1, cslot = lane >> 1;  // two lanes stage one candidate row
-    for (int r = 0; r < rounds; ++r) {
-        const int c0 = j_begin + r * KNN64_CHUNK;
-        const int cnt = max(0, min(KNN64_CHUNK, j_end - c0));
-        __syncthreads();
-        {
-            // lane pair (2c, 2c+1) loads channels [0,32) / [32,64) of candidate c and
-            // continues ONE sequential |.|^2 sum across the pair (oracle order)
-            float part = 0.0f;
-            float4v v[8];
-            const bool ok = cslot < cnt;
-            const float *row = X + (size_t)(ok ? c0 + cslot : 0) * ld + 32 * half;
-#pragma unroll
-            for (int g = 0; g < 8; ++g)
-                v[g] = ok ? *reinterpret_cast<const float4v *>(row + 4 * g) : float4v{0, 0, 0, 0};
-            const float first = 0.0f;
-            float lo = first;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const float a = v[g].x * v[g].x, b = v[g].y * v[g].y, c = v[g].z * v[g].z,
-                            d = v[g].w * v[g].w;
-                lo = lo + a;
-                lo = lo + b;
-                lo = lo + c;
-                lo = lo + d;
-            }
-            // the odd lane restarts from the even lane's partial sum
-            const float carry = __shfl(lo, lane & ~1, 64);
-            part = carry;
-            if (half) {
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const float a = v[g].x * v[g].x, b = v[g].y * v[g].y, c = v[g].z * v[g].z,
-                                d = v[g].w * v[g].w;
-                    part = part + a;
-                    part = part + b;
-                    part = part + c;
-                    part = part + d;
-                }
-                csq[wave][cslot] = part;
-            }
-#pragma unroll
-            for (int g = 0; g < 8; ++g)
-                cand[wave][cslot * 16 + half * 8 + g] = v[g];
-        }
-        __syncthreads();
-        for (int s = 0; s < cnt; ++s) {
-            float inner = 0.0f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const float4v c = cand[wave][s * 16 + g];
-                inner = fmaf(q[g].x, c.x, inner);
-                inner = fmaf(q[g].y, c.y, inner);
-                inner = fmaf(q[g].z, c.z, inner);
-                inner = fmaf(q[g].w, c.w, inner);
-            }
-            const float m2 = -2.0f * inner;
-            const float t = sqi + m2;
-            const float d = t + csq[wave][s];
             top.insert(d, c0 + s);
         }
     }
@@ -788,14 +696,9 @@ template <int K, int QW, int CS>
 static hipError_t launch_knn_scan(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
     const size_t lds = sizeof(float) * (2 * CS * KM_TILE * 68 + 2 * QW * CS * KS_QCAP * 64 + (size_t)n);
-    static bool raised = false;       // >64 KiB of dynamic LDS needs the attribute once per kernel
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn64_scan_kernel<K, QW, CS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess)
-            return e;
-        raised = true;
-    }
+    static bool raised[64] = {};
+    if (hipError_t e = raise_lds_limit(&knn64_scan_kernel<K, QW, CS>, raised); e != hipSuccess)
+        return e;
     hipLaunchKernelGGL((knn64_scan_kernel<K, QW, CS>), dim3(ceil_div(n, KM_TILE * QW), b), dim3(64 * QW * CS), lds, s,
                        n, ld, k, x, nn_idx);
     return hipSuccess;
@@ -819,7 +722,6 @@ static hipError_t launch_knn_scan(int b, int n, int ld, int k, const float *x, i
 //            repeats the scan the plain way (sorted insert per candidate): correctness never depends on the bound.
 // Both passes evaluate d with the SAME instructions on the same MFMA results, so "d <= tau" in pass B is exact
 // and the indices stay bit-identical to oracle_knn.  Matrix work: 1.25 x the N x N x 64 products.
-constexpr int KB_QCAP = 36;          // queue slots per lane-list; a query owns 2*CS*KB_QCAP (fp32 distance + 16-bit index)
 
 template <int K>
 struct MinK {                        // the K smallest values seen, ascending
@@ -841,406 +743,6 @@ struct MinK {                        // the K smallest values seen, ascending
         }
     }
 };
-
-template <int K, int QW, int CS>
-__global__ __launch_bounds__(64 * QW * CS) void knn64_bound_kernel(int n, int ld, int k,
-                                                                   const float *__restrict__ x,
-                                                                   int *__restrict__ nn_idx)
-{
-    constexpr int WAVES = QW * CS, THREADS = 64 * WAVES;
-    constexpr int KS_LD = 68;                              // staged row: [32 even channels | 32 odd | 4 pad]
-    constexpr int TILE_FLOATS = KM_TILE * KS_LD;
-    extern __shared__ __attribute__((aligned(16))) char kb_smem[];
-    // layout: tile[2][CS][TILE_FLOATS] | queue d[QW * 32 queries][QPQ] (fp32) | queue j, same shape (u16: n <= 65536) |
-    //         queue lengths [QW * 32] | sq[ntiles * 32] | 1.0 | overflow flag
-    constexpr int QPQ = 2 * CS * KB_QCAP;                  // queue slots per QUERY (its 2 * CS lanes share them)
-    float *tiles = reinterpret_cast<float *>(kb_smem);
-    float *qd_all = tiles + 2 * CS * TILE_FLOATS;
-    unsigned short *qj_all = reinterpret_cast<unsigned short *>(qd_all + QW * 32 * QPQ);
-    int *qn_all = reinterpret_cast<int *>(qj_all + QW * 32 * QPQ);
-    float *sq = reinterpret_cast<float *>(qn_all + QW * 32);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qt = wave / CS, cs = wave % CS;
-    int qgroup, cloud;
-    xcd_cloud_tile(qgroup, cloud);
-    const float *X = x + (size_t)cloud * n * ld;
-    const int ntiles = (n + KM_TILE - 1) / KM_TILE;
-
-    // |x_j|^2 of the whole cloud (oracle order: sequential un-fused sum of rounded squares); rows past the end
-    // hold +inf, so their distances come out +inf and never pass a finite threshold; sq[ntiles * 32] = 1.0
-    for (int j = tid; j < QW * 32; j += THREADS)
-        qn_all[j] = 0;
-    for (int j = tid; j <= ntiles * KM_TILE + 1; j += THREADS) {
-        // (sq[ntiles * 32] = 1.0 for the 33rd step; the word behind it = 0: the workgroup's "a queue overflowed" flag)
-        float acc = j == ntiles * KM_TILE ? 1.0f : (j > ntiles * KM_TILE ? 0.0f : __builtin_inff());
-        if (j < n) {
-            const float *row = X + (size_t)j * ld;
-            acc = 0.0f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const float4v v = *reinterpret_cast<const float4v *>(row + 4 * g);
-                const float a = v.x * v.x, b = v.y * v.y, c = v.z * v.z, d = v.w * v.w;
-                acc = acc + a;
-                acc = acc + b;
-                acc = acc + c;
-                acc = acc + d;
-            }
-        }
-        sq[j] = acc;
-    }
-
-    const int col = lane & 31, half = lane >> 5;
-    const int qi0 = (qgroup * QW + qt) * KM_TILE + col;   // this lane's query
-    const bool qvalid = qi0 < n;
-    const int qs = qvalid ? qi0 : 0;
-    // B operand: MINUS TWICE the query channels of parity `half` (scaling by -2 is exact and commutes with
-    // every rounding of the fma chain, so the 32 MFMA steps leave exactly -2 <x_q, x_c>); a 33rd step then adds
-    // |x_q|^2 (k = 0: candidate side 1, query side |x_q|^2) and |x_c|^2 (k = 1: candidate side |x_c|^2, query
-    // side 1) in the oracle's order: acc = ((-2 inner) + sq_q) + sq_c = D -- the matrix pipe delivers the
-    // finished distance, no vector arithmetic per candidate
-    float bq[32];
-    {
-        const float *row = X + (size_t)qs * ld;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const float4v v = *reinterpret_cast<const float4v *>(row + 4 * g);
-            bq[2 * g] = -2.0f * (half ? v.y : v.x);
-            bq[2 * g + 1] = -2.0f * (half ? v.w : v.z);
-        }
-    }
-
-    // pass A's sample: S tiles, every stride-th one
-    const int S = min(ntiles, max((ntiles + 3) / 4, 4));
-    const int stride = ntiles / S;
-
-    // staging: a round = CS tiles of 32 rows x 16 float4; thread -> (row tid >> 4 of tile slot u, float4 tid & 15)
-    constexpr int VECS = CS * KM_TILE * 16, PER = VECS / THREADS;
-    static_assert(PER * THREADS == VECS && (THREADS / 16) * PER == CS * KM_TILE && THREADS / 16 <= KM_TILE,
-                  "a thread stages the same row of PER tile slots");
-    constexpr int ROWS_PER_U = THREADS / 16;               // rows covered per u
-    const int srow = tid >> 4, sq4 = tid & 15;
-    const float *gsrc = X + (size_t)srow * ld + 4 * sq4;
-    float4v stage[PER];
-    auto fetch = [&](bool passA, int r) {                  // global -> registers (nothing past the last round)
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int rowu = u * ROWS_PER_U + srow;         // row within the round's CS * 32 rows
-            const int slot = r * CS + (rowu >> 5);
-            const int c0 = passA ? (slot < S ? slot * stride * KM_TILE : n) : slot * KM_TILE;
-            const int g = c0 + (rowu & 31);
-            stage[u] = g < n ? *reinterpret_cast<const float4v *>(gsrc + (size_t)(g - srow) * ld)
-                             : float4v{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto commit = [&](float *buf) {                        // registers -> LDS tile buffers
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int rowu = u * ROWS_PER_U + srow;
-            float *dst = buf + (rowu >> 5) * TILE_FLOATS + (rowu & 31) * KS_LD + 2 * sq4;
-            *reinterpret_cast<float2v *>(dst) = float2v{stage[u].x, stage[u].z};
-            *reinterpret_cast<float2v *>(dst + 32) = float2v{stage[u].y, stage[u].w};
-        }
-    };
-    const int lrow = cs * TILE_FLOATS + col * KS_LD + 32 * half;   // this lane's operand row in a round's buffer
-    // operands of the 33rd step: candidate side sq[c0 + col] for the k = 1 lanes, the 1.0 behind sq[] for k = 0
-    const int xoff = half ? col : ntiles * KM_TILE;
-    const int xmul = half;                                 // (+ c0 only for the k = 1 lanes)
-    // operands of one staged tile -> registers (8 ds_read_b128 + the 33rd step's)
-    auto operands = [&](const float *buf, int c0, float4v (&a4)[8], float &ax) {
-        const float4v *arow = reinterpret_cast<const float4v *>(buf + lrow);
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-            a4[s] = arow[s];
-        ax = sq[xoff + xmul * c0];
-    };
-
-    // The scan loop of both passes is software pipelined three deep: while the matrix pipe works on the operands
-    // of round r (in registers), the operands of round r+1 travel LDS -> registers and the rows of round r+2
-    // global -> registers -> LDS (they replace round r's, which every wave has had in registers since the
-    // barrier that ended round r-1).  One barrier per round.
-    float bx = 1.0f;                                       // query side of the 33rd step (set once sq[] is visible)
-    f32x16 acc;
-
-    // ---------------- pass A: tau ----------------
-    const int roundsA = (S + CS - 1) / CS;
-    auto c0A = [&](int r) {
-        const int slot = r * CS + cs;
-        return slot < S ? slot * stride * KM_TILE : ntiles * KM_TILE - KM_TILE;      // (idle slot: a tile again)
-    };
-    fetch(true, 0);
-    commit(tiles);
-    if (roundsA > 1) {
-        fetch(true, 1);
-        commit(tiles + CS * TILE_FLOATS);
-    }
-    __syncthreads();                                       // rounds 0 and 1 and sq[] visible
-    bx = half ? 1.0f : sq[qs];
-    MinK<K> um;
-    um.init();
-    {
-        float4v opA[8], opB[8];
-        float axA, axB = 0.0f;
-        operands(tiles, c0A(0), opA, axA);
-        auto roundA = [&](int r, float4v (&cur)[8], float axc, float4v (&nxt)[8], float &axn) {
-            if (r + 1 < roundsA)
-                operands(tiles + ((r + 1) & 1) * CS * TILE_FLOATS, c0A(r + 1), nxt, axn);
-            if (r + 2 < roundsA)
-                fetch(true, r + 2);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                acc[e] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 32; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s >> 2][s & 3], bq[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bx, acc, 0, 0, 0);
-            const bool live = r * CS + cs < S;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {                  // units: the lane's rows 8 g + 4 half + (0..3)
-                const float m = fminf(fminf(acc[4 * g], acc[4 * g + 1]), fminf(acc[4 * g + 2], acc[4 * g + 3]));
-                um.insert(live ? m : __builtin_inff());
-            }
-            if (r + 2 < roundsA)
-                commit(tiles + (r & 1) * CS * TILE_FLOATS);
-            __syncthreads();
-        };
-        int r = 0;
-        for (; r + 1 < roundsA; r += 2) {
-            roundA(r, opA, axA, opB, axB);
-            roundA(r + 1, opB, axB, opA, axA);
-        }
-        if (r < roundsA)
-            roundA(r, opA, axA, opB, axB);
-    }
-    // K-th smallest unit minimum over the 2*CS lists of the query, through the queue area of the query
-    // tile's first wave: [list][p][query]
-    float *md = qd_all + qt * 32 * QPQ;
-    unsigned short *mi = qj_all + qt * 32 * QPQ;               // (indices of the merge lists: 16 bits)
-    static_assert(2 * CS * K * 32 <= 32 * QPQ, "scratch lists must fit the queue area of one query tile");
-    const int list = cs * 2 + half;
-#pragma unroll
-    for (int p = 0; p < K; ++p)
-        md[(list * K + p) * 32 + col] = um.d[p];
-    const int roundsB = (ntiles + CS - 1) / CS;
-    fetch(false, 0);                                       // pass B's first rounds travel meanwhile
-    commit(tiles);
-    if (roundsB > 1) {
-        fetch(false, 1);
-        commit(tiles + CS * TILE_FLOATS);
-    }
-    __syncthreads();
-    float tau = __builtin_inff();
-    {
-        int head[2 * CS];
-#pragma unroll
-        for (int l = 0; l < 2 * CS; ++l)
-            head[l] = 0;
-        for (int p = 0; p < K; ++p) {
-            float bd = __builtin_inff();
-            int bl = 0;
-#pragma unroll
-            for (int l = 0; l < 2 * CS; ++l) {
-                const float d = head[l] < K ? md[(l * K + head[l]) * 32 + col] : __builtin_inff();
-                const bool better = d < bd;
-                bd = better ? d : bd;
-                bl = better ? l : bl;
-            }
-#pragma unroll
-            for (int l = 0; l < 2 * CS; ++l)
-                head[l] += (l == bl) ? 1 : 0;
-            tau = bd;                                      // after K picks: the K-th smallest
-        }
-    }
-    tau = fminf(tau, 3.4028234664e38f);                    // rows past the end (+inf) never pass
-    __syncthreads();                                       // scratch lists consumed (the queues start empty)
-
-    // ---------------- pass B: everything at or below tau ----------------
-    // The queue of a QUERY is shared by its 2 * CS lanes (the lane halves of CS waves): slots are handed out by an
-    // LDS atomic on the query's length -- a pass is rare, and one lane's share of the cloud can hold three times its
-    // fair share of a query's candidates (a per-lane queue of 36 slots overflowed in most workgroups although the
-    // average lane uses 12).
-    const int qq = qt * 32 + col;                          // this lane's query within the workgroup
-    float *qd = qd_all + qq * QPQ;
-    unsigned short *qj = qj_all + qq * QPQ;
-    // The scan only APPENDS: the sorted lists (20 registers of state) are built once, after it.  Any use of them
-    // inside the loop costs dearly twice over -- the waves of a workgroup meet at a barrier every round, so a wave
-    // that stops to insert makes the other seven wait (48 of 130 us), and every branch around code that changes
-    // the lists drags ~40 register copies along (the compiler's phi moves: 10 k instructions per wave); even an
-    // overflow handler that is merely PRESENT in the loop (inlined or called) cost 19-35 us.  So when a query's
-    // queue is full (> 144 candidates at or below tau: duplicated points, adversarial clouds) the candidate is
-    // dropped and the workgroup's flag raised; a flagged workgroup then repeats the scan the slow, plain way (sorted
-    // insert per candidate, no bound) -- correctness never depends on the bound being tight.
-    bool lost = false;
-    // candidates 4 g .. 4 g + 3 of the previous tile: a pass is rare (a few per cent), lanes that pass append
-    // (d, j) to their queue
-    f32x16 prev;
-#pragma unroll
-    for (int e = 0; e < 16; ++e)
-        prev[e] = __builtin_inff();
-    int pj = 0;
-    auto push4 = [&](int g) {
-#pragma unroll
-        for (int e = 4 * g; e < 4 * g + 4; ++e)
-            if (prev[e] <= tau) {
-                const int slot = atomicAdd(&qn_all[qq], 1);
-                if (slot < QPQ) {
-                    qd[slot] = prev[e];
-                    qj[slot] = (unsigned short)(pj + (e & 3) + 8 * (e >> 2));
-                } else {
-                    lost = true;
-                }
-            }
-    };
-    auto c0B = [&](int r) { return min(r * CS + cs, ntiles - 1) * KM_TILE; };   // (idle slot of the last round: the
-                                                                                //  last tile again, discarded below)
-    {
-        float4v opA[8], opB[8];
-        float axA, axB = 0.0f;
-        operands(tiles, c0B(0), opA, axA);
-        auto roundB = [&](int r, float4v (&cur)[8], float axc, float4v (&nxt)[8], float &axn) {
-            if (r + 1 < roundsB)
-                operands(tiles + ((r + 1) & 1) * CS * TILE_FLOATS, c0B(r + 1), nxt, axn);
-            if (r + 2 < roundsB)
-                fetch(false, r + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            // the filter of the PREVIOUS tile is issued between the MFMAs of this one (four candidates per
-            // eight MFMAs) and runs in their shadow
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                acc[e] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s >> 2][s & 3], bq[s], acc, 0, 0, 0);
-                if ((s & 7) == 7)
-                    push4(s >> 3);
-            }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(axc, bx, acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            const bool live = r * CS + cs < ntiles;
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                prev[e] = live ? acc[e] : __builtin_inff();
-            pj = c0B(r) + 4 * half;
-            if (r + 2 < roundsB)
-                commit(tiles + (r & 1) * CS * TILE_FLOATS);
-            __syncthreads();
-        };
-        int r = 0;
-        for (; r + 1 < roundsB; r += 2) {
-            roundB(r, opA, axA, opB, axB);
-            roundB(r + 1, opB, axB, opA, axA);
-        }
-        if (r < roundsB)
-            roundB(r, opA, axA, opB, axB);
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g)                            // the last tile's filter
-        push4(g);
-    int *flag = reinterpret_cast<int *>(sq + ntiles * KM_TILE + 1);
-    if (lost)
-        *flag = 1;
-    __syncthreads();
-    // the queue -> this lane's sorted list of its K best (candidates were appended in ascending index order and
-    // the insert is stable, so ties keep the lower index first)
-    TopK<K> top;
-    top.init();
-    if (*flag == 0) {
-        // The query's 2 * CS lanes take every (2 * CS)-th entry of its queue.  Slots were handed out in arrival
-        // order, not index order, so the insert compares (d, j) lexicographically (the tie rule: lower index first).
-        // Entries past the end read as (+inf, _): no branch around the insert; the next entry is in flight while the
-        // current one bubbles down.
-        const int nq_ = min(qn_all[qq], QPQ);
-        int ro = list;
-        float nd = ro < nq_ ? qd[ro] : __builtin_inff();
-        int ni = (int)qj[min(ro, QPQ - 1)];
-        for (; __any(ro < nq_); ro += 2 * CS) {
-            const float cd = nd;
-            const int ci = ni;
-            const int rn = ro + 2 * CS;
-            nd = rn < nq_ ? qd[min(rn, QPQ - 1)] : __builtin_inff();
-            ni = (int)qj[min(rn, QPQ - 1)];
-            top.insert_lex(cd, ci);
-        }
-    } else {
-        // a queue overflowed somewhere in this workgroup: the plain scan (every candidate through the sorted insert)
-        for (int r = 0; r < roundsB; ++r) {
-            __syncthreads();                               // the tile buffer is free
-            fetch(false, r);
-            commit(tiles);
-            __syncthreads();
-            float4v op[8];
-            float axp;
-            const int c0 = c0B(r);
-            operands(tiles, c0, op, axp);
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                acc[e] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 32; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(op[s >> 2][s & 3], bq[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(axp, bx, acc, 0, 0, 0);
-            if (r * CS + cs < ntiles) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    top.insert(acc[e], c0 + 4 * half + (e & 3) + 8 * (e >> 2));     // (+inf rows past the end: rejected)
-            }
-        }
-    }
-
-    // merge the 2*CS lists of every query lexicographically by (d, j) (each is sorted that way: its candidates
-    // arrived in ascending j and the insert is stable), through the queue area of the query tile's first wave
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < K; ++p) {
-        md[(list * K + p) * 32 + col] = top.d[p];
-        mi[(list * K + p) * 32 + col] = (unsigned short)top.i[p];
-    }
-    __syncthreads();
-    if (cs == 0 && half == 0 && qvalid) {
-        int head[2 * CS];
-#pragma unroll
-        for (int l = 0; l < 2 * CS; ++l)
-            head[l] = 0;
-        int *dst = nn_idx + ((size_t)cloud * n + qi0) * k;
-        for (int p = 0; p < k; ++p) {
-            float bd = __builtin_inff();
-            int bi = 0x7fffffff, bl = 0;
-#pragma unroll
-            for (int l = 0; l < 2 * CS; ++l) {
-                const int h = head[l];
-                const float d = h < K ? md[(l * K + h) * 32 + col] : __builtin_inff();
-                const int i = h < K ? (int)mi[(l * K + h) * 32 + col] : 0x7fffffff;
-                const bool better = d < bd || (d == bd && i < bi);
-                bd = better ? d : bd;
-                bi = better ? i : bi;
-                bl = better ? l : bl;
-            }
-#pragma unroll
-            for (int l = 0; l < 2 * CS; ++l)
-                head[l] += (l == bl) ? 1 : 0;
-            dst[p] = bi == 0x7fffffff ? 0 : bi;
-        }
-    }
-}
-
-template <int K, int QW, int CS>
-static hipError_t launch_knn_bound(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
-{
-    const size_t lds = sizeof(float) * (2 * CS * KM_TILE * 68 + (size_t)ceil_div(n, KM_TILE) * KM_TILE + 4) +
-                       (sizeof(float) + sizeof(unsigned short)) * QW * 32 * (2 * CS * KB_QCAP) + sizeof(int) * QW * 32;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn64_bound_kernel<K, QW, CS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess)
-            return e;
-        raised = true;
-    }
-    hipLaunchKernelGGL((knn64_bound_kernel<K, QW, CS>), dim3(ceil_div(n, KM_TILE * QW), b), dim3(64 * QW * CS), lds, s,
-                       n, ld, k, x, nn_idx);
-    return hipSuccess;
-}
 
 static size_t knn_wide_lds_bytes(int n)
 {
@@ -1548,14 +1050,9 @@ template <int K>
 static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
     const size_t lds = knn_wide_lds_bytes(n);
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn64_wide_kernel<K>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess)
-            return e;
-        raised = true;
-    }
+    static bool raised[64] = {};
+    if (hipError_t e = raise_lds_limit(&knn64_wide_kernel<K>, raised); e != hipSuccess)
+        return e;
     hipLaunchKernelGGL((knn64_wide_kernel<K>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s, n, ld, k, x, nn_idx);
     return hipSuccess;
 }
@@ -1690,14 +1187,9 @@ template <int K, int CS>
 static hipError_t launch_knn3_scan(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
     const size_t lds = 16 * (size_t)n + 8 * 4 * K3_QCAP * 64;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn3_scan_kernel<K, CS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess)
-            return e;
-        raised = true;
-    }
+    static bool raised[64] = {};
+    if (hipError_t e = raise_lds_limit(&knn3_scan_kernel<K, CS>, raised); e != hipSuccess)
+        return e;
     hipLaunchKernelGGL((knn3_scan_kernel<K, CS>), dim3(ceil_div(n, 64 * (4 / CS)), b), dim3(256), lds, s, n, ld, k, x,
                        nn_idx);
     return hipSuccess;
@@ -1711,64 +1203,61 @@ static hipError_t launch_knn3_scan(int b, int n, int ld, int k, const float *x, 
 //   1024 (B=32)    138            134                102                  76
 //   4096 (B=128)                  414                397                 289
 //   8192 (B=256)   780            631                788                 571
-// Return value / CLOUDAAE_KNN_SCAN (forces a choice; the tests cover all of them): 0 = knn64_mfma_kernel,
-// 1 / 2 = knn64_scan_kernel with one / two waves per query tile, 3 / 4 = knn64_bound_kernel with one / two,
-// 5 = knn64_wide_kernel (k <= 10 and a cloud whose norms fit its LDS: n <= ~3200; otherwise 5 means 1).
+// Return value / knob CLOUDAAE_KNN_SCAN (forces a choice; the tests cover all of them): 0 = knn64_mfma_kernel,
+// 1 / 2 = knn64_scan_kernel with one / two waves per query tile, 5 = knn64_wide_kernel (where it applies: see
+// knn_wide_fits; otherwise 5 means 1).  (3 / 4 were the 8-wave bound kernel of round 2, superseded by the wide one.)
+static bool knn_wide_fits(int n, int k)
+{
+    return k <= 10 && n >= 256 && knn_wide_lds_bytes(n) <= 158 * 1024;
+}
+
 static int knn_scan_waves(long long tiles, int n, int k)
 {
-    if (const char *e = getenv("CLOUDAAE_KNN_SCAN"))
-        return atoi(e);
-    if (tiles > 512 && k <= 10 && n >= 256 && knn_wide_lds_bytes(n) <= 158 * 1024)
+    if (CLOUDAAE_KNOB_SET("CLOUDAAE_KNN_SCAN"))
+        return CLOUDAAE_KNOB("CLOUDAAE_KNN_SCAN", 0);
+    if (tiles > 512 && knn_wide_fits(n, k))
         return 5;
     return tiles >= 4096 ? 1 : tiles >= 1024 ? 2 : 0;
 }
 
 template <int K>
-static void launch_knn(int b, int n, int c, int ld, int k, const float *x, int *nn_idx,
-                       hipStream_t s)
+static hipError_t launch_knn(int b, int n, int c, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
-    if (c == 3 && K <= 20 && n <= 6144 && !(getenv("CLOUDAAE_KNN_SCAN") && atoi(getenv("CLOUDAAE_KNN_SCAN")) == 0)) {
+    const bool first_gen = CLOUDAAE_KNOB_SET("CLOUDAAE_KNN_SCAN") && CLOUDAAE_KNOB("CLOUDAAE_KNN_SCAN", 0) == 0;
+    const bool vec = ld % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    if (c == 3 && K <= 20 && n <= 6144 && !first_gen) {
         if constexpr (K <= 20) {
             // candidate ranges per query tile: as few as still give every SIMD two waves (fewer ranges = fewer lists to
             // fill: measured, n = 1024, k = 10, ranges 4 / 2 / 1: B = 32 47 / 55 / - us, B = 64 89 / 67 / - us,
             // B = 128 170 / 127 / 105 us, B = 256 - / 243 / 202 us)
             if ((long long)ceil_div(n, 64) * b >= 2048)
-                (void)launch_knn3_scan<K, 1>(b, n, ld, k, x, nn_idx, s);
-            else if ((long long)ceil_div(n, 64) * b * 2 >= 2048)
-                (void)launch_knn3_scan<K, 2>(b, n, ld, k, x, nn_idx, s);
-            else
-                (void)launch_knn3_scan<K, 4>(b, n, ld, k, x, nn_idx, s);
+                return launch_knn3_scan<K, 1>(b, n, ld, k, x, nn_idx, s);
+            if ((long long)ceil_div(n, 64) * b * 2 >= 2048)
+                return launch_knn3_scan<K, 2>(b, n, ld, k, x, nn_idx, s);
+            return launch_knn3_scan<K, 4>(b, n, ld, k, x, nn_idx, s);
         }
-    } else if (c == 3)
-        hipLaunchKernelGGL(knn3_kernel<K>, dim3(ceil_div(n, 64), b), dim3(KNN_THREADS), 0, s, n, ld,
-                           k, x, nn_idx);
-    else if (c == 64 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && K <= 20 && n <= 16384 &&
-             knn_scan_waves((long long)ceil_div(n, KM_TILE) * b, n, K) > 0) {
+    } else if (c == 3) {
+        hipLaunchKernelGGL(knn3_kernel<K>, dim3(ceil_div(n, 64), b), dim3(KNN_THREADS), 0, s, n, ld, k, x, nn_idx);
+    } else if (c == 64 && vec && K <= 20 && n <= 16384) {
         if constexpr (K <= 20) {
             const long long tiles = (long long)ceil_div(n, KM_TILE) * b;
             const int mode = knn_scan_waves(tiles, n, K);
-            // (the bound kernel wants enough units for its bound: 8 per sampled tile, >= 4 sampled tiles)
-            if (mode == 5 && n >= 256 && K <= 10 && knn_wide_lds_bytes(n) <= 158 * 1024) {
+            if (mode == 5 && knn_wide_fits(n, K)) {
                 if constexpr (K <= 10)
-                    (void)launch_knn_wide<K>(b, n, ld, k, x, nn_idx, s);
-            } else if (mode == 4 && n >= 256)
-                (void)launch_knn_bound<K, 4, 2>(b, n, ld, k, x, nn_idx, s);
-            else if (mode == 3 && n >= 256)
-                (void)launch_knn_bound<K, 4, 1>(b, n, ld, k, x, nn_idx, s);
-            else if (mode == 2 || mode == 4)
-                (void)launch_knn_scan<K, 4, 2>(b, n, ld, k, x, nn_idx, s);
-            else
-                (void)launch_knn_scan<K, 4, 1>(b, n, ld, k, x, nn_idx, s);
+                    return launch_knn_wide<K>(b, n, ld, k, x, nn_idx, s);
+            } else if (mode == 2) {
+                return launch_knn_scan<K, 4, 2>(b, n, ld, k, x, nn_idx, s);
+            } else if (mode > 0) {
+                return launch_knn_scan<K, 4, 1>(b, n, ld, k, x, nn_idx, s);
+            }
+            hipLaunchKernelGGL(knn64_mfma_kernel<K>, dim3(ceil_div(n, KM_TILE), b), dim3(KNN_THREADS), 0, s, n, ld, k, x,
+                               nn_idx);
         }
-    } else if (c == 64 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && K <= 20)
-        hipLaunchKernelGGL(knn64_mfma_kernel<K>, dim3(ceil_div(n, KM_TILE), b), dim3(KNN_THREADS), 0, s, n,
-                           ld, k, x, nn_idx);
-    else if (c == 64 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0)
-        hipLaunchKernelGGL(knn64_kernel<K>, dim3(ceil_div(n, 64), b), dim3(KNN_THREADS), 0, s, n,
-                           ld, k, x, nn_idx);
-    else
-        hipLaunchKernelGGL(knn_generic_kernel<K>, dim3(ceil_div(n, KNN_THREADS), b),
-                           dim3(KNN_THREADS), 0, s, n, c, ld, k, x, nn_idx);
+    } else {
+        hipLaunchKernelGGL(knn_generic_kernel<K>, dim3(ceil_div(n, KNN_THREADS), b), dim3(KNN_THREADS), 0, s, n, c, ld, k, x,
+                           nn_idx);
+    }
+    return hipSuccess;
 }
 
 } // namespace cloudaae
@@ -1786,12 +1275,12 @@ CLOUDAAE_API int cloudaae_knn(int b, int n, int c, int ld, int k, const float *x
         return 0;
     CLOUDAAE_REQUIRE(k <= n, name, "k > number of points (tf.nn.top_k would reject it)");
     hipStream_t s = (hipStream_t)stream;
-    if (k <= 10)
-        launch_knn<10>(b, n, c, ld, k, x, nn_idx, s);
-    else if (k <= 20)
-        launch_knn<20>(b, n, c, ld, k, x, nn_idx, s);
-    else
-        launch_knn<32>(b, n, c, ld, k, x, nn_idx, s);
+    // (a failed launch preparation -- e.g. the LDS limit of a kernel cannot be raised on this device -- is an
+    //  error of the call, never a silently skipped kernel)
+    const hipError_t e = k <= 10 ? launch_knn<10>(b, n, c, ld, k, x, nn_idx, s)
+                       : k <= 20 ? launch_knn<20>(b, n, c, ld, k, x, nn_idx, s)
+                                 : launch_knn<32>(b, n, c, ld, k, x, nn_idx, s);
+    CLOUDAAE_CHECK_HIP(e, name);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }

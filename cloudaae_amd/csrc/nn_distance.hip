@@ -519,8 +519,8 @@ CLOUDAAE_API int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, co
     // large clouds: the search on the matrix cores, the reference's arithmetic where it decides
     // (CLOUDAAE_NN_FILTER=0/1 forces the choice, for tests and measurements)
     bool filter = n >= 512 && m >= 512 && (long long)b * ((long long)n + m) >= 64 * NF_QBLOCK;
-    if (const char *env = getenv("CLOUDAAE_NN_FILTER"))
-        filter = atoi(env) != 0 && n > 0 && m > 0;
+    if (CLOUDAAE_KNOB_SET("CLOUDAAE_NN_FILTER"))
+        filter = CLOUDAAE_KNOB("CLOUDAAE_NN_FILTER", 0) != 0 && n > 0 && m > 0;
     if (filter) {
         const int t1 = ceil_div(n, NF_QBLOCK), t2 = ceil_div(m, NF_QBLOCK);
         // A direction with fewer query blocks than the chip has CUs and many candidates (clouds of unequal size) is
@@ -536,8 +536,8 @@ CLOUDAAE_API int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, co
                 if (sp < 1)
                     sp = 1;
             }
-            if (const char *e = getenv("CLOUDAAE_NN_SPLIT"))
-                sp = atoi(e) > 0 ? atoi(e) : 1;
+            if (CLOUDAAE_KNOB_SET("CLOUDAAE_NN_SPLIT"))
+                sp = CLOUDAAE_KNOB("CLOUDAAE_NN_SPLIT", 1) > 0 ? CLOUDAAE_KNOB("CLOUDAAE_NN_SPLIT", 1) : 1;
             return sp;
         };
         const int s1 = splits_of(t1, m), s2 = splits_of(t2, n);
@@ -566,8 +566,8 @@ CLOUDAAE_API int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, co
     // LDS reads over more queries
     const long long total = (long long)b * ((long long)n + m);
     int Q = total >= 4LL * 256 * 1024 ? 4 : (total >= 256LL * 1024 ? 2 : 1);
-    if (const char *env = getenv("CLOUDAAE_NN_Q")) {   // tuning knob (queries per lane)
-        const int q = atoi(env);
+    if (CLOUDAAE_KNOB_SET("CLOUDAAE_NN_Q")) {   // tuning knob (queries per lane)
+        const int q = CLOUDAAE_KNOB("CLOUDAAE_NN_Q", 0);
         if (q == 1 || q == 2 || q == 4)
             Q = q;
     }

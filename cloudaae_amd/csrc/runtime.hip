@@ -15,7 +15,58 @@ void set_error(const char *fmt, ...)
 }
 } // namespace cloudaae
 
-CLOUDAAE_API int cloudaae_version(void) { return 200; }
+CLOUDAAE_API int cloudaae_version(void) { return 300; }
+
+// ---- development knobs (common.h) ---------------------------------------------------------------------
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+namespace cloudaae {
+constexpr int MAX_KNOBS = 64;
+static Knob g_knobs[MAX_KNOBS];
+static char g_knob_names[MAX_KNOBS][48];
+static int g_nknobs = 0;
+static std::mutex g_knob_mutex;
+Knob *knob_slot(const char *name)
+{
+    std::lock_guard<std::mutex> lock(g_knob_mutex);
+    for (int i = 0; i < g_nknobs; ++i)
+        if (strcmp(g_knobs[i].name, name) == 0)
+            return &g_knobs[i];
+    if (g_nknobs == MAX_KNOBS)
+        return &g_knobs[MAX_KNOBS - 1];
+    Knob &k = g_knobs[g_nknobs];
+    strncpy(g_knob_names[g_nknobs], name, sizeof(g_knob_names[0]) - 1);
+    k.name = g_knob_names[g_nknobs];
+    const char *e = getenv(name);       // the only place the library reads the environment
+    k.set = e != nullptr && *e != 0;
+    k.value = k.set ? atoi(e) : 0;
+    ++g_nknobs;
+    return &k;
+}
+} // namespace cloudaae
+
+CLOUDAAE_API int cloudaae_set_knob(const char *name, int value)
+{
+    if (name == nullptr || strlen(name) >= 48) {
+        cloudaae::set_error("cloudaae_set_knob: bad name");
+        return (int)hipErrorInvalidValue;
+    }
+    cloudaae::Knob *k = cloudaae::knob_slot(name);
+    k->value = value;
+    k->set = true;
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_unset_knob(const char *name)
+{
+    if (name == nullptr || strlen(name) >= 48) {
+        cloudaae::set_error("cloudaae_unset_knob: bad name");
+        return (int)hipErrorInvalidValue;
+    }
+    cloudaae::knob_slot(name)->set = false;
+    return 0;
+}
 
 // ---- CRC-32C (Castagnoli) on the HOST: the checksum of the TFRecord framing (train_cloudAAE_ycbv.py:80-135
 // reads such files) and of TensorFlow checkpoints (tf.train.Saver, :276 / :418-430), which TensorFlow computes

@@ -27,6 +27,12 @@ typedef void *cloudaae_stream_t; /* hipStream_t */
 
 int cloudaae_version(void);
 const char *cloudaae_last_error(void);
+/* Development knobs (kernel A/B choices and launch shapes for tests and sweeps; none is needed in normal use):
+ * an integer per name, initialised from the environment variable of the same name the first time the library
+ * looks at it (the library never reads the environment again), changed with these two calls.  Names are listed
+ * in DESIGN.md ("Development knobs"), e.g. "CLOUDAAE_KNN_SCAN", "CLOUDAAE_NN_FILTER". */
+int cloudaae_set_knob(const char *name, int value);
+int cloudaae_unset_knob(const char *name);
 /* HOST helper: CRC-32C (Castagnoli, reflected, init/final xor 0xffffffff) of n bytes of host memory -- the
  * checksum of the TFRecord framing (train_cloudAAE_ycbv.py:80-135) and of tf.train.Saver checkpoints
  * (:276, :418-430).  crc = 0 for a whole buffer, or the previous result to continue over the next piece. */

@@ -33,3 +33,17 @@ def hip():
     from cloudaae_amd import _lib
     _lib.lib()
     return _lib
+
+
+@pytest.fixture
+def knobs(hip):
+    """knobs(name, value): set a development knob of the HIP library for this test (cloudaae_set_knob; value None =
+    unset); every knob touched is unset again afterwards."""
+    touched = []
+
+    def set_(name, value):
+        touched.append(name)
+        hip.set_knob(name, value)
+    yield set_
+    for name in touched:
+        hip.set_knob(name, None)

@@ -17,7 +17,7 @@ for scale, off in ((0.05, 0.0), (0.05, 1.0)):
     i1, i2 = torch.empty(B, N, dtype=torch.int32, device="cuda"), torch.empty(B, N, dtype=torch.int32, device="cuda")
     out = {}
     for k in ("0", "1"):
-        os.environ["CLOUDAAE_NN_FILTER"] = k
+        _lib.set_knob("CLOUDAAE_NN_FILTER", int(k))
         f = lambda: L.cloudaae_nn_distance(B, N, a.data_ptr(), N, c.data_ptr(), d1.data_ptr(), i1.data_ptr(),
                                            d2.data_ptr(), i2.data_ptr(), _lib.stream())
         us = timeit(f, 30)
