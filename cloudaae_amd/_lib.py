@@ -62,6 +62,10 @@ _SIGNATURES = {
                                    _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P],
     "cloudaae_edgeconv_revlists": [_I, _I, _I, _I, _P, _P, _P],
     "cloudaae_input_assemble": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "cloudaae_input_assemble_noise": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _U, _P, _P],
+    "cloudaae_zero_buffers": [_I, _P, _P, _P],
+    "cloudaae_loss_tail": [_L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                           _P, _P, _P],
     "cloudaae_add_rowvec": [_I, _I, _I, _P, _P, _P, _P],
     "cloudaae_add_f32": [_L, _P, _P, _P, _P],
     "cloudaae_fill_scaled": [_L, _P, _F, _P, _P, _P],
@@ -106,7 +110,7 @@ class FcLayer(ctypes.Structure):
                 ("ema_mean", _P), ("ema_var", _P), ("save_mean", _P), ("save_var", _P), ("relu", _I), ("y", _P),
                 ("out", _P), ("tickets", _P), ("dout", _P), ("lddo", _I), ("dx", _P), ("lddx", _I), ("dw", _P),
                 ("accumulate_dw", _I), ("dgamma", _P), ("dbeta", _P), ("dbias", _P), ("accumulate_param_grads", _I),
-                ("partials", _P)]
+                ("partials", _P), ("out_rowvec", _P), ("out_rowvec_d", _I)]
 
 
 # int (*cloudaae_allreduce_fn)(void *ctx, double *buf, int count, cloudaae_stream_t stream)
@@ -118,7 +122,7 @@ class BnSyncStruct(ctypes.Structure):
     _fields_ = [("allreduce", ALLREDUCE_FN), ("ctx", _P), ("world", _I), ("buf", _P)]
 
 
-_LONGLONG_RESULTS = ["cloudaae_bn_workspace_bytes", "cloudaae_edgeconv_workspace_bytes",
+_LONGLONG_RESULTS = ["cloudaae_loss_tail_workspace_bytes", "cloudaae_bn_workspace_bytes", "cloudaae_edgeconv_workspace_bytes",
                      "cloudaae_mean_workspace_bytes", "cloudaae_gemm_f32_ordered_workspace",
                      "cloudaae_gemm_bf16_ordered_workspace"]
 
@@ -159,6 +163,7 @@ class StepPlan(object):
         # products) sit together, so ONE fill at the start of a replay clears them all instead of
         # one ~4 us clear pass per product
         self.zchunks = []          # [tensor, used bytes]
+        self.zextra = []           # other buffers to clear at the start of a replay: (tensor, bytes)
         self.internal = False      # allocator-internal torch calls are not "foreign"
         self.poison = os.environ.get("CLOUDAAE_POISON_ARENA") == "1"
 
@@ -215,17 +220,27 @@ class StepPlan(object):
         self.zchunks[-1][1] = used + padded
         return view[:n].view(shape)
 
+    def clear_at_replay(self, tensor, nbytes):
+        """`tensor`'s first nbytes (a multiple of 16, 16-byte aligned) hold zeros when a replay starts: cleared by
+        the same launch as the zero zones."""
+        if tensor.data_ptr() % 16 or nbytes % 16:
+            raise HipLibraryError("clear_at_replay: buffer must be 16-byte aligned and a multiple of 16 bytes")
+        self.zextra.append((tensor, int(nbytes)))
+        self._zargs = None
+
     # -- replay -----------------------------------------------------------------------------
     def replay(self):
         if stream() != self.stream:
             raise HipLibraryError("a recorded step must be replayed on the stream it was recorded on")
-        if self.zchunks:
-            fill = lib()._cdll.cloudaae_fill_scaled
-            if getattr(self, "_zero", None) is None:
-                self._zero = torch.zeros(1, dtype=torch.float32, device=self.device)
-            for chunk, used in self.zchunks:
-                check(fill(used // 4, self._zero.data_ptr(), 1.0, None, chunk.data_ptr(), self.stream),
-                      "cloudaae_fill_scaled")
+        if self.zchunks or self.zextra:
+            # ONE launch clears the zero zones and whatever else the step wants cleared when it starts
+            if getattr(self, "_zargs", None) is None:
+                segs = [(c.data_ptr(), (used + 15) // 16 * 16) for c, used in self.zchunks if used] + \
+                       [(t.data_ptr(), nbytes) for t, nbytes in self.zextra]
+                self._zargs = (len(segs), (ctypes.c_void_p * len(segs))(*[p for p, _ in segs]),
+                               (ctypes.c_longlong * len(segs))(*[n for _, n in segs]))
+            check(lib()._cdll.cloudaae_zero_buffers(self._zargs[0], self._zargs[1], self._zargs[2], self.stream),
+                  "cloudaae_zero_buffers")
         for fn, args, name in self.entries:
             rc = fn(*args)
             if name is not None and rc != 0:
@@ -300,6 +315,7 @@ def lib():
         cdll.cloudaae_side_stream.restype = ctypes.c_void_p
         cdll.cloudaae_fc_forward_tickets.argtypes = [_I]
         cdll.cloudaae_fc_forward_tickets.restype = ctypes.c_int
+        cdll.cloudaae_loss_tail_workspace_bytes.argtypes = []
         cdll.cloudaae_fc_forward_partials.argtypes = [_I, _I, _I]
         cdll.cloudaae_fc_forward_partials.restype = ctypes.c_longlong
         cdll.cloudaae_edgeconv_workspace_bytes.argtypes = [_I]

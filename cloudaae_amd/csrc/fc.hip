@@ -63,6 +63,8 @@ struct FcFwdArgs {
     float *y, *out;
     int *tickets;       // a product cut over K that is finished by its last slice: one arrival counter per column tile
     float *partials;    // [tiles][splits][FC_M][FC_TN]: the slices' partial tiles, summed in slice order by the last to arrive
+    const float *rowvec;    // no batch norm: y[r][c] += rowvec[r * rowvec_d + c % rowvec_d] (the "+ element_mean" of
+    int rowvec_d;           // train_cloudAAE_ycbv.py:232-233 folded into the output layers); NULL: nothing
 };
 
 struct FcGroup {        // operands of eight k: lane half h holds k + 4h .. k + 4h + 3
@@ -276,11 +278,17 @@ __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int 
         }
     }
     if (a.gamma == nullptr) {
-        if (ok)
+        if (ok) {
+            const int cd = a.rowvec != nullptr ? c % a.rowvec_d : 0;
 #pragma unroll
             for (int i = 0; i < RP; ++i)
-                if (rg + RG * i < a.M)
-                    a.y[(size_t)(rg + RG * i) * a.N + c] = v[i];
+                if (rg + RG * i < a.M) {
+                    float out = v[i];
+                    if (a.rowvec != nullptr)
+                        out = out + a.rowvec[(size_t)(rg + RG * i) * a.rowvec_d + cd];
+                    a.y[(size_t)(rg + RG * i) * a.N + c] = out;
+                }
+        }
         return;
     }
 
@@ -748,10 +756,15 @@ CLOUDAAE_API int cloudaae_fc_forward_group(int M, int count, const cloudaae_fc_l
         a.x = l.x; a.w = l.w; a.bias = l.bias; a.gamma = l.gamma; a.beta = l.beta; a.decay = decay;
         a.ema_mean = l.ema_mean; a.ema_var = l.ema_var; a.save_mean = l.save_mean; a.save_var = l.save_var;
         a.y = l.y; a.out = l.out;
+        CLOUDAAE_REQUIRE(l.out_rowvec == nullptr || (!bn && l.out_rowvec_d > 0), name,
+                         "a row vector can only be added to the output of a layer without batch norm");
+        a.rowvec = l.out_rowvec; a.rowvec_d = l.out_rowvec_d;
         // cut over K: with the partial-tile workspace the slices are summed in a fixed order by the last one to
         // arrive (y is plainly stored); without it they add into y with atomics (y cleared first)
         a.partials = (a.atomic && l.tickets != nullptr) ? l.partials : nullptr;
         a.tickets = (a.atomic && (bn || a.partials != nullptr)) ? l.tickets : nullptr;
+        CLOUDAAE_REQUIRE(a.rowvec == nullptr || !a.atomic || a.partials != nullptr, name,
+                         "adding a row vector to a product cut over K needs the tickets and the partial-tile scratch");
         if (a.atomic && a.partials == nullptr && !y_zeroed)
             CLOUDAAE_CHECK_HIP(hipMemsetAsync(l.y, 0, sizeof(float) * (size_t)M * l.N, s), name);
         blocks += tiles * splits;

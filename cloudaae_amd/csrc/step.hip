@@ -6,32 +6,54 @@
 //
 // Reference sites: train_cloudAAE_ycbv.py:194-273 (graph assembly), losses/*.py.
 #include "common.h"
+#include "philox.h"
 #include "../../include/cloudaae_hip.h"
 
 namespace cloudaae {
 
 // ---- input assembly: train_cloudAAE_ycbv.py:206-226 ---------------------------------
 // one workgroup per cloud: v = visible[:N] + noise; mean over N; pc = [v - mean, onehot]
+// noise: the caller's [B,N,3] array, or (noise == NULL, noise_std > 0) drawn HERE: the tf.random.normal(stddev) of
+// :217 as a pure function of (seed, step counter, cloud, point) -- Philox4x32-10 + Box-Muller -- so a recorded step
+// draws fresh noise at every replay without a generator kernel in front of it.
 __global__ __launch_bounds__(256) void input_assemble_kernel(int P, int N, int num_class,
                                                             const float *__restrict__ visible,
                                                             const float *__restrict__ noise,
                                                             const long long *__restrict__ class_id,
                                                             float *__restrict__ pc, float *__restrict__ mean,
-                                                            float *__restrict__ noisy)
+                                                            float *__restrict__ noisy, float noise_std,
+                                                            unsigned long long seed, const float *__restrict__ step)
 {
     __shared__ float red[3][4];
     __shared__ float mu[3];
     const int b = blockIdx.x, t = threadIdx.x;
     const float *V = visible + (size_t)b * P * 3;
     const float *Z = noise ? noise + (size_t)b * N * 3 : nullptr;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int j = t; j < N; j += 256) {
-        float x = V[3 * j], y = V[3 * j + 1], z = V[3 * j + 2];
+    const bool draw = Z == nullptr && noise_std > 0.0f;
+    const unsigned stream_id = draw && step != nullptr ? (unsigned)(long long)step[0] : 0u;
+    auto point = [&](int j, float &x, float &y, float &z) {
+        x = V[3 * j];
+        y = V[3 * j + 1];
+        z = V[3 * j + 2];
         if (Z) {
             x = x + Z[3 * j];
             y = y + Z[3 * j + 1];
             z = z + Z[3 * j + 2];
+        } else if (draw) {
+            unsigned r[4];
+            philox4x32(seed, ((unsigned long long)(unsigned)b << 32) | (unsigned)j, stream_id, r);
+            float n0, n1, n2, n3;
+            normal2(r[0], r[1], n0, n1);
+            normal2(r[2], r[3], n2, n3);
+            x = x + n0 * noise_std;
+            y = y + n1 * noise_std;
+            z = z + n2 * noise_std;
         }
+    };
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int j = t; j < N; j += 256) {
+        float x, y, z;
+        point(j, x, y, z);
         sx += x;
         sy += y;
         sz += z;
@@ -54,12 +76,8 @@ __global__ __launch_bounds__(256) void input_assemble_kernel(int P, int N, int n
     const int C = 3 + num_class;
     const long long cls = class_id ? class_id[b] : -1;
     for (int j = t; j < N; j += 256) {
-        float x = V[3 * j], y = V[3 * j + 1], z = V[3 * j + 2];
-        if (Z) {
-            x = x + Z[3 * j];
-            y = y + Z[3 * j + 1];
-            z = z + Z[3 * j + 2];
-        }
+        float x, y, z;
+        point(j, x, y, z);          // (the same values again: the draw is a function of its indices)
         if (noisy) {
             noisy[((size_t)b * N + j) * 3 + 0] = x;
             noisy[((size_t)b * N + j) * 3 + 1] = y;
@@ -72,6 +90,22 @@ __global__ __launch_bounds__(256) void input_assemble_kernel(int P, int N, int n
         for (int c = 0; c < num_class; ++c)
             row[3 + c] = (c == cls) ? 1.0f : 0.0f;
     }
+}
+
+// several buffers cleared by ONE launch (the zero zones of a recorded step + the gradient slots its split-K
+// products add into): a launch per buffer costs ~5 us of stream time whatever it moves
+constexpr int ZERO_SEGMENTS = 8;
+struct ZeroSegments {
+    int count;
+    float4v *p[ZERO_SEGMENTS];
+    long long n4[ZERO_SEGMENTS];        // 16-byte units
+};
+__global__ __launch_bounds__(256) void zero_segments_kernel(ZeroSegments z)
+{
+    const float4v zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < z.count; ++s)
+        for (long long i = blockIdx.x * 256LL + threadIdx.x; i < z.n4[s]; i += 256LL * gridDim.x)
+            z.p[s][i] = zero;
 }
 
 // out[b,r,:] = x[b,r,:] + v[b,:]   (train_cloudAAE_ycbv.py:232-233)
@@ -437,17 +471,15 @@ __global__ void loss_mix_grad_kernel(const float *g, float w0, float w1, float w
 // translation error per sample + mean, SO(3) error per sample (fp64) + Jacobian + mean, and the
 // weighted total; the backward twin turns d(total) into the three upstream gradients.  Same
 // arithmetic as the single-purpose kernels above (ten launches of ~4.5 us become two).
-__global__ __launch_bounds__(256) void pose_losses_kernel(int b, const float *__restrict__ tpred,
-                                                         const float *__restrict__ tlabel,
-                                                         const float *__restrict__ rpred,
-                                                         const double *__restrict__ rlabel,
-                                                         const float *__restrict__ xyz_loss, float w0, float w1,
-                                                         float w2, float *__restrict__ tper,
-                                                         float *__restrict__ tloss, double *__restrict__ rper,
-                                                         double *__restrict__ rjac, float *__restrict__ rloss,
-                                                         float *__restrict__ total)
+__device__ __forceinline__ void pose_losses_body(int b, const float *__restrict__ tpred,
+                                                 const float *__restrict__ tlabel,
+                                                 const float *__restrict__ rpred,
+                                                 const double *__restrict__ rlabel, float xyz_loss, float w0, float w1,
+                                                 float w2, float *__restrict__ tper,
+                                                 float *__restrict__ tloss, double *__restrict__ rper,
+                                                 double *__restrict__ rjac, float *__restrict__ rloss,
+                                                 float *__restrict__ total, double (*red)[4])
 {
-    __shared__ double red[2][4];
     double st = 0.0, sr = 0.0;
     for (int i = threadIdx.x; i < b; i += 256) {
         const float dx = tlabel[3 * i] - tpred[3 * i], dy = tlabel[3 * i + 1] - tpred[3 * i + 1],
@@ -497,8 +529,105 @@ __global__ __launch_bounds__(256) void pose_losses_kernel(int b, const float *__
         const float rl = (float)(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (double)b);
         tloss[0] = tl;
         rloss[0] = rl;
-        total[0] = (w0 * xyz_loss[0] + w1 * tl) + w2 * rl;
+        total[0] = (w0 * xyz_loss + w1 * tl) + w2 * rl;
     }
+}
+
+__global__ __launch_bounds__(256) void pose_losses_kernel(int b, const float *__restrict__ tpred,
+                                                         const float *__restrict__ tlabel,
+                                                         const float *__restrict__ rpred,
+                                                         const double *__restrict__ rlabel,
+                                                         const float *__restrict__ xyz_loss, float w0, float w1,
+                                                         float w2, float *__restrict__ tper,
+                                                         float *__restrict__ tloss, double *__restrict__ rper,
+                                                         double *__restrict__ rjac, float *__restrict__ rloss,
+                                                         float *__restrict__ total)
+{
+    __shared__ double red[2][4];
+    pose_losses_body(b, tpred, tlabel, rpred, rlabel, xyz_loss[0], w0, w1, w2, tper, tloss, rper, rjac, rloss, total, red);
+}
+
+// d(total)/d(xyz_loss, trans_pred, rot_pred) of rows i = threadIdx.x, +256, ... for the upstream gradient g
+__device__ __forceinline__ void pose_losses_grad_rows(int b, int i0, int stride, const float *__restrict__ tpred,
+                                                      const float *__restrict__ tlabel, const float *__restrict__ tper,
+                                                      const double *__restrict__ rjac, float g, float w0, float w1,
+                                                      float w2, float *__restrict__ dxyz, float *__restrict__ dtpred,
+                                                      float *__restrict__ drpred)
+{
+    if (i0 == 0)
+        dxyz[0] = g * w0;
+    const float gt = g * w1, gr = g * w2;
+    for (int i = i0; i < b; i += stride) {
+        const float gp = (gt / (float)b) / tper[i];           // d mean / d per = 1/b, d per / d pred = -(l - p)/per
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            dtpred[3 * i + a] = -(gp * (tlabel[3 * i + a] - tpred[3 * i + a]));
+            drpred[3 * i + a] = (float)((double)gr / (double)b * rjac[3 * i + a]);
+        }
+    }
+}
+
+// ---- the WHOLE loss tail of a training step in one launch (losses/chamfer_loss.py:12-14 + train...:241-268) ----
+// per = dist1 + dist2 and its mean (256 workgroups, fp64 partial sums), and in the workgroup that finishes last
+// (arrival counter; partial sums published with agent-scope stores and read back with agent-scope loads, summed in
+// index order: deterministic) the pose losses, the weighted total and -- the step's upstream gradient d(total) is a
+// constant known now -- the three gradients the backward pass starts from.  Four launches of ~5 us become one.
+struct LossTail {
+    int b;
+    const float *tpred, *tlabel, *rpred;
+    const double *rlabel;
+    float w0, w1, w2;
+    float *xyz_loss, *tper, *tloss;
+    double *rper, *rjac;
+    float *rloss, *total;
+    const float *g_total;           // NULL: no gradients
+    float *dxyz, *dtpred, *drpred;
+    int *ticket;
+};
+__global__ __launch_bounds__(256) void loss_tail_kernel(long long n, const float *__restrict__ a,
+                                                       const float *__restrict__ bb, float *__restrict__ per,
+                                                       double *__restrict__ partial, LossTail t)
+{
+    __shared__ double red[2][4];
+    __shared__ int last;
+    double s = 0.0;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) {
+        const float v = a[i] + bb[i];
+        per[i] = v;
+        s += (double)v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0)
+        red[0][threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partial[blockIdx.x], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the sum has reached the memory side before the ticket
+        const int tk = __hip_atomic_fetch_add(t.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = tk == (int)gridDim.x - 1;
+        if (last)
+            __hip_atomic_store(t.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last)
+        return;
+    double p = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)
+        p += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p = wave_sum(p);
+    if ((threadIdx.x & 63) == 0)
+        red[1][threadIdx.x >> 6] = p;
+    __syncthreads();
+    const float xyz = (float)(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (double)n);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        t.xyz_loss[0] = xyz;
+    pose_losses_body(t.b, t.tpred, t.tlabel, t.rpred, t.rlabel, xyz, t.w0, t.w1, t.w2, t.tper, t.tloss, t.rper, t.rjac,
+                     t.rloss, t.total, red);
+    if (t.g_total != nullptr)       // (a thread reads back the rows it wrote itself)
+        pose_losses_grad_rows(t.b, (int)threadIdx.x, 256, t.tpred, t.tlabel, t.tper, t.rjac, t.g_total[0], t.w0, t.w1,
+                              t.w2, t.dxyz, t.dtpred, t.drpred);
 }
 
 __global__ void pose_losses_grad_kernel(int b, const float *__restrict__ tpred, const float *__restrict__ tlabel,
@@ -507,18 +636,8 @@ __global__ void pose_losses_grad_kernel(int b, const float *__restrict__ tpred, 
                                         float *__restrict__ dxyz, float *__restrict__ dtpred,
                                         float *__restrict__ drpred)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0)
-        dxyz[0] = g[0] * w0;
-    if (i >= b)
-        return;
-    const float gt = g[0] * w1, gr = g[0] * w2;
-    const float gp = (gt / (float)b) / tper[i];           // d mean / d per = 1/b, d per / d pred = -(l - p)/per
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        dtpred[3 * i + a] = -(gp * (tlabel[3 * i + a] - tpred[3 * i + a]));
-        drpred[3 * i + a] = (float)((double)gr / (double)b * rjac[3 * i + a]);
-    }
+    pose_losses_grad_rows(b, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, tpred, tlabel, tper, rjac, g[0],
+                          w0, w1, w2, dxyz, dtpred, drpred);
 }
 
 // ---- optimiser: tf.train.AdamOptimizer (train...:263-273), TF-1.x ApplyAdam form ----
@@ -635,7 +754,46 @@ CLOUDAAE_API int cloudaae_input_assemble(int b, int p, int n, int num_class, con
     if (b == 0)
         return 0;
     hipLaunchKernelGGL(input_assemble_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, p, n, num_class,
-                       visible, noise, class_id, pc, mean, noisy);
+                       visible, noise, class_id, pc, mean, noisy, 0.0f, 0ull, (const float *)nullptr);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_input_assemble_noise(int b, int p, int n, int num_class, const float *visible,
+                                               const long long *class_id, float *pc, float *mean, float *noisy,
+                                               float noise_std, unsigned long long seed, const float *step,
+                                               cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_input_assemble_noise";
+    CLOUDAAE_REQUIRE(b >= 0 && n > 0 && p >= n && num_class >= 0, name, "bad size (need n <= rows of visible)");
+    CLOUDAAE_REQUIRE(noise_std >= 0.0f, name, "negative standard deviation");
+    if (b == 0)
+        return 0;
+    hipLaunchKernelGGL(input_assemble_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, p, n, num_class,
+                       visible, (const float *)nullptr, class_id, pc, mean, noisy, noise_std, seed, step);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_zero_buffers(int count, void *const *buffers, const long long *bytes, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_zero_buffers";
+    CLOUDAAE_REQUIRE(count >= 0 && (count == 0 || (buffers && bytes)), name, "null argument");
+    for (int first = 0; first < count; first += ZERO_SEGMENTS) {
+        ZeroSegments z = {};
+        long long most = 0;
+        for (int i = first; i < count && i < first + ZERO_SEGMENTS; ++i) {
+            CLOUDAAE_REQUIRE(((uintptr_t)buffers[i] & 15) == 0 && bytes[i] >= 0 && bytes[i] % 16 == 0, name,
+                             "buffers must be 16-byte aligned and a multiple of 16 bytes long");
+            z.p[z.count] = (float4v *)buffers[i];
+            z.n4[z.count] = bytes[i] / 16;
+            most = z.n4[z.count] > most ? z.n4[z.count] : most;
+            ++z.count;
+        }
+        if (most == 0)
+            continue;
+        hipLaunchKernelGGL(zero_segments_kernel, dim3(stream_grid(most)), dim3(256), 0, (hipStream_t)stream, z);
+    }
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }
@@ -922,6 +1080,35 @@ CLOUDAAE_API int cloudaae_pose_losses(int b, const float *trans_pred, const floa
     hipLaunchKernelGGL(pose_losses_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, b, trans_pred, trans_label,
                        rot_pred, rot_label, xyz_loss, w_xyz, w_trans, w_rot, trans_per, trans_loss, rot_per, rot_jac,
                        rot_loss, total);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API long long cloudaae_loss_tail_workspace_bytes(void) { return (long long)MEAN_BLOCKS * sizeof(double); }
+
+CLOUDAAE_API int cloudaae_loss_tail(long long n, const float *dist1, const float *dist2, float *per, float *xyz_loss,
+                                    int b, const float *trans_pred, const float *trans_label, const float *rot_pred,
+                                    const double *rot_label, float w_xyz, float w_trans, float w_rot, float *trans_per,
+                                    float *trans_loss, double *rot_per, double *rot_jac, float *rot_loss, float *total,
+                                    const float *g_total, float *d_xyz_loss, float *d_trans_pred, float *d_rot_pred,
+                                    void *workspace, int *ticket, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_loss_tail";
+    CLOUDAAE_REQUIRE(n > 0 && b > 0, name, "empty input");
+    CLOUDAAE_REQUIRE(dist1 && dist2 && per && xyz_loss && trans_pred && trans_label && rot_pred && rot_label && trans_per &&
+                         trans_loss && rot_per && rot_jac && rot_loss && total && workspace && ticket, name,
+                     "null argument");
+    CLOUDAAE_REQUIRE(g_total == nullptr || (d_xyz_loss && d_trans_pred && d_rot_pred), name, "gradient outputs missing");
+    int parts = stream_grid(n);
+    if (parts > MEAN_BLOCKS)
+        parts = MEAN_BLOCKS;
+    LossTail t;
+    t.b = b; t.tpred = trans_pred; t.tlabel = trans_label; t.rpred = rot_pred; t.rlabel = rot_label;
+    t.w0 = w_xyz; t.w1 = w_trans; t.w2 = w_rot; t.xyz_loss = xyz_loss; t.tper = trans_per; t.tloss = trans_loss;
+    t.rper = rot_per; t.rjac = rot_jac; t.rloss = rot_loss; t.total = total; t.g_total = g_total;
+    t.dxyz = d_xyz_loss; t.dtpred = d_trans_pred; t.drpred = d_rot_pred; t.ticket = ticket;
+    hipLaunchKernelGGL(loss_tail_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, n, dist1, dist2, per,
+                       (double *)workspace, t);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }

@@ -182,6 +182,12 @@ class LinearFn(torch.autograd.Function):
         return dx, gw.done(), gb_ret, None, None
 
 
+# An offer to the next fully_connected_chains call: (row vector [B, d], indices of the chains whose OUTPUT gets
+# out[b, c] += vec[b, c % d]) -- train_cloudAAE_ycbv.py:232-233's "+ element_mean" folded into the output layers'
+# epilogue.  The call that takes the offer sets this back to None (TrainGraph.forward looks at it afterwards).
+FC_OUT_ADD = None
+
+
 def fc_fits(M):
     """Rows of a fully connected layer that the one-launch-per-direction kernels take."""
     return 0 < M <= L().cloudaae_fc_max_rows()
@@ -276,7 +282,8 @@ class FcGroupFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, decay, *tensors):
-        n_in, x_index, training, relus = cfg
+        n_in, x_index, training, relus = cfg[:4]
+        rowvecs = cfg[4] if len(cfg) > 4 else (None,) * len(x_index)     # per layer: None or a [M, d] tensor added to y
         ctx.set_materialize_grads(False)
         xs = tensors[:n_in]
         per = [tensors[n_in + 6 * i:n_in + 6 * i + 6] for i in range(len(x_index))]
@@ -303,6 +310,9 @@ class FcGroupFn(torch.autograd.Function):
             l.gamma, l.beta, l.ema_mean, l.ema_var = ptr(gamma), ptr(beta), ptr(ema_mean), ptr(ema_var)
             l.save_mean, l.save_var, l.relu = ptr(save_mean), ptr(save_var), int(bool(relus[i]))
             l.y, l.out, l.tickets, l.partials = ptr(y), ptr(out), ptr(tickets), ptr(partials)
+            if rowvecs[i] is not None:
+                require(not bn and rowvecs[i].dim() == 2 and rowvecs[i].shape[0] == M, "FcGroupFn: bad row vector")
+                l.out_rowvec, l.out_rowvec_d = ptr(rowvecs[i]), int(rowvecs[i].shape[1])
             outs.append(out if bn else y)
             keep.append((y if bn else None, save_mean, save_var, tickets, partials))
         _lib.check(L().cloudaae_fc_forward_group(M, len(per), layers, int(bool(training)), ptr(decay), 0, stream()),
@@ -312,7 +322,7 @@ class FcGroupFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
-        n_in, x_index, training, relus = ctx.cfg
+        n_in, x_index, training, relus = ctx.cfg[:4]
         xs, per, keep = ctx.xs, ctx.per, ctx.keep
         M = xs[0].shape[0]
         live = [i for i, d in enumerate(douts) if d is not None]
@@ -976,6 +986,92 @@ class PoseLossFn(torch.autograd.Function):
                                                  ptr(g.contiguous()), ctx.w[0], ctx.w[1], ctx.w[2], ptr(dxyz),
                                                  ptr(dtp), ptr(drp), stream()), "cloudaae_pose_losses_grad")
         return dxyz, dtp, None, drp, None, None, None, None
+
+
+class StepLossFn(torch.autograd.Function):
+    """The loss side of the training graph as ONE node (train_cloudAAE_ycbv.py:236-268): Chamfer nn_distance both
+    ways, loss_per_sample = forward + backward distances and its mean (losses/chamfer_loss.py:8-14), translation
+    error, SO(3) error, weighted total -- two launches (the search, then cloudaae_loss_tail).  Returns
+    (total, xyz_loss, xyz_per [B,n], trans_loss, trans_per [B], axag_loss, axag_per [B] float64); only `total`
+    carries a gradient (it is what the optimiser minimises).  unit: the tensor that backward() will be given as
+    d(total) -- a constant known now -- so the tail kernel already leaves the three gradients backward starts from
+    and backward's first launch is the Chamfer gradient; any other upstream gradient takes cloudaae_pose_losses_grad."""
+
+    @staticmethod
+    def forward(ctx, pred, label, trans_pred, trans_label, rot_pred, rot_label, w0, w1, w2, unit):
+        ctx.set_materialize_grads(False)
+        require(pred.dim() == 3 and label.dim() == 3 and pred.shape[2] == 3 and label.shape[2] == 3,
+                "NnDistance requires clouds of shape (batch,#points,3)")
+        require(pred.shape[0] == label.shape[0], "NnDistance expects xyz1 and xyz2 have same batch size")
+        require(pred.shape[1] == label.shape[1], "chamfer_loss: dists_forward + dists_backward needs clouds of "
+                                                 "equal size (the reference fails the same way, chamfer_loss.py:12)")
+        pred, label = pred.contiguous(), label.contiguous()
+        b, n, _ = pred.shape
+        dev = pred.device
+        trans_pred = trans_pred.contiguous()
+        rot_pred = rot_pred.contiguous()
+        trans_label = trans_label.to(torch.float32).contiguous()
+        rot_label = rot_label.to(torch.float64).contiguous()
+        d1 = _lib.empty((b, n), dtype=torch.float32, device=dev)
+        d2 = _lib.empty((b, n), dtype=torch.float32, device=dev)
+        i1 = _lib.empty((b, n), dtype=torch.int32, device=dev)
+        i2 = _lib.empty((b, n), dtype=torch.int32, device=dev)
+        _lib.check(L().cloudaae_nn_distance(b, n, ptr(pred), n, ptr(label), ptr(d1), ptr(i1), ptr(d2), ptr(i2), stream()),
+                   "cloudaae_nn_distance")
+        per = _lib.empty((b, n), dtype=torch.float32, device=dev)
+        xyz = _lib.empty((), dtype=torch.float32, device=dev)
+        tper = _lib.empty(b, dtype=torch.float32, device=dev)
+        rper = _lib.empty(b, dtype=torch.float64, device=dev)
+        jac = _lib.empty((b, 3), dtype=torch.float64, device=dev)
+        tloss = _lib.empty((), dtype=torch.float32, device=dev)
+        rloss = _lib.empty((), dtype=torch.float32, device=dev)
+        total = _lib.empty((), dtype=torch.float32, device=dev)
+        dxyz = dtp = drp = None
+        if unit is not None:
+            dxyz = _lib.empty((), dtype=torch.float32, device=dev)
+            dtp = _lib.empty((b, 3), dtype=torch.float32, device=dev)
+            drp = _lib.empty((b, 3), dtype=torch.float32, device=dev)
+        ws = _ws(L().cloudaae_loss_tail_workspace_bytes(), dev)
+        ticket = _lib.zeros(1, dtype=torch.int32, device=dev)       # arrival counter: zero before and after
+        _lib.check(L().cloudaae_loss_tail(b * n, ptr(d1), ptr(d2), ptr(per), ptr(xyz), b, ptr(trans_pred), ptr(trans_label),
+                                          ptr(rot_pred), ptr(rot_label), w0, w1, w2, ptr(tper), ptr(tloss), ptr(rper),
+                                          ptr(jac), ptr(rloss), ptr(total), ptr(unit), ptr(dxyz), ptr(dtp), ptr(drp),
+                                          ptr(ws), ptr(ticket), stream()), "cloudaae_loss_tail")
+        ctx.save_for_backward(pred, label, i1, i2, trans_pred, trans_label, tper, jac)
+        ctx.w = (w0, w1, w2)
+        ctx.unit_ptr = unit.data_ptr() if unit is not None else None
+        ctx.ready = (dxyz, dtp, drp)
+        ctx.mark_non_differentiable(xyz, per, tloss, tper, rloss, rper)
+        return total, xyz, per, tloss, tper, rloss, rper
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        if g is None:
+            return (None,) * 10
+        pred, label, i1, i2, trans_pred, trans_label, tper, jac = ctx.saved_tensors
+        b, n, _ = pred.shape
+        dev = pred.device
+        if ctx.unit_ptr is not None and g.data_ptr() == ctx.unit_ptr:
+            dxyz, dtp, drp = ctx.ready                  # written by the forward pass's tail kernel
+        else:
+            dxyz = _lib.empty((), dtype=torch.float32, device=dev)
+            dtp = _lib.empty((b, 3), dtype=torch.float32, device=dev)
+            drp = _lib.empty((b, 3), dtype=torch.float32, device=dev)
+            _lib.check(L().cloudaae_pose_losses_grad(b, ptr(trans_pred), ptr(trans_label), ptr(tper), ptr(jac),
+                                                     ptr(g.contiguous()), ctx.w[0], ctx.w[1], ctx.w[2], ptr(dxyz),
+                                                     ptr(dtp), ptr(drp), stream()), "cloudaae_pose_losses_grad")
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g1 = g2 = None
+        if need1 or need2:
+            rec = _lib.recording() is not None
+            mk = (lambda t: _lib.zeros(t.shape, dtype=torch.float32, device=t.device)) if rec else _lib.empty_like
+            g1 = mk(pred) if need1 else None
+            g2 = mk(label) if need2 else None
+            _lib.check(L().cloudaae_nn_distance_grad_uniform(
+                b, n, ptr(pred), n, ptr(label), ptr(dxyz), 1.0 / (b * n), ptr(i1), ptr(i2), ptr(g1), ptr(g2),
+                1 if rec else 0, stream()), "cloudaae_nn_distance_grad_uniform")
+        return (g1, g2, dtp if ctx.needs_input_grad[2] else None, None, drp if ctx.needs_input_grad[4] else None,
+                None, None, None, None, None)
 
 
 class LossMixFn(torch.autograd.Function):

@@ -260,6 +260,14 @@ def fully_connected_chains(inputs, chains, bn_decay=None, is_training=None):
         variables.append(row)
     decay = _decay_tensor(bn_decay) if any(bn for chain in chains for _, _, bn in chain) else None
     depth = max(len(c) for c in chains)
+    # F.FC_OUT_ADD: (row vector, chain indices) -- taken when every named chain exists and ends in a layer without
+    # batch norm (the kernel adds the vector to a plain output only)
+    offer = F.FC_OUT_ADD
+    if offer is not None and all(i < len(chains) and not chains[i][-1][2] for i in offer[1]) and \
+            offer[0].shape[0] == inputs.shape[0]:
+        F.FC_OUT_ADD = None
+    else:
+        offer = None
     nets = [None] * len(chains)
     for d in range(depth):
         members = [i for i, c in enumerate(chains) if d < len(c)]
@@ -271,6 +279,9 @@ def fully_connected_chains(inputs, chains, bn_decay=None, is_training=None):
         for i in members:
             flat.extend(variables[i][d])
         cfg = (len(xs), tuple(x_index), bool(is_training), tuple(bool(chains[i][d][2]) for i in members))
+        if offer is not None and any(d == len(chains[i]) - 1 and i in offer[1] for i in members):
+            # the output layers of the chains named by F.FC_OUT_ADD add its row vector in their epilogue
+            cfg = cfg + (tuple(offer[0] if (d == len(chains[i]) - 1 and i in offer[1]) else None for i in members),)
         outs = F.FcGroupFn.apply(cfg, decay, *(xs + flat))
         for i, o in zip(members, outs):
             nets[i] = o

@@ -165,8 +165,14 @@ class VariableStore(object):
         limit = self.flat_grads.numel() if (zeroed and zero_limit is None) else (int(zero_limit) if zeroed else 0)
         if zeroed and limit > 0:
             from .. import _lib
-            _lib.check(_lib.lib().cloudaae_fill_scaled(limit, _lib.ptr(self._zero), 1.0, None,
-                                                       _lib.ptr(self.flat_grads), _lib.stream()),
+            plan = _lib.recording()
+            fill = _lib.lib().cloudaae_fill_scaled
+            if plan is not None and (limit * 4) % 16 == 0 and self.flat_grads.data_ptr() % 16 == 0:
+                # a recorded step clears these slots with the launch that clears its zero zones (one launch
+                # less per replay); the recording pass itself clears them now
+                plan.clear_at_replay(self.flat_grads, limit * 4)
+                fill = _lib.lib()._cdll.cloudaae_fill_scaled
+            _lib.check(fill(limit, _lib.ptr(self._zero), 1.0, None, _lib.ptr(self.flat_grads), _lib.stream()),
                        "cloudaae_fill_scaled")
         for v in self.vars.values():
             v.fresh = True

@@ -349,6 +349,8 @@ typedef struct cloudaae_fc_layer {
     int accumulate_param_grads;
     /* forward */
     float *partials;
+    const float *out_rowvec;            /* gamma NULL only: y[r][c] += out_rowvec[r * out_rowvec_d + c % out_rowvec_d] */
+    int out_rowvec_d;                   /* (train_cloudAAE_ycbv.py:232-233: xyz_recon = recon_res + element_mean) */
 } cloudaae_fc_layer;
 int cloudaae_fc_max_group(void);
 int cloudaae_fc_forward_group(int M, int count, const cloudaae_fc_layer *layers, int training,

@@ -360,6 +360,136 @@ def test_step_kernels(hip):
     assert float(b1p) == pytest.approx(0.9 ** 4, rel=1e-6)
 
 
+def test_input_assemble_draws_its_own_noise(hip):
+    """cloudaae_input_assemble_noise: the tf.random.normal(stddev=0.004/3) of train_cloudAAE_ycbv.py:217 drawn inside
+    the assembly kernel -- a pure function of (seed, step counter, cloud, point): N(0, stddev) per coordinate,
+    identical when repeated, different for another step / seed, and the rest of the assembly (:206-226) unchanged
+    (centroid of the noisy points, centred coordinates, one-hot class)."""
+    from oracle import model_oracle as MO
+    L = hip.lib()
+    B, P, N, std = 6, 3000, 2048, 0.004 / 3
+    b = MO.synthetic_batch(B, P, seed=4)
+    vis, cls = b["visiblePoints"].cuda(), b["class_id"].cuda()
+    step = torch.zeros(1, device="cuda")
+
+    def run(seed, s_):
+        step.fill_(float(s_))
+        pc, mean = torch.empty((B, N, 24), device="cuda"), torch.empty((B, 3), device="cuda")
+        noisy = torch.empty((B, N, 3), device="cuda")
+        hip.check(L.cloudaae_input_assemble_noise(B, P, N, 21, hip.ptr(vis), hip.ptr(cls), hip.ptr(pc), hip.ptr(mean),
+                                                  hip.ptr(noisy), std, seed, hip.ptr(step), hip.stream()), "assemble")
+        return pc, mean, noisy
+    pc, mean, noisy = run(77, 3)
+    z = (noisy - vis[:, :N]).double()
+    assert abs(float(z.mean())) < 5 * std / (B * N * 3) ** 0.5
+    assert abs(float(z.std()) / std - 1.0) < 0.02
+    assert abs(float((z ** 4).mean()) / std ** 4 - 3.0) < 0.15             # kurtosis of a normal
+    for a in range(3):                                                       # coordinates are independent draws
+        for c in range(a + 1, 3):
+            assert abs(float((z[..., a] * z[..., c]).mean())) / std ** 2 < 0.03
+    want_pc, want_mean, _ = MO.assemble_input(vis.cpu(), z.float().cpu(), b["class_id"], N)
+    assert _rel(mean, want_mean) < 1e-6 and float((pc.cpu() - want_pc).abs().max()) < 1e-6
+    again = run(77, 3)
+    assert all(torch.equal(x, y) for x, y in zip(again, (pc, mean, noisy)))
+    assert not torch.equal(run(77, 4)[2], noisy) and not torch.equal(run(78, 3)[2], noisy)
+    # no noise at all (stddev 0): the plain assembly
+    step.fill_(3.0)
+    hip.check(L.cloudaae_input_assemble_noise(B, P, N, 21, hip.ptr(vis), hip.ptr(cls), hip.ptr(pc), hip.ptr(mean),
+                                              hip.ptr(noisy), 0.0, 77, hip.ptr(step), hip.stream()), "assemble")
+    assert torch.equal(noisy, vis[:, :N])
+
+
+def test_loss_tail_equals_its_parts(hip):
+    """cloudaae_loss_tail (per = dist1 + dist2, its mean, pose losses, total and the gradients for a known upstream
+    d(total) in ONE launch; the last workgroup to arrive finishes) = cloudaae_add_mean_f32 + cloudaae_pose_losses +
+    cloudaae_pose_losses_grad, bit for bit, launch after launch, the arrival counter left at zero."""
+    L = hip.lib()
+    g = torch.Generator().manual_seed(5)
+    for B, n in ((32, 4096), (3, 100), (200, 1024)):
+        d1, d2 = torch.rand(B, n, generator=g).cuda(), torch.rand(B, n, generator=g).cuda()
+        tp, tl = torch.randn(B, 3, generator=g).cuda(), torch.randn(B, 3, generator=g).cuda()
+        rp = torch.randn(B, 3, generator=g).cuda()
+        rl = torch.randn(B, 3, generator=g, dtype=torch.float64).cuda()
+        up = torch.full((), 0.7, device="cuda")
+        f32 = lambda *shape: torch.full(shape, float("nan"), device="cuda")      # noqa: E731
+        f64 = lambda *shape: torch.full(shape, float("nan"), device="cuda", dtype=torch.float64)   # noqa: E731
+        ws = torch.empty(int(L.cloudaae_mean_workspace_bytes()) // 8 + 1, dtype=torch.float64, device="cuda")
+        per0, xyz0 = f32(B, n), f32()
+        hip.check(L.cloudaae_add_mean_f32(B * n, hip.ptr(d1), hip.ptr(d2), hip.ptr(per0), hip.ptr(xyz0), hip.ptr(ws),
+                                          hip.stream()), "add_mean")
+        tper0, tloss0, rper0, jac0, rloss0, tot0 = f32(B), f32(), f64(B), f64(B, 3), f32(), f32()
+        hip.check(L.cloudaae_pose_losses(B, hip.ptr(tp), hip.ptr(tl), hip.ptr(rp), hip.ptr(rl), hip.ptr(xyz0), 1000.0, 10.0,
+                                         1.0, hip.ptr(tper0), hip.ptr(tloss0), hip.ptr(rper0), hip.ptr(jac0),
+                                         hip.ptr(rloss0), hip.ptr(tot0), hip.stream()), "pose_losses")
+        dx0, dt0, dr0 = f32(), f32(B, 3), f32(B, 3)
+        hip.check(L.cloudaae_pose_losses_grad(B, hip.ptr(tp), hip.ptr(tl), hip.ptr(tper0), hip.ptr(jac0), hip.ptr(up), 1000.0,
+                                              10.0, 1.0, hip.ptr(dx0), hip.ptr(dt0), hip.ptr(dr0), hip.stream()), "grad")
+        ws2 = torch.full((int(L.cloudaae_loss_tail_workspace_bytes()) // 8 + 1,), float("nan"), dtype=torch.float64,
+                         device="cuda")
+        ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for it in range(20):
+            per, xyz = f32(B, n), f32()
+            tper, tloss, rper, jac, rloss, tot = f32(B), f32(), f64(B), f64(B, 3), f32(), f32()
+            dx, dt, dr = f32(), f32(B, 3), f32(B, 3)
+            hip.check(L.cloudaae_loss_tail(B * n, hip.ptr(d1), hip.ptr(d2), hip.ptr(per), hip.ptr(xyz), B, hip.ptr(tp),
+                                           hip.ptr(tl), hip.ptr(rp), hip.ptr(rl), 1000.0, 10.0, 1.0, hip.ptr(tper),
+                                           hip.ptr(tloss), hip.ptr(rper), hip.ptr(jac), hip.ptr(rloss), hip.ptr(tot),
+                                           hip.ptr(up), hip.ptr(dx), hip.ptr(dt), hip.ptr(dr), hip.ptr(ws2),
+                                           hip.ptr(ticket), hip.stream()), "loss_tail")
+            for a, c in ((per, per0), (xyz, xyz0), (tper, tper0), (tloss, tloss0), (rper, rper0), (jac, jac0),
+                         (rloss, rloss0), (tot, tot0), (dx, dx0), (dt, dt0), (dr, dr0)):
+                assert torch.equal(a, c), (B, n, it)
+        assert int(ticket) == 0
+        # without an upstream gradient the three gradient outputs may be NULL
+        hip.check(L.cloudaae_loss_tail(B * n, hip.ptr(d1), hip.ptr(d2), hip.ptr(per), hip.ptr(xyz), B, hip.ptr(tp),
+                                       hip.ptr(tl), hip.ptr(rp), hip.ptr(rl), 1000.0, 10.0, 1.0, hip.ptr(tper),
+                                       hip.ptr(tloss), hip.ptr(rper), hip.ptr(jac), hip.ptr(rloss), hip.ptr(tot), None, None,
+                                       None, None, hip.ptr(ws2), hip.ptr(ticket), hip.stream()), "loss_tail")
+        assert torch.equal(tot, tot0)
+
+
+def test_zero_buffers(hip):
+    """cloudaae_zero_buffers: any number of buffers cleared by one launch per eight; guards untouched."""
+    import ctypes
+    L = hip.lib()
+    sizes = [16, 4096, 1 << 20, 48, 0, 1 << 16, 32, 1024, 16, 160, 2048]
+    big = torch.full((sum(sizes) // 4 + 64 * len(sizes),), 5.0, device="cuda")
+    ptrs, nbytes, spans, off = [], [], [], 16
+    for sz in sizes:
+        ptrs.append(big.data_ptr() + 4 * off)
+        nbytes.append(sz)
+        spans.append((off, off + sz // 4))
+        off += sz // 4 + 64
+    hip.check(L._cdll.cloudaae_zero_buffers(len(sizes), (ctypes.c_void_p * len(sizes))(*ptrs),
+                                           (ctypes.c_longlong * len(sizes))(*nbytes), hip.stream()), "zero_buffers")
+    want = torch.full_like(big, 5.0)
+    for a, c in spans:
+        want[a:c] = 0.0
+    assert torch.equal(big, want)
+    rc = L._cdll.cloudaae_zero_buffers(1, (ctypes.c_void_p * 1)(big.data_ptr() + 4), (ctypes.c_longlong * 1)(16),
+                                       hip.stream())
+    assert rc != 0 and "aligned" in L.cloudaae_last_error().decode()
+
+
+def test_recorded_step_is_short(hip):
+    """The recorded B = 32-style step keeps its launch count down: the loss tail is one launch (no separate mean /
+    pose-loss / pose-gradient kernels), "+ element_mean" rides in the output layers (no add_rowvec), the input noise is
+    drawn by the assembly kernel and the gradient slots are cleared with the zero zones (no fill in the plan)."""
+    from cloudaae_amd import train_cloudAAE_ycbv as T
+    g = T.TrainGraph({"num_point": 256, "gpu": 0}, {}, {"batch_size": 8}, replay=True)
+    el = T.synthetic_element(8, 256, g.device, seed=1)
+    g.train_step(el)
+    g.train_step(el)
+    assert g.replay and g._plan is not None and not g._plan.foreign_ops
+    names = [name for _, _, name in g._plan.entries if name is not None]
+    for gone in ("cloudaae_add_rowvec", "cloudaae_add_mean_f32", "cloudaae_pose_losses", "cloudaae_pose_losses_grad",
+                 "cloudaae_fill_scaled", "cloudaae_input_assemble"):
+        assert gone not in names, gone
+    assert names.count("cloudaae_loss_tail") == 1 and names.count("cloudaae_input_assemble_noise") == 1
+    assert len(g._plan.zextra) == 1
+    print("\nrecorded step: %d C-ABI calls: %s" % (len(names), " ".join(n.replace("cloudaae_", "") for n in names)))
+
+
 def _make_graph(B, N, model_fn="get_model_dgcnn_mean_6d"):
     from cloudaae_amd import train_cloudAAE_ycbv as T
     return T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, model_fn=model_fn)

@@ -233,6 +233,38 @@ def test_fc_forward_ticket_stress(hip, fixed_order):
     assert same or not fixed_order, "fixed-order slices did not reproduce bit for bit"
 
 
+@pytest.mark.parametrize("M,K,N,d", [(32, 1024, 12288, 3), (5, 256, 3, 3), (32, 512, 100, 5)])
+def test_fc_forward_adds_a_row_vector(hip, M, K, N, d):
+    """out_rowvec of cloudaae_fc_layer: y[r][c] = (x w + b)[r][c] + vec[r][c % d] -- the "+ element_mean" of
+    train_cloudAAE_ycbv.py:232-233 in the output layer's epilogue; equal to a separate cloudaae_add_rowvec pass bit for
+    bit (same order of additions)."""
+    from cloudaae_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + N)
+    x, W = torch.randn(M, K, generator=g).cuda(), (torch.randn(K, N, generator=g) / 32).cuda()
+    b, vec = torch.randn(N, generator=g).cuda(), torch.randn(M, d, generator=g).cuda()
+    nparts = int(L.cloudaae_fc_forward_partials(K, N, 0))
+    tk = torch.zeros(L.cloudaae_fc_forward_tickets(N), dtype=torch.int32, device="cuda")
+    parts = torch.empty(max(nparts, 1), device="cuda")
+    ys = []
+    for with_vec in (False, True):
+        layer = (_lib.FcLayer * 1)()
+        l = layer[0]
+        y = torch.full((M, N), float("nan"), device="cuda")
+        l.K, l.N, l.x, l.ldx, l.w, l.bias, l.y = K, N, x.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr()
+        l.tickets, l.partials = tk.data_ptr(), parts.data_ptr() if nparts else None
+        if with_vec:
+            l.out_rowvec, l.out_rowvec_d = vec.data_ptr(), d
+        _lib.check(L.cloudaae_fc_forward_group(M, 1, layer, 1, None, 0, _lib.stream()), "fc_forward_group")
+        ys.append(y)
+    want = torch.empty(M, N // d if N % d == 0 else 1, d, device="cuda")
+    if N % d == 0:
+        _lib.check(L.cloudaae_add_rowvec(M, N // d, d, ys[0].data_ptr(), vec.data_ptr(), want.data_ptr(), _lib.stream()),
+                   "add_rowvec")
+        assert torch.equal(ys[1], want.view(M, N))
+    assert torch.equal(ys[1], ys[0] + vec.repeat(1, (N + d - 1) // d)[:, :N])
+
+
 @pytest.mark.parametrize("M,K,N,bn", [(32, 1024, 1024, True), (7, 1024, 512, True), (32, 256, 3, False),
                                       (32, 1024, 12288, False), (19, 520, 260, True), (32, 1024, 1000, False)])
 def test_fc_forward_is_bit_reproducible(hip, M, K, N, bn):
