@@ -299,6 +299,9 @@ def main():
     ap.add_argument("--sync-bn", action="store_true", help="batch-norm moments over the GLOBAL batch (all ranks)")
     ap.add_argument("--step-only", action="store_true", help="skip the Chamfer kernel micro-benchmarks and the CPU "
                     "baseline (profiling runs: only the train step's kernels in the trace)")
+    ap.add_argument("--config5", action="store_true", help="BASELINE configs[4]: N=4096, k=20 and the on-line synthesis "
+                    "(pose -> transform -> occluder -> spherical flip -> hidden point removal x2, train...:96-117) of "
+                    "every batch INSIDE the timed loop, from synthetic 8192-point object models")
     ap.add_argument("--eager", action="store_true", help="step through Python/autograd every time instead of "
                     "replaying the recorded step (TrainGraph(replay=False))")
     args = ap.parse_args()
@@ -323,6 +326,8 @@ def main():
     from cloudaae_amd import train_cloudAAE_ycbv as T
     from cloudaae_amd.utils import _functions as F
 
+    if args.config5:
+        args.num_point, args.k = 4096, 20
     B = args.per_gpu_batch or (32 if world == 1 else 128)
     N = args.num_point
     # live HIP events on the launch stream around: the dgcnn_agg forward GEMM, the three kNN launches over 64
@@ -330,11 +335,31 @@ def main():
     sites = ["agg_fwd", "knn64"] + (["exchange"] if (world > 1 or force) else [])
     for k in sites:
         F.TIMED_SITES[k] = []
+    F.TIMED_SITES["edgeconv"] = []        # recorded with the step, switched off until the timed region is over
+    F.SITES_OFF.add("edgeconv")
     graph = T.TrainGraph({"num_point": N, "gpu": local}, {"optimizer": "adam"},
                          {"batch_size": B * world, "learning_rate": 0.0008}, replay=not args.eager,
                          gemm_dtype=args.gemm_dtype, k_neighbor=args.k, sync_bn=args.sync_bn)
     el = T.synthetic_element(B, N, graph.device, seed=123456789, rank=rank)
     graph.reuse_staged_inputs = True     # one fixed batch, resident in HBM: do not re-copy it every step
+    synth = None
+    if args.config5:
+        # every step draws its batch from the synthesis pipeline: poses of the synthetic element, 8192-point models
+        # (their + the occluder's 400 points + the viewpoint fit the LDS-resident hull test), the input cloud = the first
+        # N of the visible points of model + occluder, the Chamfer target = 4N rows of the model's visible points
+        # (visible points, then random re-draws: the reference's padding rule, hidden_point_removal.py:38-40)
+        models = T.synthetic_object_models(T.NUM_CLASS, 8192, device=graph.device)
+        poses = {k: el[k] for k in ("translation", "axisangle", "class_id")}
+        graph.reuse_staged_inputs = False
+        counter = [0]
+
+        class _Synth(object):
+            device = graph.device
+
+            def train_step(self, _):
+                counter[0] += 1
+                return graph.train_step(T.get_small_data(poses, models, seed=counter[0], rows_org=4 * N))
+        synth = _Synth()
 
     ranks_seen = 1
     if world > 1 or force:
@@ -342,9 +367,19 @@ def main():
         dist.all_reduce(ones)                                   # RCCL: every rank contributes 1
         ranks_seen = int(round(float(ones)))
 
-    elapsed, out = timed_steps(graph, el, args.steps, args.warmup, world, sites)
+    elapsed, out = timed_steps(synth if synth is not None else graph, el, args.steps, args.warmup, world, sites)
     events = {k: F.TIMED_SITES.pop(k) for k in sites}
     loss = float(out["total_loss"])
+    # the edge-convolution blocks are timed AFTER the timed region (sixteen event pairs per step would cost the
+    # headline ~1 %): eight more steps of the same replayed plan with only that site switched on
+    F.TIMED_SITES["edgeconv"].clear()
+    F.SITES_OFF.discard("edgeconv")
+    F.TIMED_ON = True
+    runner = synth if synth is not None else graph
+    for _ in range(8):
+        runner.train_step(el)
+    torch.cuda.synchronize()
+    events["edgeconv"] = F.TIMED_SITES.pop("edgeconv")
 
     one_rank = None
     if world > 1:
@@ -378,9 +413,12 @@ def main():
             "dtype": "f32" if args.gemm_dtype == "f32" else "bf16 dense-layer operands, f32 accumulate and everything else",
             "data": "synthetic",
             "config": {"workload": "CloudAAE train step: get_model_dgcnn_mean_6d, all 21 YCB classes, "
-                                   "batch %d/GPU, N=%d points, k=%d, 4N-point Chamfer target, TF-Adam%s"
-                                   % (B, N, args.k, ", SyncBN" if args.sync_bn else ""),
-                       "baseline_config": ("configs[1]" if (world == 1 and B == 32 and args.gemm_dtype == "f32") else
+                                   "batch %d/GPU, N=%d points, k=%d, 4N-point Chamfer target, TF-Adam%s%s"
+                                   % (B, N, args.k, ", SyncBN" if args.sync_bn else "",
+                                      ", every batch synthesised on the GPU inside the loop (8192-point models, occluder, "
+                                      "spherical flip, hidden point removal x2)" if args.config5 else ""),
+                       "baseline_config": ("configs[4] (one GPU; on-line synthesis inside the timed loop)" if args.config5 else
+                                           "configs[1]" if (world == 1 and B == 32 and args.gemm_dtype == "f32") else
                                            "configs[2]" if (world == 1 and B == 256 and args.gemm_dtype == "bf16") else
                                            "configs[3] (128 clouds per GPU)" if (B == 128 and world > 1) else "custom"),
                        "global_batch": B * world, "per_gpu_batch": B, "num_point": N, "parallelism": "dp%d" % world,
@@ -415,6 +453,27 @@ def main():
                                       "frac": round(qf / FP32_MFMA_PEAK_TFLOPS, 4),
                                       "traffic": measured_traffic(B, N, "knn64"),
                                       "launch_ms": round(q_ms, 4), "launches_timed": q_n}
+        # third entry: the four edge-convolution blocks, forward and backward (the calls cloudaae_edgeconv_forward /
+        # _backward: their products, statistics, finalise and apply / gather kernels; the grouped weight-gradient
+        # launch that follows backward is not inside).  HBM-bound by construction (the k-fold edge tensor never
+        # exists); algorithmic bytes = every array of a layer read or written once per pass that needs it.
+        e_ms, e_n = site_ms(events["edgeconv"])
+        if e_n:
+            P = B * N
+            tot = 0.0
+            for cin, cout in ((24, 64), (64, 64), (64, 64), (64, 128)):
+                idx, pq, out_, est = 4.0 * P * args.k, 4.0 * P * 2 * cout, 4.0 * P * cout, 4.0 * P * 3 * cout
+                fwd = 4.0 * P * cin + pq + (pq + idx) + (pq + idx + out_ + est)          # product | statistics | apply
+                bwd = (est + out_) + (est + out_ + pq + 2 * idx + pq) + (pq + 4.0 * P * cin)   # stats | apply (dpq) | dX
+                tot += fwd + bwd
+            per_call = tot / 8.0                       # eight timed calls per step (4 forward + 4 backward)
+            gbs = per_call / (e_ms * 1e-3) / 1e9
+            line["roofline_edgeconv"] = {"bound": "hbm", "kernel": "cloudaae_edgeconv_forward + _backward, 4 layers "
+                                                                   "(ec_stats / ec_apply / ec_bwd_* + their products)",
+                                         "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                         "step_ms_in_edgeconv": round(e_ms * 8, 4), "calls_timed": e_n,
+                                         "algorithmic_bytes_per_step": int(tot)}
         if world > 1 or force:
             x_ms, x_n = site_ms(events["exchange"])
             line["comm"] = {"backend": "nccl (RCCL)", "ranks_seen": ranks_seen,

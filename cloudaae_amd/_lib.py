@@ -95,6 +95,7 @@ _SIGNATURES = {
     "cloudaae_random_spherical_occluder": [_I, _I, _P, _F, _F, _F, _F, _U, _P, _P],
     "cloudaae_spherical_flip": [_I, _I, _P, _I, _P, _P, _F, _P, _P, _P],
     "cloudaae_hidden_point_removal": [_I, _I, _P, _P, _U, _P, _P, _P, _P, _P],
+    "cloudaae_hidden_point_removal_rows": [_I, _I, _P, _P, _U, _I, _P, _P, _P, _P, _P],
 }
 
 

@@ -504,7 +504,7 @@ __global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, con
 __global__ __launch_bounds__(512) void hpr_gather_kernel(int n1, const unsigned char *__restrict__ flags,
                                                         const float *__restrict__ org, unsigned long long seed,
                                                         float *__restrict__ visible, long long *__restrict__ num_vis,
-                                                        int *__restrict__ visible_id)
+                                                        int *__restrict__ visible_id, int rows)
 {
     extern __shared__ int ids[];          // n1 ints: compacted vertex ids
     __shared__ int wsum[8];
@@ -540,8 +540,8 @@ __global__ __launch_bounds__(512) void hpr_gather_kernel(int n1, const unsigned 
     if (t == 0)
         num_vis[h] = nv;
     const float *O = org + (size_t)h * n1 * 3;
-    float *V = visible + (size_t)h * n1 * 3;
-    for (int r = t; r < n1; r += 512) {
+    float *V = visible + (size_t)h * rows * 3;     // rows = n1 in the reference (hidden_point_removal.py:38-40)
+    for (int r = t; r < rows; r += 512) {
         int src = -1;
         if (r < nv) {
             src = ids[r];
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(512) void hpr_gather_kernel(int n1, const unsigned 
             src = ids[rnd[0] % (unsigned)nv];        // np.random.choice(visibleId, ...)
         }
         if (visible_id)
-            visible_id[(size_t)h * n1 + r] = r < nv ? src : -1;
+            visible_id[(size_t)h * rows + r] = r < nv ? src : -1;
         V[3 * r] = src >= 0 ? O[3 * src] : 0.0f;
         V[3 * r + 1] = src >= 0 ? O[3 * src + 1] : 0.0f;
         V[3 * r + 2] = src >= 0 ? O[3 * src + 2] : 0.0f;
@@ -620,8 +620,18 @@ CLOUDAAE_API int cloudaae_hidden_point_removal(int b, int n1, const float *flipp
                                                unsigned long long seed, float *visible, long long *num_vis,
                                                int *visible_id, void *workspace, cloudaae_stream_t stream)
 {
+    return cloudaae_hidden_point_removal_rows(b, n1, flipped, org, seed, n1, visible, num_vis, visible_id, workspace,
+                                              stream);
+}
+
+CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *flipped, const float *org,
+                                                    unsigned long long seed, int rows, float *visible,
+                                                    long long *num_vis, int *visible_id, void *workspace,
+                                                    cloudaae_stream_t stream)
+{
     const char *name = "cloudaae_hidden_point_removal";
     CLOUDAAE_REQUIRE(b >= 0 && n1 >= 5 && b <= 65535 && workspace, name, "bad size (need >= 4 points + viewpoint)");
+    CLOUDAAE_REQUIRE(rows >= 1, name, "bad number of output rows");
     CLOUDAAE_REQUIRE((size_t)n1 * 12 <= 150 * 1024, name, "cloud too large for the LDS-resident hull test");
     if (b == 0)
         return 0;
@@ -653,7 +663,7 @@ CLOUDAAE_API int cloudaae_hidden_point_removal(int b, int n1, const float *flipp
     hipLaunchKernelGGL(hull_vertex_kernel, dim3(gx, b), dim3(64 * HPR_WAVES), lds, s, n1, sorted, perm,
                        index_bits(n1), flags);
     hipLaunchKernelGGL(hpr_gather_kernel, dim3(b), dim3(512), (size_t)n1 * sizeof(int), s, n1, flags, org, seed,
-                       visible, num_vis, visible_id);
+                       visible, num_vis, visible_id, rows);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }

@@ -506,10 +506,14 @@ def transform_object_model(x):
     return x
 
 
-def get_small_data(records, obj_models, seed=0):
+def get_small_data(records, obj_models, seed=0, rows=None, rows_org=None):
     """:96-117 for one batch: records = dict of device tensors translation [B,3], axisangle [B,3],
     class_id [B] (e.g. from tfrecord_io.PoseRecords.epoch); returns the reference's element dict:
-    visiblePoints [B,2449,3], visiblePoints_org [B,2049,3], occluder, model_xyz_rot_trans, ..."""
+    visiblePoints [B,2449,3], visiblePoints_org [B,2049,3], occluder, model_xyz_rot_trans, ...
+    rows / rows_org: other row counts of visiblePoints / visiblePoints_org (default: the reference's model points
+    [+ occluder points] + 1), filled by the reference's rule -- visible points, then random re-draws of visible
+    points (hidden_point_removal.py:38-40).  BASELINE configs[4] (N = 4096) needs a Chamfer target of 4N = 16384 rows,
+    more than any model has points."""
     from .utils import generate_occluder, hidden_point_removal as hpr
     x = dict(records)
     x = get_object_model(x, obj_models)
@@ -517,9 +521,9 @@ def get_small_data(records, obj_models, seed=0):
     x = transform_object_model(x)
     x = generate_occluder.get_random_spherical_occluder(x, 'ycbv', seed=seed)
     x = hpr.sphericalFlip(x, None, 0.8 * math.pi)            # center = zeros_like(translation), :103
-    x = hpr.hidden_point_removal(x, seed=seed)
+    x = hpr.hidden_point_removal(x, seed=seed, rows=rows)
     x = hpr.sphericalFlip_org(x, None, 0.8 * math.pi)
-    x = hpr.hidden_point_removal_org(x, seed=seed)
+    x = hpr.hidden_point_removal_org(x, seed=seed, rows=rows_org)
     return x
 
 
@@ -543,6 +547,24 @@ def synthetic_element(local_batch, num_point, device, seed=123456789, rank=0, si
     angle = (torch.rand((B,), generator=g, device=device, dtype=torch.float64) * 2 - 1) * math.pi
     return dict(visiblePoints=vis, visiblePoints_org=org, class_id=cls, translation=t.clone(),
                 axisangle=axis * angle[:, None])
+
+
+def synthetic_object_models(num_models=NUM_CLASS, num_point=2048, seed=123456789, device=None):
+    """Stand-ins for object_model_tfrecord/obj_models.tfrecords (train...:42-54: 21 x [2048, 6] xyz + rgb) with any
+    number of points per model -- BASELINE configs[4] feeds N = 4096 input points, more than the shipped models'
+    2048: points on closed surfaces of YCB-like extent (superellipsoids of half-axes 0.03 ... 0.11 m, exponent
+    0.6 ... 2.5: from box-like to rounded), rgb = normalised position."""
+    g = torch.Generator().manual_seed(seed)
+    out = torch.empty((num_models, num_point, 6), dtype=torch.float32)
+    for m in range(num_models):
+        half = torch.rand(3, generator=g) * 0.08 + 0.03
+        e = float(torch.rand((), generator=g) * 1.9 + 0.6)
+        d = torch.randn((num_point, 3), generator=g)
+        d = d / d.norm(dim=1, keepdim=True)
+        r = (d.abs() ** (2.0 / e)).sum(1, keepdim=True) ** (-e / 2.0)      # |x/a|^(2/e) + ... = 1 along direction d
+        out[m, :, :3] = d * r * half
+        out[m, :, 3:] = d * 0.5 + 0.5
+    return out if device is None else out.to(device)
 
 
 class ClassLossLog(object):

@@ -37,29 +37,32 @@ def sphericalFlip_org(x, center, param):
     return x
 
 
-def convexHull(points, orgPoints, seed=0, return_ids=False):
+def convexHull(points, orgPoints, seed=0, return_ids=False, rows=None):
     """(:27-43) points [B,n+1,3] flipped (+viewpoint row); returns (visiblePoints [B,n+1,3],
     num_vis_point [B] int64): rows [0,num_vis) are the visible points in ascending index, the
-    rest random re-draws of visible points."""
+    rest random re-draws of visible points.  rows: another number of output rows (default n+1, the
+    reference's), filled by the same rule."""
     points = points.to(torch.float32).contiguous()
     orgPoints = orgPoints.to(torch.float32).contiguous()
     B, n1, _ = points.shape
     require(orgPoints.shape == points.shape, "convexHull: points and orgPoints differ in shape")
-    vis = torch.empty_like(orgPoints)
+    rows = n1 if rows is None else int(rows)
+    vis = torch.empty((B, rows, 3), dtype=torch.float32, device=points.device)
     num = torch.empty((B,), dtype=torch.int64, device=points.device)
-    ids = torch.empty((B, n1), dtype=torch.int32, device=points.device) if return_ids else None
+    ids = torch.empty((B, rows), dtype=torch.int32, device=points.device) if return_ids else None
     ws = torch.empty(int(_lib.lib().cloudaae_hpr_workspace_bytes(B, n1)), dtype=torch.uint8, device=points.device)
-    _lib.check(_lib.lib().cloudaae_hidden_point_removal(B, n1, ptr(points), ptr(orgPoints), int(seed), ptr(vis),
-                                                        ptr(num), ptr(ids), ptr(ws), stream()),
+    _lib.check(_lib.lib().cloudaae_hidden_point_removal_rows(B, n1, ptr(points), ptr(orgPoints), int(seed), rows,
+                                                             ptr(vis), ptr(num), ptr(ids), ptr(ws), stream()),
                "cloudaae_hidden_point_removal")
     return (vis, num, ids) if return_ids else (vis, num)
 
 
-def hidden_point_removal(x, seed=0):
-    x['visiblePoints'], x['num_vis_point'] = convexHull(x['flippedPoints'], x['orgPoints'], seed)
+def hidden_point_removal(x, seed=0, rows=None):
+    x['visiblePoints'], x['num_vis_point'] = convexHull(x['flippedPoints'], x['orgPoints'], seed, rows=rows)
     return x
 
 
-def hidden_point_removal_org(x, seed=0):
-    x['visiblePoints_org'], x['num_vis_point_org'] = convexHull(x['flippedPoints_org'], x['orgPoints_org'], seed + 1)
+def hidden_point_removal_org(x, seed=0, rows=None):
+    x['visiblePoints_org'], x['num_vis_point_org'] = convexHull(x['flippedPoints_org'], x['orgPoints_org'], seed + 1,
+                                                                rows=rows)
     return x

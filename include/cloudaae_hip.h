@@ -512,6 +512,13 @@ long long cloudaae_hpr_workspace_bytes(int b, int n1);
 int cloudaae_hidden_point_removal(int b, int n1, const float *flipped, const float *org,
                                   unsigned long long seed, float *visible, long long *num_vis, int *visible_id,
                                   void *workspace, cloudaae_stream_t stream);
+/* The same with a chosen number of output rows: visible [b,rows,3] (visible_id [b,rows]) = the visible points in
+ * ascending index, then random re-draws of visible points up to `rows` rows -- the reference's rule
+ * (hidden_point_removal.py:38-40, where rows == n1) for a Chamfer target of 4N rows when 4N exceeds the model's
+ * point count (BASELINE configs[4]: N = 4096). */
+int cloudaae_hidden_point_removal_rows(int b, int n1, const float *flipped, const float *org,
+                                       unsigned long long seed, int rows, float *visible, long long *num_vis,
+                                       int *visible_id, void *workspace, cloudaae_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -169,3 +169,42 @@ def test_pipeline_feeds_a_train_step(hip, data):
     graph = T.TrainGraph({"num_point": 256, "gpu": 0}, {}, {"batch_size": 4})
     out = graph.train_step(el)
     assert math.isfinite(float(out["total_loss"])) and out["xyz_recon"].shape == (4, 1024, 3)
+
+
+def test_config5_synthesis_rows_and_models(hip, data):
+    """BASELINE configs[4] (N = 4096 input points): synthetic 8192-point object models and a visiblePoints_org of 4N =
+    16384 rows -- more rows than a model has points, filled by the reference's own rule (hidden_point_removal.py:38-40:
+    the visible points in ascending index, then random re-draws of visible points).  The first num_vis rows equal the
+    reference-shaped call's, every padded row is one of the visible points; the visible set of an 8193-point cloud is
+    qhull's."""
+    from cloudaae_amd import train_cloudAAE_ycbv as T
+    from oracle import synth_oracle as SO
+    _, recs = data
+    models = T.synthetic_object_models(3, 8192, seed=5, device="cuda")
+    assert tuple(models.shape) == (3, 8192, 6) and float(models[:, :, :3].abs().max()) < 0.12
+    x = _records(recs)
+    x["class_id"] = torch.tensor([0, 1, 2, 1], device="cuda")
+    ref = T.get_small_data(dict(x), models, seed=3)
+    big = T.get_small_data(dict(x), models, seed=3, rows_org=16384)
+    assert tuple(ref["visiblePoints"].shape) == (4, 8192 + 400 + 1, 3) and tuple(ref["visiblePoints_org"].shape) == (4, 8193, 3)
+    assert tuple(big["visiblePoints_org"].shape) == (4, 16384, 3) and torch.equal(big["visiblePoints"], ref["visiblePoints"])
+    assert torch.equal(big["num_vis_point_org"], ref["num_vis_point_org"])
+    for i in range(4):
+        nv = int(ref["num_vis_point_org"][i])
+        assert 500 < nv < 8192
+        assert torch.equal(big["visiblePoints_org"][i, :nv], ref["visiblePoints_org"][i, :nv])
+        vis = {tuple(r) for r in ref["visiblePoints_org"][i, :nv].cpu().numpy().tolist()}
+        pad = big["visiblePoints_org"][i, nv:].cpu().numpy()
+        assert all(tuple(r) in vis for r in pad[::37].tolist())
+        assert len({tuple(r) for r in pad.tolist()}) > min(nv, 2000) // 2          # re-draws, not one repeated point
+    # the visible set of one 8193-point cloud against qhull
+    from cloudaae_amd.utils import hidden_point_removal as hpr
+    want, _ = SO.convex_hull_visible(big["flippedPoints_org"][0].cpu().numpy())
+    _, num, ids = hpr.convexHull(big["flippedPoints_org"][:1].contiguous(), big["orgPoints_org"][:1].contiguous(), seed=0,
+                                 return_ids=True, rows=9000)
+    assert int(num[0]) == len(want) and np.array_equal(ids[0, :len(want)].cpu().numpy(), want)
+    assert (ids[0, len(want):] == -1).all() and ids.shape == (1, 9000)
+    # ... and it feeds a k = 20 train step at N = 4096
+    g = T.TrainGraph({"num_point": 4096, "gpu": 0}, {}, {"batch_size": 4}, k_neighbor=20)
+    out = g.train_step(big)
+    assert tuple(out["xyz_recon"].shape) == (4, 16384, 3) and np.isfinite(float(out["total_loss"]))
