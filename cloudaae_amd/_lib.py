@@ -317,7 +317,7 @@ def lib():
         cdll.cloudaae_fc_forward_tickets.argtypes = [_I]
         cdll.cloudaae_fc_forward_tickets.restype = ctypes.c_int
         cdll.cloudaae_loss_tail_workspace_bytes.argtypes = []
-        cdll.cloudaae_fc_forward_partials.argtypes = [_I, _I, _I, _I]
+        cdll.cloudaae_fc_forward_partials.argtypes = [_I, _I, _I]
         cdll.cloudaae_fc_forward_partials.restype = ctypes.c_longlong
         cdll.cloudaae_edgeconv_workspace_bytes.argtypes = [_I]
         for q in ("cloudaae_set_knob", "cloudaae_unset_knob"):

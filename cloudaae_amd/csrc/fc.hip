@@ -21,8 +21,7 @@ namespace cloudaae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int FC_M = 32;        // rows of one MFMA tile
-constexpr int FC_RT_MAX = 4;    // row tiles a workgroup walks: batches of up to 128 clouds
+constexpr int FC_M = 32;        // rows of one MFMA tile = the largest batch this path takes
 constexpr int FC_TN = 128;      // output columns per workgroup (4 per MFMA column lane)
 constexpr int FC_LD = FC_TN + 4;  // LDS row stride (floats), keeps rows 16-byte aligned
 
@@ -86,12 +85,7 @@ constexpr int FC_NW = 4;            // waves per workgroup
 
 // One workgroup = (column tile, K slice) of one layer; the NW waves take contiguous runs of the slice's
 // k, their partial 32 x 128 tiles meet in LDS, and the threads then finish one column each.
-// RT: row tiles of 32 clouds.  RT = 1 is the batch of at most 32; RT = 4 (33 ... 128 clouds per GPU: the per-GPU
-// shape of BASELINE configs[3]) walks the row tiles one after the other -- the slice of W is read again for each
-// (it stays in L1 / L2), the finished sums of every row tile stay in registers, and the batch norm of a column
-// sums over all of them: still ONE launch per layer depth where the generic path needs a product, a slice sum and
-// a batch norm launch per layer.
-template <int NW, bool VEC, int RT>
+template <int NW, bool VEC>
 __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int slice, float *tile,
                                             double (*red)[NW / 2][FC_TN], int *last_flag)
 {
@@ -103,98 +97,90 @@ __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int 
     const int kw0 = kb0 + wv * per, kw1 = min(kb1, kw0 + per);
     const int colq = n0 + 4 * r32;
     // rows >= M and columns >= N are computed from existing data and never written
+    const float *xrow = a.x + (size_t)min(r32, a.M - 1) * a.ldx;
     const float *wcol = a.w + (VEC ? min(colq, a.N - 4) : colq);
     const int wvalid = VEC ? 4 : a.N - colq;
 
-    constexpr int RG = NW / 2, RP = FC_M / RG;      // row groups, rows per thread and row tile
-    const int col = threadIdx.x & (FC_TN - 1), rg = threadIdx.x >> 7;
-    const int c = n0 + col;
-    const bool ok = c < a.N;
-    // the bias joins once: with the only slice, with slice 0 of a plain cut product, or (a cut product finished by
-    // its last slice) when that slice reads the finished sums back
-    const float bias = (a.bias != nullptr && ok) ? a.bias[c] : 0.0f;
-    const float bv = (!a.atomic || (a.tickets == nullptr && a.partials == nullptr && slice == 0)) ? bias : 0.0f;
-    float v[RT][RP];
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[c][r] = 0.0f;
 
+    auto load = [&](FcSet &st, int k) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        if (rt * FC_M >= a.M)       // (uniform: the whole workgroup skips an empty row tile)
-            continue;
-        const float *xrow = a.x + (size_t)min(rt * FC_M + r32, a.M - 1) * a.ldx;
-        f32x16 acc[4];
+        for (int u = 0; u < 2; ++u) {
+            const int ka = k + 8 * u + 4 * half;
+            // k beyond the run: read the run's first rows again and zero the X operand
+            const bool in = k + 8 * u < kw1;
+            const int kc = in ? ka : kb0;
+            st.g[u].a = fc_load4<VEC>(xrow + kc, VEC ? 4 : kw1 - ka, a.x);
+            st.in[u] = in;      // applied where the operand is consumed, not here: a select on the loaded
+                                // value would make the wave wait for the load inside the batch
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[cc][r] = 0.0f;
-
-        auto load = [&](FcSet &st, int k) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int ka = k + 8 * u + 4 * half;
-                // k beyond the run: read the run's first rows again and zero the X operand
-                const bool in = k + 8 * u < kw1;
-                const int kc = in ? ka : kb0;
-                st.g[u].a = fc_load4<VEC>(xrow + kc, VEC ? 4 : kw1 - ka, a.x);
-                st.in[u] = in;      // applied where the operand is consumed, not here: a select on the loaded
-                                    // value would make the wave wait for the load inside the batch
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int kr = VEC ? kc + j : min(kc + j, a.K - 1);     // (a zeroed X column pairs with it)
-                    st.g[u].b[j] = fc_load4<VEC>(wcol + (size_t)kr * a.N, wvalid, a.w);
-                }
-            }
-        };
-        auto mma = [&](const FcSet &st) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float aj = st.in[u] ? st.g[u].a[j] : 0.0f;
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc)
-                        acc[cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(aj, st.g[u].b[j][cc], acc[cc], 0, 0, 0);
-                }
-        };
-
-        // two operand sets: the loads of one are in flight behind the 32 MFMAs of the other
-        if (kw0 < kw1) {
-            FcSet s0, s1;
-            load(s0, kw0);
-            for (int k = kw0; k < kw1; k += 32) {
-                // (the barriers keep each batch of ten loads AHEAD of the MFMAs it hides behind; left alone
-                // the scheduler sinks every load next to its use and the wave has one load in flight)
-                load(s1, k + 16);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(s0);
-                __builtin_amdgcn_sched_barrier(0);
-                load(s0, k + 32);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(s1);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 4; ++j) {
+                const int kr = VEC ? kc + j : min(kc + j, a.K - 1);     // (a zeroed X column pairs with it)
+                st.g[u].b[j] = fc_load4<VEC>(wcol + (size_t)kr * a.N, wvalid, a.w);
             }
         }
+    };
+    auto mma = [&](const FcSet &st) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float aj = st.in[u] ? st.g[u].a[j] : 0.0f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(aj, st.g[u].b[j][c], acc[c], 0, 0, 0);
+            }
+    };
 
-        if (RT > 1 && rt > 0)
-            __syncthreads();        // the previous row tile's sums have been read out of LDS
-        float *mine = tile + (size_t)wv * FC_M * FC_LD;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float4v q = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-            *reinterpret_cast<float4v *>(mine + mfma_row(r, half) * FC_LD + 4 * r32) = q;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < RP; ++i) {
-            const int row = rg + RG * i;
-            float sum = 0.0f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w)
-                sum += tile[((size_t)w * FC_M + row) * FC_LD + col];
-            v[rt][i] = sum + bv;
+    // two operand sets: the loads of one are in flight behind the 32 MFMAs of the other
+    if (kw0 < kw1) {
+        FcSet s0, s1;
+        load(s0, kw0);
+        for (int k = kw0; k < kw1; k += 32) {
+            // (the barriers keep each batch of ten loads AHEAD of the MFMAs it hides behind; left alone
+            // the scheduler sinks every load next to its use and the wave has one load in flight)
+            load(s1, k + 16);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(s0);
+            __builtin_amdgcn_sched_barrier(0);
+            load(s0, k + 32);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(s1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
+    float *mine = tile + (size_t)wv * FC_M * FC_LD;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float4v v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        *reinterpret_cast<float4v *>(mine + mfma_row(r, half) * FC_LD + 4 * r32) = v;
+    }
+    __syncthreads();
+
+    constexpr int RG = NW / 2, RP = FC_M / RG;      // row groups, rows per thread
+    const int col = threadIdx.x & (FC_TN - 1), rg = threadIdx.x >> 7;
+    const int c = n0 + col;
+    const bool ok = c < a.N;
+    // the bias joins once: with the only slice, with slice 0 of a plain cut product, or (batch norm
+    // over a cut product) when the last slice to arrive reads the finished sums back
+    const float bias = (a.bias != nullptr && ok) ? a.bias[c] : 0.0f;
+    const float bv = (!a.atomic || (a.tickets == nullptr && a.partials == nullptr && slice == 0)) ? bias : 0.0f;
+    float v[RP];
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+        const int row = rg + RG * i;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            s += tile[((size_t)w * FC_M + row) * FC_LD + col];
+        v[i] = s + bv;
+    }
     if (a.atomic && a.partials != nullptr) {
         // One K slice of several, combined in a FIXED order (bit-reproducible from run to run, whatever order the
         // slices finish in): every slice publishes its partial tile with agent-scope stores (write-through to
@@ -204,14 +190,11 @@ __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int 
         // write-back or invalidate is involved (a __threadfence() here costs more than the whole product)
         // because no ordinary store takes part.  The counter returns to zero for the next launch.
         // (tests/test_capi_symbols.py checks the emitted ISA for the wait in front of the barrier.)
-        float *slot = a.partials + (size_t)(tile_x * a.splits + slice) * (RT * FC_M * FC_TN);
+        float *slot = a.partials + (size_t)(tile_x * a.splits + slice) * (FC_M * FC_TN);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int i = 0; i < RP; ++i)
-                if (rt * FC_M + rg + RG * i < a.M)
-                    __hip_atomic_store(&slot[(rt * FC_M + rg + RG * i) * FC_TN + col], v[rt][i], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < RP; ++i)
+            if (rg + RG * i < a.M)
+                __hip_atomic_store(&slot[(rg + RG * i) * FC_TN + col], v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -220,63 +203,56 @@ __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int 
             if (t == a.splits - 1)
                 __hip_atomic_store(&a.tickets[tile_x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __syncthreads();        // (also: the waves' partial tiles in LDS have been consumed)
+        __syncthreads();
         if (!*last_flag)
             return;
-        // thread t sums element pairs t, t + 256, ... of each 32 x 128 row tile (8-byte loads, a row per wave and
+        // thread t sums element pairs t, t + 256, ... of the 32 x 128 tile (8-byte loads, a row per wave and
         // instruction); four slices' loads are in flight together; the sums meet the column threads in LDS
         constexpr int PAIRS = FC_M * FC_TN / 2 / (NW * 64);
         const unsigned long long *base =
-            reinterpret_cast<const unsigned long long *>(a.partials + (size_t)tile_x * a.splits * (RT * FC_M * FC_TN));
+            reinterpret_cast<const unsigned long long *>(a.partials + (size_t)tile_x * a.splits * (FC_M * FC_TN));
+        float2v sum[PAIRS];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            if (rt * FC_M >= a.M)
-                continue;
-            float2v sum[PAIRS];
+        for (int q = 0; q < PAIRS; ++q)
+            sum[q] = float2v{0.0f, 0.0f};
+        for (int s0 = 0; s0 < a.splits; s0 += 4) {
+            unsigned long long raw[4][PAIRS];
 #pragma unroll
-            for (int q = 0; q < PAIRS; ++q)
-                sum[q] = float2v{0.0f, 0.0f};
-            for (int s0 = 0; s0 < a.splits; s0 += 4) {
-                unsigned long long raw[4][PAIRS];
+            for (int u = 0; u < 4; ++u) {
+                const int s = min(s0 + u, a.splits - 1);        // (past the end: the last slice again, not added)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int s = min(s0 + u, a.splits - 1);        // (past the end: the last slice again, not added)
+                for (int q = 0; q < PAIRS; ++q) {
+                    const int e = (int)threadIdx.x + NW * 64 * q;
+                    const int row = min(e / (FC_TN / 2), a.M - 1);      // rows >= M were never published
+                    raw[u][q] = __hip_atomic_load(&base[((size_t)s * FC_M + row) * (FC_TN / 2) + e % (FC_TN / 2)],
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (s0 + u < a.splits)
 #pragma unroll
                     for (int q = 0; q < PAIRS; ++q) {
-                        const int e = (int)threadIdx.x + NW * 64 * q;
-                        const int row = min(rt * FC_M + e / (FC_TN / 2), a.M - 1);      // rows >= M were never published
-                        raw[u][q] = __hip_atomic_load(&base[((size_t)s * (RT * FC_M) + row) * (FC_TN / 2) + e % (FC_TN / 2)],
-                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sum[q].x += __uint_as_float((unsigned)raw[u][q]);
+                        sum[q].y += __uint_as_float((unsigned)(raw[u][q] >> 32));
                     }
-                }
+        }
+        __syncthreads();        // (the waves' partial tiles in LDS have been consumed)
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (s0 + u < a.splits)
-#pragma unroll
-                        for (int q = 0; q < PAIRS; ++q) {
-                            sum[q].x += __uint_as_float((unsigned)raw[u][q]);
-                            sum[q].y += __uint_as_float((unsigned)(raw[u][q] >> 32));
-                        }
-            }
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) {
-                const int e = (int)threadIdx.x + NW * 64 * q;
-                *reinterpret_cast<float2v *>(tile + (rt * FC_M + e / (FC_TN / 2)) * FC_LD + 2 * (e % (FC_TN / 2))) = sum[q];
-            }
+        for (int q = 0; q < PAIRS; ++q) {
+            const int e = (int)threadIdx.x + NW * 64 * q;
+            *reinterpret_cast<float2v *>(tile + (e / (FC_TN / 2)) * FC_LD + 2 * (e % (FC_TN / 2))) = sum[q];
         }
         __syncthreads();
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int i = 0; i < RP; ++i)
-                v[rt][i] = tile[(rt * FC_M + rg + RG * i) * FC_LD + col] + bias;
+        for (int i = 0; i < RP; ++i)
+            v[i] = tile[(rg + RG * i) * FC_LD + col] + bias;
     } else if (a.atomic) {     // one K slice of several, added with fp32 atomics: the output was cleared by the caller
-        // (batches of at most 32 clouds only: the launcher keeps K whole for taller ones without the scratch)
         if (ok)
 #pragma unroll
             for (int i = 0; i < RP; ++i)
                 if (rg + RG * i < a.M)
-                    __hip_atomic_fetch_add(&a.y[(size_t)(rg + RG * i) * a.N + c], v[0][i], __ATOMIC_RELAXED,
+                    __hip_atomic_fetch_add(&a.y[(size_t)(rg + RG * i) * a.N + c], v[i], __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
         if (a.tickets == nullptr)
             return;
@@ -297,24 +273,20 @@ __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int 
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
             const int row = min(rg + RG * i, a.M - 1);
-            v[0][i] = __hip_atomic_load(&a.y[(size_t)row * a.N + min(c, a.N - 1)], __ATOMIC_RELAXED,
-                                        __HIP_MEMORY_SCOPE_AGENT) + bias;
+            v[i] = __hip_atomic_load(&a.y[(size_t)row * a.N + min(c, a.N - 1)], __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT) + bias;
         }
     }
     if (a.gamma == nullptr) {
         if (ok) {
             const int cd = a.rowvec != nullptr ? c % a.rowvec_d : 0;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int i = 0; i < RP; ++i) {
-                    const int row = rt * FC_M + rg + RG * i;
-                    if (row < a.M) {
-                        float out = v[rt][i];
-                        if (a.rowvec != nullptr)
-                            out = out + a.rowvec[(size_t)row * a.rowvec_d + cd];
-                        a.y[(size_t)row * a.N + c] = out;
-                    }
+            for (int i = 0; i < RP; ++i)
+                if (rg + RG * i < a.M) {
+                    float out = v[i];
+                    if (a.rowvec != nullptr)
+                        out = out + a.rowvec[(size_t)(rg + RG * i) * a.rowvec_d + cd];
+                    a.y[(size_t)(rg + RG * i) * a.N + c] = out;
                 }
         }
         return;
@@ -325,13 +297,11 @@ __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int 
     if (a.training) {
         double s = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int i = 0; i < RP; ++i)
-                if (rt * FC_M + rg + RG * i < a.M) {
-                    s += (double)v[rt][i];
-                    s2 += (double)v[rt][i] * (double)v[rt][i];
-                }
+        for (int i = 0; i < RP; ++i)
+            if (rg + RG * i < a.M) {
+                s += (double)v[i];
+                s2 += (double)v[i] * (double)v[i];
+            }
         red[0][rg][col] = s;
         red[1][rg][col] = s2;
         __syncthreads();
@@ -364,18 +334,16 @@ __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int 
     const float inv = a.gamma[c] * bn_rsqrt(var + BN_EPS);
     const float sh = a.beta[c] - mean * inv;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int i = 0; i < RP; ++i) {
-            const int row = rt * FC_M + rg + RG * i;
-            if (row < a.M) {
-                a.y[(size_t)row * a.N + c] = v[rt][i];
-                float z = v[rt][i] * inv + sh;
-                if (a.relu)
-                    z = fmaxf(z, 0.0f);
-                a.out[(size_t)row * a.N + c] = z;
-            }
+    for (int i = 0; i < RP; ++i) {
+        const int row = rg + RG * i;
+        if (row < a.M) {
+            a.y[(size_t)row * a.N + c] = v[i];
+            float z = v[i] * inv + sh;
+            if (a.relu)
+                z = fmaxf(z, 0.0f);
+            a.out[(size_t)row * a.N + c] = z;
         }
+    }
 }
 
 // which layer of the group a workgroup belongs to (block ranges are ascending)
@@ -398,25 +366,9 @@ __global__ __launch_bounds__(FC_NW * 64) void fc_fwd_kernel(FcFwdGroup g)
     const int local = (int)blockIdx.x - a.block0;
     const int tile_x = local % a.tiles, slice = local / a.tiles;
     if (a.vec)
-        fc_fwd_body<FC_NW, true, 1>(a, tile_x, slice, reinterpret_cast<float *>(tile4), red, &last);
+        fc_fwd_body<FC_NW, true>(a, tile_x, slice, reinterpret_cast<float *>(tile4), red, &last);
     else
-        fc_fwd_body<FC_NW, false, 1>(a, tile_x, slice, reinterpret_cast<float *>(tile4), red, &last);
-}
-
-// the same for 33 ... 128 rows (four row tiles per workgroup)
-__global__ __launch_bounds__(FC_NW * 64) void fc_fwd_tall_kernel(FcFwdGroup g)
-{
-    static_assert(FC_NW == FC_RT_MAX, "the final sums of all row tiles share the LDS of the waves' partial tiles");
-    __shared__ float4v tile4[FC_NW * FC_M * (FC_LD / 4)];
-    __shared__ double red[2][FC_NW / 2][FC_TN];
-    __shared__ int last;
-    const FcFwdArgs a = g.p[fc_group_member(g)];
-    const int local = (int)blockIdx.x - a.block0;
-    const int tile_x = local % a.tiles, slice = local / a.tiles;
-    if (a.vec)
-        fc_fwd_body<FC_NW, true, FC_RT_MAX>(a, tile_x, slice, reinterpret_cast<float *>(tile4), red, &last);
-    else
-        fc_fwd_body<FC_NW, false, FC_RT_MAX>(a, tile_x, slice, reinterpret_cast<float *>(tile4), red, &last);
+        fc_fwd_body<FC_NW, false>(a, tile_x, slice, reinterpret_cast<float *>(tile4), red, &last);
 }
 
 // ---- backward -----------------------------------------------------------------------------------
@@ -428,12 +380,16 @@ struct FcBwdArgs {
     float *dx, *dw, *dgamma, *dbeta, *dbias;
 };
 
-// dW[kr0.., NC columns per lane from column c0] of one 32-row tile of W: 16 MFMA steps per row tile of the batch
-template <bool VEC, int NC, int RT>
+// dW[kr0.., NC columns per lane from column c0] of one 32-row tile of W: 16 MFMA steps over the batch
+template <bool VEC, int NC>
 __device__ __forceinline__ void fc_bwd_dw(const FcBwdArgs &a, const float *dyl, int kr0, int c0, int lcol, int r32,
                                           int half)
 {
     const int krc = min(kr0 + r32, a.K - 1);    // rows of W past K: an existing one, result not written
+    float xa[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)                // rows past M meet zero rows of dY
+        xa[s] = a.x[(size_t)min(2 * s + half, a.M - 1) * a.ldx + krc];
     f32x16 acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -441,28 +397,19 @@ __device__ __forceinline__ void fc_bwd_dw(const FcBwdArgs &a, const float *dyl, 
         for (int r = 0; r < 16; ++r)
             acc[c][r] = 0.0f;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        if (RT > 1 && rt * FC_M >= a.M)
-            continue;
-        float xa[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s)                // rows past M meet zero rows of dY
-            xa[s] = a.x[(size_t)min(rt * FC_M + 2 * s + half, a.M - 1) * a.ldx + krc];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            float bq[NC];
-            const float *src = dyl + (rt * FC_M + 2 * s + half) * FC_LD + lcol;
-            if (NC == 4) {
-                const float4v t = *reinterpret_cast<const float4v *>(src);
-                bq[0] = t.x; bq[1] = t.y; bq[NC - 2] = t.z; bq[NC - 1] = t.w;
-            } else {
-                const float2v t = *reinterpret_cast<const float2v *>(src);
-                bq[0] = t.x; bq[1] = t.y;
-            }
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], bq[c], acc[c], 0, 0, 0);
+    for (int s = 0; s < 16; ++s) {
+        float bq[NC];
+        const float *src = dyl + (2 * s + half) * FC_LD + lcol;
+        if (NC == 4) {
+            const float4v t = *reinterpret_cast<const float4v *>(src);
+            bq[0] = t.x; bq[1] = t.y; bq[NC - 2] = t.z; bq[NC - 1] = t.w;
+        } else {
+            const float2v t = *reinterpret_cast<const float2v *>(src);
+            bq[0] = t.x; bq[1] = t.y;
         }
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], bq[c], acc[c], 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -493,8 +440,8 @@ __device__ __forceinline__ void fc_bwd_dw(const FcBwdArgs &a, const float *dyl, 
     }
 }
 
-// dX[:, kr0..kr0+31] += dY[:, 8 q0 .. 8 (q0+NQ)) W[tile, same columns]^T: 4 NQ MFMA steps per row tile of the batch
-template <bool VEC, int NQ, int RT>
+// dX[:, kr0..kr0+31] += dY[:, 8 q0 .. 8 (q0+NQ)) W[tile, same columns]^T: 4 NQ MFMA steps
+template <bool VEC, int NQ>
 __device__ __forceinline__ void fc_bwd_dx(const FcBwdArgs &a, const float *dyl, int kr0, int n0, int q0, int r32,
                                           int half)
 {
@@ -507,29 +454,24 @@ __device__ __forceinline__ void fc_bwd_dx(const FcBwdArgs &a, const float *dyl, 
         const int cq = n0 + 4 * half + 8 * (q0 + q);
         wq[q] = fc_load4<VEC>(wrow + (VEC ? min(cq, a.N - 4) : cq), VEC ? 4 : a.N - cq, a.w);
     }
+    f32x16 d;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        if (RT > 1 && rt * FC_M >= a.M)
-            continue;
-        f32x16 d;
+    for (int r = 0; r < 16; ++r)
+        d[r] = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            d[r] = 0.0f;
+    for (int q = 0; q < NQ; ++q) {
+        const float4v aq = *reinterpret_cast<const float4v *>(dyl + r32 * FC_LD + 8 * (q0 + q) + 4 * half);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const float4v aq = *reinterpret_cast<const float4v *>(dyl + (rt * FC_M + r32) * FC_LD + 8 * (q0 + q) + 4 * half);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                d = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j], wq[q][j], d, 0, 0, 0);
-        }
-        if (kr < a.K)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int b = rt * FC_M + mfma_row(r, half);
-                if (b < a.M)
-                    atomicAdd(&a.dx[(size_t)b * a.lddx + kr], d[r]);
-            }
+        for (int j = 0; j < 4; ++j)
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j], wq[q][j], d, 0, 0, 0);
     }
+    if (kr < a.K)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = mfma_row(r, half);
+            if (b < a.M)
+                atomicAdd(&a.dx[(size_t)b * a.lddx + kr], d[r]);
+        }
 }
 
 // The same product for the wide output layer (VEC only), W read the way it lies in memory.  Above, a lane
@@ -540,7 +482,6 @@ __device__ __forceinline__ void fc_bwd_dx(const FcBwdArgs &a, const float *dyl, 
 // there.  Both halves are requested before the first is consumed.
 constexpr int FC_WLD = 64 + 4;      // LDS row stride of the half tile (floats)
 
-template <int RT>
 __device__ __forceinline__ void fc_bwd_dx_staged(const FcBwdArgs &a, const float *dyl, float *patch, int kr0,
                                                  int n0, int r32, int half, int lane)
 {
@@ -555,12 +496,10 @@ __device__ __forceinline__ void fc_bwd_dx_staged(const FcBwdArgs &a, const float
             const int col = min(n0 + 64 * h + lcol, a.N - 4);       // past N: meets zeros of dY
             wq[h][i] = *reinterpret_cast<const float4v *>(a.w + (size_t)row * a.N + col);
         }
-    f32x16 d[RT];
+    f32x16 d;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            d[rt][r] = 0.0f;
+    for (int r = 0; r < 16; ++r)
+        d[r] = 0.0f;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -569,27 +508,21 @@ __device__ __forceinline__ void fc_bwd_dx_staged(const FcBwdArgs &a, const float
         // (wave-private patch: program order and the LDS counter are all the synchronisation needed)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
+            const float4v aq = *reinterpret_cast<const float4v *>(dyl + r32 * FC_LD + 64 * h + 8 * q + 4 * half);
             const float4v bq = *reinterpret_cast<const float4v *>(patch + r32 * FC_WLD + 8 * q + 4 * half);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const float4v aq =
-                    *reinterpret_cast<const float4v *>(dyl + (rt * FC_M + r32) * FC_LD + 64 * h + 8 * q + 4 * half);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    d[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j], bq[j], d[rt], 0, 0, 0);
-            }
+            for (int j = 0; j < 4; ++j)
+                d = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[j], bq[j], d, 0, 0, 0);
         }
     }
     const int kr = kr0 + r32;
     if (kr < a.K)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int b = rt * FC_M + mfma_row(r, half);
-                if (b < a.M)
-                    atomicAdd(&a.dx[(size_t)b * a.lddx + kr], d[rt][r]);
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int b = mfma_row(r, half);
+            if (b < a.M)
+                atomicAdd(&a.dx[(size_t)b * a.lddx + kr], d[r]);
+        }
 }
 
 struct FcBwdGroup {
@@ -602,13 +535,12 @@ struct FcBwdGroup {
 // parts = 4: the four waves share a tile -- dW columns 0..63 | 64..127, dX over columns 0..63 | 64..127 --
 //            for the layers whose whole backward is a few hundred tiles (32 MFMAs per wave, one tile per
 //            workgroup, every workgroup resident at once).
-template <bool VEC, int RT>
+template <bool VEC>
 __device__ __forceinline__ void fc_bwd_body(const FcBwdArgs &a, int slice_x, int group_y, float *dyl,
                                             double (*red)[2][FC_TN], float *patches)
 {
-    constexpr int HF = 2, RP = FC_M / HF;       // row groups of the first phase, rows per thread (one row tile)
+    constexpr int HF = 2, RP = FC_M / HF;       // row groups of the first phase, rows per thread
     const int n0 = slice_x * FC_TN;
-    if constexpr (RT == 1)
     {   // d(pre-BN output) of this slice (bn_small_bwd_kernel's arithmetic)
         const int col = threadIdx.x & (FC_TN - 1), hf = threadIdx.x >> 7;
         const int c = n0 + col;
@@ -711,107 +643,6 @@ __device__ __forceinline__ void fc_bwd_body(const FcBwdArgs &a, int slice_x, int
         }
         __syncthreads();
     }
-    else {
-        // the same for up to RT row tiles: too many rows to keep per thread, so the column sums are taken in one walk
-        // over the rows and d(pre-BN) is derived in a second one (dout and y are read twice; they sit in L2)
-        constexpr int RPT = RT * FC_M / HF;
-        const int col = threadIdx.x & (FC_TN - 1), hf = threadIdx.x >> 7;
-        const int c = n0 + col;
-        const bool ok = c < a.N;
-        const bool bn = a.gamma != nullptr;
-        const bool writer = ok && hf == 0 && group_y == 0;
-        const int cc = min(c, a.N - 1);
-        float mean = 0.0f, rstd = 1.0f, g = 0.0f, inv = 0.0f, sh = 0.0f;
-        if (bn) {
-            mean = a.save_mean[cc];
-            const float var = a.save_var[cc];
-            g = a.gamma[cc];
-            const float b = a.beta[cc];
-            rstd = bn_rsqrt(var + BN_EPS);
-            inv = g * rstd;
-            sh = b - mean * inv;
-        }
-        auto row_terms = [&](int r, float &d, float &xh) {      // d = dout through the ReLU, xh = x-hat of row r
-            const bool in = ok && r < a.M;
-            const int rr = min(r, a.M - 1);
-            d = a.dout[(size_t)rr * a.lddo + cc];
-            d = in ? d : 0.0f;
-            xh = 0.0f;
-            if (bn) {
-                float v = a.y[(size_t)rr * a.N + cc];
-                v = in ? v : 0.0f;
-                float z = v * inv + sh;
-                if (a.relu)
-                    z = fmaxf(z, 0.0f);
-                if (a.relu && !(z > 0.0f))
-                    d = 0.0f;
-                xh = (v - mean) * rstd;
-            }
-        };
-        double s = 0.0, s2 = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < RPT; ++i) {
-            const int r = hf * RPT + i;
-            float d, xh;
-            row_terms(r, d, xh);
-            if (ok && r < a.M) {
-                s += (double)d;
-                s2 += (double)d * (double)xh;
-            }
-        }
-        red[0][hf][col] = s;
-        red[1][hf][col] = s2;
-        __syncthreads();
-        double ts = 0.0, ts2 = 0.0;
-#pragma unroll
-        for (int h = 0; h < HF; ++h) {
-            ts += red[0][h][col];
-            ts2 += red[1][h][col];
-        }
-        if (writer) {
-            if (!bn) {
-                if (a.dbias != nullptr)
-                    a.dbias[c] = (a.acc_pg ? a.dbias[c] : 0.0f) + (float)ts;
-            } else {
-                if (a.dbeta != nullptr)
-                    a.dbeta[c] = (a.acc_pg ? a.dbeta[c] : 0.0f) + (float)ts;
-                if (a.dgamma != nullptr)
-                    a.dgamma[c] = (a.acc_pg ? a.dgamma[c] : 0.0f) + (float)ts2;
-            }
-        }
-        const float m1 = (bn && a.training) ? (float)(ts / (double)a.M) : 0.0f;
-        const float m2 = (bn && a.training) ? (float)(ts2 / (double)a.M) : 0.0f;
-        const float gr = g * rstd;
-        double sdy = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < RPT; ++i) {
-            const int r = hf * RPT + i;
-            float d, xh;
-            row_terms(r, d, xh);
-            float v = d;
-            if (bn) {
-                v = 0.0f;
-                if (ok && r < a.M) {
-                    v = gr * ((d - m1) - xh * m2);
-                    sdy += (double)v;
-                }
-            }
-            dyl[r * FC_LD + col] = v;
-        }
-        if (bn && a.dbias != nullptr && group_y == 0) {   // uniform per workgroup
-            __syncthreads();
-            red[0][hf][col] = sdy;
-            __syncthreads();
-            if (writer) {
-                double t = 0.0;
-#pragma unroll
-                for (int h = 0; h < HF; ++h)
-                    t += red[0][h][col];
-                a.dbias[c] = (a.acc_pg ? a.dbias[c] : 0.0f) + (float)t;
-            }
-        }
-        __syncthreads();
-    }
 
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int r32 = lane & 31, half = lane >> 5;
@@ -820,12 +651,12 @@ __device__ __forceinline__ void fc_bwd_body(const FcBwdArgs &a, int slice_x, int
     if (a.parts == 1) {
         for (int t = group_y * a.tiles_per_block + wv; t < t_end; t += 4) {
             if (a.dw != nullptr)
-                fc_bwd_dw<VEC, 4, RT>(a, dyl, t * 32, n0 + 4 * r32, 4 * r32, r32, half);
+                fc_bwd_dw<VEC, 4>(a, dyl, t * 32, n0 + 4 * r32, 4 * r32, r32, half);
             if (a.dx != nullptr) {
                 if (VEC)
-                    fc_bwd_dx_staged<RT>(a, dyl, patches + wv * (FC_M * FC_WLD), t * 32, n0, r32, half, lane);
+                    fc_bwd_dx_staged(a, dyl, patches + wv * (FC_M * FC_WLD), t * 32, n0, r32, half, lane);
                 else
-                    fc_bwd_dx<VEC, 16, RT>(a, dyl, t * 32, n0, 0, r32, half);
+                    fc_bwd_dx<VEC, 16>(a, dyl, t * 32, n0, 0, r32, half);
             }
         }
     } else {
@@ -833,9 +664,9 @@ __device__ __forceinline__ void fc_bwd_body(const FcBwdArgs &a, int slice_x, int
         for (int t = group_y * a.tiles_per_block; t < t_end; ++t) {
             if (wv < 2) {
                 if (a.dw != nullptr)
-                    fc_bwd_dw<VEC, 2, RT>(a, dyl, t * 32, n0 + 64 * side + 2 * r32, 64 * side + 2 * r32, r32, half);
+                    fc_bwd_dw<VEC, 2>(a, dyl, t * 32, n0 + 64 * side + 2 * r32, 64 * side + 2 * r32, r32, half);
             } else if (a.dx != nullptr) {
-                fc_bwd_dx<VEC, 8, RT>(a, dyl, t * 32, n0, 8 * side, r32, half);
+                fc_bwd_dx<VEC, 8>(a, dyl, t * 32, n0, 8 * side, r32, half);
             }
         }
     }
@@ -850,26 +681,9 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdGroup g)
     const int local = (int)blockIdx.x - a.block0;
     const int slice_x = local % a.slices, group_y = local / a.slices;
     if (a.vec)
-        fc_bwd_body<true, 1>(a, slice_x, group_y, reinterpret_cast<float *>(dy4), red, reinterpret_cast<float *>(patch4));
+        fc_bwd_body<true>(a, slice_x, group_y, reinterpret_cast<float *>(dy4), red, reinterpret_cast<float *>(patch4));
     else
-        fc_bwd_body<false, 1>(a, slice_x, group_y, reinterpret_cast<float *>(dy4), red, reinterpret_cast<float *>(patch4));
-}
-
-// the same for 33 ... 128 rows: d(pre-BN) of all four row tiles in LDS (68 KB: one workgroup per CU)
-__global__ __launch_bounds__(256) void fc_bwd_tall_kernel(FcBwdGroup g)
-{
-    __shared__ float4v dy4[FC_RT_MAX * FC_M * (FC_LD / 4)];
-    __shared__ double red[2][2][FC_TN];
-    __shared__ float4v patch4[4 * FC_M * (FC_WLD / 4)];
-    const FcBwdArgs a = g.p[fc_group_member(g)];
-    const int local = (int)blockIdx.x - a.block0;
-    const int slice_x = local % a.slices, group_y = local / a.slices;
-    if (a.vec)
-        fc_bwd_body<true, FC_RT_MAX>(a, slice_x, group_y, reinterpret_cast<float *>(dy4), red,
-                                     reinterpret_cast<float *>(patch4));
-    else
-        fc_bwd_body<false, FC_RT_MAX>(a, slice_x, group_y, reinterpret_cast<float *>(dy4), red,
-                                      reinterpret_cast<float *>(patch4));
+        fc_bwd_body<false>(a, slice_x, group_y, reinterpret_cast<float *>(dy4), red, reinterpret_cast<float *>(patch4));
 }
 
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -878,7 +692,7 @@ static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 // Column tiles and K slices of one forward layer.  Four waves per workgroup, each with at least sixteen k; K is
 // cut into slices until the chip is covered.  These products are short chains of load -> MFMA: what they need
 // is every load of the layer in flight at once, i.e. many workgroups.  
-static void fc_fwd_plan(int M, int K, int N, bool bn, bool whole_k, int &tiles, int &splits, int &kslice)
+static void fc_fwd_plan(int K, int N, bool bn, bool whole_k, int &tiles, int &splits, int &kslice)
 {
     const int want_bn = CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_BLOCKS", 128), want_plain = CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_BLOCKS", 192);
     const int forced = CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_SPLITS", 0);
@@ -887,9 +701,6 @@ static void fc_fwd_plan(int M, int K, int N, bool bn, bool whole_k, int &tiles, 
     const int most = K / (16 * FC_NW);
     splits = splits > most ? most : splits;
     splits = splits < 1 ? 1 : splits;
-    // (more than 32 rows: the last slice to arrive reads splits x 64 KB of partial tiles back -- at most eight)
-    if (M > FC_M && splits > 8)
-        splits = 8;
     if (forced)
         splits = forced;
     if (whole_k)
@@ -902,24 +713,23 @@ static void fc_fwd_plan(int M, int K, int N, bool bn, bool whole_k, int &tiles, 
 
 using namespace cloudaae;
 
-CLOUDAAE_API int cloudaae_fc_max_rows(void) { return FC_M * FC_RT_MAX; }
+CLOUDAAE_API int cloudaae_fc_max_rows(void) { return FC_M; }
 CLOUDAAE_API int cloudaae_fc_max_group(void) { return FC_MAX_GROUP; }
 CLOUDAAE_API int cloudaae_fc_forward_tickets(int N) { return N > 0 ? ceil_div(N, FC_TN) : 0; }
-CLOUDAAE_API long long cloudaae_fc_forward_partials(int M, int K, int N, int batch_norm)
+CLOUDAAE_API long long cloudaae_fc_forward_partials(int K, int N, int batch_norm)
 {
-    if (M <= 0 || K <= 0 || N <= 0)
+    if (K <= 0 || N <= 0)
         return 0;
     int tiles, splits, kslice;
-    fc_fwd_plan(M, K, N, batch_norm != 0, false, tiles, splits, kslice);
-    return splits > 1 ? (long long)tiles * splits * (M > FC_M ? FC_RT_MAX : 1) * FC_M * FC_TN : 0;
+    fc_fwd_plan(K, N, batch_norm != 0, false, tiles, splits, kslice);
+    return splits > 1 ? (long long)tiles * splits * FC_M * FC_TN : 0;
 }
 
 CLOUDAAE_API int cloudaae_fc_forward_group(int M, int count, const cloudaae_fc_layer *layers, int training,
                                            const float *decay, int y_zeroed, cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_fc_forward_group";
-    CLOUDAAE_REQUIRE(M > 0 && M <= FC_M * FC_RT_MAX, name, "bad size (rows must be <= 128)");
-    const bool tall = M > FC_M;
+    CLOUDAAE_REQUIRE(M > 0 && M <= FC_M, name, "bad size (rows must be <= 32)");
     CLOUDAAE_REQUIRE(count > 0 && count <= FC_MAX_GROUP && layers, name, "1 to 4 layers per call");
     hipStream_t s = (hipStream_t)stream;
     FcFwdGroup g;
@@ -935,11 +745,9 @@ CLOUDAAE_API int cloudaae_fc_forward_group(int M, int count, const cloudaae_fc_l
             CLOUDAAE_REQUIRE(training || (l.ema_mean && l.ema_var), name, "inference needs the EMA statistics");
             CLOUDAAE_REQUIRE(!training || !l.ema_mean || decay, name, "EMA update needs the decay scalar");
         }
-        // a layer with batch norm can only be cut over K when the caller provides the arrival counters; more than 32
-        // rows only with the counters AND the partial-tile scratch (there is no atomic path for them)
+        // a layer with batch norm can only be cut over K when the caller provides the arrival counters
         int tiles, splits, kslice;
-        fc_fwd_plan(M, l.K, l.N, bn, tall ? (l.tickets == nullptr || l.partials == nullptr) : (bn && l.tickets == nullptr),
-                    tiles, splits, kslice);
+        fc_fwd_plan(l.K, l.N, bn, bn && l.tickets == nullptr, tiles, splits, kslice);
         FcFwdArgs &a = g.p[i];
         a.M = M; a.K = l.K; a.N = l.N; a.ldx = l.ldx; a.kslice = kslice; a.atomic = splits > 1;
         a.training = training; a.relu = l.relu;
@@ -961,10 +769,7 @@ CLOUDAAE_API int cloudaae_fc_forward_group(int M, int count, const cloudaae_fc_l
             CLOUDAAE_CHECK_HIP(hipMemsetAsync(l.y, 0, sizeof(float) * (size_t)M * l.N, s), name);
         blocks += tiles * splits;
     }
-    if (tall)
-        hipLaunchKernelGGL(fc_fwd_tall_kernel, dim3(blocks), dim3(FC_NW * 64), 0, s, g);
-    else
-        hipLaunchKernelGGL(fc_fwd_kernel, dim3(blocks), dim3(FC_NW * 64), 0, s, g);
+    hipLaunchKernelGGL(fc_fwd_kernel, dim3(blocks), dim3(FC_NW * 64), 0, s, g);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }
@@ -973,7 +778,7 @@ CLOUDAAE_API int cloudaae_fc_backward_group(int M, int count, const cloudaae_fc_
                                             cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_fc_backward_group";
-    CLOUDAAE_REQUIRE(M > 0 && M <= FC_M * FC_RT_MAX, name, "bad size (rows must be <= 128)");
+    CLOUDAAE_REQUIRE(M > 0 && M <= FC_M, name, "bad size (rows must be <= 32)");
     CLOUDAAE_REQUIRE(count > 0 && count <= FC_MAX_GROUP && layers, name, "1 to 4 layers per call");
     hipStream_t s = (hipStream_t)stream;
     FcBwdGroup g;
@@ -1013,10 +818,7 @@ CLOUDAAE_API int cloudaae_fc_backward_group(int M, int count, const cloudaae_fc_
         a.dbeta = l.dbeta; a.dbias = l.dbias;
         blocks += slices * by;
     }
-    if (M > FC_M)
-        hipLaunchKernelGGL(fc_bwd_tall_kernel, dim3(blocks), dim3(256), 0, s, g);
-    else
-        hipLaunchKernelGGL(fc_bwd_kernel, dim3(blocks), dim3(256), 0, s, g);
+    hipLaunchKernelGGL(fc_bwd_kernel, dim3(blocks), dim3(256), 0, s, g);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }

@@ -200,11 +200,11 @@ def fc_max_group():
     return int(L().cloudaae_fc_max_group())
 
 
-def _fc_scratch(M, K, N, bn, dev):
+def _fc_scratch(K, N, bn, dev):
     """(tickets, partials) of one forward layer of csrc/fc.hip: arrival counters of its column tiles (zero before
     and after every launch) and room for the partial tiles of its K slices, which the last slice to arrive sums
     in slice order -- the forward pass is bit-reproducible from run to run.  (None, None) when K stays whole."""
-    n = int(L().cloudaae_fc_forward_partials(int(M), int(K), int(N), int(bool(bn))))
+    n = int(L().cloudaae_fc_forward_partials(int(K), int(N), int(bool(bn))))
     if n == 0:
         return None, None
     return (_lib.zeros(L().cloudaae_fc_forward_tickets(int(N)), dtype=torch.int32, device=dev),
@@ -231,7 +231,7 @@ class FcFn(torch.autograd.Function):
             save_var = _lib.empty(N, dtype=torch.float32, device=dev)
         # a product cut over K is summed in slice order by its last slice (bit-reproducible forward pass):
         # arrival counters of the column tiles (zero before and after every launch) + the slices' partial tiles
-        tickets, partials = _fc_scratch(M, K, N, bn, dev)
+        tickets, partials = _fc_scratch(K, N, bn, dev)
         y = _lib.empty((M, N), dtype=torch.float32, device=dev)
         _lib.check(L().cloudaae_fc_forward(
             M, K, N, xp, ldx, ptr(w), ptr(b), ptr(gamma), ptr(beta), int(bool(training)), ptr(decay), ptr(ema_mean),
@@ -307,7 +307,7 @@ class FcGroupFn(torch.autograd.Function):
                 save_mean = _lib.empty(N, dtype=torch.float32, device=dev)
                 save_var = _lib.empty(N, dtype=torch.float32, device=dev)
             # a product cut over K is summed in slice order by its last slice (see _fc_scratch)
-            tickets, partials = _fc_scratch(M, K, N, bn, dev)
+            tickets, partials = _fc_scratch(K, N, bn, dev)
             l = layers[i]
             l.K, l.N, l.x, l.ldx, l.w, l.bias = K, N, xp, ldx, ptr(w), ptr(b)
             l.gamma, l.beta, l.ema_mean, l.ema_var = ptr(gamma), ptr(beta), ptr(ema_mean), ptr(ema_var)

@@ -287,11 +287,8 @@ int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, float *out, int a
 
 /* tf_util.fully_connected (utils/tf_util.py:321-365: tf.matmul :351, bias_add :352, batch_norm_for_fc
  * :355, activation :358) as ONE launch per direction when the rows are the clouds of a batch of at
- * most cloudaae_fc_max_rows() (= 128): the decoder and pose heads of
- * models/pointnet_ycb_23_decoder_4.py:413-455.  Up to 32 rows are one 32-row matrix-core tile; 33 ... 128 rows
- * (the per-GPU batch of BASELINE configs[3]) are walked as four row tiles by the same workgroups (a layer cut
- * over K then needs tickets AND partials, else K stays whole).  Larger batches take cloudaae_gemm_f32 +
- * cloudaae_bn_*.
+ * most cloudaae_fc_max_rows() (= 32): the decoder and pose heads of
+ * models/pointnet_ycb_23_decoder_4.py:413-455.  Larger batches take cloudaae_gemm_f32 + cloudaae_bn_*.
  *
  * forward: y[M,N] = x[M,K] w[K,N] + bias (bias may be NULL); with gamma != NULL also the batch norm of
  * y (arguments as cloudaae_bn_forward) into out[M,N], y keeping the pre-normalisation values the
@@ -300,14 +297,14 @@ int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, float *out, int a
  * tickets: cloudaae_fc_forward_tickets(N) ints holding ZERO, left zero by the call (arrival counters
  * that let a layer WITH batch norm be cut over K: the last slice to arrive normalises the column tile);
  * NULL = such a layer keeps K whole in one workgroup per 128 columns (slower).
- * partials: cloudaae_fc_forward_partials(M, K, N, gamma != NULL) floats of scratch (any contents), or NULL.
+ * partials: cloudaae_fc_forward_partials(K, N, gamma != NULL) floats of scratch (any contents), or NULL.
  * With tickets AND partials a product cut over K is summed in a FIXED slice order by the last slice to
  * arrive: the layer is bit-reproducible from run to run (and y need not be cleared).  Without partials
  * the slices add into y with fp32 atomics: results then differ by round-off between runs.
  * Two calls in flight at the same time (different streams) need separate counters and scratch. */
 int cloudaae_fc_max_rows(void);
 int cloudaae_fc_forward_tickets(int N);
-long long cloudaae_fc_forward_partials(int M, int K, int N, int batch_norm);
+long long cloudaae_fc_forward_partials(int K, int N, int batch_norm);
 int cloudaae_fc_forward(int M, int K, int N, const float *x, int ldx, const float *w, const float *bias,
                         const float *gamma, const float *beta, int training, const float *decay,
                         float *ema_mean, float *ema_var, float *save_mean, float *save_var, int relu,

@@ -34,11 +34,7 @@ def model_oracle():
 
 SHAPES = [(32, 1024, 1024, True), (32, 1024, 512, True), (32, 512, 256, True), (32, 256, 3, False),
           (32, 1024, 12288, False), (8, 1024, 1024, True), (1, 64, 40, False), (5, 100, 37, True),
-          (31, 33, 130, True), (32, 1000, 516, False), (2, 8, 4, True),
-          # 33 ... 128 rows: four row tiles per workgroup (the per-GPU batch of BASELINE configs[3] is 128)
-          (128, 1024, 1024, True), (128, 1024, 512, True), (128, 512, 256, True), (128, 256, 3, False),
-          (128, 1024, 12288, False), (33, 1024, 1024, True), (64, 100, 37, True), (100, 33, 130, True),
-          (97, 1000, 516, False), (65, 8, 4, True)]
+          (31, 33, 130, True), (32, 1000, 516, False), (2, 8, 4, True)]
 
 
 @pytest.mark.parametrize("M,K,N,bn", SHAPES)
@@ -78,13 +74,12 @@ def test_fc_layer_vs_oracle(hip, model_oracle, M, K, N, bn, training):
             assert _rel(smd, ref_sm) < 1e-5 and _rel(svd, ref_sv) < 1e-5
 
 
-@pytest.mark.parametrize("M", [32, 128, 70])
-def test_fc_backward_accumulates(hip, M):
+def test_fc_backward_accumulates(hip):
     """dx is ADDED into what the buffer holds (several consumers of one input share it), dw and the
     per-column gradients add on request."""
     from cloudaae_amd import _lib
     L = _lib.lib()
-    K, N = 96, 200
+    M, K, N = 32, 96, 200
     g = torch.Generator().manual_seed(5)
     x, W = torch.randn(M, K, generator=g).cuda(), torch.randn(K, N, generator=g).cuda()
     dout = torch.randn(M, N, generator=g).cuda()
@@ -105,9 +100,9 @@ def test_fc_backward_accumulates(hip, M):
 def test_fc_rejects_large_batches(hip):
     from cloudaae_amd import _lib
     L = _lib.lib()
-    assert L.cloudaae_fc_max_rows() == 128
-    x, W, y = torch.zeros(129, 8).cuda(), torch.zeros(8, 8).cuda(), torch.zeros(129, 8).cuda()
-    rc = L.cloudaae_fc_forward(129, 8, 8, x.data_ptr(), 8, W.data_ptr(), None, None, None, 0, None, None, None, None,
+    assert L.cloudaae_fc_max_rows() == 32
+    x, W, y = torch.zeros(33, 8).cuda(), torch.zeros(8, 8).cuda(), torch.zeros(33, 8).cuda()
+    rc = L.cloudaae_fc_forward(33, 8, 8, x.data_ptr(), 8, W.data_ptr(), None, None, None, 0, None, None, None, None,
                                None, 0, y.data_ptr(), None, 0, None, None, _lib.stream())
     assert rc != 0 and "rows" in L.cloudaae_last_error().decode()
 
@@ -125,7 +120,7 @@ def test_fc_forward_without_tickets_keeps_k_whole(hip):
         torch.randn(N, generator=g).cuda()
     decay = torch.full((1,), 0.9, device="cuda")
     res = []
-    nparts = int(L.cloudaae_fc_forward_partials(M, K, N, 1))
+    nparts = int(L.cloudaae_fc_forward_partials(K, N, 1))
     assert nparts > 0
     for use in (True, False, "fixed order"):
         tk = torch.zeros(L.cloudaae_fc_forward_tickets(N), dtype=torch.int32, device="cuda") if use else None
@@ -150,15 +145,14 @@ def test_fc_forward_without_tickets_keeps_k_whole(hip):
     assert _rel(res[0][0], want) < 1e-5
 
 
-@pytest.mark.parametrize("B", [32, 128, 48])
-def test_fc_chains_vs_oracle(hip, model_oracle, B):
+def test_fc_chains_vs_oracle(hip, model_oracle):
     """Decoder + two pose heads over one embedding (three chains, three grouped launches per direction)
     against the oracle's layer-by-layer evaluation: outputs, every parameter gradient, and the summed
     gradient of the shared input."""
     from cloudaae_amd.utils import tf_util
     from cloudaae_amd.utils.variables import VariableStore, set_default_store
     MO = model_oracle
-    E, P = 1024, 3 * 4 * 64
+    B, E, P = 32, 1024, 3 * 4 * 64
     chains = [[('d_fc1', 1024, True), ('d_fc2', 1024, True), ('d_out', P, False)],
               [('r_fc1', 512, True), ('r_fc2', 256, True), ('r_out', 3, False)],
               [('t_fc1', 512, True), ('t_fc2', 256, True), ('t_out', 3, False)]]
@@ -210,7 +204,7 @@ def test_fc_forward_ticket_stress(hip, fixed_order):
     sm, sv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
     mean, var = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
     tk = torch.zeros(L.cloudaae_fc_forward_tickets(N), dtype=torch.int32, device="cuda")
-    parts = torch.full((int(L.cloudaae_fc_forward_partials(M, K, N, 1)),), float("nan"), device="cuda")
+    parts = torch.full((int(L.cloudaae_fc_forward_partials(K, N, 1)),), float("nan"), device="cuda")
 
     def run(tickets, y, out):
         _lib.check(L.cloudaae_fc_forward(M, K, N, x.data_ptr(), K, W.data_ptr(), b.data_ptr(), gamma.data_ptr(),
@@ -239,8 +233,7 @@ def test_fc_forward_ticket_stress(hip, fixed_order):
     assert same or not fixed_order, "fixed-order slices did not reproduce bit for bit"
 
 
-@pytest.mark.parametrize("M,K,N,d", [(32, 1024, 12288, 3), (5, 256, 3, 3), (32, 512, 100, 5), (128, 1024, 3072, 3),
-                                     (50, 256, 3, 3)])
+@pytest.mark.parametrize("M,K,N,d", [(32, 1024, 12288, 3), (5, 256, 3, 3), (32, 512, 100, 5)])
 def test_fc_forward_adds_a_row_vector(hip, M, K, N, d):
     """out_rowvec of cloudaae_fc_layer: y[r][c] = (x w + b)[r][c] + vec[r][c % d] -- the "+ element_mean" of
     train_cloudAAE_ycbv.py:232-233 in the output layer's epilogue; equal to a separate cloudaae_add_rowvec pass bit for
@@ -250,7 +243,7 @@ def test_fc_forward_adds_a_row_vector(hip, M, K, N, d):
     g = torch.Generator().manual_seed(M + N)
     x, W = torch.randn(M, K, generator=g).cuda(), (torch.randn(K, N, generator=g) / 32).cuda()
     b, vec = torch.randn(N, generator=g).cuda(), torch.randn(M, d, generator=g).cuda()
-    nparts = int(L.cloudaae_fc_forward_partials(M, K, N, 0))
+    nparts = int(L.cloudaae_fc_forward_partials(K, N, 0))
     tk = torch.zeros(L.cloudaae_fc_forward_tickets(N), dtype=torch.int32, device="cuda")
     parts = torch.empty(max(nparts, 1), device="cuda")
     ys = []
@@ -273,9 +266,7 @@ def test_fc_forward_adds_a_row_vector(hip, M, K, N, d):
 
 
 @pytest.mark.parametrize("M,K,N,bn", [(32, 1024, 1024, True), (7, 1024, 512, True), (32, 256, 3, False),
-                                      (32, 1024, 12288, False), (19, 520, 260, True), (32, 1024, 1000, False),
-                                      (128, 1024, 1024, True), (128, 1024, 12288, False), (77, 520, 260, True),
-                                      (128, 256, 3, False)])
+                                      (32, 1024, 12288, False), (19, 520, 260, True), (32, 1024, 1000, False)])
 def test_fc_forward_is_bit_reproducible(hip, M, K, N, bn):
     """With the partial-tile scratch a forward layer gives the same bits launch after launch (north star: the
     reference's CPU path is sequential, tf_nndistance.cpp:21-43 -- and evaluate_cloudAAE_ycbv.py:421-477 returns
@@ -288,7 +279,7 @@ def test_fc_forward_is_bit_reproducible(hip, M, K, N, bn):
     gamma, beta = (torch.rand(N, generator=g).cuda() + 0.5, torch.randn(N, generator=g).cuda()) if bn else (None, None)
     decay = torch.full((1,), 0.9, device="cuda")
     P = lambda t: None if t is None else t.data_ptr()      # noqa: E731
-    nparts = int(L.cloudaae_fc_forward_partials(M, K, N, int(bn)))
+    nparts = int(L.cloudaae_fc_forward_partials(K, N, int(bn)))
     tk = torch.zeros(L.cloudaae_fc_forward_tickets(N), dtype=torch.int32, device="cuda") if nparts else None
     parts = torch.full((max(nparts, 1),), float("nan"), device="cuda") if nparts else None
     runs = []
