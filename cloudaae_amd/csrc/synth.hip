@@ -242,9 +242,12 @@ __global__ __launch_bounds__(HS_THREADS) void hpr_sort_kernel(int n1, const floa
 }
 
 // constraint sequence of point `self` (sorted position): HPR_NEAR neighbours in sorted order, alternating
-// sides, then all OTHER positions in bit-reversed order
+// sides, then all OTHER positions in the order q = (p * stride) mod n1, stride ~ n1 / golden ratio and coprime
+// to n1: a permutation of [0, n1) whose every prefix is spread evenly over the (spatially sorted) cloud -- what
+// Seidel's expected O(n) needs.  (Round 2 walked the bit-reversal sequence over [0, 2^bits) and skipped what fell
+// outside [0, n1): for the reference's 2449 / 2049-point clouds 40-50 % of the positions of every scan.)
 constexpr int HPR_NEAR = 192;
-__device__ __forceinline__ int hpr_seq(int pos, int self, int n1, int bits)
+__device__ __forceinline__ int hpr_seq(int pos, int self, int n1, int stride)
 {
     if (pos < HPR_NEAR) {
         const int d = (pos >> 1) + 1;
@@ -253,15 +256,19 @@ __device__ __forceinline__ int hpr_seq(int pos, int self, int n1, int bits)
         return q;
     }
     const int p2 = pos - HPR_NEAR;
-    if (p2 >= (1 << bits))
+    if (p2 >= n1)
         return n1;
-    const int q = (int)(__brev((unsigned)p2) >> (32 - bits));
+    // (p2 * stride) mod n1 without an integer division: quotient from a float product, off by at most one
+    const int x = p2 * stride;                                  // < 2^28 (n1 <= 12800)
+    int q = x - (int)((float)x * (1.0f / (float)n1)) * n1;
+    q = q < 0 ? q + n1 : q;
+    q = q >= n1 ? q - n1 : q;
     // a neighbour already seen in the local pass is NOT offered again: the optimum sits exactly on its
     // binding constraints, and re-testing those in floating point reports round-off as a violation
     int d = q - self;
     d = d < 0 ? -d : d;
     d = min(d, n1 - d);
-    return (q < n1 && d >= 1 && d <= HPR_NEAR / 2) ? n1 : q;
+    return (d >= 1 && d <= HPR_NEAR / 2) ? n1 : q;
 }
 
 // ---- hull vertex test ---------------------------------------------------------------------
@@ -302,9 +309,8 @@ __device__ __forceinline__ Cons hpr_constraint(const float *__restrict__ pts, in
 // re-solve over the constraints seen so far (per-lane lo/hi as FRACTIONS -- compared by cross
 // multiplication, so the loop has no fp64 division -- then a wave min/max).  A lane-per-point
 // version diverged: a wave executed the SUM of its lanes' re-solves (227 ms per batch of 32).
-// Constraint order = bit-reversal (van der Corput) sequence over [0, 2^bits) restricted to
-// [0, n1): Seidel's expected O(n) needs an order uncorrelated with the geometry, and object models
-// are stored in scan order.  q == self is skipped.
+// Constraint order = hpr_seq: Seidel's expected O(n) needs an order uncorrelated with the geometry, and object
+// models are stored in scan order.  q == self is skipped.
 struct Frac {
     double num, den;   // den > 0
 };
@@ -320,11 +326,11 @@ __device__ __forceinline__ double dpp_f64(double v)
 }
 __device__ __forceinline__ bool frac_less(const Frac &x, const Frac &y) { return x.num * y.den < y.num * x.den; }
 
-__device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, int bits, const Frame &fr, int lane)
+__device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, int stride, const Frame &fr, int lane)
 {
     double vx = HPR_TAN, vy = HPR_TAN;
     const float pxf = (float)fr.px, pyf = (float)fr.py, pzf = (float)fr.pz;     // exact: p is a float
-    const int span = HPR_NEAR + (1 << bits);
+    const int span = HPR_NEAR + n1;
     int i = 0;
     while (i < span) {
         // the scan tests the current plane itself: with d = r + vx u + vy w the constraint of q reads
@@ -338,7 +344,7 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
         const float dxf = (float)dx, dyf = (float)dy, dzf = (float)dz;
         const float dl1 = (fabsf(dxf) + fabsf(dyf)) + fabsf(dzf);
         const int pos = i + lane;
-        const int q = pos < span ? hpr_seq(pos, self, n1, bits) : n1;
+        const int q = pos < span ? hpr_seq(pos, self, n1, stride) : n1;
         const bool valid = q < n1 && q != self;
         bool viol = false;
         if (valid) {
@@ -385,7 +391,7 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
             add(lane == 0 ? 1.0 : (lane == 1 ? -1.0 : 0.0), lane == 2 ? 1.0 : (lane == 3 ? -1.0 : 0.0), HPR_TAN);
         const int upto = i + first;            // sequence positions [0, upto) were already accepted
         for (int jpos = lane; jpos < upto; jpos += 64) {
-            const int r = hpr_seq(jpos, self, n1, bits);
+            const int r = hpr_seq(jpos, self, n1, stride);
             if (r >= n1 || r == self)
                 continue;
             const Cons m = hpr_constraint(pts, r, fr);
@@ -421,11 +427,11 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
 }
 
 // flags[h][j] = 1 iff point j of cloud h (n1 points, the last one is the viewpoint) is a
-// vertex of the convex hull.  One wave per point; a workgroup (8 waves) keeps the cloud in
-// dynamic LDS and walks points j = blockIdx.x*8 + wave, + 8*gridDim.x, ...
-constexpr int HPR_WAVES = 8;
+// vertex of the convex hull.  One wave per point; a workgroup (8 waves; 16 when the cloud is so large that a CU
+// holds one workgroup anyway) keeps the cloud in dynamic LDS and walks points j = blockIdx.x*W + wave, + W*gridDim.x, ...
+template <int HPR_WAVES>
 __global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, const float *__restrict__ points,
-                                                                    const int *__restrict__ perm, int bits,
+                                                                    const int *__restrict__ perm, int stride,
                                                                     unsigned char *__restrict__ flags)
 {
     extern __shared__ float pts[];
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, con
             f.wx = ry * uz - rz * uy;
             f.wy = rz * ux - rx * uz;
             f.wz = rx * uy - ry * ux;
-            vertex = hpr_lp2d_wave(pts, n1, j, bits, f, lane);
+            vertex = hpr_lp2d_wave(pts, n1, j, stride, f, lane);
         }
         if (lane == 0)     // `points` is the spatially sorted cloud: the flag goes back to the original index
             flags[(size_t)blockIdx.y * n1 + perm[(size_t)blockIdx.y * n1 + j]] = vertex ? 1 : 0;
@@ -558,12 +564,22 @@ __global__ __launch_bounds__(512) void hpr_gather_kernel(int n1, const unsigned 
     }
 }
 
-static int index_bits(int n)
+// stride of hpr_seq: ~ n / golden ratio, coprime to n
+static int hpr_stride(int n)
 {
-    int b = 1;
-    while ((1 << b) < n)
-        ++b;
-    return b;
+    auto gcd = [](int a, int b) {
+        while (b) {
+            const int t = a % b;
+            a = b;
+            b = t;
+        }
+        return a;
+    };
+    int a = (int)(n * 0.6180339887498949);
+    a = a < 1 ? 1 : a;
+    while (gcd(a, n) != 1)
+        ++a;
+    return a;
 }
 
 } // namespace cloudaae
@@ -642,26 +658,32 @@ CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *
     int *perm = (int *)(sorted + pts * 3);
     hipLaunchKernelGGL(hpr_sort_kernel, dim3(b), dim3(HS_THREADS), 0, s, n1, flipped, sorted, perm);
     const size_t lds = (size_t)n1 * 3 * sizeof(float);
+    // a cloud of more than ~6800 points leaves room for ONE workgroup per CU: it then takes 16 waves instead of 8
+    const bool wide = lds > 80 * 1024;
+    const int waves = wide ? 16 : 8;
     if (lds > 48 * 1024)
-        CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)hull_vertex_kernel,
+        CLOUDAAE_CHECK_HIP(hipFuncSetAttribute(wide ? (const void *)hull_vertex_kernel<16> : (const void *)hull_vertex_kernel<8>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
-    // workgroups per cloud: the kernel holds 108 VGPRs, i.e. two 8-wave workgroups per CU, 512 on the chip;
-    // a grid of 640 ran as one full round plus a quarter-full one.  Pick the split whose (rounds x points per
-    // wave) is smallest -- e.g. 16 x 32 clouds = 512 workgroups of 20 points per wave for the 2449-point hull.
+    // workgroups per cloud: the kernel holds 108 VGPRs, i.e. two 8-wave workgroups per CU, 512 on the chip (256 of
+    // the 16-wave form); a grid of 640 ran as one full round plus a quarter-full one.  Pick the split whose (rounds x
+    // points per wave) is smallest -- e.g. 16 x 32 clouds = 512 workgroups of 20 points per wave for the 2449-point hull.
     int gx = 1;
     {
+        const long long resident = wide ? 256 : 512;
         long long best = -1;
-        for (int cand = ceil_div(n1, HPR_WAVES * 32); cand <= ceil_div(n1, HPR_WAVES * 4); ++cand) {
-            const long long rounds = ((long long)cand * b + 511) / 512;
-            const long long cost = rounds * ceil_div(n1, HPR_WAVES * cand);
+        for (int cand = ceil_div(n1, waves * 32); cand <= ceil_div(n1, waves * 4); ++cand) {
+            const long long rounds = ((long long)cand * b + resident - 1) / resident;
+            const long long cost = rounds * ceil_div(n1, waves * cand);
             if (best < 0 || cost < best) {
                 best = cost;
                 gx = cand;
             }
         }
     }
-    hipLaunchKernelGGL(hull_vertex_kernel, dim3(gx, b), dim3(64 * HPR_WAVES), lds, s, n1, sorted, perm,
-                       index_bits(n1), flags);
+    if (wide)
+        hipLaunchKernelGGL(hull_vertex_kernel<16>, dim3(gx, b), dim3(64 * 16), lds, s, n1, sorted, perm, hpr_stride(n1), flags);
+    else
+        hipLaunchKernelGGL(hull_vertex_kernel<8>, dim3(gx, b), dim3(64 * 8), lds, s, n1, sorted, perm, hpr_stride(n1), flags);
     hipLaunchKernelGGL(hpr_gather_kernel, dim3(b), dim3(512), (size_t)n1 * sizeof(int), s, n1, flags, org, seed,
                        visible, num_vis, visible_id, rows);
     CLOUDAAE_CHECK_LAUNCH(name);
