@@ -744,10 +744,12 @@ struct MinK {                        // the K smallest values seen, ascending
     }
 };
 
+// queue slots per query of knn64_wide_kernel: 144 while the cloud's norms leave room for them, 128 above
+static int knn_wide_qpq(int n) { return n <= 3328 ? 144 : 128; }
 static size_t knn_wide_lds_bytes(int n)
 {
     return sizeof(float) * (4 * KM_TILE * 68 + (size_t)ceil_div(n, KM_TILE) * KM_TILE + 4) +
-           (sizeof(float) + sizeof(unsigned short)) * 128 * 144 + sizeof(int) * 128;
+           (sizeof(float) + sizeof(unsigned short)) * 128 * (size_t)knn_wide_qpq(n) + sizeof(int) * 128;
 }
 
 // ---- C = 64, bound pass + filtered scan with FOUR waves per SIMD (16-wave workgroups) ---------------------------
@@ -765,14 +767,19 @@ static size_t knn_wide_lds_bytes(int n)
 //     v_min_f64 / v_max_f64 per insert;
 //   * the merging lanes of the four query tiles sit in waves 0, 5, 10, 15: one per SIMD.
 // Same arithmetic, same bound, same queues (144 six-byte entries per query), same flagged fallback.
-template <int K>
+// K = 20 (BASELINE configs[4]: k = 20 neighbours, 4096 points): the bound comes from HALF of the candidate tiles
+// instead of a quarter (the expected number of candidates at or below tau is k x tiles / sampled tiles: 80 of 4096
+// from a quarter, with a tail that overflows the 128-slot queues; 40 from half), and the final merge runs in two
+// stages (the eight key lists of a query, 1280 bytes, do not fit its 768-byte share of the queue area: the lane
+// halves merge through registers first, four lists go through LDS).
+template <int K, int QPQ>
 __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, const float *__restrict__ x,
                                                           int *__restrict__ nn_idx)
 {
     constexpr int QW = 4, CS = 4, THREADS = 1024;
     constexpr int KS_LD = 68;                              // staged row: [32 even channels | 32 odd | 4 pad]
     constexpr int TILE_FLOATS = KM_TILE * KS_LD;
-    constexpr int QPQ = 144;                               // queue slots per query (its 8 lanes share them)
+    // QPQ: queue slots per query (its 8 lanes share them)
     extern __shared__ __attribute__((aligned(16))) char kw_smem[];
     // layout: tile[CS][TILE_FLOATS] | queue d[128 queries][QPQ] (fp32) | queue j, same shape (u16) | queue lengths [128] |
     //         sq[ntiles * 32] | 1.0 | overflow flag
@@ -800,7 +807,8 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     const int qi0 = (qgroup * QW + qt) * KM_TILE + col;   // this lane's query
     const bool qvalid = qi0 < n;
     const int qs = qvalid ? qi0 : qgroup * QW * KM_TILE;   // (a row whose norm the prologue computes)
-    const int S = min(ntiles, max((ntiles + 3) / 4, 4));   // pass A's sample: S tiles, every stride-th one
+    // pass A's sample: S tiles, every stride-th one (a quarter of the tiles; half of them for K > 10)
+    const int S = min(ntiles, max((ntiles + (K > 10 ? 1 : 3)) / (K > 10 ? 2 : 4), 4));
     const int stride = ntiles / S;
 
     // staging: a round = CS tiles of 32 rows; a wave brings 8 rows, each with ONE global_load_lds_dword: lane l fetches
@@ -915,9 +923,10 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
             um.insert(live ? m : __builtin_inff());
         }
     }
-    // K-th smallest unit minimum over the query's 2*CS lists, through the query tile's queue area
-    float *md = qd_all + qt * 32 * QPQ;
-    static_assert(2 * CS * K * 32 <= 32 * QPQ, "scratch lists must fit the queue area of one query tile");
+    // K-th smallest unit minimum over the query's 2*CS lists, through the query tile's share of the queue area
+    float *md = reinterpret_cast<float *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6));
+    static_assert(2 * CS * K * 32 * 4 <= 32 * QPQ * 6 && (32 * QPQ * 6) % 8 == 0,
+                  "scratch lists must fit the queue area of one query tile");
     const int list = cs * 2 + half;
     __syncthreads();
     int slot0 = list * K * 32 + col;                       // (opaque: keeps the compiler from deriving these K addresses
@@ -1010,51 +1019,83 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
         }
     }
 
-    // merge the 2*CS sorted key lists of every query, through the query tile's share of the queue area; the merging
+    // merge the sorted key lists of every query, through the query tile's share of the queue area; the merging
     // lanes of the four query tiles sit in waves 0, 5, 10, 15: one per SIMD
     __syncthreads();
     double *mk = reinterpret_cast<double *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6));
-    static_assert(2 * CS * K * 32 * 8 <= 32 * QPQ * 6 && (32 * QPQ * 6) % 8 == 0, "key lists must fit a query tile's queues");
-    int slot1 = list * K * 32 + col;
-    asm volatile("" : "+v"(slot1));
+    constexpr bool ONE_STAGE = 2 * CS * K * 32 * 8 <= 32 * QPQ * 6;
+    constexpr int LISTS = ONE_STAGE ? 2 * CS : CS;
+    static_assert(LISTS * K * 32 * 8 <= 32 * QPQ * 6, "key lists must fit a query tile's queues");
+    if constexpr (ONE_STAGE) {
+        int slot1 = list * K * 32 + col;
+        asm volatile("" : "+v"(slot1));
 #pragma unroll
-    for (int p = 0; p < K; ++p)
-        mk[slot1 + p * 32] = top.key[p];
-    __syncthreads();
+        for (int p = 0; p < K; ++p)
+            mk[slot1 + p * 32] = top.key[p];
+        __syncthreads();
+    } else {
+        // first the two lane halves of a wave: the upper half's list goes through LDS into the lower half's
+        int slot1 = cs * K * 32 + col;
+        asm volatile("" : "+v"(slot1));
+        if (half == 1) {
+#pragma unroll
+            for (int p = 0; p < K; ++p)
+                mk[slot1 + p * 32] = top.key[p];
+        }
+        __syncthreads();
+        if (half == 0) {
+            for (int p = 0; p < K; ++p)
+                top.insert(mk[slot1 + p * 32]);
+        }
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int p = 0; p < K; ++p)
+                mk[slot1 + p * 32] = top.key[p];
+        }
+        __syncthreads();
+    }
     if (cs == qt && half == 0 && qvalid) {
-        int head[2 * CS];
+        int head[LISTS];
 #pragma unroll
-        for (int l = 0; l < 2 * CS; ++l)
+        for (int l = 0; l < LISTS; ++l)
             head[l] = 0;
         int *dst = nn_idx + ((size_t)cloud * n + qi0) * k;
         for (int p = 0; p < k; ++p) {
-            double hk[2 * CS];
+            double hk[LISTS];
 #pragma unroll
-            for (int l = 0; l < 2 * CS; ++l)
+            for (int l = 0; l < LISTS; ++l)
                 hk[l] = mk[(l * K + min(head[l], K - 1)) * 32 + col];
             double best = __builtin_inf();
 #pragma unroll
-            for (int l = 0; l < 2 * CS; ++l) {
+            for (int l = 0; l < LISTS; ++l) {
                 hk[l] = head[l] < K ? hk[l] : __builtin_inf();
                 best = __builtin_fmin(best, hk[l]);
             }
 #pragma unroll
-            for (int l = 0; l < 2 * CS; ++l)
+            for (int l = 0; l < LISTS; ++l)
                 head[l] += (hk[l] == best) ? 1 : 0;      // keys are unique (a candidate is in one list) except +inf
             dst[p] = knn_key_index(best);
         }
     }
 }
 
-template <int K>
-static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
+template <int K, int QPQ>
+static hipError_t launch_knn_wide_q(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
     const size_t lds = knn_wide_lds_bytes(n);
     static bool raised[64] = {};
-    if (hipError_t e = raise_lds_limit(&knn64_wide_kernel<K>, raised); e != hipSuccess)
+    if (hipError_t e = raise_lds_limit(&knn64_wide_kernel<K, QPQ>, raised); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL((knn64_wide_kernel<K>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s, n, ld, k, x, nn_idx);
+    hipLaunchKernelGGL((knn64_wide_kernel<K, QPQ>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s, n, ld, k, x,
+                       nn_idx);
     return hipSuccess;
+}
+template <int K>
+static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
+{
+    return knn_wide_qpq(n) == 144 ? launch_knn_wide_q<K, 144>(b, n, ld, k, x, nn_idx, s)
+                                  : launch_knn_wide_q<K, 128>(b, n, ld, k, x, nn_idx, s);
 }
 
 // ---- C = 3, second generation: the selection split into filter + queued drain ------------------
@@ -1208,7 +1249,7 @@ static hipError_t launch_knn3_scan(int b, int n, int ld, int k, const float *x, 
 // knn_wide_fits; otherwise 5 means 1).  (3 / 4 were the 8-wave bound kernel of round 2, superseded by the wide one.)
 static bool knn_wide_fits(int n, int k)
 {
-    return k <= 10 && n >= 256 && knn_wide_lds_bytes(n) <= 158 * 1024;
+    return k <= 20 && n >= 256 && knn_wide_lds_bytes(n) <= 158 * 1024;
 }
 
 static int knn_scan_waves(long long tiles, int n, int k)
@@ -1243,8 +1284,7 @@ static hipError_t launch_knn(int b, int n, int c, int ld, int k, const float *x,
             const long long tiles = (long long)ceil_div(n, KM_TILE) * b;
             const int mode = knn_scan_waves(tiles, n, K);
             if (mode == 5 && knn_wide_fits(n, K)) {
-                if constexpr (K <= 10)
-                    return launch_knn_wide<K>(b, n, ld, k, x, nn_idx, s);
+                return launch_knn_wide<K>(b, n, ld, k, x, nn_idx, s);
             } else if (mode == 2) {
                 return launch_knn_scan<K, 4, 2>(b, n, ld, k, x, nn_idx, s);
             } else if (mode > 0) {

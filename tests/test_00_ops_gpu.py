@@ -181,7 +181,10 @@ def test_knn_vs_oracle(hip, oracle, b, n, c, ld, k):
                                           (2, 700, 20, 0), (140, 1024, 10, None), (2, 257, 20, 1), (5, 1000, 5, 2),
                                           (32, 1024, 10, None), (2, 4096, 20, 2), (2, 4096, 20, None), (2, 260, 10, 2),
                                           (40, 1024, 10, 5), (3, 1500, 10, 5), (2, 260, 5, 5), (2, 2048, 10, 5), (9, 3000, 10, None),
-                                          (1, 3300, 7, 5)])
+                                          (1, 3300, 7, 5),
+                                          # k = 20 and clouds of 4096+ points in the 16-wave kernel (BASELINE configs[4])
+                                          (2, 4096, 20, 5), (3, 1500, 20, 5), (2, 300, 15, 5), (1, 4500, 20, 5), (1, 6000, 10, 5),
+                                          (5, 4096, 20, None), (33, 1024, 20, None), (1, 3400, 10, 5)])
 def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, knobs, b, n, k, mode):
     """All C = 64 kernels (knob CLOUDAAE_KNN_SCAN = 0: knn64_mfma, 1 / 2: whole-cloud scan with one / two waves
     per query tile, 5: bound pass + filtered scan in 16-wave workgroups; None: the launcher's own choice) keep
@@ -198,16 +201,16 @@ def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, knobs, b, n, k, mode):
     assert np.array_equal(want, got.cpu().numpy())
 
 
-@pytest.mark.parametrize("mode", [1, 5])
+@pytest.mark.parametrize("mode,k", [(1, 10), (5, 10), (5, 20)])
 @pytest.mark.parametrize("case", ["all_equal", "few_distinct", "lattice", "large_finite", "far_cluster"])
-def test_knn_c64_bound_kernel_adversarial(hip, oracle, knobs, mode, case):
+def test_knn_c64_bound_kernel_adversarial(hip, oracle, knobs, mode, k, case):
     """The bound kernel's correctness must not depend on its bound being tight: clouds where (nearly) every
     candidate ties with the k-th distance (the queue overflows and is drained over and over), where the sampled
     tiles are unrepresentative, and where distances are huge."""
     from cloudaae_amd import _lib
     knobs("CLOUDAAE_KNN_SCAN", mode)
     rng = np.random.default_rng(7)
-    b, n, k = 3, 1024, 10
+    b, n = 3, 1024
     if case == "all_equal":
         x = np.tile(rng.standard_normal((b, 1, 64)), (1, n, 1))
     elif case == "few_distinct":
