@@ -144,7 +144,7 @@ def cpu_table(num_point):
     return rows
 
 
-def chamfer_kernel_rate(batch, n, m, iters=20):
+def chamfer_kernel_rate(batch, n, m, iters=20, distinct=None):
     """The second half of BASELINE's metric: Chamfer nn_distance forward kernel rate.
     Algorithmic bytes = B*(n+m)*20 (12 B read + 4 B dist + 4 B idx per point): arithmetic-bound
     by three orders of magnitude.  Large clouds take nn_distance_filter_kernel: the nearest candidate is
@@ -156,6 +156,11 @@ def chamfer_kernel_rate(batch, n, m, iters=20):
     g = torch.Generator(device="cuda").manual_seed(100)       # tf_nndistance.py:45-46 seeds
     a = torch.randn((batch, n, 3), generator=g, device="cuda")
     c = torch.randn((batch, m, 3), generator=g, device="cuda")
+    if distinct is not None:
+        # the reference's training targets: `distinct` visible points, then random re-draws of them
+        # (utils/hidden_point_removal.py:38-40) -- every target point exists m / distinct times
+        pick = torch.randint(0, distinct, (batch, m - distinct), generator=g, device="cuda")
+        c[:, distinct:] = torch.gather(c[:, :distinct], 1, pick[:, :, None].expand(-1, -1, 3))
     for _ in range(3):
         tf_nndistance.nn_distance(a, c)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -167,7 +172,9 @@ def chamfer_kernel_rate(batch, n, m, iters=20):
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     pairs = 2.0 * batch * n * m
     bound = 256 * 4 * 2.4e9 * 1024 / 128
-    return {"shape": "[%d,%d,3]x[%d,%d,3]" % (batch, n, batch, m), "us_per_launch": round(sec * 1e6, 2),
+    return {"shape": "[%d,%d,3]x[%d,%d,3]%s" % (batch, n, batch, m, "" if distinct is None else
+                                                 " (target = %d points + re-draws, as the reference pads)" % distinct),
+            "us_per_launch": round(sec * 1e6, 2),
             "GB/s": round(batch * (n + m) * 20 / sec / 1e9, 3), "Tpairs/s": round(pairs / sec / 1e12, 3),
             "clouds/s": round(batch / sec, 1), "frac_of_matrix_pipe_bound": round(pairs / sec / bound, 4)}
 
@@ -485,7 +492,8 @@ def main():
         if world == 1 and not args.step_only:
             # "Chamfer kernel GB/s": the train shape (n = m = 4N) and the reference's own
             # micro-benchmark shape (tf_nndistance.py:48-49), forward alone and the whole iteration it times
-            line["chamfer_kernel"] = [chamfer_kernel_rate(B, 4 * N, 4 * N), chamfer_kernel_rate(32, 16384, 1024)]
+            line["chamfer_kernel"] = [chamfer_kernel_rate(B, 4 * N, 4 * N), chamfer_kernel_rate(32, 16384, 1024),
+                                      chamfer_kernel_rate(B, 4 * N, 4 * N, distinct=N)]
             line["chamfer_reference_microbench"] = chamfer_train_rate()
             if args.cpu_batch > 0:
                 line["chamfer_kernel"][0]["cpu"] = chamfer_cpu_rate(4 * N, 4 * N)

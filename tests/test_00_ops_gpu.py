@@ -284,6 +284,31 @@ def test_nn_distance_split_candidates_vs_oracle(hip, oracle, b, n, m, split, kno
         assert np.array_equal(w, g_.cpu().numpy())
 
 
+@pytest.mark.parametrize("b,n,distinct,split", [(2, 4096, 1024, None), (3, 2049, 1000, None), (2, 16384, 4000, None),
+                                                (2, 6000, 300, 2)])
+def test_nn_distance_padded_targets_vs_oracle(hip, oracle, knobs, b, n, distinct, split):
+    """The reference's training targets: the visible points followed by random RE-DRAWS of visible points
+    (utils/hidden_point_removal.py:38-40), i.e. every target point exists two to four times.  For the matrix-core
+    search every such query has several units with bitwise equal best scores: settled by the second pass over the
+    scores (candidates at or below best + margin evaluated exactly), bit-exact incl. the first-index rule -- the
+    index returned for a duplicated point is always its FIRST copy."""
+    from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
+    knobs("CLOUDAAE_NN_FILTER", 1)
+    if split is not None:
+        knobs("CLOUDAAE_NN_SPLIT", split)
+    rng = np.random.default_rng(n + distinct)
+    base = (rng.standard_normal((b, distinct, 3)) * 0.05 + [0.1, -0.2, 0.9]).astype(np.float32)
+    pick = rng.integers(0, distinct, (b, n - distinct))
+    target = np.concatenate([base, np.take_along_axis(base, pick[:, :, None].repeat(3, 2), 1)], 1)
+    pred = (rng.standard_normal((b, n, 3)) * 0.05 + [0.1, -0.2, 0.9]).astype(np.float32)
+    pred[:, :50] = target[:, 100:150]                 # exact hits
+    want = oracle.nn_distance(pred, target, threads=8)
+    got = tf_nndistance.nn_distance(_dev(pred), _dev(target))
+    for w, g_ in zip(want, got):
+        assert np.array_equal(w, g_.cpu().numpy())
+    assert int(got[1].max()) < distinct                # nearest targets: always the first copy
+
+
 @pytest.mark.parametrize("case", ["lattice", "far_from_origin", "huge", "tiny_scale", "one_candidate", "ragged"])
 def test_nn_distance_filter_kernel_adversarial(hip, oracle, case, knobs):
     """The matrix-core search + exact verification (nn_distance_filter_kernel) on inputs built to defeat a
