@@ -420,12 +420,22 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
     }
 
     // ---- second pass: every candidate with a score <= s1 + M, exactly ----
+    // It costs the whole workgroup another walk over the candidates, so it is taken when MANY of the workgroup's
+    // queries are undecided (duplicated candidates: all of them); a stray undecided query (random clouds: one in
+    // 10^4) is cheaper to settle by the full scan below, which only occupies its own wave.
     {
-        bool need = false;
+        int mine = 0;
 #pragma unroll
         for (int q = 0; q < NF_QT; ++q)
-            need = need || theta[q] > -__builtin_inff();
-        if (__syncthreads_or(need ? 1 : 0)) {       // (the chunks are staged by the whole workgroup)
+            mine += (theta[q] > -__builtin_inff() && half == 0) ? 1 : 0;
+        const int undecided = __syncthreads_count(mine > 0) + (NF_QT > 1 ? __syncthreads_count(mine > 1) : 0);
+        if (undecided < NF_QBLOCK / 16) {
+#pragma unroll
+            for (int q = 0; q < NF_QT; ++q) {
+                full[q] = full[q] || (theta[q] > -__builtin_inff() && half == 0);
+                theta[q] = -__builtin_inff();
+            }
+        } else {
             for (int c0 = cbeg; c0 < cend; c0 += NF_CHUNK) {
                 const int cnt = min(NF_CHUNK, cend - c0);
                 const int padded = (cnt + 31) & ~31;
