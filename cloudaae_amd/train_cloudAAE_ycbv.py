@@ -282,6 +282,9 @@ class TrainGraph(object):
             F.flush_deferred_dw()          # (deferred weight-gradient products of layers whose group stayed incomplete)
         finally:
             F.SIDE_STREAM = None
+            F.drop_deferred_dw()           # (a step that raised must not leave its jobs to the next one)
+        if self.bn_sync is not None:
+            self.bn_sync.check()           # an exception inside the all-reduce callback surfaces here, as itself
         if side is not None:
             _lib.stream_wait(stream(), side)
         # RCCL all-reduce of the flat gradient buffer (no-op for 1 rank); bench.py brackets it with HIP events on
@@ -337,7 +340,9 @@ class TrainGraph(object):
             if self._plan_key is not None and self._plan is not None:
                 self._plans[self._plan_key] = (self._plan, self._plan_out, self._static)
                 while len(self._plans) > 4:
-                    self._plans.pop(next(iter(self._plans)))
+                    gone = self._plans.pop(next(iter(self._plans)))
+                    if self.bn_sync is not None:
+                        self.bn_sync.forget(gone[0])
             self._staged = None
             self._plan_key = key
             if key in self._plans:

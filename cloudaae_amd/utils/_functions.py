@@ -433,6 +433,13 @@ def flush_deferred_dw(slot=None):
             gw.done()
 
 
+def drop_deferred_dw():
+    """Forget deferred weight-gradient products that were never launched (the step that queued them raised)."""
+    for sl in list(_PENDING_DW):
+        sl.dw_jobs = []
+    del _PENDING_DW[:]
+
+
 class ConcatLinearFn(torch.autograd.Function):
     """Linear over the channel-concatenation of several [M,Ci] inputs
     (models/pointnet_ycb_23_decoder_4.py:410: conv2d(tf.concat([net1..net4], -1))).

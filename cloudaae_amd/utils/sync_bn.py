@@ -27,9 +27,16 @@ from .. import _lib
 
 
 class BnSync(object):
-    def __init__(self, group=None, world=None):
-        self.group = group
+    def __init__(self, group=None, world=None, own_communicator=True):
+        # own_communicator: the small blocking all-reduces of the batch norms get their OWN communicator (a second
+        # group over the same ranks): collectives of one communicator are serialised on its stream, so on the
+        # gradient exchange's group every batch norm of the encoder's backward pass would wait behind the large
+        # asynchronous all-reduce of the fully connected gradients (utils/grad_exchange.py) and undo its overlap
         self.world = int(world if world is not None else dist.get_world_size(group))
+        if own_communicator and dist.is_initialized() and self.world > 1:
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+            group = dist.new_group(ranks=ranks)       # (collective over the default group: every rank builds its BnSync)
+        self.group = group
         self.calls = 0               # all-reduces issued (tests and bench read it)
         self.error = None            # exception raised inside the callback (ctypes cannot propagate it)
         self._planned = {}           # data_ptr -> buffer of a recorded step (lives as long as its plan)
@@ -54,11 +61,16 @@ class BnSync(object):
     def begin_step(self):
         self._slot = 0
 
+    def forget(self, plan):
+        """Drop the buffers of a recorded step that is being discarded (they live in its arena)."""
+        self._planned = {p: t for p, t in self._planned.items() if getattr(t, "_cloudaae_plan", None) is not plan}
+
     def arg(self, C, device):
         """A `cloudaae_bn_sync *` for one layer and direction with C channels."""
         n = 2 * int(C)
         if _lib.recording() is not None:
             buf = _lib.empty(n, dtype=torch.float64, device=device)
+            buf._cloudaae_plan = _lib.recording()
             self._planned[buf.data_ptr()] = buf
         else:
             key = (self._slot, n)
