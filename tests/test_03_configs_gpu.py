@@ -4,6 +4,7 @@ recorded step, replayed), against the CPU oracle (oracle/model_oracle.py):
     configs[1]  all 21 classes, batch 32,  N = 1024, fp32
     configs[3]  per-GPU shape of the 8-GPU run: batch 128, N = 1024, fp32
     configs[2]  batch 256, N = 1024, bf16 dense-layer operands, fp32 everything else
+    configs[4]  its network shape: N = 4096, k = 20 (batch 8; the on-line synthesis in front of it: test_04_synth_gpu.py)
 
 One full iteration of train_cloudAAE_ycbv.py:344-368 from a mid-training state (step counter 2, Adam
 slots non-zero): the three losses, the reconstruction, the gradient of every variable, the BN moving
@@ -30,9 +31,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEP0 = 2            # the step counter (`batch`, train...:192) the compared iteration starts from
 
 CONFIGS = [
-    pytest.param("configs[1]", 32, 1024, "f32", id="cfg1-B32-f32"),
-    pytest.param("configs[3]/gpu", 128, 1024, "f32", id="cfg3-B128-f32"),
-    pytest.param("configs[2]", 256, 1024, "bf16", id="cfg2-B256-bf16"),
+    pytest.param("configs[1]", 32, 1024, "f32", 10, id="cfg1-B32-f32"),
+    pytest.param("configs[3]/gpu", 128, 1024, "f32", 10, id="cfg3-B128-f32"),
+    pytest.param("configs[2]", 256, 1024, "bf16", 10, id="cfg2-B256-bf16"),
+    # configs[4]'s network shape (N = 4096 points, k = 20 neighbours, a 16384-point Chamfer target) at a batch the CPU
+    # oracle finishes in under a minute; 8 clouds = 1024 query tiles: the 16-wave kNN kernel with k = 20 and 128-slot
+    # queues, the kernel bench.py --config5 runs
+    pytest.param("configs[4]/net", 8, 4096, "f32", 20, id="cfg5-B8-N4096-k20"),
 ]
 
 
@@ -68,12 +73,12 @@ def _adam_reference(p, g, m, v, lr, b1, b2, eps, b1p, b2p):
     return p.astype(np.float32), m.astype(np.float32), v.astype(np.float32)
 
 
-@pytest.mark.parametrize("name,B,N,dtype", CONFIGS)
-def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype):
+@pytest.mark.parametrize("name,B,N,dtype,k", CONFIGS)
+def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype, k):
     from cloudaae_amd import train_cloudAAE_ycbv as T
     from oracle import model_oracle as MO
     bf16 = dtype == "bf16"
-    graph = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, replay=True, gemm_dtype=dtype)
+    graph = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, replay=True, gemm_dtype=dtype, k_neighbor=k)
     V = MO.Vars(seed=31)
     with torch.no_grad():       # creates the oracle's variables (their shapes depend on N only)
         MO.forward_losses(MO.synthetic_batch(2, N, seed=1), V, N, is_training=False)
@@ -133,7 +138,7 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype):
     MO.GEMM_BF16 = bf16
     try:
         with torch.no_grad():
-            free = MO.forward_losses(batch, V, N, True, decay0, 10)
+            free = MO.forward_losses(batch, V, N, True, decay0, k)
     finally:
         MO.GEMM_BF16 = False
     for k, v in shadows.items():
@@ -147,8 +152,8 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype):
           % (name, B, N, dtype, ", ".join("%.5f" % m for m in mismatch)))
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "knn_free_running_mismatch_B%d_%s.json" % (B, dtype)), "w") as f:
-            json.dump({"config": name, "B": B, "N": N, "k": 10, "dtype": dtype,
+        with open(os.path.join(ROOT, "gpurun_out", "knn_free_running_mismatch_B%d_N%d_k%d_%s.json" % (B, N, k, dtype)), "w") as f:
+            json.dump({"config": name, "B": B, "N": N, "k": k, "dtype": dtype,
                        "mismatch_fraction_of_points_per_layer": mismatch}, f)
     except OSError:
         pass
@@ -157,13 +162,14 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype):
     # at most 0.95 % of the points at B=32, 1.14 % at B=128, 1.40 % at B=256 with bf16 operands, where a feature
     # on a rounding boundary flips).  The bounds are what was measured plus headroom for another seed, so a
     # regression of the kNN numerics cannot hide: 2 % (fp32), 3 % (bf16).
-    assert mismatch[0] < 0.001 and max(mismatch) < (0.03 if bf16 else 0.02), mismatch
+    # (k = 20 at N = 4096: twice the neighbours per point, twice the k-th / (k+1)-th near-ties: 5 % until measured)
+    assert mismatch[0] < 0.001 and max(mismatch) < (0.03 if bf16 else (0.02 if k <= 10 else 0.05)), mismatch
 
     # ---- the oracle's iteration, grouped on the GPU's indices ----
     p0 = {n: p.detach().clone() for n, p in V.p.items()}
     MO.GEMM_BF16 = bf16
     try:
-        ref, grads = MO.train_step(batch, V, opt, STEP0, N, B, nn_override=rep["idx"])
+        ref, grads = MO.train_step(batch, V, opt, STEP0, N, B, k=k, nn_override=rep["idx"])
     finally:
         MO.GEMM_BF16 = False
 
