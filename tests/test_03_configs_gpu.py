@@ -73,12 +73,12 @@ def _adam_reference(p, g, m, v, lr, b1, b2, eps, b1p, b2p):
     return p.astype(np.float32), m.astype(np.float32), v.astype(np.float32)
 
 
-@pytest.mark.parametrize("name,B,N,dtype,k", CONFIGS)
-def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype, k):
+@pytest.mark.parametrize("name,B,N,dtype,kn", CONFIGS)
+def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype, kn):
     from cloudaae_amd import train_cloudAAE_ycbv as T
     from oracle import model_oracle as MO
     bf16 = dtype == "bf16"
-    graph = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, replay=True, gemm_dtype=dtype, k_neighbor=k)
+    graph = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, replay=True, gemm_dtype=dtype, k_neighbor=kn)
     V = MO.Vars(seed=31)
     with torch.no_grad():       # creates the oracle's variables (their shapes depend on N only)
         MO.forward_losses(MO.synthetic_batch(2, N, seed=1), V, N, is_training=False)
@@ -138,7 +138,7 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype, k):
     MO.GEMM_BF16 = bf16
     try:
         with torch.no_grad():
-            free = MO.forward_losses(batch, V, N, True, decay0, k)
+            free = MO.forward_losses(batch, V, N, True, decay0, kn)
     finally:
         MO.GEMM_BF16 = False
     for k, v in shadows.items():
@@ -152,8 +152,8 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype, k):
           % (name, B, N, dtype, ", ".join("%.5f" % m for m in mismatch)))
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "knn_free_running_mismatch_B%d_N%d_k%d_%s.json" % (B, N, k, dtype)), "w") as f:
-            json.dump({"config": name, "B": B, "N": N, "k": k, "dtype": dtype,
+        with open(os.path.join(ROOT, "gpurun_out", "knn_free_running_mismatch_B%d_N%d_k%d_%s.json" % (B, N, kn, dtype)), "w") as f:
+            json.dump({"config": name, "B": B, "N": N, "k": kn, "dtype": dtype,
                        "mismatch_fraction_of_points_per_layer": mismatch}, f)
     except OSError:
         pass
@@ -162,14 +162,14 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype, k):
     # at most 0.95 % of the points at B=32, 1.14 % at B=128, 1.40 % at B=256 with bf16 operands, where a feature
     # on a rounding boundary flips).  The bounds are what was measured plus headroom for another seed, so a
     # regression of the kNN numerics cannot hide: 2 % (fp32), 3 % (bf16).
-    # (k = 20 at N = 4096: twice the neighbours per point, twice the k-th / (k+1)-th near-ties: 5 % until measured)
-    assert mismatch[0] < 0.001 and max(mismatch) < (0.03 if bf16 else (0.02 if k <= 10 else 0.05)), mismatch
+    # (k = 20 at N = 4096: twice the neighbours per point, twice the k-th / (k+1)-th near-ties: measured 0 / 0.48 / 0.93 / 2.48 %, bound 4 %)
+    assert mismatch[0] < 0.001 and max(mismatch) < (0.03 if bf16 else (0.02 if kn <= 10 else 0.04)), mismatch
 
     # ---- the oracle's iteration, grouped on the GPU's indices ----
     p0 = {n: p.detach().clone() for n, p in V.p.items()}
     MO.GEMM_BF16 = bf16
     try:
-        ref, grads = MO.train_step(batch, V, opt, STEP0, N, B, k=k, nn_override=rep["idx"])
+        ref, grads = MO.train_step(batch, V, opt, STEP0, N, B, k=kn, nn_override=rep["idx"])
     finally:
         MO.GEMM_BF16 = False
 
