@@ -327,7 +327,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     force = os.environ.get("CLOUDAAE_FORCE_COLLECTIVES") == "1" and "MASTER_ADDR" in os.environ
+    stdout_fd = None
     if world > 1 or force:
+        # RCCL prints a version banner on STDOUT when its first communicator comes up: this process's stdout is
+        # pointed at stderr until the first collective has run, so that rank 0's ONE JSON line stays alone there
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from cloudaae_amd import train_cloudAAE_ycbv as T
@@ -373,6 +379,10 @@ def main():
         ones = torch.ones(1, device=graph.device)
         dist.all_reduce(ones)                                   # RCCL: every rank contributes 1
         ranks_seen = int(round(float(ones)))
+    if stdout_fd is not None:
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        os.close(stdout_fd)
 
     elapsed, out = timed_steps(synth if synth is not None else graph, el, args.steps, args.warmup, world, sites)
     events = {k: F.TIMED_SITES.pop(k) for k in sites}
