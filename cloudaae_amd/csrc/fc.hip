@@ -215,10 +215,11 @@ __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int 
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q)
             sum[q] = float2v{0.0f, 0.0f};
-        for (int s0 = 0; s0 < a.splits; s0 += 4) {
-            unsigned long long raw[4][PAIRS];
+        constexpr int INFL = 4;     // (eight would need 280 registers: one workgroup per CU instead of two)
+        for (int s0 = 0; s0 < a.splits; s0 += INFL) {
+            unsigned long long raw[INFL][PAIRS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < INFL; ++u) {
                 const int s = min(s0 + u, a.splits - 1);        // (past the end: the last slice again, not added)
 #pragma unroll
                 for (int q = 0; q < PAIRS; ++q) {
@@ -229,7 +230,7 @@ __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int 
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < INFL; ++u)
                 if (s0 + u < a.splits)
 #pragma unroll
                     for (int q = 0; q < PAIRS; ++q) {

@@ -16,15 +16,17 @@ namespace cloudaae {
 // noise: the caller's [B,N,3] array, or (noise == NULL, noise_std > 0) drawn HERE: the tf.random.normal(stddev) of
 // :217 as a pure function of (seed, step counter, cloud, point) -- Philox4x32-10 + Box-Muller -- so a recorded step
 // draws fresh noise at every replay without a generator kernel in front of it.
-__global__ __launch_bounds__(256) void input_assemble_kernel(int P, int N, int num_class,
-                                                            const float *__restrict__ visible,
-                                                            const float *__restrict__ noise,
-                                                            const long long *__restrict__ class_id,
-                                                            float *__restrict__ pc, float *__restrict__ mean,
-                                                            float *__restrict__ noisy, float noise_std,
-                                                            unsigned long long seed, const float *__restrict__ step)
+constexpr int IA_THREADS = 1024, IA_KEEP = 4;      // a thread keeps its first IA_KEEP points in registers
+__global__ __launch_bounds__(IA_THREADS) void input_assemble_kernel(int P, int N, int num_class,
+                                                                   const float *__restrict__ visible,
+                                                                   const float *__restrict__ noise,
+                                                                   const long long *__restrict__ class_id,
+                                                                   float *__restrict__ pc, float *__restrict__ mean,
+                                                                   float *__restrict__ noisy, float noise_std,
+                                                                   unsigned long long seed, const float *__restrict__ step)
 {
-    __shared__ float red[3][4];
+    constexpr int NWV = IA_THREADS / 64;
+    __shared__ float red[3][NWV];
     __shared__ float mu[3];
     const int b = blockIdx.x, t = threadIdx.x;
     const float *V = visible + (size_t)b * P * 3;
@@ -50,10 +52,20 @@ __global__ __launch_bounds__(256) void input_assemble_kernel(int P, int N, int n
             z = z + n2 * noise_std;
         }
     };
+    // the sums run over j = t, t + 1024, ... per thread, then lanes, then waves in index order (fixed order)
+    float kx[IA_KEEP], ky[IA_KEEP], kz[IA_KEEP];
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int j = t; j < N; j += 256) {
+    int it = 0;
+    for (int j = t; j < N; j += IA_THREADS, ++it) {
         float x, y, z;
         point(j, x, y, z);
+#pragma unroll
+        for (int u = 0; u < IA_KEEP; ++u)
+            if (u == it) {
+                kx[u] = x;
+                ky[u] = y;
+                kz[u] = z;
+            }
         sx += x;
         sy += y;
         sz += z;
@@ -68,16 +80,29 @@ __global__ __launch_bounds__(256) void input_assemble_kernel(int P, int N, int n
     }
     __syncthreads();
     if (t < 3) {
-        const float s = (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+        float s = 0.0f;
+        for (int w = 0; w < NWV; ++w)
+            s += red[t][w];
         mu[t] = s / (float)N;
         mean[(size_t)b * 3 + t] = mu[t];
     }
     __syncthreads();
     const int C = 3 + num_class;
     const long long cls = class_id ? class_id[b] : -1;
-    for (int j = t; j < N; j += 256) {
-        float x, y, z;
-        point(j, x, y, z);          // (the same values again: the draw is a function of its indices)
+    it = 0;
+    for (int j = t; j < N; j += IA_THREADS, ++it) {
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (it < IA_KEEP) {
+#pragma unroll
+            for (int u = 0; u < IA_KEEP; ++u)
+                if (u == it) {
+                    x = kx[u];
+                    y = ky[u];
+                    z = kz[u];
+                }
+        } else {
+            point(j, x, y, z);      // (the same values again: the draw is a function of its indices)
+        }
         if (noisy) {
             noisy[((size_t)b * N + j) * 3 + 0] = x;
             noisy[((size_t)b * N + j) * 3 + 1] = y;
@@ -753,7 +778,7 @@ CLOUDAAE_API int cloudaae_input_assemble(int b, int p, int n, int num_class, con
     CLOUDAAE_REQUIRE(b >= 0 && n > 0 && p >= n && num_class >= 0, name, "bad size (need n <= rows of visible)");
     if (b == 0)
         return 0;
-    hipLaunchKernelGGL(input_assemble_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, p, n, num_class,
+    hipLaunchKernelGGL(input_assemble_kernel, dim3(b), dim3(IA_THREADS), 0, (hipStream_t)stream, p, n, num_class,
                        visible, noise, class_id, pc, mean, noisy, 0.0f, 0ull, (const float *)nullptr);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
@@ -769,7 +794,7 @@ CLOUDAAE_API int cloudaae_input_assemble_noise(int b, int p, int n, int num_clas
     CLOUDAAE_REQUIRE(noise_std >= 0.0f, name, "negative standard deviation");
     if (b == 0)
         return 0;
-    hipLaunchKernelGGL(input_assemble_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, p, n, num_class,
+    hipLaunchKernelGGL(input_assemble_kernel, dim3(b), dim3(IA_THREADS), 0, (hipStream_t)stream, p, n, num_class,
                        visible, (const float *)nullptr, class_id, pc, mean, noisy, noise_std, seed, step);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
