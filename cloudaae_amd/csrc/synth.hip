@@ -331,6 +331,22 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
     double vx = HPR_TAN, vy = HPR_TAN;
     const float pxf = (float)fr.px, pyf = (float)fr.py, pzf = (float)fr.pz;     // exact: p is a float
     const int span = HPR_NEAR + n1;
+    // the plane d = r + vx u + vy w under test, and its fp32 copy: recomputed only when a re-solve moved (vx, vy)
+    double dx, dy, dz;
+    float dxf, dyf, dzf, slack;
+    auto set_plane = [&]() {
+        dx = (fr.rx + vx * fr.ux) + vy * fr.wx;
+        dy = (fr.ry + vx * fr.uy) + vy * fr.wy;
+        dz = (fr.rz + vx * fr.uz) + vy * fr.wz;
+        dxf = (float)dx;
+        dyf = (float)dy;
+        dzf = (float)dz;
+        slack = -4e-6f * ((fabsf(dxf) + fabsf(dyf)) + fabsf(dzf));
+    };
+    set_plane();
+    // the strided part of the sequence advances by 64 positions per iteration: q += 64 * stride (mod n1)
+    const int step64 = (int)(((long long)64 * stride) % n1);
+    int qraw = 0, qat = -1;                 // qraw = ((qat + lane - HPR_NEAR) * stride) mod n1
     int i = 0;
     while (i < span) {
         // the scan tests the current plane itself: with d = r + vx u + vy w the constraint of q reads
@@ -339,12 +355,27 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
         // whose fp32 value is below -margin, margin = 4e-6 |d|_1 |g|_1 (>> the rounding error of the three
         // products, the sum and the fp32 copies of d and g), is satisfied for certain; only lanes inside
         // the margin repeat the test in fp64.  The decision is therefore exactly the fp64 one.
-        const double dx = (fr.rx + vx * fr.ux) + vy * fr.wx, dy = (fr.ry + vx * fr.uy) + vy * fr.wy,
-                     dz = (fr.rz + vx * fr.uz) + vy * fr.wz;
-        const float dxf = (float)dx, dyf = (float)dy, dzf = (float)dz;
-        const float dl1 = (fabsf(dxf) + fabsf(dyf)) + fabsf(dzf);
         const int pos = i + lane;
-        const int q = pos < span ? hpr_seq(pos, self, n1, stride) : n1;
+        int q;
+        if (i >= HPR_NEAR) {                // (uniform) every lane is in the strided part
+            const int p2 = pos - HPR_NEAR;
+            if (qat + 64 == i) {
+                qraw += step64;
+                qraw -= qraw >= n1 ? n1 : 0;
+            } else {                        // first time here, or the scan restarted after a re-solve
+                const int x = min(p2, n1 - 1) * stride;
+                qraw = x - (int)((float)x * (1.0f / (float)n1)) * n1;
+                qraw = qraw < 0 ? qraw + n1 : qraw;
+                qraw = qraw >= n1 ? qraw - n1 : qraw;
+            }
+            qat = i;
+            int dd = qraw - self;
+            dd = dd < 0 ? -dd : dd;
+            dd = min(dd, n1 - dd);
+            q = (p2 < n1 && !(dd >= 1 && dd <= HPR_NEAR / 2)) ? qraw : n1;
+        } else {
+            q = pos < span ? hpr_seq(pos, self, n1, stride) : n1;
+        }
         const bool valid = q < n1 && q != self;
         bool viol = false;
         if (valid) {
@@ -352,7 +383,7 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
             const float gxf = qx - pxf, gyf = qy - pyf, gzf = qz - pzf;
             const float nrmf = (fabsf(gxf) + fabsf(gyf)) + fabsf(gzf);
             const float v32 = (dxf * gxf + dyf * gyf) + dzf * gzf;
-            if (v32 > -4e-6f * dl1 * nrmf) {
+            if (v32 > slack * nrmf) {
                 const double gx = (double)qx - fr.px, gy = (double)qy - fr.py, gz = (double)qz - fr.pz;
                 const double nrm = (fabs(gx) + fabs(gy)) + fabs(gz);
                 viol = (dx * gx + dy * gy) + dz * gz > -HPR_EPS * nrm;
@@ -421,6 +452,7 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
         const double tt = pick.num / pick.den;
         vx = p0x + tt * ux;
         vy = p0y + tt * uy;
+        set_plane();
         i = upto + 1;
     }
     return true;
