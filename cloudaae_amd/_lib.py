@@ -21,6 +21,7 @@ _U = ctypes.c_ulonglong
 _SIGNATURES = {
     "cloudaae_nn_distance": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P],
     "cloudaae_nn_distance_grad": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "cloudaae_nn_distance_grad_ordered": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "cloudaae_farthest_point_sample": [_I, _I, _I, _P, _P, _P, _P],
     "cloudaae_gather_point": [_I, _I, _I, _P, _P, _P, _P],
     "cloudaae_gather_point_grad": [_I, _I, _I, _P, _P, _P, _P],

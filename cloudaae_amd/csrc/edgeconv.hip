@@ -477,7 +477,7 @@ struct EcRevJobs {
 // grid (clouds, layers): the neighbour lists of every layer of the encoder exist once its forward pass
 // is over, so the backward pass builds all their reverse lists with ONE launch (four ~11 us launches of
 // 32 workgroups each otherwise).
-__global__ __launch_bounds__(512) void ec_revlist_kernel(int B, int N, int k, EcRevJobs jobs)
+__global__ __launch_bounds__(512) void ec_revlist_kernel(int B, int N, int k, EcRevJobs jobs, int sorted)
 {
     extern __shared__ int cnt[];
     __shared__ int wsum[8];
@@ -545,6 +545,23 @@ __global__ __launch_bounds__(512) void ec_revlist_kernel(int B, int N, int k, Ec
                 const int pos = atomicAdd(&cnt[v[u]], 1);
                 src[pos] = (e0 + 512 * u) / k;
             }
+    }
+    if (sorted) {
+        // deterministic mode: the slots of a list were handed out in arrival order; sorted by source point the list --
+        // and with it the summation order of the backward gather -- is the same in every run
+        __syncthreads();
+        for (int mpt = t; mpt < N; mpt += 512) {
+            const int a = off[mpt], e = (mpt + 1 < N) ? off[mpt + 1] : E;
+            for (int i = a + 1; i < e; ++i) {
+                const int v = src[i];
+                int j = i - 1;
+                while (j >= a && src[j] > v) {
+                    src[j + 1] = src[j];
+                    --j;
+                }
+                src[j + 1] = v;
+            }
+        }
     }
 }
 
@@ -815,7 +832,8 @@ static int ec_launch_revlists(const char *name, int count, int b, int n, int k, 
     if (lds > 48 * 1024)
         CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)ec_revlist_kernel,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
-    hipLaunchKernelGGL(ec_revlist_kernel, dim3(b, count), dim3(512), lds, s, b, n, k, jobs);
+    hipLaunchKernelGGL(ec_revlist_kernel, dim3(b, count), dim3(512), lds, s, b, n, k, jobs,
+                       CLOUDAAE_KNOB("CLOUDAAE_DETERMINISTIC", 0) != 0 ? 1 : 0);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }

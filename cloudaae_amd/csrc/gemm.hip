@@ -495,6 +495,10 @@ static void gemm_plan(int M, int N, int K, int &BM, int &BN, int &splits)
             splits = splits / 8 * 8;      // whole slices per XCD (the kernel then keeps a slice's tiles on one XCD)
         splits = CLOUDAAE_KNOB("CLOUDAAE_GEMM_SPLITS", splits);
     }
+    // deterministic mode (cloudaae_set_knob("CLOUDAAE_DETERMINISTIC", 1)): no product is cut over K, so none adds its
+    // slices with atomics -- the gradient products pay for it with idle CUs
+    if (CLOUDAAE_KNOB("CLOUDAAE_DETERMINISTIC", 0) != 0)
+        splits = 1;
 }
 
 } // namespace cloudaae
@@ -677,7 +681,7 @@ CLOUDAAE_API int cloudaae_gemm_f32_tn_group(int count, const cloudaae_gemm_tn_jo
             splits = q.K / 64;
         if (splits > 8)
             splits = splits / 8 * 8;
-        if (splits < 1)
+        if (splits < 1 || CLOUDAAE_KNOB("CLOUDAAE_DETERMINISTIC", 0) != 0)
             splits = 1;
         j.kchunk = ceil_div(ceil_div(q.K, splits), GEMM_BK) * GEMM_BK;
         j.splits = ceil_div(q.K, j.kchunk);

@@ -329,6 +329,8 @@ static void gemm_bf16_plan(int M, int N, int K, int &BM, int &BN, int &splits)
         if (splits > 8)
             splits = splits / 8 * 8;      // whole slices per XCD
     }
+    if (CLOUDAAE_KNOB("CLOUDAAE_DETERMINISTIC", 0) != 0)     // deterministic mode: see gemm.hip
+        splits = 1;
 }
 
 } // namespace cloudaae

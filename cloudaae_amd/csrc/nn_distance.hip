@@ -595,6 +595,71 @@ __global__ __launch_bounds__(256) void nn_distance_grad_kernel(
     }
 }
 
+// The same gradients in the ORDER of the reference's CPU loops (tf_nndistance.cpp:126-163): one thread per output point,
+// which walks the other cloud's nearest-neighbour indices in ascending order and adds the terms that name it --
+//   grad_xyz1[p] = (sweep 1: its own term) then (sweep 2, j ascending with idx2[j] == p) -= g2_j (b_j - a_p)
+//   grad_xyz2[t] = (sweep 1, j ascending with idx1[j] == t) -= g1_j (a_j - b_t) then (sweep 2: its own term)
+// -- no atomics, every output stored once: bit-identical to the sequential sweep, and to itself from run to run.
+// O(n m) index comparisons per cloud (the indices of the other side stream through LDS as broadcast reads):
+// ~10 x the time of the atomic kernel, for the deterministic mode.
+constexpr int NG_CHUNK = 2048;
+__global__ __launch_bounds__(256) void nn_distance_grad_ordered_kernel(
+    int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    const float *__restrict__ grad_dist1, const int *__restrict__ idx1,
+    const float *__restrict__ grad_dist2, const int *__restrict__ idx2,
+    float *__restrict__ grad_xyz1, float *__restrict__ grad_xyz2, int blocks1,
+    const float *__restrict__ uniform, float uniform_scale)
+{
+    __shared__ int sidx[NG_CHUNK];
+    const int cloud = blockIdx.y;
+    const bool second = (int)blockIdx.x >= blocks1;        // outputs of xyz2
+    const int blk = second ? (int)blockIdx.x - blocks1 : (int)blockIdx.x;
+    const int p = blk * 256 + (int)threadIdx.x;
+    const int na = second ? m : n, nb = second ? n : m;     // na: this side's points, nb: the other side's
+    const float *A = (second ? xyz2 : xyz1) + (size_t)cloud * na * 3;
+    const float *B = (second ? xyz1 : xyz2) + (size_t)cloud * nb * 3;
+    const int *own_idx = (second ? idx2 : idx1) + (size_t)cloud * na;
+    const int *oth_idx = (second ? idx1 : idx2) + (size_t)cloud * nb;
+    const float *own_g = second ? grad_dist2 : grad_dist1, *oth_g = second ? grad_dist1 : grad_dist2;
+    float *out = second ? grad_xyz2 : grad_xyz1;
+    const bool live = p < na && out != nullptr;
+    const float ax = live ? A[3 * p] : 0.0f, ay = live ? A[3 * p + 1] : 0.0f, az = live ? A[3 * p + 2] : 0.0f;
+    const float gu = uniform != nullptr ? uniform[0] * uniform_scale : 0.0f;
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    auto own = [&]() {
+        const int t = own_idx[p];
+        const float g = (uniform != nullptr ? gu : own_g[(size_t)cloud * na + p]) * 2;
+        sx += g * (ax - B[3 * (size_t)t]);
+        sy += g * (ay - B[3 * (size_t)t + 1]);
+        sz += g * (az - B[3 * (size_t)t + 2]);
+    };
+    if (live && !second)
+        own();                                              // sweep 1 writes grad_xyz1[j] first
+    for (int c0 = 0; c0 < nb; c0 += NG_CHUNK) {
+        const int cnt = min(NG_CHUNK, nb - c0);
+        __syncthreads();
+        for (int q = threadIdx.x; q < cnt; q += 256)
+            sidx[q] = oth_idx[c0 + q];
+        __syncthreads();
+        if (live)
+            for (int q = 0; q < cnt; ++q)
+                if (sidx[q] == p) {
+                    const int j = c0 + q;
+                    const float g = (uniform != nullptr ? gu : oth_g[(size_t)cloud * nb + j]) * 2;
+                    sx -= g * (B[3 * (size_t)j] - ax);
+                    sy -= g * (B[3 * (size_t)j + 1] - ay);
+                    sz -= g * (B[3 * (size_t)j + 2] - az);
+                }
+    }
+    if (live && second)
+        own();                                              // sweep 2 adds grad_xyz2[j] last
+    if (live) {
+        out[((size_t)cloud * na + p) * 3 + 0] = sx;
+        out[((size_t)cloud * na + p) * 3 + 1] = sy;
+        out[((size_t)cloud * na + p) * 3 + 2] = sz;
+    }
+}
+
 } // namespace cloudaae
 
 using namespace cloudaae;
@@ -723,6 +788,32 @@ CLOUDAAE_API int cloudaae_nn_distance_grad_uniform(int b, int n, const float *xy
     const int b1 = ceil_div(n, 256), b2 = ceil_div(m, 256);
     hipLaunchKernelGGL(nn_distance_grad_kernel, dim3(b1 + b2, b), dim3(256), 0, s, n, m, xyz1, xyz2, nullptr, idx1,
                        nullptr, idx2, grad_xyz1, grad_xyz2, b1, grad, scale);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_nn_distance_grad_ordered(int b, int n, const float *xyz1, int m, const float *xyz2,
+                                                   const float *grad_dist1, const int *idx1, const float *grad_dist2,
+                                                   const int *idx2, const float *uniform, float uniform_scale,
+                                                   float *grad_xyz1, float *grad_xyz2, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_nn_distance_grad_ordered";
+    CLOUDAAE_REQUIRE(b >= 0 && n >= 0 && m >= 0 && idx1 && idx2, name, "bad argument");
+    CLOUDAAE_REQUIRE(uniform != nullptr || (grad_dist1 && grad_dist2), name, "no upstream gradient");
+    CLOUDAAE_REQUIRE(b <= 65535, name, "batch > 65535");
+    hipStream_t s = (hipStream_t)stream;
+    if (b == 0)
+        return 0;
+    if (n == 0 || m == 0) {     // (an empty cloud: nothing names anything)
+        if (grad_xyz1 && n)
+            CLOUDAAE_CHECK_HIP(hipMemsetAsync(grad_xyz1, 0, sizeof(float) * (size_t)b * n * 3, s), name);
+        if (grad_xyz2 && m)
+            CLOUDAAE_CHECK_HIP(hipMemsetAsync(grad_xyz2, 0, sizeof(float) * (size_t)b * m * 3, s), name);
+        return 0;
+    }
+    const int b1 = ceil_div(n, 256), b2 = ceil_div(m, 256);
+    hipLaunchKernelGGL(nn_distance_grad_ordered_kernel, dim3(b1 + b2, b), dim3(256), 0, s, n, m, xyz1, xyz2, grad_dist1,
+                       idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2, b1, uniform, uniform_scale);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }

@@ -51,10 +51,7 @@ class _NnDistance(torch.autograd.Function):
             grad_dist2 = torch.zeros((b, m), dtype=torch.float32, device=xyz1.device)
         g1 = _lib.empty_like(xyz1) if need1 else None
         g2 = _lib.empty_like(xyz2) if need2 else None
-        _lib.check(_lib.lib().cloudaae_nn_distance_grad(
-            b, n, ptr(xyz1), m, ptr(xyz2), ptr(grad_dist1.contiguous()), ptr(idx1),
-            ptr(grad_dist2.contiguous()), ptr(idx2), ptr(g1), ptr(g2), stream()),
-            "cloudaae_nn_distance_grad")
+        _grad(b, n, xyz1, m, xyz2, grad_dist1.contiguous(), idx1, grad_dist2.contiguous(), idx2, g1, g2)
         return g1, g2
 
 
@@ -71,8 +68,24 @@ output: idx2:  (batch_size,#point_2)   nearest neighbor from second to first
     return _NnDistance.apply(xyz1, xyz2)
 
 
-def nn_distance_grad(xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2):
-    """The NnDistanceGrad op itself (tf_nndistance.cpp:10-18): (grad_xyz1, grad_xyz2)."""
+def _grad(b, n, xyz1, m, xyz2, gd1, idx1, gd2, idx2, g1, g2, ordered=None):
+    """cloudaae_nn_distance_grad (fp32 atomics, as the reference's GPU kernel) or, in deterministic mode
+    (utils._functions.DETERMINISTIC, or ordered=True), cloudaae_nn_distance_grad_ordered: the summation order of
+    the reference's sequential CPU loops (tf_nndistance.cpp:126-163), bit for bit."""
+    from ...utils import _functions as F
+    if F.DETERMINISTIC if ordered is None else ordered:
+        _lib.check(_lib.lib().cloudaae_nn_distance_grad_ordered(
+            b, n, ptr(xyz1), m, ptr(xyz2), ptr(gd1), ptr(idx1), ptr(gd2), ptr(idx2), None, 1.0, ptr(g1), ptr(g2),
+            stream()), "cloudaae_nn_distance_grad_ordered")
+    else:
+        _lib.check(_lib.lib().cloudaae_nn_distance_grad(
+            b, n, ptr(xyz1), m, ptr(xyz2), ptr(gd1), ptr(idx1), ptr(gd2), ptr(idx2), ptr(g1), ptr(g2), stream()),
+            "cloudaae_nn_distance_grad")
+
+
+def nn_distance_grad(xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2, ordered=None):
+    """The NnDistanceGrad op itself (tf_nndistance.cpp:10-18): (grad_xyz1, grad_xyz2).  ordered=True: accumulated in
+    the order of the reference's CPU loops (bit-identical to them); default: the mode of utils._functions.DETERMINISTIC."""
     _check_cloud("xyz1", xyz1)
     _check_cloud("xyz2", xyz2)
     b, n, _ = xyz1.shape
@@ -86,8 +99,6 @@ def nn_distance_grad(xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2):
     xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
     g1 = _lib.empty_like(xyz1)
     g2 = _lib.empty_like(xyz2)
-    _lib.check(_lib.lib().cloudaae_nn_distance_grad(
-        b, n, ptr(xyz1), m, ptr(xyz2), ptr(grad_dist1.contiguous()), ptr(idx1.contiguous()),
-        ptr(grad_dist2.contiguous()), ptr(idx2.contiguous()), ptr(g1), ptr(g2), stream()),
-        "cloudaae_nn_distance_grad")
+    _grad(b, n, xyz1, m, xyz2, grad_dist1.contiguous(), idx1.contiguous(), grad_dist2.contiguous(), idx2.contiguous(),
+          g1, g2, ordered=ordered)
     return g1, g2

@@ -91,7 +91,7 @@ class TrainGraph(object):
 
     def __init__(self, general_opts=None, train_opts=None, hyperparameters=None, device=None,
                  model_fn='get_model_dgcnn_mean_6d', k_neighbor=K_NEIGHBOR, process_group=None, seed=123456789,
-                 replay=False, gemm_dtype='f32', side_stream=None, sync_bn=False):
+                 replay=False, gemm_dtype='f32', side_stream=None, sync_bn=False, deterministic=False):
         general_opts = dict(general_opts or {})
         train_opts = dict(train_opts or {})
         hyperparameters = dict(hyperparameters or {})
@@ -153,6 +153,13 @@ class TrainGraph(object):
         # HBM, batch norm, kNN, Chamfer, pose losses, Adam -- stays fp32 (BASELINE configs[2])
         require(gemm_dtype in ('f32', 'bf16'), "gemm_dtype must be 'f32' or 'bf16'")
         self.gemm_dtype = gemm_dtype
+        # deterministic=True: the whole step is bit-reproducible from run to run, as the reference's sequential CPU path
+        # is (tf_ops/nn_distance/tf_nndistance.cpp:21-43, 126-163).  The forward pass always is (every forward product is
+        # summed in a fixed order); this flag also takes the fp32 atomics out of the backward pass -- products whole over
+        # K, the fully connected stack through GEMM + batch norm, the Chamfer gradient in the reference's CPU order, sorted
+        # reverse neighbour lists -- at a price (measured: DESIGN.md).  One process, one mode: the library's knob is
+        # process-wide and set at every step.
+        self.deterministic = bool(deterministic)
         self.replay = bool(replay)
         self.reuse_staged_inputs = False
         self._plan = self._plan_key = self._plan_out = self._static = self._staged = None
@@ -179,14 +186,20 @@ class TrainGraph(object):
             early = (lo, n)
         self.exchange = GradExchange(self.store.flat_grads, early, self.pg, world=self.world, early_count=len(fc))
         # (with SyncBN the fully connected stack runs as product + batch norm, whose split-K products ADD)
+        self._set_mode()
         self._zero_limit = early[0] if (early is not None and F.fc_fits(self.local_batch) and not self.sync_bn) else None
         self.exchange.broadcast_params(self.store.flat_params)     # identical initial weights on every rank
         if early is not None and self.exchange.active:
             for v in fc:
                 v.on_ready = self.exchange.early_ready
 
+    def _set_mode(self):
+        F.DETERMINISTIC = self.deterministic
+        _lib.set_knob("CLOUDAAE_DETERMINISTIC", 1 if self.deterministic else None)
+
     def _call_model(self, pc, is_training):
         set_default_store(self.store)      # several graphs may live in one process (cf. tf.Graph.as_default)
+        self._set_mode()
         F.GEMM_DTYPE = self.gemm_dtype     # read by every dense layer's forward (its backward follows suit)
         F.BN_SYNC = self.bn_sync           # ... and by every batch norm's
         if self.is_pn:
@@ -373,6 +386,7 @@ class TrainGraph(object):
         return self._static
 
     def _planned_step(self, element):
+        self._set_mode()                   # (a replay reads the library's knob at every recorded call)
         static = self._stage_inputs(element)
         if self._plan is None:
             plan = _lib.StepPlan(self.device)

@@ -185,6 +185,14 @@ class LinearFn(torch.autograd.Function):
         return dx, gw.done(), gb_ret, None, None
 
 
+# Deterministic mode (TrainGraph(deterministic=True) sets it together with the library's CLOUDAAE_DETERMINISTIC knob): the
+# backward pass gives up its fp32 atomics -- the fully connected stack takes the GEMM + batch-norm route (the grouped
+# kernels add their dX slices with atomics), the Chamfer gradient is accumulated in the reference's CPU order
+# (cloudaae_nn_distance_grad_ordered) -- and, every product staying whole over K and the reverse neighbour lists being
+# sorted on the library's side, a training step is bit-reproducible from run to run, as the reference's CPU path is.
+DETERMINISTIC = False
+
+
 # An offer to the next fully_connected_chains call: (row vector [B, d], indices of the chains whose OUTPUT gets
 # out[b, c] += vec[b, c % d]) -- train_cloudAAE_ycbv.py:232-233's "+ element_mean" folded into the output layers'
 # epilogue.  The call that takes the offer sets this back to None (TrainGraph.forward looks at it afterwards).
@@ -193,7 +201,7 @@ FC_OUT_ADD = None
 
 def fc_fits(M):
     """Rows of a fully connected layer that the one-launch-per-direction kernels take."""
-    return 0 < M <= L().cloudaae_fc_max_rows()
+    return 0 < M <= L().cloudaae_fc_max_rows() and not DETERMINISTIC
 
 
 def fc_max_group():
@@ -834,6 +842,19 @@ class AddFn(torch.autograd.Function):
         return g, g
 
 
+def _chamfer_grad_uniform(b, n, pred, label, gscalar, i1, i2, g1, g2, zeroed):
+    """Chamfer gradient when every distance has the upstream gradient gscalar / (b n): fp32 atomics into zeroed
+    outputs, or (deterministic mode) the reference's CPU summation order without atomics."""
+    if DETERMINISTIC:
+        _lib.check(L().cloudaae_nn_distance_grad_ordered(b, n, ptr(pred), n, ptr(label), None, ptr(i1), None, ptr(i2),
+                                                         ptr(gscalar), 1.0 / (b * n), ptr(g1), ptr(g2), stream()),
+                   "cloudaae_nn_distance_grad_ordered")
+    else:
+        _lib.check(L().cloudaae_nn_distance_grad_uniform(
+            b, n, ptr(pred), n, ptr(label), ptr(gscalar), 1.0 / (b * n), ptr(i1), ptr(i2), ptr(g1), ptr(g2),
+            1 if zeroed else 0, stream()), "cloudaae_nn_distance_grad_uniform")
+
+
 class ChamferLossFn(torch.autograd.Function):
     """losses/chamfer_loss.py:8-14 as one node: nn_distance both ways, loss_per_sample = forward + backward
     distances, loss = their mean.  Returns (loss, loss_per_sample).  When only the loss is differentiated
@@ -875,17 +896,22 @@ class ChamferLossFn(torch.autograd.Function):
         if gper is None:
             rec = _lib.recording() is not None
             mk = (lambda t: _lib.zeros(t.shape, dtype=torch.float32, device=t.device)) if rec else _lib.empty_like
+            if DETERMINISTIC:
+                mk = _lib.empty_like
             g1 = mk(pred) if need1 else None
             g2 = mk(label) if need2 else None
-            _lib.check(L().cloudaae_nn_distance_grad_uniform(
-                b, n, ptr(pred), n, ptr(label), ptr(gloss.contiguous()), 1.0 / (b * n), ptr(i1), ptr(i2), ptr(g1),
-                ptr(g2), 1 if rec else 0, stream()), "cloudaae_nn_distance_grad_uniform")
+            _chamfer_grad_uniform(b, n, pred, label, gloss.contiguous(), i1, i2, g1, g2, rec)
             return g1, g2
         gd = gper.contiguous() if gloss is None else gper + gloss / (b * n)
         g1 = _lib.empty_like(pred) if need1 else None
         g2 = _lib.empty_like(label) if need2 else None
-        _lib.check(L().cloudaae_nn_distance_grad(b, n, ptr(pred), n, ptr(label), ptr(gd), ptr(i1), ptr(gd), ptr(i2),
-                                                 ptr(g1), ptr(g2), stream()), "cloudaae_nn_distance_grad")
+        if DETERMINISTIC:
+            _lib.check(L().cloudaae_nn_distance_grad_ordered(b, n, ptr(pred), n, ptr(label), ptr(gd), ptr(i1), ptr(gd),
+                                                             ptr(i2), None, 1.0, ptr(g1), ptr(g2), stream()),
+                       "cloudaae_nn_distance_grad_ordered")
+        else:
+            _lib.check(L().cloudaae_nn_distance_grad(b, n, ptr(pred), n, ptr(label), ptr(gd), ptr(i1), ptr(gd), ptr(i2),
+                                                     ptr(g1), ptr(g2), stream()), "cloudaae_nn_distance_grad")
         return g1, g2
 
 
@@ -1085,11 +1111,11 @@ class StepLossFn(torch.autograd.Function):
         if need1 or need2:
             rec = _lib.recording() is not None
             mk = (lambda t: _lib.zeros(t.shape, dtype=torch.float32, device=t.device)) if rec else _lib.empty_like
+            if DETERMINISTIC:
+                mk = _lib.empty_like
             g1 = mk(pred) if need1 else None
             g2 = mk(label) if need2 else None
-            _lib.check(L().cloudaae_nn_distance_grad_uniform(
-                b, n, ptr(pred), n, ptr(label), ptr(dxyz), 1.0 / (b * n), ptr(i1), ptr(i2), ptr(g1), ptr(g2),
-                1 if rec else 0, stream()), "cloudaae_nn_distance_grad_uniform")
+            _chamfer_grad_uniform(b, n, pred, label, dxyz, i1, i2, g1, g2, rec)
         return (g1, g2, dtp if ctx.needs_input_grad[2] else None, None, drp if ctx.needs_input_grad[4] else None,
                 None, None, None, None, None)
 

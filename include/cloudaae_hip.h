@@ -30,7 +30,12 @@ const char *cloudaae_last_error(void);
 /* Development knobs (kernel A/B choices and launch shapes for tests and sweeps; none is needed in normal use):
  * an integer per name, initialised from the environment variable of the same name the first time the library
  * looks at it (the library never reads the environment again), changed with these two calls.  Names are listed
- * in DESIGN.md ("Development knobs"), e.g. "CLOUDAAE_KNN_SCAN", "CLOUDAAE_NN_FILTER". */
+ * in DESIGN.md ("Development knobs"), e.g. "CLOUDAAE_KNN_SCAN", "CLOUDAAE_NN_FILTER".
+ * One knob is a MODE rather than a tuning aid: "CLOUDAAE_DETERMINISTIC" = 1 keeps every product of cloudaae_gemm_* whole
+ * over K (no slices added with atomics) and sorts the reverse neighbour lists of the edge convolution's backward pass;
+ * together with cloudaae_nn_distance_grad_ordered and the GEMM + batch-norm route for the fully connected stack (the
+ * host's choices: TrainGraph(deterministic=True)) a whole training step is then bit-reproducible from run to run, as
+ * the reference's sequential CPU path is. */
 int cloudaae_set_knob(const char *name, int value);
 int cloudaae_unset_knob(const char *name);
 /* HOST helper: CRC-32C (Castagnoli, reflected, init/final xor 0xffffffff) of n bytes of host memory -- the
@@ -72,6 +77,16 @@ int cloudaae_nn_distance_grad(int b, int n, const float *xyz1, int m, const floa
                               const float *grad_dist1, const int *idx1, const float *grad_dist2,
                               const int *idx2, float *grad_xyz1, float *grad_xyz2,
                               cloudaae_stream_t stream);
+/* The same gradients accumulated in the ORDER of the reference's sequential CPU loops (tf_nndistance.cpp:126-163:
+ * sweep over xyz1, then over xyz2), without atomics: bit-identical to that sweep and reproducible from run to run
+ * (the atomic kernels above agree with it to fp32 round-off only, as the reference's own GPU kernel does).
+ * uniform != NULL: every distance has the upstream gradient uniform[0] * uniform_scale (the mean of
+ * losses/chamfer_loss.py:13-14) and grad_dist1 / grad_dist2 are not read.  O(n m) index comparisons per cloud:
+ * about ten times the time of the atomic kernel -- the deterministic mode's choice. */
+int cloudaae_nn_distance_grad_ordered(int b, int n, const float *xyz1, int m, const float *xyz2,
+                                      const float *grad_dist1, const int *idx1, const float *grad_dist2,
+                                      const int *idx2, const float *uniform, float uniform_scale,
+                                      float *grad_xyz1, float *grad_xyz2, cloudaae_stream_t stream);
 /* The same when every distance has the SAME upstream gradient grad[0] * scale (the Chamfer loss is a mean
  * over them, losses/chamfer_loss.py:13-14): no per-point gradient arrays.  outputs_zeroed != 0: the caller
  * provides zero-filled outputs (otherwise the call clears them, as above). */

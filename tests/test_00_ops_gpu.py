@@ -35,6 +35,42 @@ def test_nn_distance_golden_bit_exact(hip, golden_dir, name):
     # atomics: summation order differs from the sequential CPU sweep -> fp32 tolerance
     np.testing.assert_allclose(gx1.cpu().numpy(), g["grad_xyz1"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(gx2.cpu().numpy(), g["grad_xyz2"], rtol=1e-5, atol=1e-6)
+    # the ordered kernel follows the sweep of tf_nndistance.cpp:126-163 term by term: the reference lines' own
+    # gradients (the fixtures were written by oracle/_ref), bit for bit
+    ox1, ox2 = tf_nndistance.nn_distance_grad(_dev(g["xyz1"]), _dev(g["xyz2"]), _dev(g["grad_dist1"]),
+                                              i1, _dev(g["grad_dist2"]), i2, ordered=True)
+    assert np.array_equal(ox1.cpu().numpy(), g["grad_xyz1"])
+    assert np.array_equal(ox2.cpu().numpy(), g["grad_xyz2"])
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 3, 1000), (3, 257, 255), (2, 4096, 4096), (2, 5000, 17), (5, 2100, 2049)])
+def test_nn_distance_grad_ordered_bit_exact(hip, oracle, b, n, m):
+    """cloudaae_nn_distance_grad_ordered = the reference's sequential gradient loops (tf_nndistance.cpp:126-163), bit for
+    bit: many queries share a nearest neighbour (duplicated targets, few candidates), so the ORDER of the additions
+    matters; per-point and uniform upstream gradients; a NULL output is skipped."""
+    from cloudaae_amd import _lib
+    from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
+    rng = np.random.default_rng(b * 1000 + n + m)
+    a = (rng.standard_normal((b, n, 3)) * 0.05 + [0.1, -0.2, 0.9]).astype(np.float32)
+    c = (rng.standard_normal((b, m, 3)) * 0.05 + [0.1, -0.2, 0.9]).astype(np.float32)
+    if m > 40:
+        c[:, m // 2:] = c[:, :m - m // 2]      # every target point twice (the reference's padded targets)
+    _, i1, _, i2 = oracle.nn_distance(a, c, threads=8)
+    w1, w2 = rng.standard_normal((b, n)).astype(np.float32), rng.standard_normal((b, m)).astype(np.float32)
+    want1, want2 = oracle.nn_distance_grad(a, c, w1, i1, w2, i2)
+    got1, got2 = tf_nndistance.nn_distance_grad(_dev(a), _dev(c), _dev(w1), _dev(i1), _dev(w2), _dev(i2), ordered=True)
+    assert np.array_equal(got1.cpu().numpy(), want1) and np.array_equal(got2.cpu().numpy(), want2)
+    # uniform upstream gradient u * scale for every distance, second output not wanted
+    u, scale = torch.full((), 0.37, device="cuda"), 1.0 / (b * n)
+    ones1 = np.full((b, n), np.float32(np.float32(0.37) * np.float32(scale)), np.float32)
+    ones2 = np.full((b, m), np.float32(np.float32(0.37) * np.float32(scale)), np.float32)
+    want1, _ = oracle.nn_distance_grad(a, c, ones1, i1, ones2, i2)
+    ad, cd, i1d, i2d = _dev(a), _dev(c), _dev(i1), _dev(i2)
+    out1 = torch.full((b, n, 3), float("nan"), device="cuda")
+    _lib.check(_lib.lib().cloudaae_nn_distance_grad_ordered(b, n, _lib.ptr(ad), m, _lib.ptr(cd), None, _lib.ptr(i1d), None,
+                                                            _lib.ptr(i2d), _lib.ptr(u), scale, _lib.ptr(out1), None,
+                                                            _lib.stream()), "grad_ordered")
+    assert np.array_equal(out1.cpu().numpy(), want1)
 
 
 @pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 3, 1000), (3, 257, 255), (4, 1024, 4096),
