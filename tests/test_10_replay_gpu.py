@@ -135,8 +135,8 @@ def test_deterministic_mode_is_bit_reproducible(hip, B, N, replay):
     """TrainGraph(deterministic=True): the WHOLE step -- forward, backward, optimiser -- gives the same bits from run to
     run, as the reference's sequential CPU path does (tf_nndistance.cpp:21-43, 126-163): two graphs from the same seed
     stepped three times on the same inputs end with identical weights, Adam slots and moving averages, eager or
-    replayed; and the mode changes the order of additions only: next to an ordinary graph the losses are identical
-    (the forward pass is the same code) and the gradients agree to round-off."""
+    replayed; and the mode changes the order of additions only (the fully connected stack takes its GEMM + batch-norm
+    route, no product is cut over K): next to an ordinary graph losses and gradients agree to round-off."""
     from cloudaae_amd import train_cloudAAE_ycbv as T
     mk = lambda det, rp: T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, replay=rp, deterministic=det)
     a, b_, plain = mk(True, replay), mk(True, False), mk(False, False)
@@ -156,7 +156,7 @@ def test_deterministic_mode_is_bit_reproducible(hip, B, N, replay):
         if step == 0:
             op = plain.train_step(el)
             for k in ("xyz_loss", "trans_loss", "axag_loss", "total_loss"):
-                assert float(op[k]) == float(ob[k]), k
+                assert abs(float(op[k]) - float(ob[k])) <= 1e-5 * max(1.0, abs(float(ob[k]))), k
             g1, g2 = plain.store.flat_grads, b_.store.flat_grads
             assert float((g1 - g2).abs().max()) <= 5e-3 * float(g1.abs().max())
     if replay:
