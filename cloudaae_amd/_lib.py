@@ -31,6 +31,7 @@ _SIGNATURES = {
     "cloudaae_gemm_bf16": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "cloudaae_gemm_f32_ordered": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P],
     "cloudaae_gemm_bf16_ordered": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P],
+    "cloudaae_gemm_f32_ordered_fold": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P],
     "cloudaae_gemm_f32_tn_group": [_I, _P, _P],
     "cloudaae_bn_forward": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P,
                             _P, _P, _P],

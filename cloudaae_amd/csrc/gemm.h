@@ -20,6 +20,6 @@ int gemm_bf16_launch(const char *name, int trans_a, int trans_b, int M, int N, i
 // ordered_ws (optional): room for splits * M * N floats; a product cut over K then keeps its slices apart and sums
 // them in slice order (bit-reproducible) instead of adding them with atomics.
 int gemm_slices_sum(const char *name, int M, int N, int splits, const float *ws, float *C, int ldc, const float *bias,
-                    hipStream_t stream);
+                    hipStream_t stream, int fold_shift = -1, int fold_rows = 0);
 
 } // namespace cloudaae

@@ -407,7 +407,8 @@ namespace cloudaae {
 
 // C[r][c] = ((ws[0][r][c] + ws[1][r][c]) + ... ) + bias[c]: the slices of a product cut over K, in slice order.
 __global__ __launch_bounds__(256) void gemm_slices_sum_kernel(long long total, int N, int splits, const float *__restrict__ ws,
-                                                              float *__restrict__ C, int ldc, const float *__restrict__ bias)
+                                                              float *__restrict__ C, int ldc, const float *__restrict__ bias,
+                                                              Fold fold)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total)
@@ -418,21 +419,21 @@ __global__ __launch_bounds__(256) void gemm_slices_sum_kernel(long long total, i
     const int r = (int)(i / N), c = (int)(i % N);
     if (bias != nullptr)
         v += bias[c];
-    C[(size_t)r * ldc + c] = v;
+    C[fold_off(r, c, ldc, fold)] = v;
 }
 
 int gemm_slices_sum(const char *name, int M, int N, int splits, const float *ws, float *C, int ldc, const float *bias,
-                    hipStream_t s)
+                    hipStream_t s, int fold_shift, int fold_rows)
 {
     const long long total = (long long)M * N;
     hipLaunchKernelGGL(gemm_slices_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, total, N, splits, ws,
-                       C, ldc, bias);
+                       C, ldc, bias, Fold{fold_shift, fold_rows});
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }
 
 // Tile shape and split-K slice count of a product (shared by the launcher and the query below).
-static void gemm_plan(int M, int N, int K, int &BM, int &BN, int &splits)
+static void gemm_plan(int M, int N, int K, int &BM, int &BN, int &splits, bool ordered = false)
 {
     // tile shape: small-batch FC rows -> 32-row tiles; narrow outputs -> 64 columns; a dimension
     // that is a multiple of 64 but not of 128 (the 320 concat channels of dgcnn_agg: dX has N = 320,
@@ -495,9 +496,9 @@ static void gemm_plan(int M, int N, int K, int &BM, int &BN, int &splits)
             splits = splits / 8 * 8;      // whole slices per XCD (the kernel then keeps a slice's tiles on one XCD)
         splits = CLOUDAAE_KNOB("CLOUDAAE_GEMM_SPLITS", splits);
     }
-    // deterministic mode (cloudaae_set_knob("CLOUDAAE_DETERMINISTIC", 1)): no product is cut over K, so none adds its
-    // slices with atomics -- the gradient products pay for it with idle CUs
-    if (CLOUDAAE_KNOB("CLOUDAAE_DETERMINISTIC", 0) != 0)
+    // deterministic mode (cloudaae_set_knob("CLOUDAAE_DETERMINISTIC", 1)): a product that would add its K slices with
+    // atomics stays whole (and pays with idle CUs); the slice-ordered variant (cloudaae_gemm_f32_ordered) keeps its cut
+    if (!ordered && CLOUDAAE_KNOB("CLOUDAAE_DETERMINISTIC", 0) != 0)
         splits = 1;
 }
 
@@ -541,7 +542,7 @@ int cloudaae::gemm_f32_launch(const char *name, int trans_a, int trans_b, int M,
     }
 
     int BM, BN, splits;
-    gemm_plan(M, N, K, BM, BN, splits);
+    gemm_plan(M, N, K, BM, BN, splits, ordered_ws != nullptr);
     const int tm = ceil_div(M, BM), tn = ceil_div(N, BN);
     CLOUDAAE_REQUIRE(tm <= 65535, name, "M too large");
     CLOUDAAE_REQUIRE(colstats == nullptr || (splits == 1 && accumulate == 0 && !fold_c), name,
@@ -555,17 +556,19 @@ int cloudaae::gemm_f32_launch(const char *name, int trans_a, int trans_b, int M,
     // ordered_ws: a product cut over K keeps its slices apart -- slice s stores its [M, N] result at
     // ordered_ws + s M N -- and a second kernel sums them in slice order (bit-reproducible, unlike the atomics)
     const bool ordered = ordered_ws != nullptr && splits > 1;
-    CLOUDAAE_REQUIRE(ordered_ws == nullptr || (accumulate == 0 && !fold_c && colstats == nullptr), name,
-                     "slice-ordered products overwrite an unfolded output");
+    CLOUDAAE_REQUIRE(ordered_ws == nullptr || (accumulate == 0 && colstats == nullptr), name,
+                     "slice-ordered products overwrite their output");
     float *const Cout = C;
     const int ldc_out = ldc;
     const float *const bias_out = bias;
     long long cslice = 0;
+    const Fold fc_out = fc;
     if (ordered) {
         C = ordered_ws;
         ldc = N;
         bias = nullptr;
         cslice = (long long)M * N;
+        fc = Fold{-1, 0};               // the slices are plain [M, N] blocks; the sum kernel folds the output
     } else if (splits > 1) {
         epi = EPI_ATOMIC;
         if (!accumulate) {  // slices add into a zeroed output
@@ -601,7 +604,7 @@ int cloudaae::gemm_f32_launch(const char *name, int trans_a, int trans_b, int M,
                                    vecA, vecB, fb, fc, colstats, cslice);
     CLOUDAAE_CHECK_LAUNCH(name);
     if (ordered) {
-        const int rc = gemm_slices_sum(name, M, N, splits, ordered_ws, Cout, ldc_out, bias_out, s);
+        const int rc = gemm_slices_sum(name, M, N, splits, ordered_ws, Cout, ldc_out, bias_out, s, fc_out.shift, fc_out.rows);
         if (rc != 0)
             return rc;
     }
@@ -618,7 +621,12 @@ CLOUDAAE_API int cloudaae_gemm_f32(int trans_a, int trans_b, int M, int N, int K
 
 CLOUDAAE_API long long cloudaae_gemm_f32_ordered_workspace(int M, int N, int K)
 {
-    const int splits = cloudaae_gemm_f32_splits(M, N, K);
+    if (M <= 0 || N <= 0 || K <= 0)
+        return 0;
+    int BM, BN, splits;
+    gemm_plan(M, N, K, BM, BN, splits, true);
+    const int kchunk = ceil_div(ceil_div(K, splits), GEMM_BK) * GEMM_BK;
+    splits = ceil_div(K, kchunk);
     return splits > 1 ? (long long)splits * M * N : 0;
 }
 
@@ -629,8 +637,23 @@ CLOUDAAE_API int cloudaae_gemm_f32_ordered(int trans_a, int trans_b, int M, int 
     const char *name = "cloudaae_gemm_f32_ordered";
     CLOUDAAE_REQUIRE(workspace != nullptr || cloudaae_gemm_f32_ordered_workspace(M, N, K) == 0, name,
                      "this product is cut over K: workspace needed");
+    static float dummy_ws;      // (a product that stays whole never touches it; non-NULL selects the ordered plan)
     return gemm_f32_launch(name, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, 0, 0, 0, (hipStream_t)stream,
-                           nullptr, workspace);
+                           nullptr, workspace != nullptr ? workspace : &dummy_ws);
+}
+
+// the same with the output's logical columns folded into stacked row blocks of width fold_c (0: none; the edge convolution's
+// [2*cin, cout] kernel addressed as [cin, 2*cout], see gemm.h): the deterministic mode's weight-gradient products
+CLOUDAAE_API int cloudaae_gemm_f32_ordered_fold(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                                                const float *B, int ldb, float *C, int ldc, int fold_c, float *workspace,
+                                                cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_gemm_f32_ordered_fold";
+    CLOUDAAE_REQUIRE(workspace != nullptr || cloudaae_gemm_f32_ordered_workspace(M, N, K) == 0, name,
+                     "this product is cut over K: workspace needed");
+    static float dummy_ws;      // (a product that stays whole never touches it; non-NULL selects the ordered plan)
+    return gemm_f32_launch(name, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, 0, fold_c,
+                           (hipStream_t)stream, nullptr, workspace != nullptr ? workspace : &dummy_ws);
 }
 
 CLOUDAAE_API int cloudaae_gemm_f32_colstats_parts(int M, int N, int K)

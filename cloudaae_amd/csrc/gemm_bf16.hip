@@ -289,7 +289,7 @@ static void launch_bf16(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N
 }
 
 // tile shape and K slices (same policy as gemm.hip's gemm_plan, slabs of 32)
-static void gemm_bf16_plan(int M, int N, int K, int &BM, int &BN, int &splits)
+static void gemm_bf16_plan(int M, int N, int K, int &BM, int &BN, int &splits, bool ordered = false)
 {
     // With bf16 operands these products are bound by what the CUs pull out of L2, so the side that is a multiple of
     // 160 but not of 128 (the 320 concat channels of dgcnn_agg: N of dX, M of dW) takes 160-wide tiles of five 32 x 32
@@ -329,7 +329,7 @@ static void gemm_bf16_plan(int M, int N, int K, int &BM, int &BN, int &splits)
         if (splits > 8)
             splits = splits / 8 * 8;      // whole slices per XCD
     }
-    if (CLOUDAAE_KNOB("CLOUDAAE_DETERMINISTIC", 0) != 0)     // deterministic mode: see gemm.hip
+    if (!ordered && CLOUDAAE_KNOB("CLOUDAAE_DETERMINISTIC", 0) != 0)     // deterministic mode: see gemm.hip
         splits = 1;
 }
 
@@ -369,7 +369,7 @@ int cloudaae::gemm_bf16_launch(const char *name, int trans_a, int trans_b, int M
         fc.rows = M;
     }
     int BM, BN, splits;
-    gemm_bf16_plan(M, N, K, BM, BN, splits);
+    gemm_bf16_plan(M, N, K, BM, BN, splits, ordered_ws != nullptr);
     const int tm = ceil_div(M, BM), tn = ceil_div(N, BN);
     CLOUDAAE_REQUIRE(tm <= 65535, name, "M too large");
     CLOUDAAE_REQUIRE(colstats == nullptr || (splits == 1 && accumulate == 0 && !fold_c), name,
@@ -441,7 +441,12 @@ CLOUDAAE_API int cloudaae_gemm_bf16(int trans_a, int trans_b, int M, int N, int 
 
 CLOUDAAE_API long long cloudaae_gemm_bf16_ordered_workspace(int M, int N, int K)
 {
-    const int splits = cloudaae_gemm_bf16_splits(M, N, K);
+    if (M <= 0 || N <= 0 || K <= 0)
+        return 0;
+    int BM, BN, splits;
+    gemm_bf16_plan(M, N, K, BM, BN, splits, true);
+    const int kchunk = ceil_div(ceil_div(K, splits), GB_BK) * GB_BK;
+    splits = ceil_div(K, kchunk);
     return splits > 1 ? (long long)splits * M * N : 0;
 }
 
@@ -452,8 +457,9 @@ CLOUDAAE_API int cloudaae_gemm_bf16_ordered(int trans_a, int trans_b, int M, int
     const char *name = "cloudaae_gemm_bf16_ordered";
     CLOUDAAE_REQUIRE(workspace != nullptr || cloudaae_gemm_bf16_ordered_workspace(M, N, K) == 0, name,
                      "this product is cut over K: workspace needed");
+    static float dummy_ws;      // (non-NULL selects the ordered plan; a product that stays whole never touches it)
     return gemm_bf16_launch(name, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, 0, 0, 0, (hipStream_t)stream,
-                            nullptr, workspace);
+                            nullptr, workspace != nullptr ? workspace : &dummy_ws);
 }
 
 CLOUDAAE_API int cloudaae_gemm_bf16_colstats_parts(int M, int N, int K)

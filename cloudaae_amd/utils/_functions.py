@@ -104,14 +104,23 @@ SIDE_EDGE = True      # edge-convolution layers use it too (else only the dgcnn_
 SIDE_AGG = True       # the dgcnn_agg weight gradient uses it
 
 
-def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, accumulate=0, site=None, bf16=False, on=None):
+def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, accumulate=0, site=None, bf16=False, on=None, device=None):
     rec = TIMED_SITES.get(site) if site is not None else None
     if rec is not None:
         _lib.host(_mark, rec)
-    fn = L().cloudaae_gemm_bf16 if bf16 else L().cloudaae_gemm_f32
-    _lib.check(fn(int(ta), int(tb), M, N, K, A, lda, B, ldb, C, ldc, bias, int(accumulate),
-                  stream() if on is None else on),
-               "cloudaae_gemm_bf16" if bf16 else "cloudaae_gemm_f32")
+    if DETERMINISTIC and int(accumulate) != 1 and on is None and device is not None:
+        # deterministic mode: a product cut over K keeps its slices apart and sums them in slice order
+        # (cloudaae_gemm_*_ordered) instead of staying whole on a handful of CUs
+        wsq = L().cloudaae_gemm_bf16_ordered_workspace if bf16 else L().cloudaae_gemm_f32_ordered_workspace
+        n = int(wsq(M, N, K))
+        ws = _lib.empty(n, dtype=torch.float32, device=device) if n else None
+        fn = L().cloudaae_gemm_bf16_ordered if bf16 else L().cloudaae_gemm_f32_ordered
+        _lib.check(fn(int(ta), int(tb), M, N, K, A, lda, B, ldb, C, ldc, bias, ptr(ws), stream()), "cloudaae_gemm_ordered")
+    else:
+        fn = L().cloudaae_gemm_bf16 if bf16 else L().cloudaae_gemm_f32
+        _lib.check(fn(int(ta), int(tb), M, N, K, A, lda, B, ldb, C, ldc, bias, int(accumulate),
+                      stream() if on is None else on),
+                   "cloudaae_gemm_bf16" if bf16 else "cloudaae_gemm_f32")
     if rec is not None:
         _lib.host(_mark, rec)
 
@@ -171,10 +180,10 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx, acc = _gemm_out((M, K), N, x.device, ctx.bf16)
-            gemm(0, 1, M, K, N, dyp, lddy, ptr(w), N, ptr(dx), K, None, acc, bf16=ctx.bf16)
+            gemm(0, 1, M, K, N, dyp, lddy, ptr(w), N, ptr(dx), K, None, acc, bf16=ctx.bf16, device=x.device)
         gw = _ParamGrad(w, ctx.needs_input_grad[1])
         if gw.needed:
-            gemm(1, 0, K, N, M, xp, ldx, dyp, lddy, ptr(gw.buf), N, None, gw.gemm_acc, bf16=ctx.bf16)
+            gemm(1, 0, K, N, M, xp, ldx, dyp, lddy, ptr(gw.buf), N, None, gw.gemm_acc, bf16=ctx.bf16, device=x.device)
         gb_ret = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _ParamGrad(ctx.bvar, True)
@@ -513,7 +522,7 @@ class ConcatLinearFn(torch.autograd.Function):
         dcat = None
         if any(ctx.needs_input_grad[4:]):
             dcat = _lib.empty((M, Ktot), dtype=torch.float32, device=w.device)
-            gemm(0, 1, M, Ktot, N, ptr(dy), N, ptr(w), N, ptr(dcat), Ktot, bf16=ctx.bf16)
+            gemm(0, 1, M, Ktot, N, ptr(dy), N, ptr(w), N, ptr(dcat), Ktot, bf16=ctx.bf16, device=w.device)
             if ctx.slot is not None and ctx.cat is None:
                 ctx.slot.dcat = dcat
         gw = _ParamGrad(w, ctx.needs_input_grad[1])
@@ -521,7 +530,8 @@ class ConcatLinearFn(torch.autograd.Function):
             side = SIDE_STREAM if (gw.own is None and SIDE_AGG) else None   # (a returned gradient is consumed at once)
             if side is not None:
                 _lib.stream_wait(side, stream())                    # dy is complete
-            gemm(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.gemm_acc, bf16=ctx.bf16, on=side)
+            gemm(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.gemm_acc, bf16=ctx.bf16, on=side,
+                 device=w.device)
         gb_ret = None
         if ctx.bias_here and ctx.needs_input_grad[2]:
             gb = _ParamGrad(ctx.bvar, True)
@@ -757,12 +767,15 @@ class EdgeConvFn(torch.autograd.Function):
         # the weight gradient (nothing reads it before the optimiser) joins the other layers' in ONE grouped launch
         # at the end of the encoder's backward pass: alone it is a single wave of short split-K workgroups
         defer = (slot_r is not None and rev_ready and gw.needed and gw.own is None and not gw.accumulate and side is None
-                 and not ctx.bf16)
+                 and not ctx.bf16 and not DETERMINISTIC)
+        # deterministic mode: the weight gradient is issued here as a slice-ordered product (the kernel's own one would
+        # stay whole over the B*N rows of K on a few CUs)
+        det_dw = DETERMINISTIC and gw.needed and not gw.accumulate and not ctx.bf16 and side is None
         head = (B, N, k, cin, cout, x.data_ptr(), x.stride(1), ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
                 training, pool_mode, ptr(pq), ptr(save_mean), ptr(save_var),
                 fwd_out.data_ptr() if fwd_out is not None else None, fwd_out.stride(1) if fwd_out is not None else 0,
                 ptr(ties), dout.data_ptr(), dout.stride(1), ptr(dpq), ptr(rev), rev_ready, dx_ptr, lddx, acc_dx,
-                None if defer else ptr(gw.buf), 1 if (gw.needed and gw.gemm_acc == 2) else 0, ptr(gb.buf), ptr(gg.buf),
+                None if (defer or det_dw) else ptr(gw.buf), 1 if (gw.needed and gw.gemm_acc == 2) else 0, ptr(gb.buf), ptr(gg.buf),
                 ptr(gbe.buf), ptr(ctx.estats), int(ctx.bf16), ptr(ws))
         rec = TIMED_SITES.get("edgeconv")
         if rec is not None:
@@ -777,6 +790,12 @@ class EdgeConvFn(torch.autograd.Function):
         for g in shared:
             L().cloudaae_add_f32(g.buf.numel(), ptr(tmp[id(g)]), ptr(g.buf), ptr(tmp[id(g)]), stream())
             g.buf = tmp[id(g)]
+        if det_dw:
+            n_ws = int(L().cloudaae_gemm_f32_ordered_workspace(cin, 2 * cout, B * N))
+            ws2 = _lib.empty(n_ws, dtype=torch.float32, device=dev) if n_ws else None
+            _lib.check(L().cloudaae_gemm_f32_ordered_fold(1, 0, cin, 2 * cout, B * N, x.data_ptr(), x.stride(1), ptr(dpq),
+                                                          2 * cout, ptr(gw.buf), cout, cout, ptr(ws2), stream()),
+                       "cloudaae_gemm_f32_ordered_fold")
         if defer:
             # [dW_c | dW_n] = X^T [dP' | dQ] over the folded kernel (as cloudaae_edgeconv_backward would issue it)
             slot_r.dw_jobs.append(((cin, 2 * cout, B * N, x.data_ptr(), x.stride(1), ptr(dpq), 2 * cout, ptr(gw.buf), cout,

@@ -187,6 +187,11 @@ typedef struct cloudaae_gemm_tn_job {
     int zeroed;
 } cloudaae_gemm_tn_job;
 int cloudaae_gemm_f32_tn_group(int count, const cloudaae_gemm_tn_job *jobs, cloudaae_stream_t stream);
+/* cloudaae_gemm_f32_ordered with C's logical columns folded into stacked row blocks of width fold_c (as in
+ * cloudaae_gemm_tn_job; 0: none), no bias: the edge convolution's weight gradients in deterministic mode. */
+int cloudaae_gemm_f32_ordered_fold(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
+                                   const float *B, int ldb, float *C, int ldc, int fold_c, float *workspace,
+                                   cloudaae_stream_t stream);
 /* The same product with both operands rounded to bfloat16 (round to nearest even) on their way
  * to the matrix cores (v_mfma_f32_32x32x16_bf16), fp32 accumulate; A, B, C, bias stay fp32 in
  * memory, so the call is interchangeable with cloudaae_gemm_f32 (BASELINE configs[2]: bf16 MLPs). */
