@@ -191,16 +191,17 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype, kn):
             report.append((float(got.abs().max()) / ((1e-2 if bf16 else 1e-3) * gmax + 1e-3), nme, "zero-bias"))
             continue
         if bf16:
-            err, tol, how = _nrm(got, g), 1e-1, "L2"
+            err, tol, how = _nrm(got, g), 2e-2, "L2"          # (measured <= 3.2e-3)
         elif nme.startswith("dgcnn_output/"):
             # 4096 x 4096 Chamfer pairs per cloud: a few nearest-neighbour assignments sit on 1e-7 near-ties
             # and flip between the two implementations, which moves one point's whole gradient to another
             # column of this layer -- a discrete change for those columns, invisible in the norm
-            err, tol, how = _nrm(got, g), 1e-2, "L2"
+            err, tol, how = _nrm(got, g), 5e-3, "L2"           # (measured < 2e-3)
         else:
             encoder = nme.startswith("dgcnn") and nme.split("/")[0] in ("dgcnn1", "dgcnn2", "dgcnn3", "dgcnn4",
                                                                          "dgcnn_agg")
-            err, tol, how = _rel(got, g), (3e-3 if encoder else 1e-3), "max"
+            # measured at these sizes (profiles of round 3): encoder <= 6e-4, fully connected stack <= 5.6e-4
+            err, tol, how = _rel(got, g), (1.5e-3 if encoder else 1e-3), "max"
         report.append((err / tol, nme, "%s %.2e (tol %.0e)" % (how, err, tol)))
     report.sort(reverse=True)
     print("%s: gradient error / tolerance, worst five: %s" % (name, "; ".join("%s %.2f [%s]" % (n, r, h)
@@ -235,7 +236,7 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype, kn):
         den += float(du_ref.pow(2).sum())
     upd_err = (num / den) ** 0.5
     print("%s: relative L2 error of the parameter update vs the oracle's: %.2e" % (name, upd_err))
-    assert upd_err < (1e-1 if bf16 else 1e-2), upd_err
+    assert upd_err < (5e-2 if bf16 else 2e-3), upd_err      # (measured 1.7e-2 / 1.9e-4 ... 5.2e-4)
 
     # step scalars advanced by the optimiser kernel's last workgroup (step.hip: AdamTail)
     step1, b1p1, b2p1, decay1 = rep["scalars"]
