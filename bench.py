@@ -179,6 +179,25 @@ def chamfer_kernel_rate(batch, n, m, iters=20, distinct=None):
             "clouds/s": round(batch / sec, 1), "frac_of_matrix_pipe_bound": round(pairs / sec / bound, 4)}
 
 
+def fps_kernel_rate(batch, n, m, iters=5):
+    """Farthest point sampling n -> m (the op the inference path runs on the 4N reconstructed points,
+    evaluate_cloudAAE_ycbv.py:450): m - 1 dependent rounds, one workgroup per cloud -- a latency chain, priced per round."""
+    from cloudaae_amd.tf_ops.sampling import tf_sampling
+    g = torch.Generator(device="cuda").manual_seed(100)
+    x = torch.randn((batch, n, 3), generator=g, device="cuda")
+    for _ in range(2):
+        tf_sampling.farthest_point_sample(m, x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        tf_sampling.farthest_point_sample(m, x)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    return {"shape": "[%d,%d,3] -> %d" % (batch, n, m), "us_per_launch": round(sec * 1e6, 1),
+            "us_per_round": round(sec * 1e6 / max(m - 1, 1), 3), "clouds/s": round(batch / sec, 1)}
+
+
 def chamfer_train_rate(batch=32, n=16384, m=1024, iters=20):
     """The reference's own micro-benchmark, as it runs it (tf_ops/nn_distance/tf_nndistance.py:45-66):
     an SGD step on loss = sum(dist1) + sum(dist2) with xyz1 the variable, i.e. per iteration the forward
@@ -505,6 +524,7 @@ def main():
             line["chamfer_kernel"] = [chamfer_kernel_rate(B, 4 * N, 4 * N), chamfer_kernel_rate(32, 16384, 1024),
                                       chamfer_kernel_rate(B, 4 * N, 4 * N, distinct=N)]
             line["chamfer_reference_microbench"] = chamfer_train_rate()
+            line["fps_kernel"] = [fps_kernel_rate(B, 4 * N, N), fps_kernel_rate(1, 4 * N, N)]
             if args.cpu_batch > 0:
                 line["chamfer_kernel"][0]["cpu"] = chamfer_cpu_rate(4 * N, 4 * N)
         if world == 1 and args.cpu_batch > 0 and not args.step_only:
