@@ -128,14 +128,37 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// max of a 64-bit key over the wave, the same value in every lane.  Inside a row of 16 lanes the partner comes through
+// DPP (quad swaps, then the half-row and row mirrors: after the quad steps a quad is uniform, so the mirrors act as
+// "xor 4" and "xor 8"); the four row maxima are read as scalars (v_readlane) and meet on the scalar unit -- no trip
+// through the LDS crossbar (six ds_bpermute pairs in the shuffle version: most of a farthest-point-sampling round).
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 {
+    unsigned long long o;
+    o = dpp_u64<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = o > v ? o : v;
+    o = dpp_u64<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = o > v ? o : v;
+    o = dpp_u64<0x141>(v);      // row_half_mirror
+    v = o > v ? o : v;
+    o = dpp_u64<0x140>(v);      // row_mirror
+    v = o > v ? o : v;
+    unsigned long long best = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        unsigned long long o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
+    for (int row = 0; row < 4; ++row) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 16 * row);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 16 * row);
+        const unsigned long long r = ((unsigned long long)hi << 32) | lo;
+        best = r > best ? r : best;
     }
-    return v;
+    return best;
 }
 
 } // namespace cloudaae
