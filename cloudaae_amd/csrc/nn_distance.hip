@@ -384,17 +384,13 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
         const bool decided = g.s3 > g.s1 + margin;      // false for NaN / overflow as well
 
         // those two units in the reference's arithmetic: one per lane of the pair, 32 candidates each
-        // (unit = 2 * tile pair + lane half: rows 4h..4h+3, 8+4h.. of tiles 2p and 2p+1).  Usually already the SECOND
-        // best unit is out of the margin: then only the best one can hold the answer, and the two lanes share its 32
-        // candidates (half the exact evaluations: they are 30 % of the kernel at 1024 candidates per query).
+        // (unit = 2 * tile pair + lane half: rows 4h..4h+3, 8+4h.. of tiles 2p and 2p+1)
         unsigned kb = 0xffffffffu;
         int ki = 0x7fffffff;
-        const bool only_best = g.s2 > g.s1 + margin;
-        const int unit = (half && !only_best) ? g.u2 : g.u1;
+        const int unit = half ? g.u2 : g.u1;
         const int base = (unit >> 1) * 64 + 4 * (unit & 1);
-        const int s_lo = only_best ? 16 * half : 0, s_hi = only_best ? s_lo + 16 : 32;
 #pragma unroll 4
-        for (int s = s_lo; s < s_hi; ++s) {
+        for (int s = 0; s < 32; ++s) {
             const int k = base + (s & 3) + 8 * (s >> 2);
             if (k < cend) {
                 const float d = sqdist(to[3 * (size_t)k], to[3 * (size_t)k + 1], to[3 * (size_t)k + 2], qx[q],
