@@ -44,6 +44,16 @@ __device__ __forceinline__ size_t foldb_off(int r, int c, int ld, FoldB f)
     return (size_t)((c >> f.shift) * f.rows + r) * ld + (c & ((1 << f.shift) - 1));
 }
 
+// two floats -> two bfloat16 (round to nearest even) in one 32-bit word, lo first
+__device__ __forceinline__ unsigned pack2(float lo, float hi)
+{
+    const bf16x2 p = {(__bf16)lo, (__bf16)hi};
+    unsigned w;
+    __builtin_memcpy(&w, &p, 4);
+    asm volatile("" : "+v"(w));      // keep the pair packed (the compiler otherwise selects halves and re-packs)
+    return w;
+}
+
 // One operand slab: ROWS outer indices x 32 k.  KC: memory is [outer][k]; else [k][outer].
 template <int ROWS, bool KC>
 struct SlabB {
@@ -52,6 +62,17 @@ struct SlabB {
     static constexpr int ITEMS = KC ? ROWS * (GB_BK / 4) : (GB_BK / 2) * (ROWS / 4);
     static constexpr int PER = (ITEMS + GB_THREADS - 1) / GB_THREADS;
     float4v r0[PER], r1[KC ? 1 : PER];
+
+    // !KC items = 16 k-pairs x ROWS/4 groups of four outer indices.  A 32-bit LDS store is served per half wave over
+    // 32 banks, and the rows of one item are 4 * 20 dwords apart (a multiple of 16 banks): with the lanes of a half wave
+    // on 32 consecutive groups of ONE k-pair (the obvious, fully coalesced order) every store hit 2 banks, a 16-way
+    // conflict that cost more LDS cycles than the slab's MFMAs (the W operand of every forward product, both operands
+    // of every weight-gradient product).  Instead a half wave covers 4 k-pairs x 8 groups (still whole 128-byte
+    // lines of 8 consecutive groups per k row), and lane by lane the four rows are written in a rotated order
+    // ((oq >> 1) & 3): bank = 16 (oq & 1) + 20 ((i + rot) & 3) + kp mod 32 takes all 32 values.
+    static_assert(KC || ROWS % 32 == 0, "groups of 8 x 4 outer indices");
+    static __device__ __forceinline__ int item_kp(int it) { return ((it >> 5) & 3) * 4 + (it & 3); }
+    static __device__ __forceinline__ int item_oq(int it) { return (it >> 7) * 8 + ((it >> 2) & 7); }
 
     __device__ __forceinline__ float4v fetch4(const float *__restrict__ src, int avail, bool vec) const
     {
@@ -81,7 +102,7 @@ struct SlabB {
                     if (go < nouter && gk < kend)
                         a = fetch4(P + foldb_off(go, gk, ld, fold), kend - gk, vec);
                 } else {
-                    const int kp = it / (ROWS / 4), oq = it % (ROWS / 4);
+                    const int kp = item_kp(it), oq = item_oq(it);
                     const int gk = k0 + 2 * kp, go = outer0 + 4 * oq;
                     if (go < nouter) {
                         if (gk < kend)
@@ -97,6 +118,38 @@ struct SlabB {
         }
     }
 
+    // FAST path (whole tiles, whole slabs, 16-byte aligned rows, no fold: decided at launch): the slab is addressed
+    // as ONE wave-uniform pointer that advances per slab plus per-thread byte offsets computed once -- a load is a
+    // single global_load_dwordx4 with no bounds checks.  (The generic path spends ~400 scalar and vector instructions
+    // per slab on predicates and 64-bit addresses next to 8 MFMAs: with bf16 operands the matrix pipe is 16 x faster
+    // than with fp32 ones, and those instructions were what the dgcnn_agg products waited on.)
+    unsigned boff[PER];
+    __device__ __forceinline__ void fast_init(int ld)
+    {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int it = u * GB_THREADS + (int)threadIdx.x;
+            if (KC)
+                boff[u] = 4u * (unsigned)((it / (GB_BK / 4)) * ld + 4 * (it % (GB_BK / 4)));
+            else
+                boff[u] = 4u * (unsigned)(2 * item_kp(it) * ld + 4 * item_oq(it));
+        }
+    }
+    __device__ __forceinline__ void fast_load(const float *__restrict__ P0, int ld)
+    {
+        const char *base = reinterpret_cast<const char *>(P0);
+        const char *base1 = reinterpret_cast<const char *>(P0 + ld);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int it = u * GB_THREADS + (int)threadIdx.x;
+            if (ITEMS % GB_THREADS == 0 || it < ITEMS) {
+                r0[u] = *reinterpret_cast<const float4v *>(base + boff[u]);
+                if (!KC)
+                    r1[u] = *reinterpret_cast<const float4v *>(base1 + boff[u]);
+            }
+        }
+    }
+
     __device__ __forceinline__ void stage(__bf16 *__restrict__ lds) const
     {
 #pragma unroll
@@ -108,14 +161,21 @@ struct SlabB {
                     bf16x4 p = {(__bf16)r0[u].x, (__bf16)r0[u].y, (__bf16)r0[u].z, (__bf16)r0[u].w};
                     *reinterpret_cast<bf16x4 *>(lds + o * GB_LDK + 4 * kq) = p;
                 } else {
-                    const int kp = it / (ROWS / 4), oq = it % (ROWS / 4);
+                    const int kp = item_kp(it), oq = item_oq(it);
+                    // (packed first, rotated as 32-bit words: eight selects per item)
+                    const unsigned p0 = pack2(r0[u].x, r1[u].x), p1 = pack2(r0[u].y, r1[u].y),
+                                   p2 = pack2(r0[u].z, r1[u].z), p3 = pack2(r0[u].w, r1[u].w);
+                    // the four rows 4 oq .. 4 oq + 3 are written in the order (i + rot) & 3: see item_kp
+                    const int rot = (oq >> 1) & 3;
+                    const unsigned t0 = (rot & 1) ? p1 : p0, t1 = (rot & 1) ? p2 : p1, t2 = (rot & 1) ? p3 : p2,
+                                   t3 = (rot & 1) ? p0 : p3;
+                    const unsigned q0 = (rot & 2) ? t2 : t0, q1 = (rot & 2) ? t3 : t1, q2 = (rot & 2) ? t0 : t2,
+                                   q3 = (rot & 2) ? t1 : t3;
                     __bf16 *dst = lds + (4 * oq) * GB_LDK + 2 * kp;
-                    const bf16x2 p0 = {(__bf16)r0[u].x, (__bf16)r1[u].x}, p1 = {(__bf16)r0[u].y, (__bf16)r1[u].y},
-                                 p2 = {(__bf16)r0[u].z, (__bf16)r1[u].z}, p3 = {(__bf16)r0[u].w, (__bf16)r1[u].w};
-                    *reinterpret_cast<bf16x2 *>(dst) = p0;
-                    *reinterpret_cast<bf16x2 *>(dst + GB_LDK) = p1;
-                    *reinterpret_cast<bf16x2 *>(dst + 2 * GB_LDK) = p2;
-                    *reinterpret_cast<bf16x2 *>(dst + 3 * GB_LDK) = p3;
+                    *reinterpret_cast<unsigned *>(dst + ((0 + rot) & 3) * GB_LDK) = q0;
+                    *reinterpret_cast<unsigned *>(dst + ((1 + rot) & 3) * GB_LDK) = q1;
+                    *reinterpret_cast<unsigned *>(dst + ((2 + rot) & 3) * GB_LDK) = q2;
+                    *reinterpret_cast<unsigned *>(dst + ((3 + rot) & 3) * GB_LDK) = q3;
                 }
             }
         }
@@ -123,7 +183,7 @@ struct SlabB {
 };
 
 // C[M,N] (+)= bf16(op(A))[M,K] * bf16(op(B))[K,N] (+ bias[N]), fp32 accumulate
-template <int BM, int BN, int WM, int WN, bool TA, bool TB>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool FAST>
 __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int K, const float *__restrict__ A,
                                                                int lda, const float *__restrict__ B, int ldb,
                                                                float *__restrict__ C, int ldc,
@@ -168,22 +228,9 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
             for (int r = 0; r < 16; ++r)
                 acc[i][j][r] = 0.0f;
 
-    SA sa;
-    SB sb;
-    const FoldB nofold = {-1, 0};
-    sa.load(A, lda, m0, M, kbeg, kend, vecA != 0, nofold);
-    sb.load(B, ldb, n0, N, kbeg, kend, vecB != 0, foldB);
-
     const int fr = lane & 31, fk = lane >> 5;
-    for (int k0 = kbeg; k0 < kend; k0 += GB_BK) {
-        __syncthreads();
-        sa.stage(ldsA);
-        sb.stage(ldsB);
-        __syncthreads();
-        if (k0 + GB_BK < kend) {
-            sa.load(A, lda, m0, M, k0 + GB_BK, kend, vecA != 0, nofold);
-            sb.load(B, ldb, n0, N, k0 + GB_BK, kend, vecB != 0, foldB);
-        }
+    // the slab in LDS times the accumulators: two MFMA k-steps
+    auto multiply = [&]() {
 #pragma unroll
         for (int s = 0; s < GB_BK / 16; ++s) {
             bf16x8 a[TM], b[TN];
@@ -198,6 +245,50 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (FAST) {
+        // wave-uniform slab origins, advanced by one slab per iteration
+        const float *pa = A + (TA ? (size_t)kbeg * lda + m0 : (size_t)m0 * lda + kbeg);
+        const float *pb = B + (TB ? (size_t)n0 * ldb + kbeg : (size_t)kbeg * ldb + n0);
+        const size_t stepa = TA ? (size_t)GB_BK * lda : (size_t)GB_BK;
+        const size_t stepb = TB ? (size_t)GB_BK : (size_t)GB_BK * ldb;
+        SA sa;
+        SB sb;
+        sa.fast_init(lda);
+        sb.fast_init(ldb);
+        sa.fast_load(pa, lda);
+        sb.fast_load(pb, ldb);
+        for (int k0 = kbeg; k0 < kend; k0 += GB_BK) {
+            __syncthreads();
+            sa.stage(ldsA);
+            sb.stage(ldsB);
+            __syncthreads();
+            if (k0 + GB_BK < kend) {
+                pa += stepa;
+                pb += stepb;
+                sa.fast_load(pa, lda);
+                sb.fast_load(pb, ldb);
+            }
+            multiply();
+        }
+    } else {
+        SA sa;
+        SB sb;
+        const FoldB nofold = {-1, 0};
+        sa.load(A, lda, m0, M, kbeg, kend, vecA != 0, nofold);
+        sb.load(B, ldb, n0, N, kbeg, kend, vecB != 0, foldB);
+        for (int k0 = kbeg; k0 < kend; k0 += GB_BK) {
+            __syncthreads();
+            sa.stage(ldsA);
+            sb.stage(ldsB);
+            __syncthreads();
+            if (k0 + GB_BK < kend) {
+                sa.load(A, lda, m0, M, k0 + GB_BK, kend, vecA != 0, nofold);
+                sb.load(B, ldb, n0, N, k0 + GB_BK, kend, vecB != 0, foldB);
+            }
+            multiply();
         }
     }
 
@@ -217,7 +308,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                    if (row < M) {
+                    if (FAST || row < M) {
                         const double v = (double)(acc[i][j][r] + bv);
                         s1 += v;
                         s2 += v * v;
@@ -241,6 +332,29 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
                 colstats[((size_t)(m0 / BM) * 2 + which) * N + n0 + cl] = v;
             }
         }
+    }
+    if (FAST) {
+        // whole tile, unfolded output: one per-lane pointer, wave-uniform row offsets
+        float *c0 = C + (size_t)(m0 + wm * TM * 32 + 4 * fk) * ldc + (n0 + wn * TN * 32 + fr);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float bv = add_bias ? bias[n0 + (wn * TN + j) * 32 + fr] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float *dst = c0 + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32;
+                    const float v = acc[i][j][r] + bv;
+                    if (epilogue == GB_STORE)
+                        *dst = v;
+                    else if (epilogue == GB_ACCUM)
+                        *dst = *dst + v;
+                    else
+                        atomicAdd(dst, v);
+                }
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -268,24 +382,40 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
     }
 }
 
+template <int BM, int BN, int WM, int WN, bool FAST>
+static void launch_bf16_as(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A, int lda,
+                           const float *B, int ldb, float *C, int ldc, const float *bias, int epi, int kchunk,
+                           int vecA, int vecB, FoldB fb, FoldB fc, double *cs, long long cslice)
+{
+    dim3 block(GB_THREADS);
+    if (!ta && !tb)
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, false, FAST>), grid, block, 0, s, M, N, K, A, lda,
+                           B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
+    else if (!ta && tb)
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true, FAST>), grid, block, 0, s, M, N, K, A, lda,
+                           B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
+    else if (ta && !tb)
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, false, FAST>), grid, block, 0, s, M, N, K, A, lda,
+                           B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
+    else
+        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true, FAST>), grid, block, 0, s, M, N, K, A, lda,
+                           B, ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_bf16(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N, int K, const float *A, int lda,
                         const float *B, int ldb, float *C, int ldc, const float *bias, int epi, int kchunk,
                         int vecA, int vecB, FoldB fb, FoldB fc, double *cs, long long cslice)
 {
-    dim3 block(GB_THREADS);
-    if (!ta && !tb)
-        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
-    else if (!ta && tb)
-        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
-    else if (ta && !tb)
-        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
+    // whole tiles, whole slabs in every K slice, 16-byte aligned rows, no folded operand: the lean loop
+    const bool fast = M % BM == 0 && N % BN == 0 && K % GB_BK == 0 && vecA && vecB && fb.shift < 0 && fc.shift < 0 &&
+                      CLOUDAAE_KNOB("CLOUDAAE_BF16_FAST", 1) != 0;
+    if (fast)
+        launch_bf16_as<BM, BN, WM, WN, true>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA,
+                                             vecB, fb, fc, cs, cslice);
     else
-        hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, bias, epi, kchunk, vecA, vecB, fb, fc, cs, cslice);
+        launch_bf16_as<BM, BN, WM, WN, false>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA,
+                                              vecB, fb, fc, cs, cslice);
 }
 
 // tile shape and K slices (same policy as gemm.hip's gemm_plan, slabs of 32)

@@ -8,7 +8,8 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
-         "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT"; do
+         "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" \
+         ${PMC_EXTRA:+"$PMC_EXTRA"}; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $C -d "$OUT/p$i" -o p -- "$@" > "$OUT/p$i.log" 2>&1
 done
@@ -25,4 +26,4 @@ for db in glob.glob(out + "/p*/**/*_results.db", recursive=True):
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
-rm -rf "$OUT"/p1 "$OUT"/p2
+rm -rf "$OUT"/p1 "$OUT"/p2 "$OUT"/p3
