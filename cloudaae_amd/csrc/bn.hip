@@ -312,36 +312,6 @@ __global__ __launch_bounds__(256) void bn_bwd_colsum_kernel(BnBwdArgs a, double 
     }
 }
 
-// Mean pool over groups of `rows` rows with nothing else consuming the activation: the upstream gradient
-// of every row of group g is the same number dpooled[g][c] / rows (times the ReLU mask), so the column
-// sums the backward pass starts with are that number times what the FORWARD apply pass counted per group
-// (rows passing the ReLU, sum of their x_hat, sum of all x_hat).  One partial-sum row per group replaces a
-// pass over y (134 MB for dgcnn_agg).
-__global__ __launch_bounds__(256) void bn_bwd_pool_partials_kernel(int C, int groups, int rows,
-                                                                  const float *__restrict__ dpooled,
-                                                                  const double *__restrict__ pool_stats,
-                                                                  double *__restrict__ partial)
-{
-    // grid.y = parts <= BN_MAX_PARTS partial-sum rows; part p takes the groups p, p + parts, ... (a batch of more
-    // than 128 clouds per GPU: BASELINE configs[2] runs 256)
-    const int c = blockIdx.x * 256 + threadIdx.x, parts = gridDim.y;
-    if (c >= C)
-        return;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int g = blockIdx.y; g < groups; g += parts) {
-        const double gv = (double)(dpooled[(size_t)g * C + c] / (float)rows);
-        const double *ps = pool_stats + (size_t)g * 3 * C + c;
-        s0 += gv * ps[0];
-        s1 += gv * ps[C];
-        s2 += ps[2 * (size_t)C];
-    }
-    partial[((size_t)blockIdx.y * 2 + 0) * C + c] = s0;
-    partial[((size_t)blockIdx.y * 2 + 1) * C + c] = s1;
-    double *p3 = partial + (size_t)BN_MAX_PARTS * 2 * C;
-    p3[((size_t)blockIdx.y * 2 + 0) * C + c] = s2;
-    p3[((size_t)blockIdx.y * 2 + 1) * C + c] = 0.0;
-}
-
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a, const float *__restrict__ m12,
                                                           float *__restrict__ dy, int lddy, int slab)
 {

@@ -6,6 +6,7 @@ store's flat gradient buffer (first write of a backward pass stores, later ones 
 and `None` is returned to autograd.  Foreign tensors get ordinary returned gradients.
 """
 import ctypes
+import os
 
 import torch
 
@@ -88,6 +89,20 @@ GEMM_DTYPE = "f32"
 # SyncBN (utils/sync_bn.BnSync) or None: read when a batch-norm layer's FORWARD runs in training mode; its
 # backward follows suit.  With it set, moments and backward means are over the batch of ALL ranks.
 BN_SYNC = None
+
+
+# With bf16 dense-layer operands (GEMM_DTYPE "bf16"): keep the widest activations of the step -- the concatenated
+# encoder features, dgcnn_agg's output y and its gradient -- in HBM as bfloat16 (csrc/gemm_b16.hip, bn16.hip).  The
+# products see the values they would have rounded to anyway; the one new rounding point is the stored y.  Off in
+# deterministic mode and under SyncBN (those take the fp32-storage kernels).
+ACT_BF16 = os.environ.get("CLOUDAAE_ACT_BF16", "1") != "0"
+
+
+def to_bf16(t):
+    """bfloat16 copy (round to nearest even) of a contiguous fp32 tensor whose element count is a multiple of 8."""
+    out = _lib.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    _lib.check(L().cloudaae_to_bf16(t.numel(), t.data_ptr(), out.data_ptr(), stream()), "cloudaae_to_bf16")
+    return out
 
 
 def gemm_is_bf16():
@@ -487,8 +502,32 @@ class ConcatLinearFn(torch.autograd.Function):
             xp, ldx = cat.data_ptr(), Ktot
             ctx.cat = cat
         N = w.shape[1]
-        y = _lib.empty((M, N), dtype=torch.float32, device=w.device)
         ctx.bf16 = gemm_is_bf16()
+        ctx.x16 = ctx.w16 = None
+        if (ctx.bf16 and ACT_BF16 and not DETERMINISTIC and BN_SYNC is None and int(bias_grad_by_bn) & 2 and
+                xp % 16 == 0 and w.is_contiguous() and N % 256 == 0 and
+                int(L().cloudaae_gemm_b16_colstats_parts(M, N, Ktot)) > 0 and
+                L().cloudaae_gemm_b16_supported(0, 1, M, Ktot, N) and L().cloudaae_gemm_b16_supported(1, 0, Ktot, N, M)):
+            # activations in bf16: x, W rounded once, y stored as bf16, column sums from the fp32 accumulators
+            parts = int(L().cloudaae_gemm_b16_colstats_parts(M, N, Ktot))
+            x16 = _lib.empty((M, Ktot), dtype=torch.bfloat16, device=w.device)
+            _lib.check(L().cloudaae_to_bf16(M * Ktot, xp, x16.data_ptr(), stream()), "cloudaae_to_bf16")
+            w16 = to_bf16(w)
+            y = _lib.empty((M, N), dtype=torch.bfloat16, device=w.device)
+            ws = _lib.empty(parts * 2 * N, dtype=torch.float64, device=w.device)
+            rec = TIMED_SITES.get("agg_fwd")
+            if rec is not None:
+                _lib.host(_mark, rec)
+            _lib.check(L().cloudaae_gemm_b16(0, 0, M, N, Ktot, x16.data_ptr(), Ktot, w16.data_ptr(), N, y.data_ptr(), N, 1,
+                                             ptr(b) if b is not None else None, 0, ptr(ws), stream()), "cloudaae_gemm_b16")
+            if rec is not None:
+                _lib.host(_mark, rec)
+            y._cloudaae_colstats = (ws, parts, M, N)
+            ctx.x16, ctx.w16 = x16, w16
+            ctx.save_for_backward(w, *nets)
+            ctx.widths, ctx.xp, ctx.bvar = widths, xp, b
+            return y
+        y = _lib.empty((M, N), dtype=torch.float32, device=w.device)
         # bias_grad_by_bn & 2: a training-mode batch norm consumes y next -- the product leaves the column
         # sums of its tiles in the batch norm's workspace and the statistics pass over y is skipped
         parts_fn = L().cloudaae_gemm_bf16_colstats_parts if ctx.bf16 else L().cloudaae_gemm_f32_colstats_parts
@@ -518,6 +557,8 @@ class ConcatLinearFn(torch.autograd.Function):
         M = nets[0].shape[0]
         Ktot, N = w.shape
         dy = dy.contiguous()
+        if ctx.x16 is not None:
+            return ConcatLinearFn._backward16(ctx, dy, w, M, Ktot, N)
         xp = ctx.cat.data_ptr() if ctx.cat is not None else ctx.xp
         dcat = None
         if any(ctx.needs_input_grad[4:]):
@@ -544,6 +585,36 @@ class ConcatLinearFn(torch.autograd.Function):
             grads.append(dcat[:, off:off + wd] if (dcat is not None and ctx.needs_input_grad[4 + i]) else None)
             off += wd
         return (None, gw.done(), gb_ret, None) + tuple(grads)
+
+
+def _concat_linear_backward16(ctx, dy, w, M, Ktot, N):
+    """ConcatLinearFn.backward with bf16 storage: dy, x and W are bfloat16 in memory (csrc/gemm_b16.hip)."""
+    require(dy.dtype == torch.bfloat16, "ConcatLinearFn: a bfloat16 output takes a bfloat16 gradient")
+    dcat = None
+    if any(ctx.needs_input_grad[4:]):
+        dcat = _lib.empty((M, Ktot), dtype=torch.float32, device=w.device)
+        _lib.check(L().cloudaae_gemm_b16(0, 1, M, Ktot, N, dy.data_ptr(), N, ctx.w16.data_ptr(), N, dcat.data_ptr(), Ktot,
+                                         0, None, 0, None, stream()), "cloudaae_gemm_b16")
+        if ctx.slot is not None and ctx.cat is None:
+            ctx.slot.dcat = dcat
+    gw = _ParamGrad(w, ctx.needs_input_grad[1])
+    if gw.needed:
+        side = SIDE_STREAM if (gw.own is None and SIDE_AGG) else None
+        if side is not None:
+            _lib.stream_wait(side, stream())                    # dy is complete
+        _lib.check(L().cloudaae_gemm_b16(1, 0, Ktot, N, M, ctx.x16.data_ptr(), Ktot, dy.data_ptr(), N, ptr(gw.buf), N, 0,
+                                         None, gw.gemm_acc, None, stream() if side is None else side),
+                   "cloudaae_gemm_b16")
+    require(not (ctx.bias_here and ctx.needs_input_grad[2]), "ConcatLinearFn: with bf16 activations the batch norm "
+                                                             "writes the bias gradient")
+    grads, off = [], 0
+    for i, wd in enumerate(ctx.widths):
+        grads.append(dcat[:, off:off + wd] if (dcat is not None and ctx.needs_input_grad[4 + i]) else None)
+        off += wd
+    return (None, gw.done(), None, None) + tuple(grads)
+
+
+ConcatLinearFn._backward16 = staticmethod(_concat_linear_backward16)
 
 
 class BatchNormFn(torch.autograd.Function):
@@ -577,6 +648,21 @@ class BatchNormFn(torch.autograd.Function):
         if not (pre is not None and pre[2] == M and pre[3] == C and ldy == C and training):
             pre = None
         ws = _ws(L().cloudaae_bn_workspace_bytes(C), dev)
+        ctx.y16 = y.dtype == torch.bfloat16
+        if ctx.y16:
+            # y stored as bfloat16 by the product that made it (ConcatLinearFn with ACT_BF16): csrc/bn16.hip
+            require(pre is not None and pstats is not None and BN_SYNC is None,
+                    "BatchNormFn: a bfloat16 y takes the training-mode mean-pool path fed with the product's column sums")
+            _lib.check(L().cloudaae_bn_meanpool_forward16(
+                M, C, yp, ldy, ptr(gamma), ptr(beta), ptr(decay), ptr(ema_mean), ptr(ema_var), ptr(save_mean),
+                ptr(save_var), int(pool_rows), ptr(pooled), ptr(pstats), ptr(ws), ptr(pre[0]), int(pre[1]), stream()),
+                "cloudaae_bn_meanpool_forward16")
+            ctx.sync = None
+            ctx.save_for_backward(y, gamma, beta, save_mean, save_var, pooled, ties)
+            ctx.pstats = pstats
+            ctx.cfg = (int(training), int(relu), int(pool_rows), int(pool_mode))
+            ctx.mark_non_differentiable(save_mean, save_var)
+            return pooled, save_mean, save_var
         ctx.sync = BN_SYNC if training else None
         if ctx.sync is not None:
             _lib.check(L().cloudaae_bn_forward_sync(
@@ -622,7 +708,7 @@ class BatchNormFn(torch.autograd.Function):
             dpooled = torch.zeros_like(pooled) if dpooled is None else dpooled.contiguous()
         if dout is None and pool_mode == 0:
             return (None,) * 12
-        dy = _lib.empty((M, C), dtype=torch.float32, device=y.device)
+        dy = _lib.empty((M, C), dtype=torch.bfloat16 if ctx.y16 else torch.float32, device=y.device)
         gg = _ParamGrad(gamma, ctx.needs_input_grad[1])
         gb = _ParamGrad(beta, ctx.needs_input_grad[2])
         glb = _ParamGrad(ctx.lin_bias, ctx.lin_bias is not None and ctx.needs_input_grad[11])
@@ -633,7 +719,13 @@ class BatchNormFn(torch.autograd.Function):
                 if not g.accumulate:
                     g.buf.zero_()
         ws = _ws(L().cloudaae_bn_workspace_bytes(C), y.device)
-        if ctx.sync is not None:
+        if ctx.y16:
+            require(dout is None and pool_mode == 1, "BatchNormFn: bfloat16 y is the mean-pool path")
+            _lib.check(L().cloudaae_bn_meanpool_backward16(
+                M, C, yp, ldy, ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_var), pool_rows, ptr(dpooled), dy.data_ptr(),
+                C, ptr(gg.buf), ptr(gb.buf), ptr(glb.buf), acc, ptr(ctx.pstats), ptr(ws), stream()),
+                "cloudaae_bn_meanpool_backward16")
+        elif ctx.sync is not None:
             _lib.check(L().cloudaae_bn_backward_sync(
                 M, C, yp, ldy, ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_var), training, relu, ptr(dout), C,
                 pool_rows, pool_mode, ptr(dpooled), ptr(pooled), ptr(ties), ptr(dy), C, ptr(gg.buf), ptr(gb.buf),

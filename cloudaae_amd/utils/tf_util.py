@@ -456,6 +456,8 @@ class LazyActivation(object):
         self.shape = tuple(shape)
 
     def tensor(self):
+        if self._y.dtype == torch.bfloat16:     # y was stored as bfloat16 (F.ACT_BF16): the fp32 kernel reads a widened copy
+            self._y = self._y.to(torch.float32)
         out, _, _ = F.BatchNormFn.apply(self._y, self._gamma, self._beta, self._mean, self._var, None, False, True,
                                         0, 0, True)
         return out.reshape(self.shape)

@@ -19,6 +19,8 @@
 #ifndef CLOUDAAE_HIP_H
 #define CLOUDAAE_HIP_H
 
+#include <stdint.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -209,6 +211,36 @@ int cloudaae_gemm_bf16_colstats_parts(int M, int N, int K);
 int cloudaae_gemm_bf16_colstats(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                                 const float *B, int ldb, float *C, int ldc, const float *bias, double *colstats,
                                 cloudaae_stream_t stream);
+
+/* ---- activations kept as bfloat16 in HBM (BASELINE configs[2]: "bf16 MLPs") --------------------------------------
+ * The same products as cloudaae_gemm_bf16 (conv2d 1x1 and its two gradient products, utils/tf_util.py:161-166) with
+ * operands that already ARE bfloat16 in memory (uint16_t = the upper half of the fp32 pattern, round to nearest
+ * even), fp32 accumulate; C is fp32, or bfloat16 when c_is_bf16 != 0.  Served: whole tiles only --
+ * cloudaae_gemm_b16_supported() says whether (trans_a, trans_b, M, N, K) is (K % 64 == 0, M and N multiples of the
+ * 128 / 160 tile sides, not both operands transposed); rows of A, B (and of a bf16 C) 16-byte aligned.
+ * colstats (optional, as cloudaae_gemm_f32_colstats, cloudaae_gemm_b16_colstats_parts(M, N, K) tile rows): column
+ * sums and sums of squares of the fp32 values C was rounded from.  accumulate: 0 overwrite, 1 add to C (fp32 C). */
+int cloudaae_gemm_b16_supported(int trans_a, int trans_b, int M, int N, int K);
+int cloudaae_gemm_b16_colstats_parts(int M, int N, int K);
+int cloudaae_gemm_b16(int trans_a, int trans_b, int M, int N, int K, const uint16_t *A, int lda, const uint16_t *B,
+                      int ldb, void *C, int ldc, int c_is_bf16, const float *bias, int accumulate, double *colstats,
+                      cloudaae_stream_t stream);
+/* dst[i] = bfloat16(src[i]) (round to nearest even), n a multiple of 8, both 16-byte aligned. */
+int cloudaae_to_bf16(long long n, const float *src, uint16_t *dst, cloudaae_stream_t stream);
+/* batch_norm_template + ReLU + reduce_mean over groups of pool_rows rows (models/pointnet_ycb_23_decoder_4.py:
+ * 410-419) in training mode on a bfloat16 y[M,C]: the moments come from `colstats` (the fp32 column sums the product
+ * left), the EMA shadows are updated, pooled[M/pool_rows, C] and pool_stats[M/pool_rows][3][C] are written as by
+ * cloudaae_bn_forward_colstats(pool_mode 1, relu).  C % 256 == 0, pool_rows % 64 == 0. */
+int cloudaae_bn_meanpool_forward16(int M, int C, const uint16_t *y, int ldy, const float *gamma, const float *beta,
+                                   const float *decay, float *ema_mean, float *ema_var, float *save_mean,
+                                   float *save_var, int pool_rows, float *pooled, double *pool_stats, void *workspace,
+                                   const double *colstats, int colstats_parts, cloudaae_stream_t stream);
+/* Its gradient: dy[M,C] (bfloat16) from dpooled[M/pool_rows, C]; dgamma / dbeta / dbias as cloudaae_bn_backward. */
+int cloudaae_bn_meanpool_backward16(int M, int C, const uint16_t *y, int ldy, const float *gamma, const float *beta,
+                                    const float *save_mean, const float *save_var, int pool_rows, const float *dpooled,
+                                    uint16_t *dy, int lddy, float *dgamma, float *dbeta, float *dbias,
+                                    int accumulate_param_grads, const double *pool_stats, void *workspace,
+                                    cloudaae_stream_t stream);
 
 /* batch_norm_template (utils/tf_util.py:473-511) on rows y[M,C] (+ ReLU), writing the
  * activation out[M,C] and/or its pool over groups of pool_rows consecutive rows

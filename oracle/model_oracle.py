@@ -63,14 +63,15 @@ class Vars(object):
 # --------------------------------------------------------------------------------------
 # utils/tf_util.py
 # --------------------------------------------------------------------------------------
-def batch_norm(x, scope, V, is_training, bn_decay):
-    """batch_norm_template, utils/tf_util.py:473-511, moments over all axes but the last."""
+def batch_norm(x, scope, V, is_training, bn_decay, stats_from=None):
+    """batch_norm_template, utils/tf_util.py:473-511, moments over all axes but the last.
+    stats_from: take the batch moments from this tensor instead of x (ACT_BF16: x is the bfloat16-stored copy of it)."""
     C = x.shape[-1]
     beta = V.get(scope + "/beta", (C,), "zeros")
     gamma = V.get(scope + "/gamma", (C,), "ones")
     sm = V.shadow(scope + "/moments/Squeeze/ExponentialMovingAverage", (C,))
     sv = V.shadow(scope + "/moments/Squeeze_1/ExponentialMovingAverage", (C,))
-    flat = x.reshape(-1, C)
+    flat = (x if stats_from is None else stats_from).reshape(-1, C)
     if is_training:
         mean = flat.mean(0)                                        # tf.nn.moments
         var = ((flat - mean.detach()) ** 2).mean(0)                # biased; stop_gradient(mean) inside
@@ -96,6 +97,21 @@ def batch_norm(x, scope, V, is_training, bn_decay):
 # then evaluated in the split form y_ij = (x_i Wc - x_i Wn + b) + x_j Wn, because rounding x_j - x_i
 # is not rounding x_j and x_i.
 GEMM_BF16 = False
+# ACT_BF16 = True (with GEMM_BF16, training mode): the output y of dgcnn_agg is STORED as bfloat16 -- the batch norm
+# takes its moments from the fp32 y and normalises the rounded copy, the gradient passes the rounding unchanged.
+# (The other bf16-stored tensors of that mode -- the concatenated features, W, dy -- are operands of products
+# that round them anyway, so they move no rounding point.)
+ACT_BF16 = False
+
+
+class _StoreBf16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
 
 
 def _bf(t):
@@ -135,14 +151,16 @@ def edge_conv_split(x, nn_idx, cout, scope, V, is_training, bn_decay):
     return torch.relu(y)
 
 
-def conv2d_1x1(x, cout, scope, V, bn, is_training, bn_decay, relu=True):
+def conv2d_1x1(x, cout, scope, V, bn, is_training, bn_decay, relu=True, store_bf16=False):
     """conv2d with a [1,1] kernel, utils/tf_util.py:111-179: matmul over the last axis + bias
     (+BN, +ReLU)."""
     cin = x.shape[-1]
     W = V.get(scope + "/weights", (1, 1, cin, cout), "xavier", fan=(cin, cout))
     b = V.get(scope + "/biases", (cout,), "zeros")
     y = mm(x, W.reshape(cin, cout)) + b
-    if bn:
+    if bn and store_bf16 and GEMM_BF16 and ACT_BF16 and is_training:
+        y = batch_norm(_StoreBf16.apply(y), scope + "/bn", V, is_training, bn_decay, stats_from=y)
+    elif bn:
         y = batch_norm(y, scope + "/bn", V, is_training, bn_decay)
     return torch.relu(y) if relu else y
 
@@ -237,7 +255,7 @@ def get_model_dgcnn_6d(point_cloud, is_training_pl_encoder, is_training, k_neigh
         nets.append(net)
         end_points["nn_idx%d" % (i + 1)] = nn_idx
     net = conv2d_1x1(torch.cat(nets, dim=-1), 1024, prefix + "dgcnn_agg", V, True, is_training_pl_encoder,
-                     bn_decay)
+                     bn_decay, store_bf16=True)
     end_points["layer_before_embedding"] = net
     net = red(net, 1)
     embedding = net.reshape(B, -1)

@@ -135,12 +135,12 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype, kn):
 
     # ---- free-running grouping: how often do the neighbour SETS differ when the oracle groups on its own? ----
     shadows = {k: v.clone() for k, v in V.s.items()}
-    MO.GEMM_BF16 = bf16
+    MO.GEMM_BF16 = MO.ACT_BF16 = bf16
     try:
         with torch.no_grad():
             free = MO.forward_losses(batch, V, N, True, decay0, kn)
     finally:
-        MO.GEMM_BF16 = False
+        MO.GEMM_BF16 = MO.ACT_BF16 = False
     for k, v in shadows.items():
         V.s[k].copy_(v)
     mismatch = []
@@ -167,11 +167,11 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype, kn):
 
     # ---- the oracle's iteration, grouped on the GPU's indices ----
     p0 = {n: p.detach().clone() for n, p in V.p.items()}
-    MO.GEMM_BF16 = bf16
+    MO.GEMM_BF16 = MO.ACT_BF16 = bf16       # (bf16 mode: dgcnn_agg's y is stored as bfloat16, F.ACT_BF16)
     try:
         ref, grads = MO.train_step(batch, V, opt, STEP0, N, B, k=kn, nn_override=rep["idx"])
     finally:
-        MO.GEMM_BF16 = False
+        MO.GEMM_BF16 = MO.ACT_BF16 = False
 
     ltol = 2e-3 if bf16 else 1e-5             # north star: fp32 Chamfer / pose losses within 1e-5
     for k in ("xyz_loss", "trans_loss", "axag_loss"):
