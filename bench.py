@@ -469,13 +469,19 @@ def main():
         }
         if args.gemm_dtype == "bf16":
             # with bf16 operands the same product leaves the matrix pipe (2.5 PFLOP/s dense) and is bound by
-            # HBM: activations in (M x 320), weights, fp32 output out (M x 1024)
-            nbytes = 4.0 * (M * K + K * Nn + Nn + M * Nn)
+            # HBM.  Activations kept as bfloat16 (F.ACT_BF16, the default): x (M x 320) and W in as bf16, y
+            # (M x 1024) out as bf16; else fp32 tensors in and out (rounded on the way into LDS)
+            from cloudaae_amd.utils import _functions as F_
+            act16 = bool(F_.ACT_BF16) and M % 128 == 0 and not args.sync_bn
+            esz = 2.0 if act16 else 4.0
+            nbytes = esz * (M * K + K * Nn + M * Nn) + 4.0 * Nn
             gbs = nbytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-            line["roofline"] = {"bound": "hbm", "kernel": "gemm_bf16_kernel<128,128,2,2> dgcnn_agg forward "
-                                                          "[%d x 320] x [320 x 1024]" % M,
+            kname = ("gemm_b16_kernel<128,128,2,2> (bf16 x, W in; bf16 y out)" if act16 else
+                     "gemm_bf16_kernel<128,128,2,2> (fp32 in / out)")
+            line["roofline"] = {"bound": "hbm", "kernel": kname + " dgcnn_agg forward [%d x 320] x [320 x 1024]" % M,
                                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(B, N, "agg_fwd_bf16"),
+                                "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                "traffic": measured_traffic(B, N, "agg_fwd_b16" if act16 else "agg_fwd_bf16"),
                                 "launch_ms": round(k_ms, 4), "launches_timed": k_n}
         # second roofline entry: the kNN over 64 feature channels (layers 2-4), the kernel furthest below its
         # bound.  Algorithmic flops = the N x N x 64 inner products of every cloud (2 N^2 C B), on the fp32
