@@ -504,7 +504,7 @@ class ConcatLinearFn(torch.autograd.Function):
         N = w.shape[1]
         ctx.bf16 = gemm_is_bf16()
         ctx.x16 = ctx.w16 = None
-        if (ctx.bf16 and ACT_BF16 and not DETERMINISTIC and BN_SYNC is None and int(bias_grad_by_bn) & 2 and
+        if (ctx.bf16 and ACT_BF16 and not DETERMINISTIC and BN_SYNC is None and (int(bias_grad_by_bn) & 6) == 6 and
                 xp % 16 == 0 and w.is_contiguous() and N % 256 == 0 and
                 int(L().cloudaae_gemm_b16_colstats_parts(M, N, Ktot)) > 0 and
                 L().cloudaae_gemm_b16_supported(0, 1, M, Ktot, N) and L().cloudaae_gemm_b16_supported(1, 0, Ktot, N, M)):

@@ -433,8 +433,11 @@ def conv2d_concat(inputs_list, num_output_channels, scope, bn_decay=None, is_tra
     w2._cloudaae_var = kernel
     # (flag 1: the batch norm writes the bias gradient; 2: it runs in training mode right after, so the
     # product leaves it the column sums of y)
-    y = F.ConcatLinearFn.apply(slot, w2, biases.data, 3 if is_training else 1, *rows)
     mode = {None: 0, 'mean': 1, 'max': 2}[pool]
+    # (flag 4: the consumer is the training-mode batch norm + ReLU + MEAN pool -- with bf16 operands the product may
+    # then keep y as bfloat16, F.ACT_BF16; csrc/bn16.hip pools groups that are multiples of 64 rows)
+    y = F.ConcatLinearFn.apply(slot, w2, biases.data, (3 if is_training else 1) | (4 if (is_training and mode == 1 and N % 64 == 0) else 0),
+                               *rows)
     if mode == 0:
         act, mean, var = F.BatchNormFn.apply(y, gamma.data, beta.data, ema_mean.data, ema_var.data,
                                              _decay_tensor(bn_decay), bool(is_training), True, 0, 0, True,

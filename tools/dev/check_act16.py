@@ -16,7 +16,7 @@ decay = torch.full((1,), 0.9, device="cuda")
 dpooled = torch.randn(B, C, generator=g).cuda()
 F.GEMM_DTYPE = "bf16"
 rows = [X[:, :64], X[:, 64:128], X[:, 128:192], X[:, 192:]]
-y = F.ConcatLinearFn.apply(None, W, b, 3, *rows)
+y = F.ConcatLinearFn.apply(None, W, b, 7, *rows)
 print("y dtype", y.dtype)
 pooled, sm, sv = F.BatchNormFn.apply(y, gamma, beta, em, ev, decay, True, True, N, 1, False, b)
 pooled.backward(dpooled)
