@@ -118,13 +118,16 @@ struct SlabB {
         }
     }
 
-    // FAST path (whole tiles, whole slabs, 16-byte aligned rows, no fold: decided at launch): the slab is addressed
+    // FAST path (whole tiles, whole slabs, 16-byte aligned rows: decided at launch): the slab is addressed
     // as ONE wave-uniform pointer that advances per slab plus per-thread byte offsets computed once -- a load is a
     // single global_load_dwordx4 with no bounds checks.  (The generic path spends ~400 scalar and vector instructions
     // per slab on predicates and 64-bit addresses next to 8 MFMAs: with bf16 operands the matrix pipe is 16 x faster
     // than with fp32 ones, and those instructions were what the dgcnn_agg products waited on.)
     unsigned boff[PER];
-    __device__ __forceinline__ void fast_init(int ld)
+    // fold (the B operand only; see FoldB): a k-contiguous operand folds over k and its slabs lie inside one fold block
+    // (checked at launch), so the fold only moves the slab origin (fast_origin); a [k][outer] operand folds over the outer
+    // index, a per-thread constant -- its offsets carry the tile origin outer0 and the slab origin is row k alone.
+    __device__ __forceinline__ void fast_init(int ld, FoldB fold, int outer0)
     {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -132,8 +135,13 @@ struct SlabB {
             if (KC)
                 boff[u] = 4u * (unsigned)((it / (GB_BK / 4)) * ld + 4 * (it % (GB_BK / 4)));
             else
-                boff[u] = 4u * (unsigned)(2 * item_kp(it) * ld + 4 * item_oq(it));
+                boff[u] = 4u * (unsigned)foldb_off(2 * item_kp(it), outer0 + 4 * item_oq(it), ld, fold);
         }
+    }
+    static __device__ __forceinline__ const float *fast_origin(const float *__restrict__ P, int ld, FoldB fold, int outer0,
+                                                               int k)
+    {
+        return KC ? P + foldb_off(outer0, k, ld, fold) : P + (size_t)k * ld;
     }
     __device__ __forceinline__ void fast_load(const float *__restrict__ P0, int ld)
     {
@@ -250,14 +258,14 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
 
     if (FAST) {
         // wave-uniform slab origins, advanced by one slab per iteration
-        const float *pa = A + (TA ? (size_t)kbeg * lda + m0 : (size_t)m0 * lda + kbeg);
-        const float *pb = B + (TB ? (size_t)n0 * ldb + kbeg : (size_t)kbeg * ldb + n0);
+        const FoldB nofold = {-1, 0};
+        const float *pa = SA::fast_origin(A, lda, nofold, m0, kbeg);
+        const float *pb = SB::fast_origin(B, ldb, foldB, n0, kbeg);
         const size_t stepa = TA ? (size_t)GB_BK * lda : (size_t)GB_BK;
-        const size_t stepb = TB ? (size_t)GB_BK : (size_t)GB_BK * ldb;
         SA sa;
         SB sb;
-        sa.fast_init(lda);
-        sb.fast_init(ldb);
+        sa.fast_init(lda, nofold, m0);
+        sb.fast_init(ldb, foldB, n0);
         sa.fast_load(pa, lda);
         sb.fast_load(pb, ldb);
         for (int k0 = kbeg; k0 < kend; k0 += GB_BK) {
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
             __syncthreads();
             if (k0 + GB_BK < kend) {
                 pa += stepa;
-                pb += stepb;
+                pb = SB::fast_origin(B, ldb, foldB, n0, k0 + GB_BK);
                 sa.fast_load(pa, lda);
                 sb.fast_load(pb, ldb);
             }
@@ -334,16 +342,18 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
         }
     }
     if (FAST) {
-        // whole tile, unfolded output: one per-lane pointer, wave-uniform row offsets
-        float *c0 = C + (size_t)(m0 + wm * TM * 32 + 4 * fk) * ldc + (n0 + wn * TN * 32 + fr);
+        // whole tile: one per-lane pointer per column, wave-uniform row offsets
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const float bv = add_bias ? bias[n0 + (wn * TN + j) * 32 + fr] : 0.0f;
+            const int col = n0 + (wn * TN + j) * 32 + fr;
+            // (a folded output keeps the rows of one column ldc apart: the fold only moves the column's origin)
+            float *c0 = C + foldb_off(m0 + wm * TM * 32 + 4 * fk, col, ldc, foldC);
+            const float bv = add_bias ? bias[col] : 0.0f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float *dst = c0 + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32;
+                    float *dst = c0 + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc;
                     const float v = acc[i][j][r] + bv;
                     if (epilogue == GB_STORE)
                         *dst = v;
@@ -407,8 +417,10 @@ static void launch_bf16(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N
                         const float *B, int ldb, float *C, int ldc, const float *bias, int epi, int kchunk,
                         int vecA, int vecB, FoldB fb, FoldB fc, double *cs, long long cslice)
 {
-    // whole tiles, whole slabs in every K slice, 16-byte aligned rows, no folded operand: the lean loop
-    const bool fast = M % BM == 0 && N % BN == 0 && K % GB_BK == 0 && vecA && vecB && fb.shift < 0 && fc.shift < 0 &&
+    // whole tiles, whole slabs in every K slice, 16-byte aligned rows: the lean loop
+    // (a folded k-contiguous B: every 32-wide slab inside one fold block)
+    const bool fold_ok = fb.shift < 0 || !tb || (1 << fb.shift) % GB_BK == 0;
+    const bool fast = M % BM == 0 && N % BN == 0 && K % GB_BK == 0 && vecA && vecB && fold_ok &&
                       CLOUDAAE_KNOB("CLOUDAAE_BF16_FAST", 1) != 0;
     if (fast)
         launch_bf16_as<BM, BN, WM, WN, true>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA,
