@@ -1,5 +1,7 @@
 #!/bin/bash
-# SQ counter passes over one program: bash tools/pmc_kernel.sh TAG KERNEL_SUBSTRING -- python3 prog.py args...
+# SQ counter passes over one program: bash tools/pmc_kernel.sh TAG KERNEL_SUBSTRING -- python3 /abs/path/prog.py args...
+# (the passes run from /tmp: give the program by absolute path, e.g. $GRAFT_REPO_ROOT/tools/dev/run_f32_agg.py 32 fwd;
+#  PMC_EXTRA="COUNTER ..." adds a third pass, e.g. TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; PAT=$2; shift 3
