@@ -52,6 +52,7 @@ _SIGNATURES = {
     "cloudaae_gemm_bf16_colstats": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P],
     "cloudaae_gemm_b16": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _P],
     "cloudaae_to_bf16": [ctypes.c_longlong, _P, _P, _P],
+    "cloudaae_gemm_bf16x3": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P],
     "cloudaae_bn_meanpool_forward16": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
     "cloudaae_bn_meanpool_backward16": [_I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P],
     "cloudaae_bn_forward_colstats": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P,
@@ -319,6 +320,10 @@ def lib():
         cdll.cloudaae_gemm_b16_colstats_parts.restype = ctypes.c_int
         cdll.cloudaae_gemm_b16_supported.argtypes = [_I, _I, _I, _I, _I]
         cdll.cloudaae_gemm_b16_supported.restype = ctypes.c_int
+        cdll.cloudaae_gemm_bf16x3_colstats_parts.argtypes = [_I, _I, _I]
+        cdll.cloudaae_gemm_bf16x3_colstats_parts.restype = ctypes.c_int
+        cdll.cloudaae_gemm_bf16x3_supported.argtypes = [_I, _I, _I, _I, _I]
+        cdll.cloudaae_gemm_bf16x3_supported.restype = ctypes.c_int
         for q in ("cloudaae_fc_max_rows", "cloudaae_fc_max_group"):
             getattr(cdll, q).argtypes = []
             getattr(cdll, q).restype = ctypes.c_int

@@ -71,7 +71,8 @@ def get_training_argparser():
                        'ycb_video_data_tfRecords/train_syn/ (:31-39); empty = synthetic batches')
     extra.add_argument('--restore', default='', help='checkpoint to resume from: a TensorFlow V2 prefix (model.ckpt) or an .npz')
     extra.add_argument('--ckpt_format', default='npz', choices=['npz', 'tf'], help="format of the epoch checkpoints")
-    extra.add_argument('--gemm_dtype', default='f32', help="f32, or bf16 = bf16 operands for the dense layers")
+    extra.add_argument('--gemm_dtype', default='f32', help="f32; bf16 = bf16 operands for the dense layers; bf16x3 = fp32 with the dgcnn_agg products as split "
+                            "products on the bf16 matrix cores (fp32 accuracy)")
     extra.add_argument('--print_every', type=int, default=1, help='print the losses every n batches (each print syncs)')
     return parser
 
@@ -151,7 +152,7 @@ class TrainGraph(object):
         # gemm_dtype='bf16': the per-point conv1x1 products (and their gradient products) round their operands
         # to bfloat16 on the way to the matrix cores, fp32 accumulate; everything else -- tensors in
         # HBM, batch norm, kNN, Chamfer, pose losses, Adam -- stays fp32 (BASELINE configs[2])
-        require(gemm_dtype in ('f32', 'bf16'), "gemm_dtype must be 'f32' or 'bf16'")
+        require(gemm_dtype in ('f32', 'bf16', 'bf16x3'), "gemm_dtype must be 'f32', 'bf16' or 'bf16x3'")
         self.gemm_dtype = gemm_dtype
         # deterministic=True: the whole step is bit-reproducible from run to run, as the reference's sequential CPU path
         # is (tf_ops/nn_distance/tf_nndistance.cpp:21-43, 126-163).  The forward pass always is (every forward product is

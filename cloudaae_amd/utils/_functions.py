@@ -106,8 +106,15 @@ def to_bf16(t):
 
 
 def gemm_is_bf16():
-    require(GEMM_DTYPE in ("f32", "bf16"), "GEMM_DTYPE must be 'f32' or 'bf16'")
+    require(GEMM_DTYPE in ("f32", "bf16", "bf16x3"), "GEMM_DTYPE must be 'f32', 'bf16' or 'bf16x3'")
     return GEMM_DTYPE == "bf16"
+
+
+def gemm_is_x3():
+    """GEMM_DTYPE "bf16x3" (opt-in): fp32 everywhere, but the three dgcnn_agg products run as split products on the bf16
+    matrix cores (csrc/gemm_x3.hip: every operand element = three bfloat16 pieces, six piece products, fp32 accumulate --
+    the accuracy of an fp32 product at 2.7 x less matrix-pipe time).  Off in deterministic mode."""
+    return GEMM_DTYPE == "bf16x3" and not DETERMINISTIC
 
 
 # Work nobody waits for until the optimiser runs (the weight-gradient products of the per-point layers) and
@@ -504,6 +511,7 @@ class ConcatLinearFn(torch.autograd.Function):
         N = w.shape[1]
         ctx.bf16 = gemm_is_bf16()
         ctx.x16 = ctx.w16 = None
+        ctx.x3 = False
         if (ctx.bf16 and ACT_BF16 and not DETERMINISTIC and BN_SYNC is None and (int(bias_grad_by_bn) & 6) == 6 and
                 xp % 16 == 0 and w.is_contiguous() and N % 256 == 0 and
                 int(L().cloudaae_gemm_b16_colstats_parts(M, N, Ktot)) > 0 and
@@ -528,6 +536,25 @@ class ConcatLinearFn(torch.autograd.Function):
             ctx.widths, ctx.xp, ctx.bvar = widths, xp, b
             return y
         y = _lib.empty((M, N), dtype=torch.float32, device=w.device)
+        ctx.x3 = (gemm_is_x3() and xp % 16 == 0 and w.is_contiguous() and
+                  bool(L().cloudaae_gemm_bf16x3_supported(0, 0, M, N, Ktot)) and
+                  bool(L().cloudaae_gemm_bf16x3_supported(0, 1, M, Ktot, N)) and
+                  bool(L().cloudaae_gemm_bf16x3_supported(1, 0, Ktot, N, M)))
+        if ctx.x3:
+            parts = int(L().cloudaae_gemm_bf16x3_colstats_parts(M, N, Ktot)) if int(bias_grad_by_bn) & 2 else 0
+            ws = _lib.empty(parts * 2 * N, dtype=torch.float64, device=w.device) if parts > 0 else None
+            rec = TIMED_SITES.get("agg_fwd")
+            if rec is not None:
+                _lib.host(_mark, rec)
+            _lib.check(L().cloudaae_gemm_bf16x3(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None,
+                                                0, ptr(ws), stream()), "cloudaae_gemm_bf16x3")
+            if rec is not None:
+                _lib.host(_mark, rec)
+            if parts > 0:
+                y._cloudaae_colstats = (ws, parts, M, N)
+            ctx.save_for_backward(w, *nets)
+            ctx.widths, ctx.xp, ctx.bvar = widths, xp, b
+            return y
         # bias_grad_by_bn & 2: a training-mode batch norm consumes y next -- the product leaves the column
         # sums of its tiles in the batch norm's workspace and the statistics pass over y is skipped
         parts_fn = L().cloudaae_gemm_bf16_colstats_parts if ctx.bf16 else L().cloudaae_gemm_f32_colstats_parts
@@ -563,7 +590,11 @@ class ConcatLinearFn(torch.autograd.Function):
         dcat = None
         if any(ctx.needs_input_grad[4:]):
             dcat = _lib.empty((M, Ktot), dtype=torch.float32, device=w.device)
-            gemm(0, 1, M, Ktot, N, ptr(dy), N, ptr(w), N, ptr(dcat), Ktot, bf16=ctx.bf16, device=w.device)
+            if ctx.x3:
+                _lib.check(L().cloudaae_gemm_bf16x3(0, 1, M, Ktot, N, ptr(dy), N, ptr(w), N, ptr(dcat), Ktot, None, 0, None,
+                                                    stream()), "cloudaae_gemm_bf16x3")
+            else:
+                gemm(0, 1, M, Ktot, N, ptr(dy), N, ptr(w), N, ptr(dcat), Ktot, bf16=ctx.bf16, device=w.device)
             if ctx.slot is not None and ctx.cat is None:
                 ctx.slot.dcat = dcat
         gw = _ParamGrad(w, ctx.needs_input_grad[1])
@@ -571,8 +602,12 @@ class ConcatLinearFn(torch.autograd.Function):
             side = SIDE_STREAM if (gw.own is None and SIDE_AGG) else None   # (a returned gradient is consumed at once)
             if side is not None:
                 _lib.stream_wait(side, stream())                    # dy is complete
-            gemm(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.gemm_acc, bf16=ctx.bf16, on=side,
-                 device=w.device)
+            if ctx.x3:
+                _lib.check(L().cloudaae_gemm_bf16x3(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.gemm_acc,
+                                                    None, stream() if side is None else side), "cloudaae_gemm_bf16x3")
+            else:
+                gemm(1, 0, Ktot, N, M, xp, Ktot, ptr(dy), N, ptr(gw.buf), N, None, gw.gemm_acc, bf16=ctx.bf16, on=side,
+                     device=w.device)
         gb_ret = None
         if ctx.bias_here and ctx.needs_input_grad[2]:
             gb = _ParamGrad(ctx.bvar, True)

@@ -212,6 +212,19 @@ int cloudaae_gemm_bf16_colstats(int trans_a, int trans_b, int M, int N, int K, c
                                 const float *B, int ldb, float *C, int ldc, const float *bias, double *colstats,
                                 cloudaae_stream_t stream);
 
+/* fp32 products on the bf16 matrix cores by error-free splitting (opt-in; `gemm_dtype = "bf16x3"` in the Python host):
+ * every operand element is split exactly into three bfloat16 pieces and the six piece products of weight >= 2^-16
+ * are accumulated in fp32 -- what is dropped is below 2^-23 of each product, the size of one fp32 rounding, so the
+ * result agrees with cloudaae_gemm_f32 at the level of an fp32 accumulation in another order -- at 2.7 x less matrix-pipe
+ * time (six 32-cycle bf16 MFMAs per 16 k against eight 64-cycle fp32 MFMAs).  Arguments as cloudaae_gemm_f32 plus the
+ * optional column sums of cloudaae_gemm_f32_colstats (cloudaae_gemm_bf16x3_colstats_parts tile rows).  Served: whole
+ * tiles of 128 / 160, K % 32 == 0, 16-byte aligned rows, not both operands transposed
+ * (cloudaae_gemm_bf16x3_supported); accumulate: 0 overwrite, 1 add, 2 add into a C the caller cleared. */
+int cloudaae_gemm_bf16x3_supported(int trans_a, int trans_b, int M, int N, int K);
+int cloudaae_gemm_bf16x3_colstats_parts(int M, int N, int K);
+int cloudaae_gemm_bf16x3(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
+                         float *C, int ldc, const float *bias, int accumulate, double *colstats, cloudaae_stream_t stream);
+
 /* ---- activations kept as bfloat16 in HBM (BASELINE configs[2]: "bf16 MLPs") --------------------------------------
  * The same products as cloudaae_gemm_bf16 (conv2d 1x1 and its two gradient products, utils/tf_util.py:161-166) with
  * operands that already ARE bfloat16 in memory (uint16_t = the upper half of the fp32 pattern, round to nearest

@@ -786,6 +786,58 @@ def test_gemm_b16(hip, ta, tb, M, N, K):
                 assert _rel(stats[0], Cd.sum(0)) < 1e-9 and _rel(stats[1], (Cd * Cd).sum(0)) < 1e-9
 
 
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 0, 4096, 1024, 320), (0, 0, 128, 128, 32), (0, 1, 4096, 320, 1024),
+                                         (0, 1, 256, 128, 96), (1, 0, 320, 1024, 32768), (1, 0, 128, 256, 640)])
+def test_gemm_bf16x3(hip, ta, tb, M, N, K):
+    """cloudaae_gemm_bf16x3: fp32 operands split exactly into three bfloat16 pieces, six piece products, fp32
+    accumulate.  Against the float64 product of the fp32 operands it must be as close as the fp32 MFMA kernel is (the
+    same 2e-5 / sqrt(K) bound as test_gemm, and within 2 x of cloudaae_gemm_f32's own error) -- NOT a bf16 product,
+    whose error on the same data is three orders larger; column sums and accumulation as the fp32 entry points."""
+    L = hip.lib()
+    assert L.cloudaae_gemm_bf16x3_supported(ta, tb, M, N, K) == 1
+    rng = np.random.default_rng(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = torch.from_numpy(rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)).cuda()
+    B = torch.from_numpy(rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).cuda()
+    Ad, Bd = A.double(), B.double()
+    want = (Ad.T if ta else Ad) @ (Bd.T if tb else Bd) + bias.double()
+    P = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    C3, C32, Cb = (torch.full((M, N), float("nan"), device="cuda") for _ in range(3))
+    parts = L.cloudaae_gemm_bf16x3_colstats_parts(M, N, K) if not (ta or tb) else 0
+    cs = torch.zeros(max(parts, 1) * 2 * N, dtype=torch.float64, device="cuda")
+    hip.check(L.cloudaae_gemm_bf16x3(ta, tb, M, N, K, P(A), A.shape[1], P(B), B.shape[1], P(C3), N, P(bias), 0,
+                                     P(cs) if parts else None, hip.stream()), "gemm_bf16x3")
+    hip.check(L.cloudaae_gemm_f32(ta, tb, M, N, K, P(A), A.shape[1], P(B), B.shape[1], P(C32), N, P(bias), 0, hip.stream()),
+              "gemm_f32")
+    hip.check(L.cloudaae_gemm_bf16(ta, tb, M, N, K, P(A), A.shape[1], P(B), B.shape[1], P(Cb), N, P(bias), 0, hip.stream()),
+              "gemm_bf16")
+    scale = np.sqrt(K) + 1
+    e3 = float((C3.double() - want).abs().max())
+    e32 = float((C32.double() - want).abs().max())
+    eb = float((Cb.double() - want).abs().max())
+    assert e3 / scale < 2e-5 and e3 <= 2.0 * e32 + 1e-6, (e3, e32)
+    if K >= 96:
+        assert eb > 100 * e3, (eb, e3)                  # a bf16 product is a different thing altogether
+    if parts:
+        stats = cs.reshape(parts, 2, N).sum(0)
+        Cd = C3.double()
+        assert _rel(stats[0], Cd.sum(0)) < 1e-9 and _rel(stats[1], (Cd * Cd).sum(0)) < 1e-9
+    hip.check(L.cloudaae_gemm_bf16x3(ta, tb, M, N, K, P(A), A.shape[1], P(B), B.shape[1], P(C3), N, None, 1, None,
+                                     hip.stream()), "gemm_bf16x3")
+    assert float((C3.double() - (2 * want - bias.double())).abs().max()) / scale < 4e-5
+
+
+def test_gemm_bf16x3_refuses_what_it_does_not_serve(hip):
+    L = hip.lib()
+    assert L.cloudaae_gemm_bf16x3_supported(0, 0, 100, 128, 32) == 0
+    assert L.cloudaae_gemm_bf16x3_supported(0, 0, 128, 128, 24) == 0
+    assert L.cloudaae_gemm_bf16x3_supported(1, 1, 128, 128, 32) == 0
+    a = torch.zeros(128, 128, device="cuda")
+    rc = L.cloudaae_gemm_bf16x3(0, 0, 100, 128, 32, a.data_ptr(), 32, a.data_ptr(), 128, a.data_ptr(), 128, None, 0, None,
+                                hip.stream())
+    assert rc != 0 and "not served" in L.cloudaae_last_error().decode()
+
+
 def test_gemm_b16_refuses_what_it_does_not_serve(hip):
     L = hip.lib()
     assert L.cloudaae_gemm_b16_supported(0, 0, 100, 128, 64) == 0         # partial row tile

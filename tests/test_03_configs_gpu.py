@@ -34,6 +34,9 @@ CONFIGS = [
     pytest.param("configs[1]", 32, 1024, "f32", 10, id="cfg1-B32-f32"),
     pytest.param("configs[3]/gpu", 128, 1024, "f32", 10, id="cfg3-B128-f32"),
     pytest.param("configs[2]", 256, 1024, "bf16", 10, id="cfg2-B256-bf16"),
+    # configs[1] with the three dgcnn_agg products as error-free 3 x bf16 splits on the bf16 matrix cores (opt-in,
+    # csrc/gemm_x3.hip): held to the fp32 tolerances against the fp32 oracle -- it is an fp32-accurate product
+    pytest.param("configs[1]/split products", 32, 1024, "bf16x3", 10, id="cfg1-B32-bf16x3"),
     # configs[4]'s network shape (N = 4096 points, k = 20 neighbours, a 16384-point Chamfer target) at a batch the CPU
     # oracle finishes in under a minute; 8 clouds = 1024 query tiles: the 16-wave kNN kernel with k = 20 and 128-slot
     # queues, the kernel bench.py --config5 runs
