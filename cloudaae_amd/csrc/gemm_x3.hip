@@ -32,12 +32,30 @@ constexpr int X3_THREADS = 256;
 enum { X3_STORE = 0, X3_ACCUM = 1, X3_ATOMIC = 2 };
 
 // v = h + m + l exactly (each a bfloat16, round to nearest even)
+__device__ __forceinline__ __bf16 top_half(float v)       // the upper 16 bits of v, as a bfloat16 (truncation)
+{
+    const unsigned short u = (unsigned short)(__float_as_uint(v) >> 16);
+    __bf16 b;
+    __builtin_memcpy(&b, &u, 2);
+    return b;
+}
 __device__ __forceinline__ void split3(float v, __bf16 &h, __bf16 &m, __bf16 &l)
 {
+#ifdef X3_TRUNCATE
+    // (experiment) pieces by truncation: v & 0xffff0000, exact remainders; four operations instead of seven per element
+    const float hf = __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+    const float r1 = v - hf;
+    const float mf = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    const float lf = r1 - mf;
+    h = top_half(hf);
+    m = top_half(mf);
+    l = top_half(lf);
+#else
     h = (__bf16)v;
     const float r1 = v - (float)h;
     m = (__bf16)r1;
     l = (__bf16)(r1 - (float)m);
+#endif
 }
 __device__ __forceinline__ unsigned pack_pair(__bf16 lo, __bf16 hi)
 {
@@ -168,7 +186,6 @@ __global__ __launch_bounds__(X3_THREADS, 2) void gemm_x3_kernel(int M, int N, in
     const int m0 = (vid / (int)gridDim.x) * BM, n0 = (vid % (int)gridDim.x) * BN;
     const int kbeg = slice * kchunk;
     const int kend = min(K, kbeg + kchunk);
-
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -217,42 +234,43 @@ __global__ __launch_bounds__(X3_THREADS, 2) void gemm_x3_kernel(int M, int N, in
         }
     };
     if (DEPTH == 2) {
-        // two slabs in flight: the slab staged in iteration i was requested in iteration i - 2 (a slab iteration is ~1500
-        // cycles of MFMA + ~1000 of splitting against a memory round trip of several thousand); the two register sets
-        // alternate, so the loop is unrolled by two
-        sa.template load<0>(pa, lda);
-        sb.template load<0>(pb, ldb);
-        if (kbeg + X3_BK < kend) {
-            sa.template load<1>(pa + stepa, lda);
-            sb.template load<1>(pb + stepb, ldb);
-        }
-        for (int k0 = kbeg; k0 < kend; k0 += 2 * X3_BK) {
+        // two slabs in flight: the slab staged in iteration i was requested in iteration i - 2; the two register sets
+        // alternate, so the loop is unrolled by two.  Every iteration issues its loads UNCONDITIONALLY (past the end of
+        // the K range it asks for the last slab again, which nobody consumes): with a branch around a load the
+        // compiler's wait-count bookkeeping has to assume the path on which the load was not issued, and then waits
+        // for the most recent loads where the older ones were meant -- which is one slab in flight again.
+        const int nslab = (kend - kbeg) / X3_BK;
+        auto slab_a = [&](int i) { return pa + (size_t)(i < nslab ? i : nslab - 1) * stepa; };
+        auto slab_b = [&](int i) { return pb + (size_t)(i < nslab ? i : nslab - 1) * stepb; };
+        sa.template load<0>(slab_a(0), lda);
+        sb.template load<0>(slab_b(0), ldb);
+        // (the first set's loads must all be OLDER than the second set's, here as in the loop: interleaved by the
+        // scheduler, the loop's first wait has to cover the second set on the entry path, and the compiler then uses
+        // that count on the back edge too)
+        __builtin_amdgcn_sched_barrier(0);
+        sa.template load<1>(slab_a(1), lda);
+        sb.template load<1>(slab_b(1), ldb);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < nslab; i += 2) {
             __syncthreads();
             sa.template stage<0>(ldsA);
             sb.template stage<0>(ldsB);
             __syncthreads();
-            if (k0 + 2 * X3_BK < kend) {
-                sa.template load<0>(pa + 2 * stepa, lda);
-                sb.template load<0>(pb + 2 * stepb, ldb);
-            }
+            sa.template load<0>(slab_a(i + 2), lda);
+            sb.template load<0>(slab_b(i + 2), ldb);
             __builtin_amdgcn_sched_barrier(0);
             multiply();
             __builtin_amdgcn_sched_barrier(0);
-            if (k0 + X3_BK < kend) {
-                __syncthreads();
-                sa.template stage<1>(ldsA);
-                sb.template stage<1>(ldsB);
-                __syncthreads();
-                if (k0 + 3 * X3_BK < kend) {
-                    sa.template load<1>(pa + 3 * stepa, lda);
-                    sb.template load<1>(pb + 3 * stepb, ldb);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                multiply();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            pa += 2 * stepa;
-            pb += 2 * stepb;
+            // (the launcher takes this variant only when every K slice holds an even number of slabs)
+            __syncthreads();
+            sa.template stage<1>(ldsA);
+            sb.template stage<1>(ldsB);
+            __syncthreads();
+            sa.template load<1>(slab_a(i + 3), lda);
+            sb.template load<1>(slab_b(i + 3), ldb);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply();
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
         sa.template load<0>(pa, lda);
@@ -416,14 +434,24 @@ CLOUDAAE_API int cloudaae_gemm_bf16x3(int trans_a, int trans_b, int M, int N, in
     CLOUDAAE_REQUIRE(M / BM <= 65535, name, "M too large");
     dim3 grid(N / BN, M / BM, splits);
     int rc;
-    if (!trans_a && !trans_b)
+    // CLOUDAAE_X3_DEPTH2=1: two slabs in flight for the 128 x 128 tiles (every K slice an even number of slabs).  Measured
+    // equal to one slab in flight (forward 146 vs 150 us at B = 32): the kernel is not waiting for memory -- per slab a
+    // wave spends ~640 cycles splitting, ~1540 in its 48 MFMAs, and the two waves of a SIMD contend for both pipes.
+    const bool deep = K % kchunk == 0 && (kchunk / X3_BK) % 2 == 0 && CLOUDAAE_KNOB("CLOUDAAE_X3_DEPTH2", 0) != 0;
+    if (!trans_a && !trans_b && !deep)
+        rc = launch_x3<128, 128, 2, 2, false, false, 1>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
+    else if (!trans_a && !trans_b)
         rc = launch_x3<128, 128, 2, 2, false, false, 2>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
     else if (!trans_a && BN == 160)
         rc = launch_x3<128, 160, 4, 1, false, true, 1>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
+    else if (!trans_a && !deep)
+        rc = launch_x3<128, 128, 2, 2, false, true, 1>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
     else if (!trans_a)
         rc = launch_x3<128, 128, 2, 2, false, true, 2>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
     else if (BM == 160)
         rc = launch_x3<160, 128, 1, 4, true, false, 1>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
+    else if (!deep)
+        rc = launch_x3<128, 128, 2, 2, true, false, 1>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
     else
         rc = launch_x3<128, 128, 2, 2, true, false, 2>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
     if (rc != 0)
