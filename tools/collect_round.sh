@@ -21,6 +21,8 @@ timeout 300 bash tools/pmc_kernel.sh r03_knn64_wide_k20_n4096 knn64_wide -- pyth
 python3 bench.py > "$OUT/r03_bench_b32_n1024.json" 2> "$OUT/bench_b32.err"
 python3 bench.py --per-gpu-batch 128 --step-only > "$OUT/r03_bench_b128_n1024.json" 2>/dev/null
 python3 bench.py --per-gpu-batch 256 --gemm-dtype bf16 --step-only > "$OUT/r03_bench_b256_n1024_bf16.json" 2>/dev/null
+python3 bench.py --gemm-dtype bf16x3 --step-only > "$OUT/r03_bench_b32_n1024_bf16x3.json" 2>/dev/null
+python3 bench.py --gemm-dtype bf16x3 --per-gpu-batch 128 --step-only > "$OUT/r03_bench_b128_n1024_bf16x3.json" 2>/dev/null
 python3 bench.py --config5 --step-only --steps 20 --warmup 5 > "$OUT/r03_bench_config5_b32_n4096_k20.json" 2>/dev/null
 # the RCCL path with ONE rank (no second GPU on this box): the same replayed step with the gradient exchange's two
 # all-reduces (and, second line, SyncBN's 22) going through RCCL -- the `comm` block of the N > 1 bench line
