@@ -320,8 +320,10 @@ def main():
     ap.add_argument("--k", type=int, default=10, help="neighbours of the edge convolution (BASELINE configs[4]: 20)")
     ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="train steps of the CPU-baseline sample")
-    ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "bf16", "bf16x3"], help="bf16: BASELINE configs[2]'s "
-                    "arithmetic (dense-layer operands rounded to bf16, fp32 accumulate; everything else fp32)")
+    ap.add_argument("--gemm-dtype", default="bf16x3", choices=["f32", "bf16", "bf16x3"], help="bf16x3 (default): an fp32 step "
+                    "whose three dgcnn_agg products run as error-free 3 x bf16 split products on the bf16 matrix cores (fp32 "
+                    "accuracy: six exact piece products, fp32 accumulate); f32: those products on the fp32 matrix cores; bf16: "
+                    "BASELINE configs[2]'s arithmetic (dense-layer operands rounded to bf16, fp32 accumulate; everything else fp32)")
     ap.add_argument("--sync-bn", action="store_true", help="batch-norm moments over the GLOBAL batch (all ranks)")
     ap.add_argument("--step-only", action="store_true", help="skip the Chamfer kernel micro-benchmarks and the CPU "
                     "baseline (profiling runs: only the train step's kernels in the trace)")
@@ -456,8 +458,8 @@ def main():
                                       ", every batch synthesised on the GPU inside the loop (8192-point models, occluder, "
                                       "spherical flip, hidden point removal x2)" if args.config5 else ""),
                        "baseline_config": ("configs[4] (one GPU; on-line synthesis inside the timed loop)" if args.config5 else
-                                           "configs[1]" if (world == 1 and B == 32 and args.gemm_dtype == "f32") else
-                                           "configs[1] shape, opt-in split products" if (world == 1 and B == 32 and args.gemm_dtype == "bf16x3") else
+                                           "configs[1]" if (world == 1 and B == 32 and args.gemm_dtype == "bf16x3") else
+                                           "configs[1], dgcnn_agg products on the fp32 matrix cores" if (world == 1 and B == 32 and args.gemm_dtype == "f32") else
                                            "configs[2]" if (world == 1 and B == 256 and args.gemm_dtype == "bf16") else
                                            "configs[3] (128 clouds per GPU)" if (B == 128 and world > 1) else "custom"),
                        "global_batch": B * world, "per_gpu_batch": B, "num_point": N, "parallelism": "dp%d" % world,
@@ -473,10 +475,10 @@ def main():
         if args.gemm_dtype == "bf16x3":
             # the split product issues six bf16 MFMAs where the fp32 kernel issues eight fp32 ones: priced on the bf16
             # matrix pipe (2.5 PFLOP/s dense) with the flops it really issues (6 x the algorithmic ones)
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_x3_kernel<128,128,2,2> dgcnn_agg forward [%d x 320] x "
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_x3s_kernel dgcnn_agg forward [%d x 320] x "
                                                           "[320 x 1024] as 3 x bf16 splits (6 piece products)" % M,
                                 "achieved": round(6.0 * achieved, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                                "frac": round(6.0 * achieved / 2500.0, 4), "traffic": None,
+                                "frac": round(6.0 * achieved / 2500.0, 4), "traffic": measured_traffic(B, N, "agg_fwd_x3"),
                                 "algorithmic_tflops": round(achieved, 2), "launch_ms": round(k_ms, 4),
                                 "launches_timed": k_n}
         if args.gemm_dtype == "bf16":

@@ -53,6 +53,9 @@ _SIGNATURES = {
     "cloudaae_gemm_b16": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P, _P],
     "cloudaae_to_bf16": [ctypes.c_longlong, _P, _P, _P],
     "cloudaae_gemm_bf16x3": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P],
+    "cloudaae_x3_split": [_I, _I, _P, _I, _I, _P, _P],
+    "cloudaae_x3_split_weight": [_I, _I, _P, _I, _P, _P, _P],
+    "cloudaae_gemm_bf16x3p": [_I, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _P],
     "cloudaae_bn_meanpool_forward16": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
     "cloudaae_bn_meanpool_backward16": [_I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P],
     "cloudaae_bn_forward_colstats": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P,
@@ -130,7 +133,7 @@ class BnSyncStruct(ctypes.Structure):
     _fields_ = [("allreduce", ALLREDUCE_FN), ("ctx", _P), ("world", _I), ("buf", _P)]
 
 
-_LONGLONG_RESULTS = ["cloudaae_loss_tail_workspace_bytes", "cloudaae_bn_workspace_bytes", "cloudaae_edgeconv_workspace_bytes",
+_LONGLONG_RESULTS = ["cloudaae_x3_planes_bytes", "cloudaae_loss_tail_workspace_bytes", "cloudaae_bn_workspace_bytes", "cloudaae_edgeconv_workspace_bytes",
                      "cloudaae_mean_workspace_bytes", "cloudaae_gemm_f32_ordered_workspace",
                      "cloudaae_gemm_bf16_ordered_workspace"]
 
@@ -324,6 +327,10 @@ def lib():
         cdll.cloudaae_gemm_bf16x3_colstats_parts.restype = ctypes.c_int
         cdll.cloudaae_gemm_bf16x3_supported.argtypes = [_I, _I, _I, _I, _I]
         cdll.cloudaae_gemm_bf16x3_supported.restype = ctypes.c_int
+        for q in ("cloudaae_gemm_bf16x3p_supported", "cloudaae_gemm_bf16x3p_colstats_parts"):
+            getattr(cdll, q).argtypes = [_I, _I, _I]
+            getattr(cdll, q).restype = ctypes.c_int
+        cdll.cloudaae_x3_planes_bytes.argtypes = [_I, _I]
         for q in ("cloudaae_fc_max_rows", "cloudaae_fc_max_group"):
             getattr(cdll, q).argtypes = []
             getattr(cdll, q).restype = ctypes.c_int

@@ -32,30 +32,16 @@ constexpr int X3_THREADS = 256;
 enum { X3_STORE = 0, X3_ACCUM = 1, X3_ATOMIC = 2 };
 
 // v = h + m + l exactly (each a bfloat16, round to nearest even)
-__device__ __forceinline__ __bf16 top_half(float v)       // the upper 16 bits of v, as a bfloat16 (truncation)
-{
-    const unsigned short u = (unsigned short)(__float_as_uint(v) >> 16);
-    __bf16 b;
-    __builtin_memcpy(&b, &u, 2);
-    return b;
-}
+// The leading piece saturates at the largest finite bfloat16 (|v| >= 0x7f7f8000 would round to infinity and the remainder
+// to -infinity): every FINITE v is split exactly.  A non-finite v gives NaN pieces (inf - inf), so every result it
+// contributes to is NaN -- where an fp32 product gives +-inf or NaN.
+constexpr float X3_H_MAX = __builtin_bit_cast(float, 0x7f7f7fffu);      // the largest fp32 that rounds to a finite bfloat16
 __device__ __forceinline__ void split3(float v, __bf16 &h, __bf16 &m, __bf16 &l)
 {
-#ifdef X3_TRUNCATE
-    // (experiment) pieces by truncation: v & 0xffff0000, exact remainders; four operations instead of seven per element
-    const float hf = __uint_as_float(__float_as_uint(v) & 0xffff0000u);
-    const float r1 = v - hf;
-    const float mf = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-    const float lf = r1 - mf;
-    h = top_half(hf);
-    m = top_half(mf);
-    l = top_half(lf);
-#else
-    h = (__bf16)v;
+    h = (__bf16)__builtin_amdgcn_fmed3f(v, -X3_H_MAX, X3_H_MAX);
     const float r1 = v - (float)h;
     m = (__bf16)r1;
     l = (__bf16)(r1 - (float)m);
-#endif
 }
 __device__ __forceinline__ unsigned pack_pair(__bf16 lo, __bf16 hi)
 {
@@ -389,9 +375,404 @@ static int launch_x3(const char *name, dim3 grid, hipStream_t s, int M, int N, i
     return 0;
 }
 
+
+// =====================================================================================================================
+// Second generation (round 4): "streamed" products -- the big operand is split in REGISTERS, the small one ONCE.
+//
+// What the kernel above pays per 32 k: every element of both operands goes global -> registers -> seven VALU operations
+// -> three LDS planes (ds_write) -> barrier -> fragment reads, in phases that no wave overlaps with its own MFMAs
+// (forward product at B = 32: 146 us against a matrix-pipe floor of 52 us; 114 us with the MFMAs removed).  The two
+// products with a k-contiguous big operand, y = x W (utils/tf_util.py:161-166) and dx = dy W^T, are reorganised:
+//   * the SMALL operand (the weight, 320 x 1024) is split once per step by x3_split_kernel into bf16 planes laid out
+//     the way the matrix cores read them ([K/16 step][plane][row][16 k], the two 16-byte units of a row swapped in
+//     every other group of eight rows), so a workgroup's share of a step is linear 1 KB pieces that go global -> LDS by
+//     DMA (global_load_lds_dwordx4): no VALU, no ds_write, no registers; a ring of three steps;
+//   * the BIG operand stays fp32 and also goes global -> LDS by DMA, in whole 128-byte lines (8 rows x 128 B per wave
+//     instruction, the 16-byte units of a row permuted on the SOURCE side so that the fragment reads are conflict
+//     free); each wave reads the 8 consecutive k of ITS OWN rows (two ds_read_b128) and splits them in registers into
+//     the three MFMA operands -- once per element (the four waves of a workgroup are stacked along M, so no two waves
+//     share a row), between the MFMAs of the previous 16 k.  Its rows are private to the wave, so there is ONE buffer,
+//     refilled in place as soon as the wave has read the slab's second half;
+//   * one barrier per 16 k, in the middle of the step's MFMAs: behind it the next step's planes are visible and the DMA
+//     of the step after goes out;
+//   * two workgroups per CU (<= 256 registers, <= 80 KB of LDS): two waves per SIMD, so one wave's splitting, LDS reads,
+//     DMA issue, barrier waits and epilogue stores sit under the other's MFMAs.
+// Per 16 k and wave (64 x 128 tile): 48 MFMAs, 16 ds_read_b128, ~100 VALU.
+// Arithmetic is unchanged: the same six piece products in the same order per accumulator, so results are bit-identical
+// to the kernel above for a product that is not cut over K.
+//
+// (Finite / non-finite operands: see split3 above -- the same pieces here.)
+__device__ __forceinline__ void split8(const float4v &x, const float4v &y, bf16x8 &h, bf16x8 &m, bf16x8 &l)
+{
+    const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hh = (__bf16)__builtin_amdgcn_fmed3f(v[e], -X3_H_MAX, X3_H_MAX);
+        const float r1 = v[e] - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        h[e] = hh;
+        m[e] = mm;
+        l[e] = (__bf16)(r1 - (float)mm);
+    }
+}
+
+// planes of a [rows][K] operand: element (n, k), piece p at  ((k / 16 * 3 + p) * rows + n) * 16 + ((k % 16 / 8) ^ (n >> 3 & 1)) * 8 + k % 8
+// src: [rows][K] (transposed == 0) or [K][rows] (transposed != 0), leading dimension ld
+// (two jobs per launch: blockIdx.y picks (rows, K, transposed, planes) -- a weight is split for its forward and its
+//  backward product at once)
+__global__ __launch_bounds__(256) void x3_split_kernel(int rows0, int K0, int tr0, __bf16 *__restrict__ planes0, int rows1, int K1,
+                                                       int tr1, __bf16 *__restrict__ planes1, const float *__restrict__ src, int ld)
+{
+    const bool second = blockIdx.y != 0;
+    const int rows = second ? rows1 : rows0, K = second ? K1 : K0, transposed = second ? tr1 : tr0;
+    __bf16 *__restrict__ planes = second ? planes1 : planes0;
+    const int units = K >> 3;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)rows * units)
+        return;
+    int n, u;
+    float4v x, y;
+    if (transposed) {       // threads along n: every k row is read coalesced
+        n = (int)(t % rows);
+        u = (int)(t / rows);
+        const float *s = src + (size_t)(8 * u) * ld + n;
+        x = float4v{s[0], s[(size_t)ld], s[(size_t)2 * ld], s[(size_t)3 * ld]};
+        y = float4v{s[(size_t)4 * ld], s[(size_t)5 * ld], s[(size_t)6 * ld], s[(size_t)7 * ld]};
+    } else {
+        u = (int)(t % units);
+        n = (int)(t / units);
+        const float4v *s = reinterpret_cast<const float4v *>(src + (size_t)n * ld + 8 * u);
+        x = s[0];
+        y = s[1];
+    }
+    bf16x8 h, m, l;
+    split8(x, y, h, m, l);
+    const int step = u >> 1, q = (u & 1) ^ ((n >> 3) & 1);
+    __bf16 *d = planes + ((size_t)step * 3 * rows + n) * 16 + q * 8;
+    *reinterpret_cast<bf16x8 *>(d) = h;
+    *reinterpret_cast<bf16x8 *>(d + (size_t)rows * 16) = m;
+    *reinterpret_cast<bf16x8 *>(d + (size_t)2 * rows * 16) = l;
+}
+
+template <int TM, int TN, int AS>
+struct X3S {
+    static constexpr int BM = 128 * TM, BN = 32 * TN;
+    static constexpr int A_WAVE = 32 * TM * 128;        // bytes of one wave's rows, one slab of 32 k (fp32)
+    static constexpr int A_STAGE = 4 * A_WAVE;
+    static constexpr int A_BYTES = AS * A_STAGE;        // AS = 1: one buffer refilled in place; 2: two slabs in flight
+    static constexpr int P_PLANE = BN * 32;             // bytes of one plane of the small operand, one step of 16 k
+    static constexpr int P_STAGE = 3 * P_PLANE;
+    static constexpr int P_PIECES = 3 * TN;             // 1 KB DMA pieces per step: [plane][32 rows]
+    static constexpr int LDS = A_BYTES + 3 * P_STAGE;
+    static constexpr int JB = (TN - 1) / 2;             // the step's barrier sits behind the MFMAs of tile JB
+};
+
+// C[M,N] (+)= A[M,K] * P^T (+ bias[N]); P = x3_split_kernel planes of the [N][K] operand.  M % (128 TM) == 0, N % (32 TN) == 0,
+// K % 32 == 0.  grid.x = tiles.
+template <int TM, int TN, int AS>
+__global__ __launch_bounds__(256, 2) void gemm_x3s_kernel(int M, int N, int K, const float *__restrict__ A, int lda,
+                                                          const __bf16 *__restrict__ P, float *__restrict__ C, int ldc,
+                                                          const float *__restrict__ bias, int accumulate,
+                                                          double *__restrict__ colstats)
+{
+    typedef X3S<TM, TN, AS> G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char x3_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int fr = lane & 31, fk = lane >> 5;
+    const int tiles_n = N / G::BN;
+    const int vid = xcd_contiguous(blockIdx.x, gridDim.x);       // the tiles that share rows of A: one XCD's L2
+    const int m0 = (vid / tiles_n) * G::BM, n0 = (vid % tiles_n) * G::BN;
+    const int nslab = K >> 5, nstep = K >> 4;
+
+    // ---- DMA sources.  A: wave instruction t brings rows 8t .. 8t+7 of this wave's 32 TM rows; lane -> (row 8t + lane/8,
+    // stored unit lane%8), which holds the row's unit (lane%8) ^ (row/2 % 8) [= (lane%8) ^ (lane/16) ^ 4 (t odd)].
+    const float *asrc = A + (size_t)(m0 + wave * 32 * TM + (lane >> 3)) * lda + 4 * ((lane & 7) ^ (lane >> 4));
+    const size_t a8 = (size_t)8 * lda;
+    unsigned char *lds_a = x3_lds + wave * G::A_WAVE;
+    auto dma_a = [&](int slab, int stage) {
+        const float *ga = asrc + (size_t)slab * 32;
+        unsigned char *la = lds_a + stage * G::A_STAGE;
+#pragma unroll
+        for (int t = 0; t < 4 * TM; ++t)
+            __builtin_amdgcn_global_load_lds(ga + t * a8 + ((t & 1) ? ((lane & 4) ? -16 : 16) : 0), la + t * 1024, 16, 0, 0);
+    };
+    // P: piece pc (1 KB, linear) = plane pc / TN, rows 32 (pc % TN) ..; this wave takes pc = wave, wave + 4, ...
+    const __bf16 *psrc = P + (size_t)n0 * 16 + 8 * lane;
+    const size_t pplane = (size_t)N * 16, pstep = 3 * pplane;
+    auto dma_p = [&](int step, int ring) {
+        unsigned char *sp = x3_lds + G::A_BYTES + ring * G::P_STAGE;
+        const __bf16 *gp = psrc + (size_t)step * pstep;
+#pragma unroll
+        for (int i = 0; i < (G::P_PIECES + 3) / 4; ++i) {
+            const int pc = wave + 4 * i;
+            if (G::P_PIECES % 4 == 0 || pc < G::P_PIECES) {
+                const int plane = pc / TN, rg = pc % TN;
+                __builtin_amdgcn_global_load_lds(gp + plane * pplane + (size_t)rg * 512, sp + pc * 1024, 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment addresses (bytes)
+    const int swa = (fr >> 1) & 7;
+    int offa[2][2];
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+            offa[ss][hh] = wave * G::A_WAVE + fr * 128 + (((4 * ss + 2 * fk + hh) ^ swa) << 4);
+    const int offp = G::A_BYTES + fr * 32 + ((fk ^ ((fr >> 3) & 1)) << 4);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[i][j][r] = 0.0f;
+
+    bf16x8 af[2][3][TM], bp[2][3];
+    // the wave's operands of half ss of the slab in the A buffer -> register set buf
+    auto prepare_a = [&](int buf, int ss, int stage) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float4v x = *reinterpret_cast<const float4v *>(x3_lds + offa[ss][0] + i * 4096 + stage * G::A_STAGE);
+            const float4v y = *reinterpret_cast<const float4v *>(x3_lds + offa[ss][1] + i * 4096 + stage * G::A_STAGE);
+            split8(x, y, af[buf][0][i], af[buf][1][i], af[buf][2][i]);
+        }
+    };
+    auto read_p = [&](int pb, int ring, int j) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            bp[pb][p] = *reinterpret_cast<const bf16x8 *>(x3_lds + offp + ring * G::P_STAGE + p * G::P_PLANE + j * 1024);
+    };
+    // the six piece products of column tile j, smallest first
+    auto tile = [&](int abuf, int pb, int j) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[abuf][PA[q]][i], bp[pb][PB[q]], acc[i][j], 0, 0, 0);
+    };
+    // One step of 16 k.  On entry: af[abuf] = the step's A operands, bp[pb0] = its first column tile, its planes in `ring`;
+    // on exit the same for the next step (af[abuf ^ 1], bp[pb0 ^ (TN & 1)], ring + 1).  Every DMA is issued UNCONDITIONALLY
+    // (past the end it asks for the last step / slab again, which nobody reads): a branch would end the scheduling region
+    // and the preparation would not be spread between the MFMAs.
+    auto step = [&](int g, int ring, int abuf, int pb0, bool second_half) {
+        const int ring1 = ring == 2 ? 0 : ring + 1, ring2 = ring == 0 ? 2 : ring - 1;
+        const int slab = g >> 1, ast = AS == 2 ? (slab & 1) : 0;
+        if (!second_half)
+            prepare_a(abuf ^ 1, 1, ast);                   // (first half of the slab: the second half is there already)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int pb = (pb0 + j) & 1;
+            if (j + 1 < TN)
+                read_p(pb ^ 1, ring, j + 1);
+            else
+                read_p(pb ^ 1, ring1, 0);
+            tile(abuf, pb, j);
+            if (j == G::JB) {
+                // planes of step g + 1 (and, in a slab's second half, the next slab of A): this wave's pieces have landed
+                // (vmcnt), everyone's (barrier); every wave is past step g - 1, whose ring slot the DMA below refills.
+                // AS == 2: the slab of A requested one step ago (behind the planes awaited here) may stay in flight.
+                if (AS == 2 && second_half)
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * TM) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                dma_p(min(g + 2, nstep - 1), ring2);
+                if (!second_half)          // this wave has read both halves of its rows: refill that buffer
+                    dma_a(min(slab + AS, nslab - 1), ast);
+                else
+                    prepare_a(abuf ^ 1, 0, AS == 2 ? (ast ^ 1) : 0);
+            }
+        }
+    };
+
+    dma_a(0, 0);
+    if (AS == 2)
+        dma_a(min(1, nslab - 1), 1);
+    dma_p(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    dma_p(min(1, nstep - 1), 1);
+    prepare_a(0, 0, 0);
+    read_p(0, 0, 0);
+    int ring = 0;
+    for (int s = 0; s < nslab; ++s) {
+        step(2 * s, ring, 0, 0, false);
+        ring = ring == 2 ? 0 : ring + 1;
+        step(2 * s + 1, ring, 1, TN & 1, true);
+        ring = ring == 2 ? 0 : ring + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the repeated last pieces: nothing of them is read, but they
+    __syncthreads();                                         //  must have landed before the statistics below reuse the space)
+
+    // epilogue: lane holds column (lane & 31), rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int wrow = m0 + wave * 32 * TM;
+    if (colstats != nullptr) {
+        // column sums / sums of squares of this tile in fp64 (as gemm_f32_kernel); the staging array lies over the slabs
+        double (*cs)[4][G::BN] = reinterpret_cast<double (*)[4][G::BN]>(x3_lds);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cl = j * 32 + fr;
+            const float bv = bias != nullptr ? bias[n0 + cl] : 0.0f;
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const double v = (double)(acc[i][j][r] + bv);
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (fk == 0) {
+                cs[0][wave][cl] = s1;
+                cs[1][wave][cl] = s2;
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * G::BN; t += 256) {
+            const int which = t / G::BN, cl = t % G::BN;
+            const double v = ((cs[which][0][cl] + cs[which][1][cl]) + cs[which][2][cl]) + cs[which][3][cl];
+            colstats[((size_t)(m0 / G::BM) * 2 + which) * N + n0 + cl] = v;
+        }
+    }
+    float *c0 = C + (size_t)(wrow + 4 * fk) * ldc + (n0 + fr);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const float bv = bias != nullptr ? bias[n0 + j * 32 + fr] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *dst = c0 + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32;
+                const float v = acc[i][j][r] + bv;
+                *dst = accumulate ? *dst + v : v;
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int AS>
+static int launch_x3s(const char *name, hipStream_t s, int M, int N, int K, const float *A, int lda, const void *planes, float *C,
+                      int ldc, const float *bias, int accumulate, double *cs)
+{
+    typedef X3S<TM, TN, AS> G;
+    static bool raised[64] = {};
+    int dev = 0;
+    CLOUDAAE_CHECK_HIP(hipGetDevice(&dev), name);
+    if (dev >= 0 && dev < 64 && !raised[dev]) {
+        CLOUDAAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x3s_kernel<TM, TN, AS>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS), name);
+        raised[dev] = true;
+    }
+    const int tiles = (M / G::BM) * (N / G::BN);
+    hipLaunchKernelGGL((gemm_x3s_kernel<TM, TN, AS>), dim3(tiles), dim3(256), G::LDS, s, M, N, K, A, lda,
+                       reinterpret_cast<const __bf16 *>(planes), C, ldc, bias, accumulate, cs);
+    return 0;
+}
+
+// tile shape of a streamed product; false when it is not served
+static bool gemm_x3s_plan(int M, int N, int K, int &TM, int &TN)
+{
+    if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0 || M % 128 != 0)
+        return false;
+    TN = N % 128 == 0 ? 4 : (N % 160 == 0 ? 5 : 0);
+    if (TN == 0)
+        return false;
+    // 256-row tiles (a wave's 64 x 128 tile reads each small-operand fragment for two row tiles) when they still give
+    // every CU its two workgroups; 160-column tiles keep 128 rows (five accumulator tiles per row tile: 256 registers)
+    TM = (TN == 4 && M % 256 == 0 && (long long)(M / 256) * (N / 128) >= 512 && CLOUDAAE_KNOB("CLOUDAAE_X3_TM", 2) == 2) ? 2 : 1;
+    return true;
+}
+
 } // namespace cloudaae
 
 using namespace cloudaae;
+
+CLOUDAAE_API long long cloudaae_x3_planes_bytes(int rows, int k)
+{
+    return rows > 0 && k > 0 && k % 32 == 0 ? (long long)rows * k * 6 : 0;
+}
+
+CLOUDAAE_API int cloudaae_x3_split(int rows, int k, const float *src, int ld, int transposed, void *planes, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_x3_split";
+    CLOUDAAE_REQUIRE(rows > 0 && k > 0 && k % 32 == 0 && src && planes, name, "rows, k > 0, k a multiple of 32, non-null pointers");
+    CLOUDAAE_REQUIRE(ld >= (transposed ? rows : k), name, "leading dimension too small");
+    CLOUDAAE_REQUIRE(transposed || (ld % 4 == 0 && ((uintptr_t)src & 15) == 0), name, "rows must be 16-byte aligned");
+    CLOUDAAE_REQUIRE(((uintptr_t)planes & 15) == 0, name, "planes must be 16-byte aligned");
+    const long long items = (long long)rows * (k / 8);
+    hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)((items + 255) / 256), 1), dim3(256), 0, (hipStream_t)stream, rows, k, transposed,
+                       reinterpret_cast<__bf16 *>(planes), 0, 0, 0, (__bf16 *)nullptr, src, ld);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_x3_split_weight(int K, int N, const float *W, int ldw, void *planes_fwd, void *planes_bwd,
+                                          cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_x3_split_weight";
+    CLOUDAAE_REQUIRE(K > 0 && N > 0 && K % 32 == 0 && N % 32 == 0 && W && planes_fwd && planes_bwd, name,
+                     "K, N multiples of 32, non-null pointers");
+    CLOUDAAE_REQUIRE(ldw >= N && ldw % 4 == 0 && ((uintptr_t)W & 15) == 0, name, "rows of W must be 16-byte aligned");
+    CLOUDAAE_REQUIRE(((uintptr_t)planes_fwd & 15) == 0 && ((uintptr_t)planes_bwd & 15) == 0, name, "planes must be 16-byte aligned");
+    const long long items = (long long)K * N / 8;
+    // job 0: the planes of W^T ([N][K], for y = x W); job 1: the planes of W ([K][N], for dx = dy W^T)
+    hipLaunchKernelGGL(x3_split_kernel, dim3((unsigned)((items + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream, N, K, 1,
+                       reinterpret_cast<__bf16 *>(planes_fwd), K, N, 0, reinterpret_cast<__bf16 *>(planes_bwd), W, ldw);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_gemm_bf16x3p_supported(int M, int N, int K)
+{
+    int TM, TN;
+    return gemm_x3s_plan(M, N, K, TM, TN) ? 1 : 0;
+}
+
+CLOUDAAE_API int cloudaae_gemm_bf16x3p_colstats_parts(int M, int N, int K)
+{
+    int TM, TN;
+    return gemm_x3s_plan(M, N, K, TM, TN) ? M / (128 * TM) : 0;
+}
+
+CLOUDAAE_API int cloudaae_gemm_bf16x3p(int M, int N, int K, const float *A, int lda, const void *planes, float *C, int ldc,
+                                       const float *bias, int accumulate, double *colstats, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_gemm_bf16x3p";
+    int TM, TN;
+    CLOUDAAE_REQUIRE(gemm_x3s_plan(M, N, K, TM, TN), name,
+                     "product not served (M % 128 == 0, N a multiple of 128 or 160, K % 32 == 0; see cloudaae_gemm_bf16x3p_supported)");
+    CLOUDAAE_REQUIRE(A && planes && C, name, "null argument");
+    CLOUDAAE_REQUIRE(lda >= K && ldc >= N, name, "leading dimension too small");
+    CLOUDAAE_REQUIRE(lda % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)planes & 15) == 0, name,
+                     "operand rows must be 16-byte aligned");
+    CLOUDAAE_REQUIRE(colstats == nullptr || accumulate == 0, name, "column statistics need an overwriting product");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    const bool deep = CLOUDAAE_KNOB("CLOUDAAE_X3_AS", 2) == 2;
+    if (TM == 2)
+        rc = launch_x3s<2, 4, 1>(name, s, M, N, K, A, lda, planes, C, ldc, bias, accumulate, colstats);
+    else if (TN == 4 && deep)
+        rc = launch_x3s<1, 4, 2>(name, s, M, N, K, A, lda, planes, C, ldc, bias, accumulate, colstats);
+    else if (TN == 4)
+        rc = launch_x3s<1, 4, 1>(name, s, M, N, K, A, lda, planes, C, ldc, bias, accumulate, colstats);
+    else if (deep)
+        rc = launch_x3s<1, 5, 2>(name, s, M, N, K, A, lda, planes, C, ldc, bias, accumulate, colstats);
+    else
+        rc = launch_x3s<1, 5, 1>(name, s, M, N, K, A, lda, planes, C, ldc, bias, accumulate, colstats);
+    if (rc != 0)
+        return rc;
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
 
 CLOUDAAE_API int cloudaae_gemm_bf16x3_supported(int trans_a, int trans_b, int M, int N, int K)
 {
@@ -404,6 +785,10 @@ CLOUDAAE_API int cloudaae_gemm_bf16x3_colstats_parts(int M, int N, int K)
     int BM, BN, splits;
     if (!gemm_x3_plan(0, 0, M, N, K, BM, BN, splits) || splits != 1)
         return 0;
+    int TMs, TNs;
+    if (CLOUDAAE_KNOB("CLOUDAAE_X3_GEN1", 0) == 0 && gemm_x3s_plan(M, N, K, TMs, TNs) &&
+        (long long)(M / (128 * TMs)) * (N / (32 * TNs)) >= 192)
+        return M / (128 * TMs);
     return M / BM;
 }
 
@@ -420,6 +805,21 @@ CLOUDAAE_API int cloudaae_gemm_bf16x3(int trans_a, int trans_b, int M, int N, in
     CLOUDAAE_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, name,
                      "operand rows must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    int TMs, TNs;
+    // (a product with few output tiles is cut over K by the first-generation kernel below; the streamed one keeps K whole)
+    if (!trans_a && gemm_x3s_plan(M, N, K, TMs, TNs) && (long long)(M / (128 * TMs)) * (N / (32 * TNs)) >= 192 &&
+        CLOUDAAE_KNOB("CLOUDAAE_X3_GEN1", 0) == 0) {
+        // the streamed kernel wants the second operand as planes: split it into scratch of this call (stream ordered).
+        // A caller that multiplies by the same matrix more than once splits it itself (cloudaae_x3_split) and calls
+        // cloudaae_gemm_bf16x3p.
+        void *planes = nullptr;
+        CLOUDAAE_CHECK_HIP(scratch_alloc(&planes, (size_t)cloudaae_x3_planes_bytes(N, K), s), name);
+        int rc = cloudaae_x3_split(N, K, B, ldb, trans_b ? 0 : 1, planes, stream);
+        if (rc == 0)
+            rc = cloudaae_gemm_bf16x3p(M, N, K, A, lda, planes, C, ldc, bias, accumulate, colstats, stream);
+        CLOUDAAE_CHECK_HIP(hipFreeAsync(planes, s), name);
+        return rc;
+    }
     int kchunk = ceil_div(ceil_div(K, splits), X3_BK) * X3_BK;
     splits = ceil_div(K, kchunk);
     CLOUDAAE_REQUIRE(colstats == nullptr || (splits == 1 && accumulate == 0), name,
@@ -459,3 +859,4 @@ CLOUDAAE_API int cloudaae_gemm_bf16x3(int trans_a, int trans_b, int M, int N, in
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }
+

@@ -71,8 +71,9 @@ def get_training_argparser():
                        'ycb_video_data_tfRecords/train_syn/ (:31-39); empty = synthetic batches')
     extra.add_argument('--restore', default='', help='checkpoint to resume from: a TensorFlow V2 prefix (model.ckpt) or an .npz')
     extra.add_argument('--ckpt_format', default='npz', choices=['npz', 'tf'], help="format of the epoch checkpoints")
-    extra.add_argument('--gemm_dtype', default='f32', help="f32; bf16 = bf16 operands for the dense layers; bf16x3 = fp32 with the dgcnn_agg products as split "
-                            "products on the bf16 matrix cores (fp32 accuracy)")
+    extra.add_argument('--gemm_dtype', default='bf16x3', help="bf16x3 (default) = fp32 everywhere, the three dgcnn_agg products computed as error-free "
+                            "3 x bfloat16 split products on the bf16 matrix cores (fp32 accuracy); f32 = those products on the fp32 "
+                            "matrix cores too; bf16 = bf16 operands for the dense layers (BASELINE configs[2])")
     extra.add_argument('--print_every', type=int, default=1, help='print the losses every n batches (each print syncs)')
     return parser
 
@@ -92,7 +93,7 @@ class TrainGraph(object):
 
     def __init__(self, general_opts=None, train_opts=None, hyperparameters=None, device=None,
                  model_fn='get_model_dgcnn_mean_6d', k_neighbor=K_NEIGHBOR, process_group=None, seed=123456789,
-                 replay=False, gemm_dtype='f32', side_stream=None, sync_bn=False, deterministic=False):
+                 replay=False, gemm_dtype='bf16x3', side_stream=None, sync_bn=False, deterministic=False):
         general_opts = dict(general_opts or {})
         train_opts = dict(train_opts or {})
         hyperparameters = dict(hyperparameters or {})
@@ -149,6 +150,11 @@ class TrainGraph(object):
         # C-ABI calls in issue order, buffers from the plan's arena) and later steps re-issue it
         # without Python layers or autograd in between -- the host cost of a step drops from ~3 ms
         # to the launches themselves, which is what keeps a batch-32 step GPU-bound.
+        # gemm_dtype='bf16x3' (default): an fp32 step; the three dgcnn_agg products (tf_util.py:161-166 and its two gradient
+        # products, 29 % of an fp32-MFMA step) split every operand element EXACTLY into three bfloat16 pieces and take the
+        # six piece products of weight >= 2^-16 on the bf16 matrix cores, fp32 accumulate -- what is dropped is below one
+        # fp32 rounding of each product (csrc/gemm_x3.hip; tests: test_gemm_bf16x3*, cfg1-B32 at the fp32 tolerances).
+        # 'f32': the same products on v_mfma_f32_32x32x2_f32.
         # gemm_dtype='bf16': the per-point conv1x1 products (and their gradient products) round their operands
         # to bfloat16 on the way to the matrix cores, fp32 accumulate; everything else -- tensors in
         # HBM, batch norm, kNN, Chamfer, pose losses, Adam -- stays fp32 (BASELINE configs[2])

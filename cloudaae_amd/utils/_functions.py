@@ -111,7 +111,7 @@ def gemm_is_bf16():
 
 
 def gemm_is_x3():
-    """GEMM_DTYPE "bf16x3" (opt-in): fp32 everywhere, but the three dgcnn_agg products run as split products on the bf16
+    """GEMM_DTYPE "bf16x3" (TrainGraph's default): fp32 everywhere, but the three dgcnn_agg products run as split products on the bf16
     matrix cores (csrc/gemm_x3.hip: every operand element = three bfloat16 pieces, six piece products, fp32 accumulate --
     the accuracy of an fp32 product at 2.7 x less matrix-pipe time).  Off in deterministic mode."""
     return GEMM_DTYPE == "bf16x3" and not DETERMINISTIC
@@ -536,18 +536,24 @@ class ConcatLinearFn(torch.autograd.Function):
             ctx.widths, ctx.xp, ctx.bvar = widths, xp, b
             return y
         y = _lib.empty((M, N), dtype=torch.float32, device=w.device)
-        ctx.x3 = (gemm_is_x3() and xp % 16 == 0 and w.is_contiguous() and
-                  bool(L().cloudaae_gemm_bf16x3_supported(0, 0, M, N, Ktot)) and
-                  bool(L().cloudaae_gemm_bf16x3_supported(0, 1, M, Ktot, N)) and
+        ctx.x3 = (gemm_is_x3() and xp % 16 == 0 and w.is_contiguous() and Ktot % 32 == 0 and N % 32 == 0 and
+                  bool(L().cloudaae_gemm_bf16x3p_supported(M, N, Ktot)) and
+                  bool(L().cloudaae_gemm_bf16x3p_supported(M, Ktot, N)) and
                   bool(L().cloudaae_gemm_bf16x3_supported(1, 0, Ktot, N, M)))
         if ctx.x3:
-            parts = int(L().cloudaae_gemm_bf16x3_colstats_parts(M, N, Ktot)) if int(bias_grad_by_bn) & 2 else 0
+            # the weight is split into its bfloat16 planes ONCE per step, for the forward and the input-gradient product
+            pbytes = int(L().cloudaae_x3_planes_bytes(N, Ktot))
+            ctx.planes_bwd = _lib.empty(pbytes // 2, dtype=torch.bfloat16, device=w.device)
+            planes_fwd = _lib.empty(pbytes // 2, dtype=torch.bfloat16, device=w.device)
+            _lib.check(L().cloudaae_x3_split_weight(Ktot, N, ptr(w), N, ptr(planes_fwd), ptr(ctx.planes_bwd), stream()),
+                       "cloudaae_x3_split_weight")
+            parts = int(L().cloudaae_gemm_bf16x3p_colstats_parts(M, N, Ktot)) if int(bias_grad_by_bn) & 2 else 0
             ws = _lib.empty(parts * 2 * N, dtype=torch.float64, device=w.device) if parts > 0 else None
             rec = TIMED_SITES.get("agg_fwd")
             if rec is not None:
                 _lib.host(_mark, rec)
-            _lib.check(L().cloudaae_gemm_bf16x3(0, 0, M, N, Ktot, xp, ldx, ptr(w), N, ptr(y), N, ptr(b) if b is not None else None,
-                                                0, ptr(ws), stream()), "cloudaae_gemm_bf16x3")
+            _lib.check(L().cloudaae_gemm_bf16x3p(M, N, Ktot, xp, ldx, ptr(planes_fwd), ptr(y), N, ptr(b) if b is not None else None,
+                                                 0, ptr(ws), stream()), "cloudaae_gemm_bf16x3p")
             if rec is not None:
                 _lib.host(_mark, rec)
             if parts > 0:
@@ -591,8 +597,8 @@ class ConcatLinearFn(torch.autograd.Function):
         if any(ctx.needs_input_grad[4:]):
             dcat = _lib.empty((M, Ktot), dtype=torch.float32, device=w.device)
             if ctx.x3:
-                _lib.check(L().cloudaae_gemm_bf16x3(0, 1, M, Ktot, N, ptr(dy), N, ptr(w), N, ptr(dcat), Ktot, None, 0, None,
-                                                    stream()), "cloudaae_gemm_bf16x3")
+                _lib.check(L().cloudaae_gemm_bf16x3p(M, Ktot, N, ptr(dy), N, ptr(ctx.planes_bwd), ptr(dcat), Ktot, None, 0, None,
+                                                     stream()), "cloudaae_gemm_bf16x3p")
             else:
                 gemm(0, 1, M, Ktot, N, ptr(dy), N, ptr(w), N, ptr(dcat), Ktot, bf16=ctx.bf16, device=w.device)
             if ctx.slot is not None and ctx.cat is None:

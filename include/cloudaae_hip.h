@@ -224,6 +224,26 @@ int cloudaae_gemm_bf16x3_supported(int trans_a, int trans_b, int M, int N, int K
 int cloudaae_gemm_bf16x3_colstats_parts(int M, int N, int K);
 int cloudaae_gemm_bf16x3(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda, const float *B, int ldb,
                          float *C, int ldc, const float *bias, int accumulate, double *colstats, cloudaae_stream_t stream);
+/* The same split products with the second operand split ONCE by the caller (a weight multiplies every row tile of a
+ * step's forward AND backward product): cloudaae_x3_split writes the three bfloat16 planes of a [rows][k] matrix
+ * (src = [rows][k], or [k][rows] when transposed != 0; cloudaae_x3_planes_bytes(rows, k) = 6 rows k bytes, 16-byte
+ * aligned, k % 32 == 0) in the order the matrix cores read them, and cloudaae_gemm_bf16x3p computes
+ * C[M,N] (+)= A[M,K] P^T (+ bias) with P the planes of the [N][K] operand -- y = x W with the planes of W^T
+ * (cloudaae_x3_split(N, K, W, ldw, 1, ..)), dx = dy W^T with the planes of W (cloudaae_x3_split(K_w, N_w, W, ldw, 0, ..)).
+ * A stays fp32 and is split in registers, once per element.  Served: M % 128 == 0, N a multiple of 128 or 160,
+ * K % 32 == 0, rows of A 16-byte aligned (cloudaae_gemm_bf16x3p_supported); colstats as cloudaae_gemm_f32_colstats with
+ * cloudaae_gemm_bf16x3p_colstats_parts(M, N, K) tile rows.  cloudaae_gemm_bf16x3 itself takes this route for
+ * trans_a == 0 with planes in stream-ordered scratch of the call. */
+long long cloudaae_x3_planes_bytes(int rows, int k);
+int cloudaae_x3_split(int rows, int k, const float *src, int ld, int transposed, void *planes, cloudaae_stream_t stream);
+/* both plane sets of a weight W[K][N] in one launch: planes_fwd = cloudaae_x3_split(N, K, W, ldw, 1, ..) for y = x W,
+ * planes_bwd = cloudaae_x3_split(K, N, W, ldw, 0, ..) for dx = dy W^T (6 K N bytes each; K, N multiples of 32) */
+int cloudaae_x3_split_weight(int K, int N, const float *W, int ldw, void *planes_fwd, void *planes_bwd,
+                             cloudaae_stream_t stream);
+int cloudaae_gemm_bf16x3p_supported(int M, int N, int K);
+int cloudaae_gemm_bf16x3p_colstats_parts(int M, int N, int K);
+int cloudaae_gemm_bf16x3p(int M, int N, int K, const float *A, int lda, const void *planes, float *C, int ldc,
+                          const float *bias, int accumulate, double *colstats, cloudaae_stream_t stream);
 
 /* ---- activations kept as bfloat16 in HBM (BASELINE configs[2]: "bf16 MLPs") --------------------------------------
  * The same products as cloudaae_gemm_bf16 (conv2d 1x1 and its two gradient products, utils/tf_util.py:161-166) with

@@ -827,6 +827,121 @@ def test_gemm_bf16x3(hip, ta, tb, M, N, K):
     assert float((C3.double() - (2 * want - bias.double())).abs().max()) / scale < 4e-5
 
 
+@pytest.mark.parametrize("ta,tb,M,N,K", [(0, 0, 4096, 1024, 320), (0, 1, 32768, 320, 1024), (1, 0, 320, 1024, 4096)])
+def test_gemm_bf16x3_operands_the_split_treats_differently(hip, ta, tb, M, N, K):
+    """The split product on operands a bfloat16 split could mishandle (both kernel generations: the streamed kernels for
+    the first two shapes, the K-sliced one for the third):
+      * |v| up to FLT_MAX, where bf16(v) would round to infinity: the leading piece saturates, the split stays exact, the
+        results are the fp32 kernel's;
+      * denormal operands (pieces are denormal bfloat16s): no NaN / inf, results within a few denormal ulps;
+      * +-inf and NaN: every output the fp32 kernel makes non-finite is non-finite here too (NaN: the split does not tell
+        inf from NaN), every other output is untouched."""
+    L = hip.lib()
+    assert L.cloudaae_gemm_bf16x3_supported(ta, tb, M, N, K) == 1
+    rng = np.random.default_rng(5 * M + N + K)
+    P = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    FLT_MAX = float(np.finfo(np.float32).max)
+
+    def run(A, B):
+        C3 = torch.full((M, N), float("nan"), device="cuda")
+        C32 = torch.full((M, N), float("nan"), device="cuda")
+        hip.check(L.cloudaae_gemm_bf16x3(ta, tb, M, N, K, P(A), A.shape[1], P(B), B.shape[1], P(C3), N, None, 0, None,
+                                         hip.stream()), "gemm_bf16x3")
+        hip.check(L.cloudaae_gemm_f32(ta, tb, M, N, K, P(A), A.shape[1], P(B), B.shape[1], P(C32), N, None, 0, hip.stream()),
+                  "gemm_f32")
+        Ad, Bd = A.double(), B.double()
+        return C3, C32, (Ad.T if ta else Ad) @ (Bd.T if tb else Bd)
+
+    a_shape, b_shape = ((K, M) if ta else (M, K)), ((N, K) if tb else (K, N))
+    # (1) magnitudes up to FLT_MAX in A (signs mixed), B scaled so that the sums stay finite
+    a = rng.uniform(0.5, 1.0, a_shape).astype(np.float32) * np.float32(FLT_MAX)
+    a *= rng.choice([-1.0, 1.0], a_shape).astype(np.float32)
+    a.flat[:: 7] = np.float32(FLT_MAX)
+    a.flat[3:: 11] = -np.float32(FLT_MAX)
+    a.flat[5:: 13] = np.float32(3.3961775e38)         # just below / at the bfloat16 rounding boundary
+    a.flat[6:: 17] = np.frombuffer(np.uint32(0x7f7f8000).tobytes(), dtype=np.float32)[0]
+    b = (rng.standard_normal(b_shape) * 2.0 ** -110).astype(np.float32)
+    C3, C32, want = run(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    assert bool(torch.isfinite(C3).all()) and bool(torch.isfinite(C32).all())
+    scale = float(want.abs().max())
+    e3, e32 = float((C3.double() - want).abs().max()) / scale, float((C32.double() - want).abs().max()) / scale
+    assert e3 < 2e-5 / np.sqrt(K) * 30 and e3 <= 2.0 * e32 + 1e-7, (e3, e32)
+    # ... and the same with the roles swapped (the big magnitudes in the operand that is split once / staged through LDS)
+    C3, C32, want = run(torch.from_numpy((rng.standard_normal(a_shape) * 2.0 ** -110).astype(np.float32)).cuda(),
+                        torch.from_numpy((rng.uniform(0.5, 1.0, b_shape) * FLT_MAX * rng.choice([-1.0, 1.0], b_shape))
+                                         .astype(np.float32)).cuda())
+    scale = float(want.abs().max())
+    assert bool(torch.isfinite(C3).all())
+    assert float((C3.double() - want).abs().max()) / scale <= 2.0 * float((C32.double() - want).abs().max()) / scale + 1e-7
+    # (2) denormals
+    a = (rng.standard_normal(a_shape) * 1e-40).astype(np.float32)
+    b = rng.standard_normal(b_shape).astype(np.float32)
+    C3, C32, want = run(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    assert bool(torch.isfinite(C3).all())
+    assert float((C3.double() - want).abs().max()) < 1e-37       # (either kernel may flush: results are ~1e-39)
+    # (3) +-inf and NaN in either operand
+    a = rng.standard_normal(a_shape).astype(np.float32)
+    b = rng.standard_normal(b_shape).astype(np.float32)
+    a[3, 5], a[7, 2], a[64, 33] = np.inf, np.nan, -np.inf
+    b[9, 4], b[40, 77] = -np.inf, np.nan
+    b[5, :] = 0.5                                      # (exactly representable rows: their lower pieces are zero)
+    C3, C32, want = run(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    bad32, bad3 = ~torch.isfinite(C32), ~torch.isfinite(C3)
+    assert bool(bad32.any()) and torch.equal(bad32, bad3)
+    ok = ~bad32
+    good = torch.isfinite(want)
+    assert torch.equal(ok, good.cuda() if not good.is_cuda else good)
+    scale = float(want[good].abs().max())
+    assert float((C3.double() - want)[ok].abs().max()) / scale < 2e-6
+
+
+def test_gemm_bf16x3p_planes_entry_points(hip):
+    """cloudaae_x3_split_weight + cloudaae_gemm_bf16x3p (what the dgcnn_agg layer calls: the weight split once per step)
+    give bit for bit what cloudaae_gemm_bf16x3 gives with the split inside the call, column sums included."""
+    L = hip.lib()
+    M, K, N = 16384, 320, 1024           # (enough row tiles that cloudaae_gemm_bf16x3 takes the streamed route for both products)
+    rng = np.random.default_rng(11)
+    X = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).cuda()
+    W = torch.from_numpy((rng.standard_normal((K, N)) / 18).astype(np.float32)).cuda()
+    dY = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda()
+    bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).cuda()
+    P = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    assert L.cloudaae_gemm_bf16x3p_supported(M, N, K) == 1 and L.cloudaae_gemm_bf16x3p_supported(M, K, N) == 1
+    assert L.cloudaae_x3_planes_bytes(N, K) == 6 * N * K
+    pf = torch.empty(3 * N * K, dtype=torch.bfloat16, device="cuda")
+    pb = torch.empty(3 * N * K, dtype=torch.bfloat16, device="cuda")
+    hip.check(L.cloudaae_x3_split_weight(K, N, P(W), N, P(pf), P(pb), hip.stream()), "x3_split_weight")
+    # the two single-job splits write the same planes
+    pf1, pb1 = torch.empty_like(pf), torch.empty_like(pb)
+    hip.check(L.cloudaae_x3_split(N, K, P(W), N, 1, P(pf1), hip.stream()), "x3_split")
+    hip.check(L.cloudaae_x3_split(K, N, P(W), N, 0, P(pb1), hip.stream()), "x3_split")
+    assert torch.equal(pf.view(torch.int16), pf1.view(torch.int16)) and torch.equal(pb.view(torch.int16), pb1.view(torch.int16))
+    # the planes add up to W exactly: h + m + l == w for every element
+    planes = pb.float().reshape(N // 16, 3, K, 2, 8)               # [step][plane][row][unit][8]
+    rows = torch.arange(K, device="cuda")
+    swap = ((rows >> 3) & 1).bool()
+    planes = torch.where(swap[None, None, :, None, None], planes.flip(3), planes)
+    back = planes.sum(1).permute(1, 0, 2, 3).reshape(K, N)
+    assert torch.equal(back, W)
+    parts = L.cloudaae_gemm_bf16x3p_colstats_parts(M, N, K)
+    assert parts == L.cloudaae_gemm_bf16x3_colstats_parts(M, N, K) and parts > 0
+    Y, Y0 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    cs, cs0 = (torch.zeros(parts * 2 * N, dtype=torch.float64, device="cuda") for _ in range(2))
+    hip.check(L.cloudaae_gemm_bf16x3p(M, N, K, P(X), K, P(pf), P(Y), N, P(bias), 0, P(cs), hip.stream()), "gemm_bf16x3p")
+    hip.check(L.cloudaae_gemm_bf16x3(0, 0, M, N, K, P(X), K, P(W), N, P(Y0), N, P(bias), 0, P(cs0), hip.stream()), "gemm_bf16x3")
+    assert torch.equal(Y, Y0) and torch.equal(cs, cs0)
+    dX, dX0 = torch.empty(M, K, device="cuda"), torch.empty(M, K, device="cuda")
+    hip.check(L.cloudaae_gemm_bf16x3p(M, K, N, P(dY), N, P(pb), P(dX), K, None, 0, None, hip.stream()), "gemm_bf16x3p")
+    hip.check(L.cloudaae_gemm_bf16x3(0, 1, M, K, N, P(dY), N, P(W), N, P(dX0), K, None, 0, None, hip.stream()), "gemm_bf16x3")
+    assert torch.equal(dX, dX0)
+    want = X.double() @ W.double() + bias.double()
+    assert float((Y.double() - want).abs().max()) / (np.sqrt(K) + 1) < 2e-5
+    # refusals
+    assert L.cloudaae_gemm_bf16x3p_supported(100, 128, 32) == 0 and L.cloudaae_gemm_bf16x3p_supported(128, 96, 32) == 0
+    rc = L.cloudaae_gemm_bf16x3p(100, 128, 32, P(X), K, P(pf), P(Y), N, None, 0, None, hip.stream())
+    assert rc != 0 and "not served" in L.cloudaae_last_error().decode()
+
+
 def test_gemm_bf16x3_refuses_what_it_does_not_serve(hip):
     L = hip.lib()
     assert L.cloudaae_gemm_bf16x3_supported(0, 0, 100, 128, 32) == 0
