@@ -261,6 +261,32 @@ def measured_traffic(B, N, kernel_key):
     return rec.get("traffic_bytes_per_launch")
 
 
+def bit_checksum(t):
+    """64-bit sum of the 32-bit patterns of a float32 tensor (order independent, exact)."""
+    return int(t.detach().contiguous().view(torch.int32).to(torch.int64).sum().item())
+
+
+def replica_check(graph, loss, world):
+    """After the timed steps: gather (checksum of flat_params, checksum of the post-exchange flat_grads, loss) from every
+    rank.  Data-parallel replicas start from broadcast weights and apply the same all-reduced gradient, so the first two
+    must agree bit for bit on every rank; the per-rank losses differ (different shards) and their spread is reported."""
+    mine = torch.tensor([bit_checksum(graph.store.flat_params), bit_checksum(graph.store.flat_grads)], dtype=torch.int64,
+                        device=graph.device)
+    lmine = torch.tensor([loss], dtype=torch.float64, device=graph.device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        allc = [torch.zeros_like(mine) for _ in range(world)]
+        alll = [torch.zeros_like(lmine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        dist.all_gather(alll, lmine)
+    else:
+        allc, alll = [mine], [lmine]
+    sums = [[int(v) for v in c.tolist()] for c in allc]
+    losses = [float(v) for v in alll]
+    return {"identical": all(c == sums[0] for c in sums), "checksums": {"flat_params": [c[0] for c in sums],
+                                                                          "flat_grads": [c[1] for c in sums]},
+            "loss_rank_spread": round(max(losses) - min(losses), 6)}
+
+
 def launch_children(args):
     """--gpus N without a launcher: run N ranks as children of THIS process (which has not touched the
     GPU and will not), relay their output, return the exit code."""
@@ -419,6 +445,13 @@ def main():
     torch.cuda.synchronize()
     events["edgeconv"] = F.TIMED_SITES.pop("edgeconv")
 
+    # N > 1 (and the forced one-rank RCCL run): the replicas must be IDENTICAL after the timed steps -- same weights, same
+    # post-exchange gradient buffer on every rank (a 64-bit sum of the bit patterns of each, gathered over the ranks);
+    # a stream-ordering slip between the asynchronous early all-reduce and the kernels around it shows up here
+    replicas = None
+    if world > 1 or force:
+        replicas = replica_check(graph, float(out["total_loss"]), world)
+
     one_rank = None
     if world > 1:
         # the same per-GPU batch on rank 0 ALONE (no collectives, the others wait at the barrier)
@@ -536,6 +569,10 @@ def main():
                             "allreduce_exposed_ms": round(x_ms, 4), "exchanges_timed": x_n,
                             "bytes_per_step": int(graph.store.flat_grads.numel()) * 4,
                             "sync_bn": bool(args.sync_bn)}
+        if replicas is not None:
+            line["replicas_identical"] = replicas["identical"]
+            line["loss_rank_spread"] = replicas["loss_rank_spread"]
+            line["comm"]["replica_checksums"] = replicas["checksums"]
         if one_rank is not None:
             line["one_rank_same_shape"] = one_rank
         if world == 1 and not args.step_only:
@@ -551,8 +588,12 @@ def main():
             line["cpu_table"] = cpu_table(N)
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_batch, args.cpu_steps)
         print(json.dumps(line))
+    diverged = replicas is not None and not replicas["identical"]
     if dist.is_initialized():
         dist.destroy_process_group()
+    if diverged:
+        sys.stderr.write("bench.py: the data-parallel replicas DIVERGED (see replica_checksums)\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

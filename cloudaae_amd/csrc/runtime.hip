@@ -22,11 +22,15 @@ CLOUDAAE_API int cloudaae_version(void) { return 300; }
 #include <string.h>
 #include <mutex>
 namespace cloudaae {
-constexpr int MAX_KNOBS = 64;
+constexpr int MAX_KNOBS = 128;
 static Knob g_knobs[MAX_KNOBS];
 static char g_knob_names[MAX_KNOBS][48];
 static int g_nknobs = 0;
 static std::mutex g_knob_mutex;
+// A full table never aliases names: every further name shares ONE slot that is never set (a reader falls back to its
+// default; cloudaae_set_knob / _unset_knob refuse it).  The fields are plain ints: knobs are set between launches by the
+// thread that launches (tests, sweeps), not concurrently with it.
+static Knob g_knob_overflow = {"(knob table full)", 0, false};
 Knob *knob_slot(const char *name)
 {
     std::lock_guard<std::mutex> lock(g_knob_mutex);
@@ -34,7 +38,7 @@ Knob *knob_slot(const char *name)
         if (strcmp(g_knobs[i].name, name) == 0)
             return &g_knobs[i];
     if (g_nknobs == MAX_KNOBS)
-        return &g_knobs[MAX_KNOBS - 1];
+        return &g_knob_overflow;
     Knob &k = g_knobs[g_nknobs];
     strncpy(g_knob_names[g_nknobs], name, sizeof(g_knob_names[0]) - 1);
     k.name = g_knob_names[g_nknobs];
@@ -53,6 +57,10 @@ CLOUDAAE_API int cloudaae_set_knob(const char *name, int value)
         return (int)hipErrorInvalidValue;
     }
     cloudaae::Knob *k = cloudaae::knob_slot(name);
+    if (k == &cloudaae::g_knob_overflow) {
+        cloudaae::set_error("cloudaae_set_knob: knob table full (%d names)", cloudaae::MAX_KNOBS);
+        return (int)hipErrorInvalidValue;
+    }
     k->value = value;
     k->set = true;
     return 0;
@@ -64,7 +72,12 @@ CLOUDAAE_API int cloudaae_unset_knob(const char *name)
         cloudaae::set_error("cloudaae_unset_knob: bad name");
         return (int)hipErrorInvalidValue;
     }
-    cloudaae::knob_slot(name)->set = false;
+    cloudaae::Knob *k = cloudaae::knob_slot(name);
+    if (k == &cloudaae::g_knob_overflow) {
+        cloudaae::set_error("cloudaae_unset_knob: knob table full (%d names)", cloudaae::MAX_KNOBS);
+        return (int)hipErrorInvalidValue;
+    }
+    k->set = false;
     return 0;
 }
 

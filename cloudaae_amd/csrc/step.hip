@@ -23,7 +23,7 @@ __global__ __launch_bounds__(IA_THREADS) void input_assemble_kernel(int P, int N
                                                                    const long long *__restrict__ class_id,
                                                                    float *__restrict__ pc, float *__restrict__ mean,
                                                                    float *__restrict__ noisy, float noise_std,
-                                                                   unsigned long long seed, const float *__restrict__ step)
+                                                                   unsigned long long seed, unsigned long long *__restrict__ draws)
 {
     constexpr int NWV = IA_THREADS / 64;
     __shared__ float red[3][NWV];
@@ -32,7 +32,11 @@ __global__ __launch_bounds__(IA_THREADS) void input_assemble_kernel(int P, int N
     const float *V = visible + (size_t)b * P * 3;
     const float *Z = noise ? noise + (size_t)b * N * 3 : nullptr;
     const bool draw = Z == nullptr && noise_std > 0.0f;
-    const unsigned stream_id = draw && step != nullptr ? (unsigned)(long long)step[0] : 0u;
+    // draws[0]: how many times this kernel has drawn (the Philox stream of THIS launch; its own counter, not the float
+    // global-step variable: that one stops changing at 2^24 and follows a restored checkpoint); draws[1]: arrival ticket.
+    // Every workgroup reads the counter when it starts and the LAST one to finish advances it -- by then all have read.
+    const unsigned long long draw_no = draw && draws != nullptr ? draws[0] : 0ull;
+    const unsigned stream_id = (unsigned)draw_no ^ (unsigned)(draw_no >> 32) * 0x9E3779B9u;
     auto point = [&](int j, float &x, float &y, float &z) {
         x = V[3 * j];
         y = V[3 * j + 1];
@@ -114,6 +118,12 @@ __global__ __launch_bounds__(IA_THREADS) void input_assemble_kernel(int P, int N
         row[2] = z - mu[2];
         for (int c = 0; c < num_class; ++c)
             row[3 + c] = (c == cls) ? 1.0f : 0.0f;
+    }
+    if (draw && draws != nullptr && t == 0) {
+        if (atomicAdd(&draws[1], 1ull) == (unsigned long long)gridDim.x - 1ull) {
+            draws[1] = 0ull;
+            draws[0] = draw_no + 1ull;
+        }
     }
 }
 
@@ -779,14 +789,14 @@ CLOUDAAE_API int cloudaae_input_assemble(int b, int p, int n, int num_class, con
     if (b == 0)
         return 0;
     hipLaunchKernelGGL(input_assemble_kernel, dim3(b), dim3(IA_THREADS), 0, (hipStream_t)stream, p, n, num_class,
-                       visible, noise, class_id, pc, mean, noisy, 0.0f, 0ull, (const float *)nullptr);
+                       visible, noise, class_id, pc, mean, noisy, 0.0f, 0ull, (unsigned long long *)nullptr);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }
 
 CLOUDAAE_API int cloudaae_input_assemble_noise(int b, int p, int n, int num_class, const float *visible,
                                                const long long *class_id, float *pc, float *mean, float *noisy,
-                                               float noise_std, unsigned long long seed, const float *step,
+                                               float noise_std, unsigned long long seed, unsigned long long *draws,
                                                cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_input_assemble_noise";
@@ -795,7 +805,7 @@ CLOUDAAE_API int cloudaae_input_assemble_noise(int b, int p, int n, int num_clas
     if (b == 0)
         return 0;
     hipLaunchKernelGGL(input_assemble_kernel, dim3(b), dim3(IA_THREADS), 0, (hipStream_t)stream, p, n, num_class,
-                       visible, (const float *)nullptr, class_id, pc, mean, noisy, noise_std, seed, step);
+                       visible, (const float *)nullptr, class_id, pc, mean, noisy, noise_std, seed, draws);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }

@@ -81,7 +81,7 @@ def _dgcnn_6d(point_cloud, is_training_pl_encoder, is_training, k_neighbor, bn_d
     # decoder and both heads read the embedding: three chains, evaluated depth by depth
     net, net_rot, net_trans = tf_util.fully_connected_chains(
         embedding, [_decoder_chain(num_point * mult * dim, prefix)] + _pose_chains(prefix), bn_decay=bn_decay,
-        is_training=is_training)
+        is_training=is_training, point_outputs={0: dim, 2: 3})
     net_recon = net.reshape(batch_size, num_point * mult, dim)
     return net_recon, net_rot, net_trans, end_points
 
@@ -181,7 +181,7 @@ def get_model_pn(point_cloud, is_training, bn_decay=None):
         [[('pn_fc1_decoder', 1024, True), ('pn_fc2_decoder', 1024, True), ('pn_output', num_point * 3 * 4, False)],
          [('pn_rot_fc1', 512, True), ('pn_rot_fc2', 256, True), ('pn_output_rot', 3, False)],
          [('pn_trans_fc1', 512, True), ('pn_trans_fc2', 256, True), ('pn_output_trans', 3, False)]],
-        bn_decay=bn_decay, is_training=is_training)
+        bn_decay=bn_decay, is_training=is_training, point_outputs={0: 3, 2: 3})
     net_recon = net.reshape(batch_size, num_point * 4, 3)
 
     return net_recon, net_rot, net_trans, end_points

@@ -145,6 +145,7 @@ class TrainGraph(object):
         self._one = torch.ones((), dtype=torch.float32, device=dev)           # d(total_loss)/d(total_loss)
         # seed of this rank's input noise (:217; tf.set_random_seed(123456789), :160)
         self.noise_seed = (int(seed) + 0x9E3779B97F4A7C15 * (self.rank + 1)) % (1 << 64)
+        self.noise_draws = torch.zeros(2, dtype=torch.int64, device=dev)     # {draw counter, ticket} of the assembly kernel
         self._adam_ticket = torch.zeros(1, dtype=torch.int32, device=dev)   # arrival counter of the optimiser kernel
         # replay=True: the first train_step of a given input shape is RECORDED (_lib.StepPlan: the
         # C-ABI calls in issue order, buffers from the plan's arena) and later steps re-issue it
@@ -230,11 +231,12 @@ class TrainGraph(object):
         cls = element['class_id'].to(torch.int64).contiguous()
         if noise is None and is_training:
             # tf.random.normal(shape, stddev=0.004/3), :217, drawn inside the assembly kernel: a function of
-            # (this rank's seed, the step counter `batch`, cloud, point) -- fresh at every step, also when a
-            # recorded step is replayed, and no generator kernel in front of the step
+            # (this rank's seed, the kernel's own draw counter, cloud, point) -- fresh at every step, also when a
+            # recorded step is replayed, independent of the global-step variable (as the reference's generator
+            # is), and no generator kernel in front of the step
             _lib.check(_lib.lib().cloudaae_input_assemble_noise(B, P, N, NUM_CLASS, ptr(vis), ptr(cls), ptr(pc),
                                                                 ptr(element_mean), ptr(noisy), NOISE_STDDEV,
-                                                                self.noise_seed, ptr(self.batch), stream()),
+                                                                self.noise_seed, ptr(self.noise_draws), stream()),
                        "cloudaae_input_assemble_noise")
         else:
             _lib.check(_lib.lib().cloudaae_input_assemble(B, P, N, NUM_CLASS, ptr(vis),
@@ -247,9 +249,11 @@ class TrainGraph(object):
         visiblePoints_org_final = org[:, 0:N * 4, :].contiguous()
 
         # :232-233 -- xyz_recon = recon_res + mean, trans_pred = trans_res + mean: offered to the fully connected
-        # stack, whose output layers (decoder: chain 0, translation head: chain 2) add the row vector in their own
-        # epilogue when they run as grouped launches (tf_util.fully_connected_chains takes the offer and clears it)
-        F.FC_OUT_ADD = (element_mean, (0, 2))
+        # stack: the output layers of the chains the MODEL declares as point outputs (point_outputs: decoder and
+        # translation head) add the row vector in their own epilogue when they run as grouped launches
+        # (tf_util.fully_connected_chains takes the offer and clears it; a model that declares nothing, or whose
+        # decoder emits vectors of another width, leaves it and the additions below run)
+        F.FC_OUT_ADD = element_mean
         try:
             xyz_recon_res, rot_pred, trans_pred_res, endpoint = self._call_model(pc, is_training)
         finally:

@@ -224,9 +224,11 @@ class LinearFn(torch.autograd.Function):
 DETERMINISTIC = False
 
 
-# An offer to the next fully_connected_chains call: (row vector [B, d], indices of the chains whose OUTPUT gets
-# out[b, c] += vec[b, c % d]) -- train_cloudAAE_ycbv.py:232-233's "+ element_mean" folded into the output layers'
-# epilogue.  The call that takes the offer sets this back to None (TrainGraph.forward looks at it afterwards).
+# An offer to the next fully_connected_chains call: a row vector [B, d]; the chains the MODEL declares as point
+# outputs (tf_util.fully_connected_chains(point_outputs={chain: d})) get out[b, c] += vec[b, c % d] --
+# train_cloudAAE_ycbv.py:232-233's "+ element_mean" folded into the output layers' epilogue.  The call that takes the
+# offer sets this back to None (TrainGraph.forward looks at it afterwards); a model that declares no point outputs, or
+# whose decoder emits vectors of another width (the *_hand decoder: 5), leaves it untouched.
 FC_OUT_ADD = None
 
 

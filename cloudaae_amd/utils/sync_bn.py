@@ -26,6 +26,21 @@ import torch.distributed as dist
 from .. import _lib
 
 
+# the batch norms' own communicator, one per set of ranks and process (created at the first BnSync over those ranks,
+# reused by every later one, destroyed by close_communicators())
+_OWN_GROUPS = {}
+
+
+def close_communicators():
+    """Destroy the communicators BnSync created (end of a process that builds many graphs, tests)."""
+    for g in _OWN_GROUPS.values():
+        try:
+            dist.destroy_process_group(g)
+        except Exception:      # noqa: BLE001 -- already gone with the default group
+            pass
+    _OWN_GROUPS.clear()
+
+
 class BnSync(object):
     def __init__(self, group=None, world=None, own_communicator=True):
         # own_communicator: the small blocking all-reduces of the batch norms get their OWN communicator (a second
@@ -34,8 +49,13 @@ class BnSync(object):
         # asynchronous all-reduce of the fully connected gradients (utils/grad_exchange.py) and undo its overlap
         self.world = int(world if world is not None else dist.get_world_size(group))
         if own_communicator and dist.is_initialized() and self.world > 1:
-            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-            group = dist.new_group(ranks=ranks)       # (collective over the default group: every rank builds its BnSync)
+            # dist.new_group is a collective over the DEFAULT group: every rank of the default group must construct its
+            # first BnSync over these ranks (ranks outside `group` included), in the same order relative to other
+            # new_group calls.  Later BnSyncs over the same ranks reuse the communicator: no further collective, no leak.
+            ranks = tuple(dist.get_process_group_ranks(group) if group is not None else range(dist.get_world_size()))
+            if ranks not in _OWN_GROUPS:
+                _OWN_GROUPS[ranks] = dist.new_group(ranks=list(ranks))
+            group = _OWN_GROUPS[ranks]
         self.group = group
         self.calls = 0               # all-reduces issued (tests and bench read it)
         self.error = None            # exception raised inside the callback (ctypes cannot propagate it)

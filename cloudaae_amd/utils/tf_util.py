@@ -234,13 +234,16 @@ def _fc_variables(scope, num_inputs, num_outputs, bn, use_xavier=True, stddev=1e
     return weights.data, biases.data, gamma, beta, ema_mean, ema_var
 
 
-def fully_connected_chains(inputs, chains, bn_decay=None, is_training=None):
+def fully_connected_chains(inputs, chains, bn_decay=None, is_training=None, point_outputs=None):
     """Several independent chains of fully_connected layers over one input -- the decoder and the two
     pose heads of models/pointnet_ycb_23_decoder_4.py:413-455 -- evaluated depth by depth: with a batch of
     <= 32 clouds the layers of one depth share a launch per direction (F.FcGroupFn), otherwise each layer
     runs as fully_connected() does.  chains: list of chains; a chain is a list of
     (scope, num_outputs, bn) with ReLU exactly on the bn layers.  Variables are created chain by chain,
-    i.e. in the order separate fully_connected() calls would create them.  Returns the chain outputs."""
+    i.e. in the order separate fully_connected() calls would create them.  Returns the chain outputs.
+    point_outputs: {chain index: d} -- the MODEL's statement that this chain's output is a list of d-vectors in
+    camera coordinates (reconstruction [B, rows * d], translation [B, d]); only such chains may take the training
+    step's offer F.FC_OUT_ADD (a [B, d] row vector added in the output layer's epilogue, train...:232-233)."""
     require(inputs.dim() == 2, "fully_connected_chains: inputs must be BxN")
     if not F.fc_fits(inputs.shape[0]) or len(chains) > F.fc_max_group() or (is_training and F.BN_SYNC is not None):
         outs = []
@@ -260,14 +263,17 @@ def fully_connected_chains(inputs, chains, bn_decay=None, is_training=None):
         variables.append(row)
     decay = _decay_tensor(bn_decay) if any(bn for chain in chains for _, _, bn in chain) else None
     depth = max(len(c) for c in chains)
-    # F.FC_OUT_ADD: (row vector, chain indices) -- taken when every named chain exists and ends in a layer without
-    # batch norm (the kernel adds the vector to a plain output only)
-    offer = F.FC_OUT_ADD
-    if offer is not None and all(i < len(chains) and not chains[i][-1][2] for i in offer[1]) and \
-            offer[0].shape[0] == inputs.shape[0]:
+    # F.FC_OUT_ADD: the [B, d] row vector the step wants added to the model's point outputs.  Taken only when the model
+    # declared which chains those are (point_outputs), every one of them has width d per point (a decoder of 5-vectors
+    # does not take a 3-vector) and ends in a layer without batch norm (the kernel adds to a plain output only);
+    # otherwise the offer stays and the caller adds the vector itself (F.AddRowVecFn, which checks the shapes)
+    vec = F.FC_OUT_ADD
+    offer = None
+    if vec is not None and point_outputs and vec.dim() == 2 and vec.shape[0] == inputs.shape[0] and \
+            all(0 <= i < len(chains) and not chains[i][-1][2] and int(d) == vec.shape[1] and chains[i][-1][1] % int(d) == 0
+                for i, d in point_outputs.items()):
+        offer = (vec, tuple(sorted(point_outputs)))
         F.FC_OUT_ADD = None
-    else:
-        offer = None
     nets = [None] * len(chains)
     for d in range(depth):
         members = [i for i, c in enumerate(chains) if d < len(c)]

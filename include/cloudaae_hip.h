@@ -491,6 +491,15 @@ int cloudaae_edgeconv_backward(int b, int n, int k, int cin, int cout, const flo
 int cloudaae_input_assemble(int b, int p, int n, int num_class, const float *visible, const float *noise,
                             const long long *class_id, float *pc, float *mean, float *noisy,
                             cloudaae_stream_t stream);
+/* The same with the noise of :217 (tf.random.normal, stddev = noise_std) drawn INSIDE the kernel: Philox4x32-10 keyed by
+ * `seed`, counter = (cloud, point), stream = draws[0] -- the number of launches that have drawn so far, kept in the two
+ * 64-bit device words `draws` ({counter, arrival ticket}, both zero to start with; the last workgroup of a launch
+ * advances the counter, so a recorded step replayed with the same arguments draws fresh noise every time and the noise
+ * does not depend on the global-step variable).  Same distribution as the reference's generator, not the same stream.
+ * draws == NULL: stream 0 at every launch. */
+int cloudaae_input_assemble_noise(int b, int p, int n, int num_class, const float *visible, const long long *class_id,
+                                  float *pc, float *mean, float *noisy, float noise_std, unsigned long long seed,
+                                  unsigned long long *draws, cloudaae_stream_t stream);
 /* :232-233  out[b,r,:] = x[b,r,:] + v[b,:] */
 int cloudaae_add_rowvec(int b, int r, int d, const float *x, const float *v, float *out,
                         cloudaae_stream_t stream);

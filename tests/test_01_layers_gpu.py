@@ -370,14 +370,15 @@ def test_input_assemble_draws_its_own_noise(hip):
     B, P, N, std = 6, 3000, 2048, 0.004 / 3
     b = MO.synthetic_batch(B, P, seed=4)
     vis, cls = b["visiblePoints"].cuda(), b["class_id"].cuda()
-    step = torch.zeros(1, device="cuda")
+    draws = torch.zeros(2, dtype=torch.int64, device="cuda")     # {draw counter, ticket}
 
     def run(seed, s_):
-        step.fill_(float(s_))
+        draws[0] = s_
         pc, mean = torch.empty((B, N, 24), device="cuda"), torch.empty((B, 3), device="cuda")
         noisy = torch.empty((B, N, 3), device="cuda")
         hip.check(L.cloudaae_input_assemble_noise(B, P, N, 21, hip.ptr(vis), hip.ptr(cls), hip.ptr(pc), hip.ptr(mean),
-                                                  hip.ptr(noisy), std, seed, hip.ptr(step), hip.stream()), "assemble")
+                                                  hip.ptr(noisy), std, seed, hip.ptr(draws), hip.stream()), "assemble")
+        assert draws.tolist() == [s_ + 1, 0]                     # the launch advanced its counter, the ticket is back at 0
         return pc, mean, noisy
     pc, mean, noisy = run(77, 3)
     z = (noisy - vis[:, :N]).double()
@@ -392,11 +393,22 @@ def test_input_assemble_draws_its_own_noise(hip):
     again = run(77, 3)
     assert all(torch.equal(x, y) for x, y in zip(again, (pc, mean, noisy)))
     assert not torch.equal(run(77, 4)[2], noisy) and not torch.equal(run(78, 3)[2], noisy)
-    # no noise at all (stddev 0): the plain assembly
-    step.fill_(3.0)
+    # a counter beyond 2^32 (and beyond 2^24, where a float step counter stops changing) still gives a new stream
+    big = run(77, (1 << 32) + 3)[2]
+    assert not torch.equal(big, noisy) and not torch.equal(big, run(77, (1 << 32) + 4)[2])
+    # back-to-back launches with the same arguments (a replayed step) draw fresh noise each time
+    draws[0] = 3
+    seq = []
+    for _ in range(3):
+        hip.check(L.cloudaae_input_assemble_noise(B, P, N, 21, hip.ptr(vis), hip.ptr(cls), hip.ptr(pc), hip.ptr(mean),
+                                                  hip.ptr(noisy), std, 77, hip.ptr(draws), hip.stream()), "assemble")
+        seq.append(noisy.clone())
+    assert torch.equal(seq[0], again[2]) and torch.equal(seq[1], run(77, 4)[2]) and not torch.equal(seq[1], seq[2])
+    # no noise at all (stddev 0): the plain assembly, and nothing is drawn
+    draws[0] = 3
     hip.check(L.cloudaae_input_assemble_noise(B, P, N, 21, hip.ptr(vis), hip.ptr(cls), hip.ptr(pc), hip.ptr(mean),
-                                              hip.ptr(noisy), 0.0, 77, hip.ptr(step), hip.stream()), "assemble")
-    assert torch.equal(noisy, vis[:, :N])
+                                              hip.ptr(noisy), 0.0, 77, hip.ptr(draws), hip.stream()), "assemble")
+    assert torch.equal(noisy, vis[:, :N]) and draws.tolist() == [3, 0]
 
 
 def test_loss_tail_equals_its_parts(hip):

@@ -83,6 +83,42 @@ def test_grad_exchange_world2():
     assert dict(out) == {0: True, 1: True}
 
 
+def _replica_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        import types
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        g = torch.Generator().manual_seed(3)
+        params, grads = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+        graph = types.SimpleNamespace(device=torch.device("cpu"),
+                                      store=types.SimpleNamespace(flat_params=params.clone(), flat_grads=grads.clone()))
+        same = bench.replica_check(graph, 1.0 + 0.25 * rank, world)
+        # one ulp in one weight of ONE rank must be seen (and a permutation of equal values must not matter)
+        if rank == 1:
+            graph.store.flat_params[17] = torch.nextafter(graph.store.flat_params[17], torch.tensor(10.0))
+        diff = bench.replica_check(graph, 1.0, world)
+        graph.store.flat_params.copy_(params.flip(0) if rank == 1 else params)
+        perm = bench.replica_check(graph, 1.0, world)
+        out[rank] = (same["identical"], same["loss_rank_spread"], diff["identical"], perm["identical"],
+                     len(same["checksums"]["flat_params"]), bench.bit_checksum(torch.tensor([1.0, -1.0])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_replica_check_world2():
+    """bench.py's N > 1 self-check: identical replicas pass, a one-ulp difference on one rank fails, the per-rank loss
+    spread is reported (world 2 over gloo)."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_replica_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    want = (True, 0.25, False, True, 2, 0x3f800000 + 0xbf800000 - (1 << 32))
+    assert dict(out) == {0: want, 1: want}
+
+
 def test_shard_range_errors():
     from cloudaae_amd.utils.grad_exchange import shard_range
     assert shard_range(1024, 8, 3) == (384, 512)
