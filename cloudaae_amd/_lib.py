@@ -20,6 +20,7 @@ _U = ctypes.c_ulonglong
 # argument types of every entry point of include/cloudaae_hip.h (stream last)
 _SIGNATURES = {
     "cloudaae_nn_distance": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P],
+    "cloudaae_nn_distance_prefix": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "cloudaae_nn_distance_grad": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "cloudaae_nn_distance_grad_ordered": [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "cloudaae_farthest_point_sample": [_I, _I, _I, _P, _P, _P, _P],
@@ -105,7 +106,7 @@ _SIGNATURES = {
     "cloudaae_random_spherical_occluder": [_I, _I, _P, _F, _F, _F, _F, _U, _P, _P],
     "cloudaae_spherical_flip": [_I, _I, _P, _I, _P, _P, _F, _P, _P, _P],
     "cloudaae_hidden_point_removal": [_I, _I, _P, _P, _U, _P, _P, _P, _P, _P],
-    "cloudaae_hidden_point_removal_rows": [_I, _I, _P, _P, _U, _I, _P, _P, _P, _P, _P],
+    "cloudaae_hidden_point_removal_rows": [_I, _I, _P, _P, _U, _I, _P, _P, _P, _P, _P, _P],
 }
 
 

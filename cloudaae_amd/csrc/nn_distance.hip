@@ -45,11 +45,38 @@ __device__ __forceinline__ float sqdist(float cx, float cy, float cz, float qx, 
     return dx * dx + dy * dy + dz * dz;
 }
 
+// rows of xyz2 that are distinct points (cloudaae_nn_distance_prefix); all of them without a count, or with a count
+// outside (0, m]
+__device__ __forceinline__ int prefix_rows(const long long *count2, int cloud, int m)
+{
+    if (count2 == nullptr)
+        return m;
+    const long long c = count2[cloud];
+    return c > 0 && c < m ? (int)c : m;
+}
+
+// results of the copies: row j >= count2[cloud] of xyz2 is a copy of row row_src[j] < count2[cloud]
+__global__ __launch_bounds__(256) void nn_distance_expand_kernel(int m, const long long *__restrict__ count2,
+                                                               const int *__restrict__ row_src, float *__restrict__ dist2,
+                                                               int *__restrict__ idx2)
+{
+    const int cloud = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    const int m_eff = prefix_rows(count2, cloud, m);
+    if (j < m_eff || j >= m)
+        return;
+    const size_t base = (size_t)cloud * m;
+    const int r = row_src[base + j];
+    if (r >= 0 && r < m_eff) {
+        dist2[base + j] = dist2[base + r];
+        idx2[base + j] = idx2[base + r];
+    }
+}
+
 template <int Q>
 __global__ __launch_bounds__(NN_THREADS) void nn_distance_kernel(
     int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
     float *__restrict__ dist1, int *__restrict__ idx1, float *__restrict__ dist2,
-    int *__restrict__ idx2, int tiles1)
+    int *__restrict__ idx2, int tiles1, const long long *__restrict__ count2)
 {
     __shared__ float4v lds[NN_CHUNK / 4 * 3];
 
@@ -57,12 +84,16 @@ __global__ __launch_bounds__(NN_THREADS) void nn_distance_kernel(
     const int cloud = blockIdx.y;
     const bool second = (int)blockIdx.x >= tiles1;
     const int tile = second ? (int)blockIdx.x - tiles1 : (int)blockIdx.x;
-    const int nq = second ? m : n;   // queries in this direction
-    const int nc = second ? n : m;   // candidates
-    const float *from = (second ? xyz2 : xyz1) + (size_t)cloud * nq * 3;
-    const float *to = (second ? xyz1 : xyz2) + (size_t)cloud * nc * 3;
-    float *dist = (second ? dist2 : dist1) + (size_t)cloud * nq;
-    int *idx = (second ? idx2 : idx1) + (size_t)cloud * nq;
+    const int m_eff = prefix_rows(count2, cloud, m);      // (see nn_distance_filter_kernel)
+    const int nq = second ? m_eff : n;   // queries in this direction
+    const int nc = second ? n : m_eff;   // candidates
+    const int sq = second ? m : n, sc = second ? n : m;
+    const float *from = (second ? xyz2 : xyz1) + (size_t)cloud * sq * 3;
+    const float *to = (second ? xyz1 : xyz2) + (size_t)cloud * sc * 3;
+    float *dist = (second ? dist2 : dist1) + (size_t)cloud * sq;
+    int *idx = (second ? idx2 : idx1) + (size_t)cloud * sq;
+    if (tile * (NN_THREADS * Q) >= nq)
+        return;
 
     float qx[Q], qy[Q], qz[Q];
     unsigned best[Q];
@@ -246,7 +277,7 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
     int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
     float *__restrict__ dist1, int *__restrict__ idx1, float *__restrict__ dist2,
     int *__restrict__ idx2, int blocks1, int split1, int split2, unsigned long long *__restrict__ keys1,
-    unsigned long long *__restrict__ keys2)
+    unsigned long long *__restrict__ keys2, const long long *__restrict__ count2)
 {
     // split > 1: the candidates of that direction are cut into `split` ranges (multiples of NF_CHUNK), one
     // workgroup per (query block, range); every range delivers its exact first-index minimum and the ranges meet
@@ -264,12 +295,19 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
     const int split = second ? split2 : split1;
     const int lin = second ? (int)blockIdx.x - blocks1 : (int)blockIdx.x;
     const int blk = lin / split, part = lin % split;
-    const int nq = second ? m : n, nc = second ? n : m;
-    const float *from = (second ? xyz2 : xyz1) + (size_t)cloud * nq * 3;
-    const float *to = (second ? xyz1 : xyz2) + (size_t)cloud * nc * 3;
-    float *dist = (second ? dist2 : dist1) + (size_t)cloud * nq;
-    int *idx = (second ? idx2 : idx1) + (size_t)cloud * nq;
-    unsigned long long *keys = (second ? keys2 : keys1) + (size_t)cloud * nq;
+    // count2 (cloudaae_nn_distance_prefix): only the first count2[cloud] rows of xyz2 are distinct points, the rest are
+    // copies of them -- they are neither candidates (first index wins: the answer is among the originals) nor queries
+    // (nn_distance_expand_kernel copies their results from the originals)
+    const int m_eff = prefix_rows(count2, cloud, m);
+    const int nq = second ? m_eff : n, nc = second ? n : m_eff;
+    const int sq = second ? m : n, sc = second ? n : m;     // row counts of the arrays
+    const float *from = (second ? xyz2 : xyz1) + (size_t)cloud * sq * 3;
+    const float *to = (second ? xyz1 : xyz2) + (size_t)cloud * sc * 3;
+    float *dist = (second ? dist2 : dist1) + (size_t)cloud * sq;
+    int *idx = (second ? idx2 : idx1) + (size_t)cloud * sq;
+    unsigned long long *keys = (second ? keys2 : keys1) + (size_t)cloud * sq;
+    if (blk * NF_QBLOCK >= nq)
+        return;                                         // (a query block of copies only)
     // this workgroup's candidate range
     const int range = ((nc + split - 1) / split + NF_CHUNK - 1) / NF_CHUNK * NF_CHUNK;
     const int cbeg = min(part * range, nc), cend = min(cbeg + range, nc);
@@ -664,11 +702,10 @@ __global__ __launch_bounds__(256) void nn_distance_grad_ordered_kernel(
 
 using namespace cloudaae;
 
-CLOUDAAE_API int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2,
-                                      float *dist1, int *idx1, float *dist2, int *idx2,
-                                      cloudaae_stream_t stream)
+static int nn_distance_impl(const char *name, int b, int n, const float *xyz1, int m, const float *xyz2,
+                            const long long *count2, const int *row_src2, float *dist1, int *idx1, float *dist2, int *idx2,
+                            cloudaae_stream_t stream)
 {
-    const char *name = "cloudaae_nn_distance";
     CLOUDAAE_REQUIRE(b >= 0 && n >= 0 && m >= 0, name, "negative size");
     if (b == 0 || (n == 0 && m == 0))
         return 0;
@@ -708,13 +745,15 @@ CLOUDAAE_API int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, co
             k2 = keys + c1;
         }
         hipLaunchKernelGGL(nn_distance_filter_kernel, dim3(t1 * s1 + t2 * s2, b), dim3(NF_WAVES * 64), 0, s, n, m, xyz1,
-                           xyz2, dist1, idx1, dist2, idx2, t1 * s1, s1, s2, k1, k2);
+                           xyz2, dist1, idx1, dist2, idx2, t1 * s1, s1, s2, k1, k2, count2);
         if (c1)
             hipLaunchKernelGGL(nn_distance_unpack_kernel, dim3(ceil_div((long long)c1, 256)), dim3(256), 0, s,
                                (long long)c1, k1, dist1, idx1);
         if (c2)
             hipLaunchKernelGGL(nn_distance_unpack_kernel, dim3(ceil_div((long long)c2, 256)), dim3(256), 0, s,
                                (long long)c2, k2, dist2, idx2);
+        if (count2 != nullptr && m > 0)
+            hipLaunchKernelGGL(nn_distance_expand_kernel, dim3(ceil_div(m, 256), b), dim3(256), 0, s, m, count2, row_src2, dist2, idx2);
         CLOUDAAE_CHECK_LAUNCH(name);
         if (keys != nullptr)
             CLOUDAAE_CHECK_HIP(hipFreeAsync(keys, s), name);
@@ -733,15 +772,33 @@ CLOUDAAE_API int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, co
     dim3 grid(t1 + t2, b), block(NN_THREADS);
     if (Q == 4)
         hipLaunchKernelGGL(nn_distance_kernel<4>, grid, block, 0, s, n, m, xyz1, xyz2, dist1, idx1,
-                           dist2, idx2, t1);
+                           dist2, idx2, t1, count2);
     else if (Q == 2)
         hipLaunchKernelGGL(nn_distance_kernel<2>, grid, block, 0, s, n, m, xyz1, xyz2, dist1, idx1,
-                           dist2, idx2, t1);
+                           dist2, idx2, t1, count2);
     else
         hipLaunchKernelGGL(nn_distance_kernel<1>, grid, block, 0, s, n, m, xyz1, xyz2, dist1, idx1,
-                           dist2, idx2, t1);
+                           dist2, idx2, t1, count2);
+    if (count2 != nullptr && m > 0)
+        hipLaunchKernelGGL(nn_distance_expand_kernel, dim3(ceil_div(m, 256), b), dim3(256), 0, s, m, count2, row_src2, dist2, idx2);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
+}
+
+CLOUDAAE_API int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2,
+                                      float *dist1, int *idx1, float *dist2, int *idx2,
+                                      cloudaae_stream_t stream)
+{
+    return nn_distance_impl("cloudaae_nn_distance", b, n, xyz1, m, xyz2, nullptr, nullptr, dist1, idx1, dist2, idx2, stream);
+}
+
+CLOUDAAE_API int cloudaae_nn_distance_prefix(int b, int n, const float *xyz1, int m, const float *xyz2,
+                                             const long long *count2, const int *row_src2, float *dist1, int *idx1,
+                                             float *dist2, int *idx2, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_nn_distance_prefix";
+    CLOUDAAE_REQUIRE((count2 == nullptr) == (row_src2 == nullptr), name, "count2 and row_src2 come together");
+    return nn_distance_impl(name, b, n, xyz1, m, xyz2, count2, row_src2, dist1, idx1, dist2, idx2, stream);
 }
 
 CLOUDAAE_API int cloudaae_nn_distance_grad(int b, int n, const float *xyz1, int m,

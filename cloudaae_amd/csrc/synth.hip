@@ -542,7 +542,7 @@ __global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, con
 __global__ __launch_bounds__(512) void hpr_gather_kernel(int n1, const unsigned char *__restrict__ flags,
                                                         const float *__restrict__ org, unsigned long long seed,
                                                         float *__restrict__ visible, long long *__restrict__ num_vis,
-                                                        int *__restrict__ visible_id, int rows)
+                                                        int *__restrict__ visible_id, int *__restrict__ row_src, int rows)
 {
     extern __shared__ int ids[];          // n1 ints: compacted vertex ids
     __shared__ int wsum[8];
@@ -580,16 +580,20 @@ __global__ __launch_bounds__(512) void hpr_gather_kernel(int n1, const unsigned 
     const float *O = org + (size_t)h * n1 * 3;
     float *V = visible + (size_t)h * rows * 3;     // rows = n1 in the reference (hidden_point_removal.py:38-40)
     for (int r = t; r < rows; r += 512) {
-        int src = -1;
+        int src = -1, row = -1;               // row: the output row (< nv) this row equals
         if (r < nv) {
             src = ids[r];
+            row = r;
         } else if (nv > 0) {
             unsigned rnd[4];
             philox4x32(seed, ((unsigned long long)h << 32) | (unsigned)r, 7u, rnd);
-            src = ids[rnd[0] % (unsigned)nv];        // np.random.choice(visibleId, ...)
+            row = (int)(rnd[0] % (unsigned)nv);
+            src = ids[row];                          // np.random.choice(visibleId, ...)
         }
         if (visible_id)
             visible_id[(size_t)h * rows + r] = r < nv ? src : -1;
+        if (row_src)
+            row_src[(size_t)h * rows + r] = row;
         V[3 * r] = src >= 0 ? O[3 * src] : 0.0f;
         V[3 * r + 1] = src >= 0 ? O[3 * src + 1] : 0.0f;
         V[3 * r + 2] = src >= 0 ? O[3 * src + 2] : 0.0f;
@@ -668,13 +672,13 @@ CLOUDAAE_API int cloudaae_hidden_point_removal(int b, int n1, const float *flipp
                                                unsigned long long seed, float *visible, long long *num_vis,
                                                int *visible_id, void *workspace, cloudaae_stream_t stream)
 {
-    return cloudaae_hidden_point_removal_rows(b, n1, flipped, org, seed, n1, visible, num_vis, visible_id, workspace,
-                                              stream);
+    return cloudaae_hidden_point_removal_rows(b, n1, flipped, org, seed, n1, visible, num_vis, visible_id, nullptr,
+                                              workspace, stream);
 }
 
 CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *flipped, const float *org,
                                                     unsigned long long seed, int rows, float *visible,
-                                                    long long *num_vis, int *visible_id, void *workspace,
+                                                    long long *num_vis, int *visible_id, int *row_src, void *workspace,
                                                     cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_hidden_point_removal";
@@ -717,7 +721,7 @@ CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *
     else
         hipLaunchKernelGGL(hull_vertex_kernel<8>, dim3(gx, b), dim3(64 * 8), lds, s, n1, sorted, perm, hpr_stride(n1), flags);
     hipLaunchKernelGGL(hpr_gather_kernel, dim3(b), dim3(512), (size_t)n1 * sizeof(int), s, n1, flags, org, seed,
-                       visible, num_vis, visible_id, rows);
+                       visible, num_vis, visible_id, row_src, rows);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }

@@ -17,7 +17,7 @@ def _check_cloud(name, t):
 
 class _NnDistance(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz1, xyz2):
+    def forward(ctx, xyz1, xyz2, count2=None, row_src2=None):
         ctx.set_materialize_grads(False)
         _check_cloud("xyz1", xyz1)
         _check_cloud("xyz2", xyz2)
@@ -31,9 +31,8 @@ class _NnDistance(torch.autograd.Function):
         idx1 = _lib.empty((b, n), dtype=torch.int32, device=xyz1.device)
         dist2 = _lib.empty((b, m), dtype=torch.float32, device=xyz1.device)
         idx2 = _lib.empty((b, m), dtype=torch.int32, device=xyz1.device)
-        _lib.check(_lib.lib().cloudaae_nn_distance(b, n, ptr(xyz1), m, ptr(xyz2), ptr(dist1),
-                                                   ptr(idx1), ptr(dist2), ptr(idx2), stream()),
-                   "cloudaae_nn_distance")
+        from ...utils import _functions as F
+        F.nn_search(b, n, xyz1, m, xyz2, dist1, idx1, dist2, idx2, None if count2 is None else (count2, row_src2))
         ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
         ctx.mark_non_differentiable(idx1, idx2)
         return dist1, idx1, dist2, idx2
@@ -44,7 +43,7 @@ class _NnDistance(torch.autograd.Function):
         xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
         b, n, _ = xyz1.shape
         m = xyz2.shape[1]
-        need1, need2 = ctx.needs_input_grad
+        need1, need2 = ctx.needs_input_grad[:2]
         if grad_dist1 is None:
             grad_dist1 = torch.zeros((b, n), dtype=torch.float32, device=xyz1.device)
         if grad_dist2 is None:
@@ -52,10 +51,10 @@ class _NnDistance(torch.autograd.Function):
         g1 = _lib.empty_like(xyz1) if need1 else None
         g2 = _lib.empty_like(xyz2) if need2 else None
         _grad(b, n, xyz1, m, xyz2, grad_dist1.contiguous(), idx1, grad_dist2.contiguous(), idx2, g1, g2)
-        return g1, g2
+        return g1, g2, None, None
 
 
-def nn_distance(xyz1, xyz2):
+def nn_distance(xyz1, xyz2, distinct2=None):
     """
 Computes the distance of nearest neighbors for a pair of point clouds
 input: xyz1: (batch_size,#points_1,3)  the first point cloud
@@ -64,8 +63,14 @@ output: dist1: (batch_size,#point_1)   distance from first to second
 output: idx1:  (batch_size,#point_1)   nearest neighbor from first to second
 output: dist2: (batch_size,#point_2)   distance from second to first
 output: idx2:  (batch_size,#point_2)   nearest neighbor from second to first
+distinct2 (extra, optional): (count [batch] int64, row_src [batch,#points_2] int32) -- the caller's knowledge that cloud
+    b of xyz2 is count[b] distinct points followed by bitwise copies of them, row j a copy of row row_src[b, j] < count[b]
+    (the reference's Chamfer targets: visible points, then random re-draws, utils/hidden_point_removal.py:38-43;
+    hidden_point_removal.convexHull(return_src=True) gives both).  The outputs are the same bit for bit; the search
+    visits the distinct points only.
     """
-    return _NnDistance.apply(xyz1, xyz2)
+    count2, row_src2 = distinct2 if distinct2 is not None else (None, None)
+    return _NnDistance.apply(xyz1, xyz2, count2, row_src2)
 
 
 def _grad(b, n, xyz1, m, xyz2, gd1, idx1, gd2, idx2, g1, g2, ordered=None):

@@ -247,6 +247,12 @@ class TrainGraph(object):
         # :214 -- a slice, so fewer than 4N rows pass through here (and fail in chamfer_loss.py:12,
         # whose sum needs n == m, exactly as in the reference)
         visiblePoints_org_final = org[:, 0:N * 4, :].contiguous()
+        # the on-line synthesis says which rows of the target are distinct points and which are re-draws of them
+        # (hidden_point_removal.py:38-43): the nearest-neighbour search then visits the distinct points only
+        count2 = row_src2 = None
+        if element.get('visiblePoints_org_src') is not None and element.get('num_vis_point_org') is not None:
+            count2 = element['num_vis_point_org'].to(torch.int64).contiguous()
+            row_src2 = element['visiblePoints_org_src'][:, 0:N * 4].to(torch.int32).contiguous()
 
         # :232-233 -- xyz_recon = recon_res + mean, trans_pred = trans_res + mean: offered to the fully connected
         # stack: the output layers of the chains the MODEL declares as point outputs (point_outputs: decoder and
@@ -269,7 +275,7 @@ class TrainGraph(object):
         (total_loss, xyz_loss, xyz_loss_per_sample, trans_loss, trans_loss_perSample, axag_loss,
          axag_loss_perSample) = F.StepLossFn.apply(xyz_recon, visiblePoints_org_final, trans_pred, element['translation'],
                                                    rot_pred, element['axisangle'], *LOSS_WEIGHTS,
-                                                   self._one if is_training else None)
+                                                   self._one if is_training else None, count2, row_src2)
         return dict(total_loss=total_loss, xyz_loss=xyz_loss, trans_loss=trans_loss, axag_loss=axag_loss,
                     xyz_recon=xyz_recon, xyz_loss_per_sample=xyz_loss_per_sample,
                     trans_loss_perSample=trans_loss_perSample, axag_loss_perSample=axag_loss_perSample,
@@ -355,7 +361,12 @@ class TrainGraph(object):
                'translation': element['translation'], 'axisangle': element['axisangle'],
                'class_id': element['class_id']}
         dtypes = {'visiblePoints': torch.float32, 'visiblePoints_org': torch.float32,
-                  'translation': torch.float32, 'axisangle': torch.float64, 'class_id': torch.int64}
+                  'translation': torch.float32, 'axisangle': torch.float64, 'class_id': torch.int64,
+                  'num_vis_point_org': torch.int64, 'visiblePoints_org_src': torch.int32}
+        if element.get('visiblePoints_org_src') is not None and element.get('num_vis_point_org') is not None:
+            # (the synthesis' account of which target rows are re-draws: forward() hands it to the Chamfer search)
+            src['num_vis_point_org'] = element['num_vis_point_org']
+            src['visiblePoints_org_src'] = element['visiblePoints_org_src'][:, 0:N * 4]
         own_noise = element.get('noise') is not None
         key = tuple((k, tuple(v.shape), str(dtypes[k])) for k, v in src.items()) + (('noise', own_noise),)
         if key != self._plan_key:

@@ -1009,6 +1009,24 @@ def _chamfer_grad_uniform(b, n, pred, label, gscalar, i1, i2, g1, g2, zeroed):
             1 if zeroed else 0, stream()), "cloudaae_nn_distance_grad_uniform")
 
 
+def nn_search(b, n, pred, m, label, d1, i1, d2, i2, distinct=None):
+    """cloudaae_nn_distance, or cloudaae_nn_distance_prefix when the caller knows that cloud c's `label` is
+    distinct[0][c] distinct points followed by copies of them, row j a copy of row distinct[1][c, j] (the reference's
+    Chamfer targets: visible points, then re-draws -- utils/hidden_point_removal.py:38-43): same results, the cost of the
+    distinct points only."""
+    if distinct is None:
+        _lib.check(L().cloudaae_nn_distance(b, n, ptr(pred), m, ptr(label), ptr(d1), ptr(i1), ptr(d2), ptr(i2), stream()),
+                   "cloudaae_nn_distance")
+        return
+    count, src = distinct
+    require(count.dtype == torch.int64 and tuple(count.shape) == (b,) and count.is_contiguous(),
+            "nn_distance: distinct counts must be a contiguous int64 [batch]")
+    require(src.dtype == torch.int32 and tuple(src.shape) == (b, m) and src.is_contiguous(),
+            "nn_distance: distinct row sources must be a contiguous int32 [batch, #points_2]")
+    _lib.check(L().cloudaae_nn_distance_prefix(b, n, ptr(pred), m, ptr(label), ptr(count), ptr(src), ptr(d1), ptr(i1),
+                                               ptr(d2), ptr(i2), stream()), "cloudaae_nn_distance_prefix")
+
+
 class ChamferLossFn(torch.autograd.Function):
     """losses/chamfer_loss.py:8-14 as one node: nn_distance both ways, loss_per_sample = forward + backward
     distances, loss = their mean.  Returns (loss, loss_per_sample).  When only the loss is differentiated
@@ -1016,7 +1034,7 @@ class ChamferLossFn(torch.autograd.Function):
     gradient d(loss)/N (cloudaae_nn_distance_grad_uniform)."""
 
     @staticmethod
-    def forward(ctx, pred, label):
+    def forward(ctx, pred, label, count2=None, row_src2=None):
         ctx.set_materialize_grads(False)
         require(pred.dim() == 3 and label.dim() == 3 and pred.shape[2] == 3 and label.shape[2] == 3,
                 "NnDistance requires clouds of shape (batch,#points,3)")
@@ -1030,8 +1048,7 @@ class ChamferLossFn(torch.autograd.Function):
         d2 = _lib.empty((b, n), dtype=torch.float32, device=dev)
         i1 = _lib.empty((b, n), dtype=torch.int32, device=dev)
         i2 = _lib.empty((b, n), dtype=torch.int32, device=dev)
-        _lib.check(L().cloudaae_nn_distance(b, n, ptr(pred), n, ptr(label), ptr(d1), ptr(i1), ptr(d2), ptr(i2), stream()),
-                   "cloudaae_nn_distance")
+        nn_search(b, n, pred, n, label, d1, i1, d2, i2, None if count2 is None else (count2, row_src2))
         per = _lib.empty((b, n), dtype=torch.float32, device=dev)
         loss = _lib.empty((), dtype=torch.float32, device=dev)
         ws = _ws(L().cloudaae_mean_workspace_bytes(), dev)
@@ -1046,7 +1063,7 @@ class ChamferLossFn(torch.autograd.Function):
         b, n, _ = pred.shape
         need1, need2 = ctx.needs_input_grad
         if gloss is None and gper is None:
-            return None, None
+            return None, None, None, None
         if gper is None:
             rec = _lib.recording() is not None
             mk = (lambda t: _lib.zeros(t.shape, dtype=torch.float32, device=t.device)) if rec else _lib.empty_like
@@ -1055,7 +1072,7 @@ class ChamferLossFn(torch.autograd.Function):
             g1 = mk(pred) if need1 else None
             g2 = mk(label) if need2 else None
             _chamfer_grad_uniform(b, n, pred, label, gloss.contiguous(), i1, i2, g1, g2, rec)
-            return g1, g2
+            return g1, g2, None, None
         gd = gper.contiguous() if gloss is None else gper + gloss / (b * n)
         g1 = _lib.empty_like(pred) if need1 else None
         g2 = _lib.empty_like(label) if need2 else None
@@ -1066,7 +1083,7 @@ class ChamferLossFn(torch.autograd.Function):
         else:
             _lib.check(L().cloudaae_nn_distance_grad(b, n, ptr(pred), n, ptr(label), ptr(gd), ptr(i1), ptr(gd), ptr(i2),
                                                      ptr(g1), ptr(g2), stream()), "cloudaae_nn_distance_grad")
-        return g1, g2
+        return g1, g2, None, None
 
 
 class MeanFn(torch.autograd.Function):
@@ -1198,7 +1215,8 @@ class StepLossFn(torch.autograd.Function):
     and backward's first launch is the Chamfer gradient; any other upstream gradient takes cloudaae_pose_losses_grad."""
 
     @staticmethod
-    def forward(ctx, pred, label, trans_pred, trans_label, rot_pred, rot_label, w0, w1, w2, unit):
+    def forward(ctx, pred, label, trans_pred, trans_label, rot_pred, rot_label, w0, w1, w2, unit, count2=None,
+                row_src2=None):
         ctx.set_materialize_grads(False)
         require(pred.dim() == 3 and label.dim() == 3 and pred.shape[2] == 3 and label.shape[2] == 3,
                 "NnDistance requires clouds of shape (batch,#points,3)")
@@ -1216,8 +1234,7 @@ class StepLossFn(torch.autograd.Function):
         d2 = _lib.empty((b, n), dtype=torch.float32, device=dev)
         i1 = _lib.empty((b, n), dtype=torch.int32, device=dev)
         i2 = _lib.empty((b, n), dtype=torch.int32, device=dev)
-        _lib.check(L().cloudaae_nn_distance(b, n, ptr(pred), n, ptr(label), ptr(d1), ptr(i1), ptr(d2), ptr(i2), stream()),
-                   "cloudaae_nn_distance")
+        nn_search(b, n, pred, n, label, d1, i1, d2, i2, None if count2 is None else (count2, row_src2))
         per = _lib.empty((b, n), dtype=torch.float32, device=dev)
         xyz = _lib.empty((), dtype=torch.float32, device=dev)
         tper = _lib.empty(b, dtype=torch.float32, device=dev)
@@ -1247,7 +1264,7 @@ class StepLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, *unused):
         if g is None:
-            return (None,) * 10
+            return (None,) * 12
         pred, label, i1, i2, trans_pred, trans_label, tper, jac = ctx.saved_tensors
         b, n, _ = pred.shape
         dev = pred.device
@@ -1271,7 +1288,7 @@ class StepLossFn(torch.autograd.Function):
             g2 = mk(label) if need2 else None
             _chamfer_grad_uniform(b, n, pred, label, dxyz, i1, i2, g1, g2, rec)
         return (g1, g2, dtp if ctx.needs_input_grad[2] else None, None, drp if ctx.needs_input_grad[4] else None,
-                None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 class LossMixFn(torch.autograd.Function):

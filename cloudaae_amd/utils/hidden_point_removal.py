@@ -37,11 +37,12 @@ def sphericalFlip_org(x, center, param):
     return x
 
 
-def convexHull(points, orgPoints, seed=0, return_ids=False, rows=None):
+def convexHull(points, orgPoints, seed=0, return_ids=False, rows=None, return_src=False):
     """(:27-43) points [B,n+1,3] flipped (+viewpoint row); returns (visiblePoints [B,n+1,3],
     num_vis_point [B] int64): rows [0,num_vis) are the visible points in ascending index, the
     rest random re-draws of visible points.  rows: another number of output rows (default n+1, the
-    reference's), filled by the same rule."""
+    reference's), filled by the same rule.  return_src: also row_src [B,rows] int32 -- the row < num_vis every
+    output row equals (what tf_nndistance.nn_distance(..., distinct2=) takes)."""
     points = points.to(torch.float32).contiguous()
     orgPoints = orgPoints.to(torch.float32).contiguous()
     B, n1, _ = points.shape
@@ -50,11 +51,17 @@ def convexHull(points, orgPoints, seed=0, return_ids=False, rows=None):
     vis = torch.empty((B, rows, 3), dtype=torch.float32, device=points.device)
     num = torch.empty((B,), dtype=torch.int64, device=points.device)
     ids = torch.empty((B, rows), dtype=torch.int32, device=points.device) if return_ids else None
+    src = torch.empty((B, rows), dtype=torch.int32, device=points.device) if return_src else None
     ws = torch.empty(int(_lib.lib().cloudaae_hpr_workspace_bytes(B, n1)), dtype=torch.uint8, device=points.device)
     _lib.check(_lib.lib().cloudaae_hidden_point_removal_rows(B, n1, ptr(points), ptr(orgPoints), int(seed), rows,
-                                                             ptr(vis), ptr(num), ptr(ids), ptr(ws), stream()),
+                                                             ptr(vis), ptr(num), ptr(ids), ptr(src), ptr(ws), stream()),
                "cloudaae_hidden_point_removal")
-    return (vis, num, ids) if return_ids else (vis, num)
+    out = (vis, num)
+    if return_ids:
+        out = out + (ids,)
+    if return_src:
+        out = out + (src,)
+    return out
 
 
 def hidden_point_removal(x, seed=0, rows=None):
@@ -63,6 +70,8 @@ def hidden_point_removal(x, seed=0, rows=None):
 
 
 def hidden_point_removal_org(x, seed=0, rows=None):
-    x['visiblePoints_org'], x['num_vis_point_org'] = convexHull(x['flippedPoints_org'], x['orgPoints_org'], seed + 1,
-                                                                rows=rows)
+    # (+ 'visiblePoints_org_src': the row each row of the Chamfer target equals -- an extra key the train step hands
+    #  to the nearest-neighbour search, which then looks at the distinct points only)
+    x['visiblePoints_org'], x['num_vis_point_org'], x['visiblePoints_org_src'] = convexHull(
+        x['flippedPoints_org'], x['orgPoints_org'], seed + 1, rows=rows, return_src=True)
     return x

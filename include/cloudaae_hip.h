@@ -68,6 +68,16 @@ int cloudaae_stream_wait(cloudaae_stream_t waiter, cloudaae_stream_t signaller);
  * that later calls reuse the memory instead of returning it to the driver at every synchronisation. */
 int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, const float *xyz2, float *dist1,
                          int *idx1, float *dist2, int *idx2, cloudaae_stream_t stream);
+/* The same search when cloud c's xyz2 is `count2[c]` distinct points followed by copies of them -- the reference's own
+ * Chamfer targets: the visible points, then random re-draws of visible points up to a fixed row count
+ * (utils/hidden_point_removal.py:38-43, 72; sliced at train_cloudAAE_ycbv.py:211-214).  row_src2 [b,m] names, for every
+ * row j >= count2[c], the row < count2[c] it is a bitwise copy of (cloudaae_hidden_point_removal_rows writes both).
+ * Results are those of cloudaae_nn_distance bit for bit ("first index wins" puts every answer among the originals; a
+ * copy's own answer is its original's), at the cost of the distinct points only.  count2[c] outside (0, m]: all m rows
+ * are searched.  Both NULL: cloudaae_nn_distance. */
+int cloudaae_nn_distance_prefix(int b, int n, const float *xyz1, int m, const float *xyz2, const long long *count2,
+                                const int *row_src2, float *dist1, int *idx1, float *dist2, int *idx2,
+                                cloudaae_stream_t stream);
 
 /* NnDistanceGrad.
  * Replaces: void NmDistanceGradKernelLauncher(int b,int n,const float* xyz1,int m,
@@ -609,10 +619,12 @@ int cloudaae_hidden_point_removal(int b, int n1, const float *flipped, const flo
 /* The same with a chosen number of output rows: visible [b,rows,3] (visible_id [b,rows]) = the visible points in
  * ascending index, then random re-draws of visible points up to `rows` rows -- the reference's rule
  * (hidden_point_removal.py:38-40, where rows == n1) for a Chamfer target of 4N rows when 4N exceeds the model's
- * point count (BASELINE configs[4]: N = 4096). */
+ * point count (BASELINE configs[4]: N = 4096).  row_src [b,rows] (optional): for every output row the row < num_vis it
+ * is equal to (itself for the visible points, the drawn one for a re-draw; -1 when nothing is visible) -- what
+ * cloudaae_nn_distance_prefix needs to search the distinct target points only. */
 int cloudaae_hidden_point_removal_rows(int b, int n1, const float *flipped, const float *org,
                                        unsigned long long seed, int rows, float *visible, long long *num_vis,
-                                       int *visible_id, void *workspace, cloudaae_stream_t stream);
+                                       int *visible_id, int *row_src, void *workspace, cloudaae_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -345,6 +345,68 @@ def test_nn_distance_padded_targets_vs_oracle(hip, oracle, knobs, b, n, distinct
     assert int(got[1].max()) < distinct                # nearest targets: always the first copy
 
 
+@pytest.mark.parametrize("b,n,m,filt", [(4, 4096, 4096, 1), (3, 2049, 2049, 1), (2, 16384, 16384, 1), (4, 700, 900, 0),
+                                         (3, 300, 5000, 0), (2, 6000, 6000, 1)])
+def test_nn_distance_prefix_equals_full_search(hip, oracle, knobs, b, n, m, filt):
+    """cloudaae_nn_distance_prefix (tf_nndistance.nn_distance(..., distinct2=(count, row_src))): the caller says that
+    cloud c's targets are count[c] distinct points followed by copies of them -- the reference's Chamfer targets
+    (utils/hidden_point_removal.py:38-43) -- and the search visits the distinct points only.  Bit for bit the results of
+    the full search (= the oracle's: first index wins, so every answer is an original; a copy's answer is its
+    original's), for both kernels, counts that differ per cloud, a cloud without copies (count = m), and counts the
+    entry point must ignore (0, negative, > m); gradients follow from the indices."""
+    from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
+    knobs("CLOUDAAE_NN_FILTER", filt)
+    rng = np.random.default_rng(n + m)
+    counts = [max(1, m // 4), m, max(2, m // 3), 0][:b]
+    if b > 2:
+        counts[2] = m + 5 if m % 2 else 37
+    target = np.empty((b, m, 3), dtype=np.float32)
+    src = np.empty((b, m), dtype=np.int32)
+    for c in range(b):
+        k = counts[c] if 0 < counts[c] <= m else m
+        base = (rng.standard_normal((k, 3)) * 0.05 + [0.1, -0.2, 0.9]).astype(np.float32)
+        pick = rng.integers(0, k, m - k)
+        target[c, :k] = base
+        target[c, k:] = base[pick]
+        src[c, :k] = np.arange(k)
+        src[c, k:] = pick
+    pred = (rng.standard_normal((b, n, 3)) * 0.05 + [0.1, -0.2, 0.9]).astype(np.float32)
+    pred[:, :40] = target[:, 10:50]                  # exact hits
+    count = torch.tensor(counts, dtype=torch.int64, device="cuda")
+    p, t = _dev(pred), _dev(target)
+    full = tf_nndistance.nn_distance(p, t)
+    pre = tf_nndistance.nn_distance(p, t, distinct2=(count, torch.from_numpy(src).cuda()))
+    for f, g_ in zip(full, pre):
+        assert torch.equal(f, g_)
+    if n * m <= 4096 * 4096:
+        want = oracle.nn_distance(pred, target, threads=8)
+        for w, g_ in zip(want, pre):
+            assert np.array_equal(w, g_.cpu().numpy())
+    for c in range(b):                                   # nearest targets: always an original
+        k = counts[c] if 0 < counts[c] <= m else m
+        assert int(pre[1][c].max()) < k
+    # through autograd: same gradients (they are a function of the indices)
+    p1, t1 = p.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    p2, t2 = p.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    knobs("CLOUDAAE_DETERMINISTIC", 1)
+    from cloudaae_amd.utils import _functions as F
+    det = F.DETERMINISTIC
+    F.DETERMINISTIC = True
+    try:
+        d1, _, d2, _ = tf_nndistance.nn_distance(p1, t1)
+        (d1.sum() + 2 * d2.sum()).backward()
+        e1, _, e2, _ = tf_nndistance.nn_distance(p2, t2, distinct2=(count, torch.from_numpy(src).cuda()))
+        (e1.sum() + 2 * e2.sum()).backward()
+    finally:
+        F.DETERMINISTIC = det
+    assert torch.equal(p1.grad, p2.grad) and torch.equal(t1.grad, t2.grad)
+    # malformed hints are refused
+    with pytest.raises(Exception):
+        tf_nndistance.nn_distance(p, t, distinct2=(count.int(), torch.from_numpy(src).cuda()))
+    with pytest.raises(Exception):
+        tf_nndistance.nn_distance(p, t, distinct2=(count, torch.from_numpy(src[:, :-1].copy()).cuda()))
+
+
 @pytest.mark.parametrize("case", ["lattice", "far_from_origin", "huge", "tiny_scale", "one_candidate", "ragged"])
 def test_nn_distance_filter_kernel_adversarial(hip, oracle, case, knobs):
     """The matrix-core search + exact verification (nn_distance_filter_kernel) on inputs built to defeat a
