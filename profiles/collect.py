@@ -47,6 +47,7 @@ def per_kernel(db, counter):
 SITES = [
     ("agg_fwd", r"^gemm_f32_kernel<128, ?128, ?2, ?2, ?false, ?false, ?true", None,
      ["cloudaae_amd/csrc/gemm.hip", "cloudaae_amd/csrc/gemm.h"]),
+    ("agg_fwd_x3", r"^gemm_x3s_kernel<2, ?4", "largest", ["cloudaae_amd/csrc/gemm_x3.hip"]),
     ("agg_fwd_bf16", r"^gemm_bf16_kernel<128, ?128", "largest", ["cloudaae_amd/csrc/gemm_bf16.hip", "cloudaae_amd/csrc/gemm.h"]),
     ("agg_fwd_b16", r"^gemm_b16_kernel<128, ?128, ?2, ?2, ?false, ?false, ?true", "largest", ["cloudaae_amd/csrc/gemm_b16.hip"]),
     ("agg_dw", r"^gemm_f32_kernel<64, ?128, ?2, ?2, ?true, ?false", "largest", ["cloudaae_amd/csrc/gemm.hip", "cloudaae_amd/csrc/gemm.h"]),
