@@ -4,13 +4,25 @@
  *
  * Conventions:
  *   - every pointer is a DEVICE pointer to contiguous row-major memory owned by
- *     the caller (outputs and workspaces included); nothing is allocated here;
+ *     the caller (outputs and workspaces included).  Two entry points take
+ *     stream-ordered scratch of ONE call themselves (hipMallocAsync / hipFreeAsync
+ *     on the caller's stream, nothing outlives the call): cloudaae_nn_distance*
+ *     when it cuts a direction's candidates into ranges, and cloudaae_gemm_bf16x3
+ *     for the planes of its second operand (cloudaae_gemm_bf16x3p takes them from
+ *     the caller instead);
  *   - float = IEEE fp32, int = int32; sizes are element counts;
  *   - every function takes the HIP stream to launch on as its last argument
  *     (a hipStream_t passed as void*; NULL = the default stream), is re-entrant,
- *     keeps no global state, never synchronises, and returns 0 or a hipError_t
- *     value (cloudaae_last_error() describes the most recent failure of the
- *     calling thread);
+ *     never synchronises, and returns 0 or a hipError_t value
+ *     (cloudaae_last_error() describes the most recent failure of the calling
+ *     thread).  Process-wide state is limited to: the table of development knobs
+ *     (cloudaae_set_knob; set them between launches, not concurrently with them),
+ *     one low-priority side stream (cloudaae_side_stream), and per-device flags
+ *     that record which kernels had their dynamic-LDS limit raised;
+ *   - a workspace whose size comes from a cloudaae_*_workspace / *_partials query
+ *     is only as large as the K split the knobs implied AT THE QUERY: do not change
+ *     CLOUDAAE_GEMM_SPLITS / CLOUDAAE_FC_FWD_SPLITS / CLOUDAAE_FC_FWD_BLOCKS /
+ *     CLOUDAAE_DETERMINISTIC between the query and the launches that use it;
  *   - gradient outputs are zero-filled by the callee.
  * The reference's launchers have C++ linkage, no stream and no status
  * (tf_nndistance.cpp:168,208; tf_sampling.cpp:65,94,125,150); each entry point

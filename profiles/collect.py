@@ -82,6 +82,8 @@ def main(d, tag, workload):
     traffic = {}
     for site, pat, pick, srcs in SITES:
         cands = [r for r in rows if re.search(pat, r[0])]
+        if site == "agg_fwd":       # (the same template instance serves small edge-conv products: the agg product writes > 100 MB)
+            cands = [r for r in cands if r[6] > 100e6 * (1 if "B=32" in workload else 4)]
         if not cands:
             continue
         r = max(cands, key=lambda x: x[6])
