@@ -1061,7 +1061,7 @@ class ChamferLossFn(torch.autograd.Function):
     def backward(ctx, gloss, gper):
         pred, label, i1, i2 = ctx.saved_tensors
         b, n, _ = pred.shape
-        need1, need2 = ctx.needs_input_grad
+        need1, need2 = ctx.needs_input_grad[:2]
         if gloss is None and gper is None:
             return None, None, None, None
         if gper is None:
