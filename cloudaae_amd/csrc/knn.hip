@@ -723,6 +723,9 @@ static hipError_t launch_knn_scan(int b, int n, int ld, int k, const float *x, i
 // Both passes evaluate d with the SAME instructions on the same MFMA results, so "d <= tau" in pass B is exact
 // and the indices stay bit-identical to oracle_knn.  Matrix work: 1.25 x the N x N x 64 products.
 
+// the LDS address of a pointer into shared memory (a flat LDS address is aperture : offset)
+__device__ __forceinline__ unsigned lds_offset(const void *p) { return (unsigned)(uintptr_t)p; }
+
 template <int K>
 struct MinK {                        // the K smallest values seen, ascending
     float d[K];
@@ -748,7 +751,7 @@ struct MinK {                        // the K smallest values seen, ascending
 static int knn_wide_qpq(int n) { return n <= 3328 ? 144 : 128; }
 static size_t knn_wide_lds_bytes(int n)
 {
-    return sizeof(float) * (4 * KM_TILE * 68 + (size_t)ceil_div(n, KM_TILE) * KM_TILE + 4) +
+    return sizeof(float) * (4 * KM_TILE * 68 + (size_t)ceil_div(n, KM_TILE) * KM_TILE + 4 + 32 + 128) +
            (sizeof(float) + sizeof(unsigned short)) * 128 * (size_t)knn_wide_qpq(n) + sizeof(int) * 128;
 }
 
@@ -759,9 +762,10 @@ static size_t knn_wide_lds_bytes(int n)
 // tile is scanned by CS = 4 waves (a quarter of the candidate tiles each), a workgroup is QW x CS = 16 waves, so
 // every SIMD has four waves to overlap and each wave's chain is half as long.  What that costs: 128 registers per
 // lane (no operand double-buffering, the filter runs right after its tile's MFMAs) and one LDS tile buffer per wave
-// slot (two barriers per round: tiles landed / operands read).  What else differs from the kernel above:
+// slot (two barriers per round: tiles landed / operands read, the second one inside the MFMA chain).  What else differs
+// from the kernel above:
 //   * tiles go global -> LDS without passing through registers (global_load_lds_dword, one staged row per instruction);
-//   * |x_j|^2 is computed from the staged tiles (waves 0 and 1, one row per lane, between the two barriers), so the
+//   * |x_j|^2 is computed from the staged tiles (two waves, one row per lane, after the round's first barrier), so the
 //     workgroup never reads the cloud a second time;
 //   * sorted inserts and merges run on ONE orderable double per (distance, index) pair (knn_key / TopKey): 10 pairs of
 //     v_min_f64 / v_max_f64 per insert;
@@ -772,7 +776,10 @@ static size_t knn_wide_lds_bytes(int n)
 // from a quarter, with a tail that overflows the 128-slot queues; 40 from half), and the final merge runs in two
 // stages (the eight key lists of a query, 1280 bytes, do not fit its 768-byte share of the queue area: the lane
 // halves merge through registers first, four lists go through LDS).
-template <int K, int QPQ>
+// REUSE (the launcher sets it when pass A is at most two rounds: K <= 10, n <= 1024): the sampled tiles' distances stay
+// in registers until tau is known, go through the filter then, and pass B covers only the tiles that were NOT sampled:
+// 1.0 x the N x N x 64 products instead of 1.25 x, two rounds fewer.
+template <int K, int QPQ, bool REUSE>
 __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, const float *__restrict__ x,
                                                           int *__restrict__ nn_idx)
 {
@@ -782,7 +789,7 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     // QPQ: queue slots per query (its 8 lanes share them)
     extern __shared__ __attribute__((aligned(16))) char kw_smem[];
     // layout: tile[CS][TILE_FLOATS] | queue d[128 queries][QPQ] (fp32) | queue j, same shape (u16) | queue lengths [128] |
-    //         sq[ntiles * 32] | 1.0 | overflow flag
+    //         sq[ntiles * 32] | 1.0 | overflow flag | (pad) | REUSE: pass B's tile list [32] | tau [128 queries]
     float *tiles = reinterpret_cast<float *>(kw_smem);
     float *qd_all = tiles + CS * TILE_FLOATS;
     unsigned short *qj_all = reinterpret_cast<unsigned short *>(qd_all + QW * 32 * QPQ);
@@ -810,6 +817,19 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     // pass A's sample: S tiles, every stride-th one (a quarter of the tiles; half of them for K > 10)
     const int S = min(ntiles, max((ntiles + (K > 10 ? 1 : 3)) / (K > 10 ? 2 : 4), 4));
     const int stride = ntiles / S;
+    // REUSE: pass B's tile list = the tiles pass A did not take, ascending: below S * stride the non-multiples of stride,
+    // then the rest
+    // (a table in LDS: computed where it is needed, the two integer divisions cost every wave ~45 vector instructions
+    // per round, and a vector instruction costs matrix time here -- see the round below)
+    const int nB = REUSE ? ntiles - S : ntiles;
+    int *tile_list = reinterpret_cast<int *>(sq + ntiles * KM_TILE + 4);
+    if (REUSE && tid < 32) {
+        const int sm1 = stride - 1, below = S * sm1;
+        tile_list[tid] = tid < below ? (tid / max(sm1, 1)) * stride + 1 + tid % max(sm1, 1) : S * stride + (tid - below);
+    }
+    auto tile_b = [&](int u, bool uniform) {               // u < 32
+        return !REUSE ? u : uniform ? __builtin_amdgcn_readfirstlane(tile_list[u]) : tile_list[u];
+    };
 
     // staging: a round = CS tiles of 32 rows; a wave brings 8 rows, each with ONE global_load_lds_dword: lane l fetches
     // the channel that belongs at position l of the staged row ([32 even | 32 odd]), the 256 bytes land in LDS without
@@ -817,40 +837,50 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     // end repeat row n - 1: their |x|^2 reads +inf, so their distances are +inf.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int chan = 2 * col + half;
-    auto stage_rows = [&](int what, int r) {               // what: 0 = pass B's tiles, 1 = pass A's sample, 2 = the query tiles
+    // first row of the tile in slot `slot` of round r.  what: 0 = pass B's tiles, 1 = pass A's sample, 2 = the query
+    // tiles, 3 = every tile in order (the fallback scan)
+    auto tile_row0 = [&](int what, int slot, bool uniform) {
+        return what == 1   ? (slot < S ? slot * stride * KM_TILE : n)
+               : what == 2 ? (qgroup * QW + slot) * KM_TILE
+               : what == 0 ? (slot < nB ? tile_b(REUSE ? min(slot, 31) : slot, uniform) * KM_TILE : n)
+                           : slot * KM_TILE;
+    };
+    float *qstage = qd_all;                                // the query tiles are staged in the (still unused) queue area
+    auto stage_rows = [&](int what, int r) {
+        const int slot = r * CS + (wave_u >> 2);           // a wave's 8 rows belong to one tile
+        const int c0 = tile_row0(what, slot, true);
+        float *dst = (what == 2 ? qstage : tiles) + (wave_u >> 2) * TILE_FLOATS;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int rowu = wave_u * 8 + u;               // row within the round's 128 rows
-            const int slot = r * CS + (rowu >> 5);
-            const int c0 = what == 1 ? (slot < S ? slot * stride * KM_TILE : n)
-                                     : (what == 2 ? qgroup * QW + slot : slot) * KM_TILE;
-            const int g = min(c0 + (rowu & 31), n - 1);
-            __builtin_amdgcn_global_load_lds(X + (size_t)g * ld + chan,
-                                             tiles + (rowu >> 5) * TILE_FLOATS + (rowu & 31) * KS_LD, 4, 0, 0);
+            const int row = (wave_u & 3) * 8 + u;          // row within the tile
+            const int g = min(c0 + row, n - 1);
+            __builtin_amdgcn_global_load_lds(X + (size_t)g * ld + chan, dst + row * KS_LD, 4, 0, 0);
         }
     };
-    auto staged = [&]() {                                  // this wave's rows have landed; then the barrier
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto staged = [&]() {                                  // this wave's rows have landed (and its queue writes); then the barrier
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
     };
-    // |x|^2 of the 128 staged rows, the un-fused sequential sum the oracle defines: waves 0 and 1, one row per lane,
-    // between the round's two barriers (the 33rd step's operand is read after the second one)
+    // |x|^2 of the 128 staged rows, the un-fused sequential sum the oracle defines: two waves, one row per lane, between
+    // the round's two barriers (the 33rd step's operand is read after the second one).  A vector instruction takes matrix
+    // time on its SIMD (tools/dev/mfma_valu_overlap.hip: the two do not overlap), so the pair of waves alternates between
+    // SIMDs 0-1 and 2-3 from round to round, and the squares are packed multiplies (two per instruction, same rounding).
+    typedef float float2v __attribute__((ext_vector_type(2)));
     auto norms = [&](int what, int r) {
-        if (wave_u < 2) {
-            const int rowu = wave_u * 64 + lane;
-            const int slot = r * CS + (rowu >> 5);
-            const int c0 = what == 1 ? (slot < S ? slot * stride * KM_TILE : n)
-                                     : (what == 2 ? qgroup * QW + slot : slot) * KM_TILE;
-            const int g = c0 + (rowu & 31);
-            const float4v *ev = reinterpret_cast<const float4v *>(tiles + (rowu >> 5) * TILE_FLOATS + (rowu & 31) * KS_LD);
+        if ((wave_u >> 1) == (r & 1)) {
+            const int rowu = (wave_u & 1) * 64 + lane;
+            const int g = tile_row0(what, r * CS + (rowu >> 5), false) + (rowu & 31);
+            const float4v *ev = reinterpret_cast<const float4v *>((what == 2 ? qstage : tiles) + (rowu >> 5) * TILE_FLOATS +
+                                                                  (rowu & 31) * KS_LD);
             float acc = 0.0f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {                  // channels 8 q .. 8 q + 7 = even[4q..4q+3] interleaved with odd[..]
                 if (q == 4)
                     __builtin_amdgcn_sched_barrier(0);     // (two batches of eight 16-byte reads: 32 registers, not 64)
                 const float4v e = ev[q], o = ev[8 + q];
-                const float a0 = e.x * e.x, a1 = o.x * o.x, a2 = e.y * e.y, a3 = o.y * o.y;
-                const float a4_ = e.z * e.z, a5 = o.z * o.z, a6 = e.w * e.w, a7 = o.w * o.w;
+                const float2v e0 = {e.x, e.y}, e1 = {e.z, e.w}, o0 = {o.x, o.y}, o1 = {o.z, o.w};
+                const float2v pe0 = e0 * e0, pe1 = e1 * e1, po0 = o0 * o0, po1 = o1 * o1;
+                const float a0 = pe0.x, a1 = po0.x, a2 = pe0.y, a3 = po0.y, a4_ = pe1.x, a5 = po1.x, a6 = pe1.y, a7 = po1.y;
                 acc = acc + a0;
                 acc = acc + a1;
                 acc = acc + a2;
@@ -871,23 +901,32 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     f32x16 acc;
     float bq[32];                                         // B operand: -2 x the query's channels of parity `half`
     float bx = 1.0f;
-    // one round: operands of this wave's tile -> registers, next round's tiles -> LDS, the 33 MFMA steps
+    // one round: operands of this wave's tile -> registers, the 33 MFMA steps, next round's tiles -> LDS.  The round's
+    // second barrier ("every wave holds its operands: the buffer is free") sits INSIDE the MFMA chain, after PRE steps:
+    // placed before the chain every wave idled while the operands travelled (measured, B = 32: 69.7 us with PRE = 0,
+    // 64.7 / 63.2 / 63.0 with PRE = 4 / 16 / 24)
+    constexpr int PRE = 24;
     auto round = [&](int what, int r, int rounds, int c0) {
         staged();                                          // this round's tiles are in LDS
-        norms(what, r);                                    // (waves 0 and 1; before their operand reads: registers)
+        norms(what, r);                                    // (two waves; before their operand reads: registers)
         float4v a4[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s)
             a4[s] = arow[s];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            acc[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < PRE; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s >> 2][s & 3], bq[s], acc, 0, 0, 0);
+        if (PRE > 0)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();                                   // every wave holds its operands: the buffer is free
         const float ax = sq[xoff + xmul * c0];
         if (r + 1 < rounds)
             stage_rows(what, r + 1);                       // travels behind the MFMAs
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-            acc[e] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < 32; ++s)
+        for (int s = PRE; s < 32; ++s)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s >> 2][s & 3], bq[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, acc, 0, 0, 0);
     };
@@ -895,10 +934,11 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     // ---------------- pass A: tau ----------------
     const int roundsA = (S + CS - 1) / CS;
     stage_rows(2, 0);                                      // the workgroup's 4 query tiles, staged like candidate tiles
+    stage_rows(1, 0);                                      // (the first sample tiles travel with them)
     staged();
     norms(2, 0);
     {
-        const float4v *qrow = reinterpret_cast<const float4v *>(tiles + qt * TILE_FLOATS + col * KS_LD + 32 * half);
+        const float4v *qrow = reinterpret_cast<const float4v *>(qstage + qt * TILE_FLOATS + col * KS_LD + 32 * half);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const float4v v = qrow[s];
@@ -908,11 +948,15 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
             bq[4 * s + 3] = -2.0f * v.w;
         }
     }
-    __syncthreads();                                       // every wave holds its query operands: the buffer is free
+    __syncthreads();                                       // the query norms are in sq
     bx = half ? 1.0f : sq[qs];
-    stage_rows(1, 0);
     MinK<K> um;
     um.init();
+    // REUSE: the sampled tiles' distances are kept for the filter: the last round's in `acc`, the round before in the
+    // part of the query tile's queue area that the scratch lists below leave free ([16 values][4 waves x 64 lanes])
+    float *svl = reinterpret_cast<float *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6) + 2 * CS * K * 32 * 4) +
+                 cs * 64 + lane;
+    static_assert(!REUSE || 2 * CS * K * 32 * 4 + 16 * CS * 64 * 4 <= 32 * QPQ * 6, "saved distances must fit beside the lists");
     for (int r = 0; r < roundsA; ++r) {
         const int slot = r * CS + cs;
         round(1, r, roundsA, slot < S ? slot * stride * KM_TILE : ntiles * KM_TILE - KM_TILE);
@@ -921,6 +965,13 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
         for (int g = 0; g < 4; ++g) {                      // units: the lane's rows 8 g + 4 half + (0..3)
             const float m = fminf(fminf(acc[4 * g], acc[4 * g + 1]), fminf(acc[4 * g + 2], acc[4 * g + 3]));
             um.insert(live ? m : __builtin_inff());
+        }
+        if constexpr (REUSE) {
+            if (r + 1 < roundsA) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    svl[e * CS * 64] = acc[e];
+            }
         }
     }
     // K-th smallest unit minimum over the query's 2*CS lists, through the query tile's share of the queue area
@@ -934,13 +985,17 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
 #pragma unroll
     for (int p = 0; p < K; ++p)
         md[slot0 + p * 32] = um.d[p];
-    const int roundsB = (ntiles + CS - 1) / CS;
-    stage_rows(0, 0);                                      // pass B's first tiles travel during the merge below
+    const int roundsB = (nB + CS - 1) / CS;
+    if (roundsB > 0)
+        stage_rows(0, 0);                                  // pass B's first tiles travel during the merge below
     __syncthreads();
-    float tau = __builtin_inff();
-    {
+    // K-th smallest over the query's lists: ONE wave per query tile merges (waves 0, 5, 10, 15: one per SIMD), the bound
+    // reaches the other lanes through LDS after the next barrier
+    float *tauv = sq + ntiles * KM_TILE + 4 + 32;
+    if (cs == qt) {
+        float t = __builtin_inff();
         // K steps of "smallest head, advance it" over the 2*CS sorted lists.  Equal heads advance together, which can
-        // only make tau larger (the bound stays valid); every lane of the query computes the same value.
+        // only make the bound larger (it stays valid).
         int head[2 * CS];
 #pragma unroll
         for (int l = 0; l < 2 * CS; ++l)
@@ -958,33 +1013,83 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
 #pragma unroll
             for (int l = 0; l < 2 * CS; ++l)
                 head[l] += hv[l] == m ? 32 : 0;
-            tau = m;
+            t = m;
         }
+        if (half == 0)
+            tauv[qt * 32 + col] = fminf(t, 3.4028234664e38f);                 // rows past the end (+inf) never pass
     }
-    tau = fminf(tau, 3.4028234664e38f);                    // rows past the end (+inf) never pass
-    // (the scratch lists are consumed before the first round's second barrier; the queues are only appended to after it)
 
     // ---------------- pass B: everything at or below tau goes to the query's queue ----------------
     const int qq = qt * 32 + col;
     float *qd = qd_all + qq * QPQ;
     unsigned short *qj = qj_all + qq * QPQ;
-    for (int r = 0; r < roundsB; ++r) {
-        const int slot = r * CS + cs;
-        const int c0 = min(slot, ntiles - 1) * KM_TILE;
-        round(0, r, roundsB, c0);
-        if (slot < ntiles) {
-            const int jb = c0 + 4 * half;
+    // the lane's entries of one tile: ONE slot request for all of them (a request per entry is a dependent LDS round
+    // trip per accumulator register that the wave finishing its MFMAs last cannot hide); past the end of a full queue the
+    // last slot is overwritten: the count still says "overflowed".
+    // The LDS instructions are written out: behind `atomicAdd` and plain stores the compiler waits for the tile loads in
+    // flight first (vmcnt(0): they write LDS too, and it cannot tell the regions apart), which serialises the push behind
+    // the next round's tiles.  The waves wait for these writes (lgkmcnt) at the next barrier.
+    const unsigned qn_at = lds_offset(&qn_all[qq]), qd_at = lds_offset(qd), qj_at = lds_offset(qj);
+    float tau = 0.0f;                                      // (read after the next barrier)
+    auto push_tile = [&](const f32x16 &d, int jb) {
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            cnt += d[e] <= tau ? 1 : 0;
+        if (cnt > 0) {
+            int sl;
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(sl) : "v"(qn_at), "v"(cnt) : "memory");
+            if (sl + cnt <= QPQ) {                         // (nearly always: no clamping, two running addresses)
+                unsigned ad = qd_at + 4 * sl, aj = qj_at + 2 * sl;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (d[e] <= tau) {
+                        const int j = jb + (e & 3) + 8 * (e >> 2);
+                        asm volatile("ds_write_b32 %0, %1\n\tds_write_b16 %2, %3" ::"v"(ad), "v"(d[e]), "v"(aj), "v"(j) : "memory");
+                        ad += 4;
+                        aj += 2;
+                    }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (d[e] <= tau) {
+                        const int at = min(sl, QPQ - 1);
+                        const int j = jb + (e & 3) + 8 * (e >> 2);
+                        asm volatile("ds_write_b32 %0, %1\n\tds_write_b16 %2, %3" ::"v"(qd_at + 4 * at), "v"(d[e]), "v"(qj_at + 2 * at),
+                                     "v"(j)
+                                     : "memory");
+                        ++sl;
+                    }
+            }
+        }
+    };
+    if constexpr (REUSE) {
+        f32x16 sv;
+        if (roundsA > 1) {
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                if (acc[e] <= tau) {
-                    // past the end of a full queue the last slot is overwritten: the count still says "overflowed"
-                    const int sl = min(atomicAdd(&qn_all[qq], 1), QPQ - 1);
-                    qd[sl] = acc[e];
-                    qj[sl] = (unsigned short)(jb + (e & 3) + 8 * (e >> 2));
-                }
+                sv[e] = svl[e * CS * 64];
         }
+        __syncthreads();                                   // lists and saved distances are consumed: the queues may fill
+        tau = tauv[qq];
+        if (roundsA > 1)
+            push_tile(sv, cs * stride * KM_TILE + 4 * half);                  // (round 0: slot cs < S always)
+        if ((roundsA - 1) * CS + cs < S)
+            push_tile(acc, ((roundsA - 1) * CS + cs) * stride * KM_TILE + 4 * half);
+    }
+    // (not REUSE: the scratch lists are consumed and the bounds written before the first round's second barrier; the
+    //  queues are only appended to after it)
+    for (int r = 0; r < roundsB; ++r) {
+        const int slot = r * CS + cs;
+        const int c0 = tile_b(min(slot, nB - 1), true) * KM_TILE;
+        round(0, r, roundsB, c0);
+        if (!REUSE && r == 0)
+            tau = tauv[qq];                                // (written before this round's barriers)
+        if (slot < nB)
+            push_tile(acc, c0 + 4 * half);
     }
     int *flag = reinterpret_cast<int *>(sq + ntiles * KM_TILE + 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (the queue writes of push_tile)
     __syncthreads();
     if (qn_all[qq] > QPQ)
         *flag = 1;
@@ -1006,11 +1111,12 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
         }
     } else {
         // a queue overflowed somewhere in this workgroup: the plain scan (every candidate through the sorted insert)
-        stage_rows(0, 0);
-        for (int r = 0; r < roundsB; ++r) {
+        const int roundsF = (ntiles + CS - 1) / CS;
+        stage_rows(3, 0);
+        for (int r = 0; r < roundsF; ++r) {
             const int slot = r * CS + cs;
             const int c0 = min(slot, ntiles - 1) * KM_TILE;
-            round(0, r, roundsB, c0);
+            round(3, r, roundsF, c0);
             if (slot < ntiles) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
@@ -1080,22 +1186,27 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     }
 }
 
-template <int K, int QPQ>
+template <int K, int QPQ, bool REUSE>
 static hipError_t launch_knn_wide_q(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
     const size_t lds = knn_wide_lds_bytes(n);
     static bool raised[64] = {};
-    if (hipError_t e = raise_lds_limit(&knn64_wide_kernel<K, QPQ>, raised); e != hipSuccess)
+    if (hipError_t e = raise_lds_limit(&knn64_wide_kernel<K, QPQ, REUSE>, raised); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL((knn64_wide_kernel<K, QPQ>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s, n, ld, k, x,
-                       nn_idx);
+    hipLaunchKernelGGL((knn64_wide_kernel<K, QPQ, REUSE>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s, n, ld, k,
+                       x, nn_idx);
     return hipSuccess;
 }
 template <int K>
 static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
-    return knn_wide_qpq(n) == 144 ? launch_knn_wide_q<K, 144>(b, n, ld, k, x, nn_idx, s)
-                                  : launch_knn_wide_q<K, 128>(b, n, ld, k, x, nn_idx, s);
+    if constexpr (K <= 10) {
+        // pass A of at most two rounds (n <= 1024): its distances are kept and pass B skips the sampled tiles
+        if (ceil_div(n, KM_TILE) <= 32 && CLOUDAAE_KNOB("CLOUDAAE_KNN_REUSE", 1) != 0)
+            return launch_knn_wide_q<K, 144, true>(b, n, ld, k, x, nn_idx, s);
+    }
+    return knn_wide_qpq(n) == 144 ? launch_knn_wide_q<K, 144, false>(b, n, ld, k, x, nn_idx, s)
+                                  : launch_knn_wide_q<K, 128, false>(b, n, ld, k, x, nn_idx, s);
 }
 
 // ---- C = 3, second generation: the selection split into filter + queued drain ------------------

@@ -220,7 +220,9 @@ def test_knn_vs_oracle(hip, oracle, b, n, c, ld, k):
                                           (1, 3300, 7, 5),
                                           # k = 20 and clouds of 4096+ points in the 16-wave kernel (BASELINE configs[4])
                                           (2, 4096, 20, 5), (3, 1500, 20, 5), (2, 300, 15, 5), (1, 4500, 20, 5), (1, 6000, 10, 5),
-                                          (5, 4096, 20, None), (33, 1024, 20, None), (1, 3400, 10, 5)])
+                                          (5, 4096, 20, None), (33, 1024, 20, None), (1, 3400, 10, 5),
+                                          # sampled tiles reused, pass B over the rest: tile counts 17 / 25 / 29 / 9 / 32
+                                          (3, 530, 10, 5), (2, 800, 10, 5), (2, 900, 7, 5), (3, 270, 10, 5), (2, 1024, 1, 5)])
 def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, knobs, b, n, k, mode):
     """All C = 64 kernels (knob CLOUDAAE_KNN_SCAN = 0: knn64_mfma, 1 / 2: whole-cloud scan with one / two waves
     per query tile, 5: bound pass + filtered scan in 16-wave workgroups; None: the launcher's own choice) keep

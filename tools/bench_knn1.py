@@ -9,7 +9,11 @@ g = torch.Generator(device="cuda").manual_seed(1)
 x = torch.relu(torch.randn((b, n, ld), device="cuda", generator=g))     # post-ReLU features, like net1..net3
 out = torch.empty((b, n, k), dtype=torch.int32, device="cuda")
 go = lambda: _lib.check(L.cloudaae_knn(b, n, c, ld, k, x.data_ptr(), out.data_ptr(), _lib.stream()), "knn")
-for _ in range(3): go()
+import time
+t_end = time.time() + float(os.environ.get('WARM_S', '1.5'))      # clocks ramp from idle: warm up by time
+while time.time() < t_end:
+    for _ in range(50): go()
+    torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(iters): go()
