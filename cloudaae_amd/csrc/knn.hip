@@ -16,6 +16,7 @@
 // ascending j, then wave 0 merges the four sorted lists in wave order with the
 // same stable insertion, which preserves the tie rule.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "../../include/cloudaae_hip.h"
 
@@ -131,7 +132,37 @@ struct TopKey {                      // the K smallest keys, ascending
             x = hi;
         }
     }
+    // the same while only the first T slots are occupied (the T-th insert into an empty list): T pairs instead of K
+    template <int T>
+    __device__ __forceinline__ void insert_first(double x)
+    {
+        static_assert(T < K, "a full list takes insert()");
+#pragma unroll
+        for (int p = 0; p < T; ++p) {
+            double lo, hi;
+            asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(key[p]), "v"(x));
+            asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(key[p]), "v"(x));
+            key[p] = lo;
+            x = hi;
+        }
+        key[T] = x;
+    }
 };
+
+template <int N, typename F, int I = 0>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, F, I + 1>(static_cast<F &&>(f));
+    }
+}
+
+// index of an orderable key that is not +inf: its low 16 bits (the key is an integer below 2^48: exact after + 2^52)
+__device__ __forceinline__ int knn_key_low16(double key)
+{
+    return (int)(__double_as_longlong(key + 4503599627370496.0) & 0xffff);
+}
 
 template <int K>
 __device__ __forceinline__ void merge_and_store(TopK<K> &top, float *mbuf_d, int *mbuf_i, int wave,
@@ -1097,17 +1128,30 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     TopKey<K> top;
     top.init();
     if (*flag == 0) {
-        // the query's 8 lanes take every 8th entry of its queue (they arrive in any order: keyed insert)
+        // the query's 8 lanes take every 8th entry of its queue (they arrive in any order: keyed insert); the t-th
+        // insert into an empty list is t min/max pairs, not K
         const int nq_ = min(qn_all[qq], QPQ);
         int ro = list;
         float nd = qd[min(ro, QPQ - 1)];
         int ni = (int)qj[min(ro, QPQ - 1)];
-        for (; __any(ro < nq_); ro += 2 * CS) {
+        auto next_key = [&]() {
             const double key = ro < nq_ ? knn_key(nd, ni) : __builtin_inf();
-            const int rn = min(ro + 2 * CS, QPQ - 1);
+            ro += 2 * CS;
+            const int rn = min(ro, QPQ - 1);
             nd = qd[rn];
             ni = (int)qj[rn];
-            top.insert(key);
+            return key;
+        };
+        bool more = __any(ro < nq_);
+        static_for<K>([&](auto t) {
+            if (more) {
+                top.template insert_first<decltype(t)::value>(next_key());
+                more = __any(ro < nq_);
+            }
+        });
+        while (more) {
+            top.insert(next_key());
+            more = __any(ro < nq_);
         }
     } else {
         // a queue overflowed somewhere in this workgroup: the plain scan (every candidate through the sorted insert)
@@ -1128,20 +1172,23 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     // merge the sorted key lists of every query, through the query tile's share of the queue area; the merging
     // lanes of the four query tiles sit in waves 0, 5, 10, 15: one per SIMD
     __syncthreads();
+    // lists of K keys and a +inf behind them (a head that has taken a whole list reads the sentinel)
     double *mk = reinterpret_cast<double *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6));
-    constexpr bool ONE_STAGE = 2 * CS * K * 32 * 8 <= 32 * QPQ * 6;
+    constexpr int KL = K + 1;
+    constexpr bool ONE_STAGE = 2 * CS * KL * 32 * 8 <= 32 * QPQ * 6;
     constexpr int LISTS = ONE_STAGE ? 2 * CS : CS;
-    static_assert(LISTS * K * 32 * 8 <= 32 * QPQ * 6, "key lists must fit a query tile's queues");
+    static_assert(LISTS * KL * 32 * 8 <= 32 * QPQ * 6, "key lists must fit a query tile's queues");
     if constexpr (ONE_STAGE) {
-        int slot1 = list * K * 32 + col;
+        int slot1 = list * KL * 32 + col;
         asm volatile("" : "+v"(slot1));
 #pragma unroll
         for (int p = 0; p < K; ++p)
             mk[slot1 + p * 32] = top.key[p];
+        mk[slot1 + K * 32] = __builtin_inf();
         __syncthreads();
     } else {
         // first the two lane halves of a wave: the upper half's list goes through LDS into the lower half's
-        int slot1 = cs * K * 32 + col;
+        int slot1 = cs * KL * 32 + col;
         asm volatile("" : "+v"(slot1));
         if (half == 1) {
 #pragma unroll
@@ -1158,30 +1205,34 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
 #pragma unroll
             for (int p = 0; p < K; ++p)
                 mk[slot1 + p * 32] = top.key[p];
+            mk[slot1 + K * 32] = __builtin_inf();
         }
         __syncthreads();
     }
     if (cs == qt && half == 0 && qvalid) {
-        int head[LISTS];
+        // k steps of "smallest head, advance it": one lane per query, the heads as running addresses (keys are unique -- a
+        // candidate is in one list -- except +inf, which only shows when the lists hold fewer than k keys: never, k <= n)
+        const double *hp[LISTS];
 #pragma unroll
         for (int l = 0; l < LISTS; ++l)
-            head[l] = 0;
+            hp[l] = mk + l * KL * 32 + col;
         int *dst = nn_idx + ((size_t)cloud * n + qi0) * k;
-        for (int p = 0; p < k; ++p) {
-            double hk[LISTS];
 #pragma unroll
-            for (int l = 0; l < LISTS; ++l)
-                hk[l] = mk[(l * K + min(head[l], K - 1)) * 32 + col];
-            double best = __builtin_inf();
+        for (int p = 0; p < K; ++p) {
+            if (p < k) {
+                double hk[LISTS];
 #pragma unroll
-            for (int l = 0; l < LISTS; ++l) {
-                hk[l] = head[l] < K ? hk[l] : __builtin_inf();
-                best = __builtin_fmin(best, hk[l]);
+                for (int l = 0; l < LISTS; ++l)
+                    hk[l] = *hp[l];
+                double best = hk[0];
+#pragma unroll
+                for (int l = 1; l < LISTS; ++l)
+                    asm("v_min_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(hk[l]));
+#pragma unroll
+                for (int l = 0; l < LISTS; ++l)
+                    hp[l] += hk[l] == best ? 32 : 0;
+                dst[p] = best < __builtin_inf() ? knn_key_low16(best) : 0;
             }
-#pragma unroll
-            for (int l = 0; l < LISTS; ++l)
-                head[l] += (hk[l] == best) ? 1 : 0;      // keys are unique (a candidate is in one list) except +inf
-            dst[p] = knn_key_index(best);
         }
     }
 }
