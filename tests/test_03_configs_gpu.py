@@ -41,6 +41,11 @@ CONFIGS = [
     # oracle finishes in under a minute; 8 clouds = 1024 query tiles: the 16-wave kNN kernel with k = 20 and 128-slot
     # queues, the kernel bench.py --config5 runs
     pytest.param("configs[4]/net", 8, 4096, "f32", 20, id="cfg5-B8-N4096-k20"),
+    # the same at configs[4]'s own batch of 32 (the oracle step takes ~1 minute on the GPU boxes' 256 host cores;
+    # CLOUDAAE_SKIP_FULL_CFG5=1 leaves it out on a small host)
+    pytest.param("configs[4]/net, full batch", 32, 4096, "f32", 20, id="cfg5-B32-N4096-k20",
+                 marks=pytest.mark.skipif(os.environ.get("CLOUDAAE_SKIP_FULL_CFG5") == "1",
+                                          reason="full-size configs[4] parity skipped (CLOUDAAE_SKIP_FULL_CFG5=1)")),
 ]
 
 
