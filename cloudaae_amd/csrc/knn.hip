@@ -1260,6 +1260,268 @@ static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, i
                                   : launch_knn_wide_q<K, 128, false>(b, n, ld, k, x, nn_idx, s);
 }
 
+// ---- C = 3 on the matrix cores: the bound pass + filtered scan of knn64_wide_kernel without its rounds ----------------
+// knn3_scan_kernel below spends its time in the vector pipe: ~11 instructions per candidate and lane for the distance and
+// the branch-free push, then the sorted inserts of every lane's own stream (a wave pays the maximum over its lanes).  Here
+// the distances of a 32 x 32 tile are THREE v_mfma_f32_32x32x2_f32 (channels x, y | z, 0 | the two norms) -- the same fma
+// chain from +0 in channel order, so the same bits as knn3_kernel / oracle_knn -- and the selection is the one of
+// knn64_wide_kernel: a bound tau on the k-th distance from a sample of the tiles (unit minima), every candidate at or
+// below it appended to its query's LDS queue (one slot request per lane and tile), keyed inserts and a list merge at the
+// end, a flagged plain rescan when a queue overflows.  The whole cloud (x, y, z, |.|^2) sits in LDS from the start, so
+// the passes need no staging, no barriers and no per-round norms: a wave simply walks its quarter of the tiles.
+// A workgroup = 16 waves = 4 query tiles x 4 candidate slices, one per CU.
+static int knn3_wide_qpq(int n, int k) { return n <= 2048 ? 144 : (k > 10 ? 124 : 112); }
+static size_t knn3_wide_lds_bytes(int n, int k)
+{
+    return 16 * (size_t)ceil_div(n, KM_TILE) * KM_TILE + 6 * 128 * (size_t)knn3_wide_qpq(n, k) + 4 * 128 + 16 + 4 * 128;
+}
+
+template <int K, int QPQ>
+__global__ __launch_bounds__(1024) void knn3_wide_kernel(int n, int ld, int k, const float *__restrict__ x,
+                                                         int *__restrict__ nn_idx)
+{
+    constexpr int QW = 4, CS = 4, THREADS = 1024;
+    extern __shared__ __attribute__((aligned(16))) char k3w_smem[];
+    // layout: cloud float4[ntiles * 32] (x, y, z, |.|^2; rows past the end 0, 0, 0, +inf) | queue d[128 queries][QPQ] (fp32) |
+    //         queue j, same shape (u16) | queue lengths [128] | overflow flag (+ pad) | tau [128]
+    const int ntiles = (n + KM_TILE - 1) / KM_TILE;
+    float4v *cand = reinterpret_cast<float4v *>(k3w_smem);
+    float *qd_all = reinterpret_cast<float *>(cand + ntiles * KM_TILE);
+    unsigned short *qj_all = reinterpret_cast<unsigned short *>(qd_all + QW * 32 * QPQ);
+    int *qn_all = reinterpret_cast<int *>(qj_all + QW * 32 * QPQ);
+    int *flag = qn_all + QW * 32;
+    float *tauv = reinterpret_cast<float *>(flag + 4);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qt = wave / CS, cs = wave % CS;
+    int qgroup, cloud;
+    xcd_cloud_tile(qgroup, cloud);
+    const float *X = x + (size_t)cloud * n * ld;
+    for (int j = tid; j < ntiles * KM_TILE; j += THREADS) {
+        const float *row = X + (size_t)min(j, n - 1) * ld;
+        const float cx = row[0], cy = row[1], cz = row[2];
+        const float a = cx * cx, b = cy * cy, c = cz * cz;
+        float sq = 0.0f + a;                               // the un-fused sequential sum the oracle defines
+        sq = sq + b;
+        sq = sq + c;
+        cand[j] = j < n ? float4v{cx, cy, cz, sq} : float4v{0.0f, 0.0f, 0.0f, __builtin_inff()};
+    }
+    if (tid < QW * 32)
+        qn_all[tid] = 0;
+    if (tid == 0)
+        *flag = 0;
+    __syncthreads();
+
+    const int col = lane & 31, half = lane >> 5;
+    const int qi0 = (qgroup * QW + qt) * KM_TILE + col;   // this lane's query
+    const bool qvalid = qi0 < n;
+    const float4v me = cand[qvalid ? qi0 : 0];
+    // B operands: -2 x the query's channel of parity `half` (steps 0 and 1; the fourth channel is a zero), then the norms
+    const float bq0 = -2.0f * (half ? me.y : me.x), bq1 = half ? 0.0f : -2.0f * me.z, bx = half ? 1.0f : me.w;
+    const int S = min(ntiles, max((ntiles + (K > 10 ? 1 : 3)) / (K > 10 ? 2 : 4), 4));   // the sample: every stride-th tile
+    const int stride = ntiles / S;
+
+    f32x16 acc;
+    auto tile = [&](int t) {                               // distances of candidate tile t to this lane's query
+        const float4v c = cand[t * KM_TILE + col];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? c.y : c.x, bq0, f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c.z, bq1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? c.w : 1.0f, bx, acc, 0, 0, 0);
+    };
+
+    // ---------------- pass A: tau ----------------
+    MinK<K> um;
+    um.init();
+    for (int s = cs; s < S; s += CS) {
+        tile(s * stride);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)                        // units: the lane's rows 8 g + 4 half + (0..3)
+            um.insert(fminf(fminf(acc[4 * g], acc[4 * g + 1]), fminf(acc[4 * g + 2], acc[4 * g + 3])));
+    }
+    float *md = reinterpret_cast<float *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6));
+    static_assert(2 * CS * K * 32 * 4 <= 32 * QPQ * 6 && (32 * QPQ * 6) % 8 == 0,
+                  "scratch lists must fit the queue area of one query tile");
+    const int list = cs * 2 + half;
+#pragma unroll
+    for (int p = 0; p < K; ++p)
+        md[(list * K + p) * 32 + col] = um.d[p];
+    __syncthreads();
+    if (cs == qt) {
+        float t = __builtin_inff();
+        // K steps of "smallest head, advance it" over the 2*CS sorted lists.  Equal heads advance together, which can
+        // only make the bound larger (it stays valid).
+        int head[2 * CS];
+#pragma unroll
+        for (int l = 0; l < 2 * CS; ++l)
+            head[l] = (l * K) * 32 + col;
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            float hv[2 * CS];
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l)
+                hv[l] = md[head[l]];                       // (a head moves at most once per step: never past its list)
+            float m = hv[0];
+#pragma unroll
+            for (int l = 1; l < 2 * CS; ++l)
+                m = fminf(m, hv[l]);
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l)
+                head[l] += hv[l] == m ? 32 : 0;
+            t = m;
+        }
+        if (half == 0)
+            tauv[qt * 32 + col] = fminf(t, 3.4028234664e38f);                 // rows past the end (+inf) never pass
+    }
+    __syncthreads();                                       // the lists are consumed, the bounds written: the queues may fill
+
+    // ---------------- pass B: everything at or below tau goes to the query's queue ----------------
+    const int qq = qt * 32 + col;
+    float *qd = qd_all + qq * QPQ;
+    unsigned short *qj = qj_all + qq * QPQ;
+    const float tau = tauv[qq];
+    for (int t = cs; t < ntiles; t += CS) {
+        tile(t);
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            cnt += acc[e] <= tau ? 1 : 0;
+        if (cnt > 0) {                                     // ONE slot request for the lane's entries of the tile
+            int sl = atomicAdd(&qn_all[qq], cnt);
+            const int jb = t * KM_TILE + 4 * half;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (acc[e] <= tau) {
+                    // past the end of a full queue the last slot is overwritten: the count still says "overflowed"
+                    const int at = min(sl, QPQ - 1);
+                    qd[at] = acc[e];
+                    qj[at] = (unsigned short)(jb + (e & 3) + 8 * (e >> 2));
+                    ++sl;
+                }
+        }
+    }
+    __syncthreads();
+    if (qn_all[qq] > QPQ)
+        *flag = 1;
+    __syncthreads();
+    TopKey<K> top;
+    top.init();
+    if (*flag == 0) {
+        // the query's 8 lanes take every 8th entry of its queue (they arrive in any order: keyed insert); the t-th
+        // insert into an empty list is t min/max pairs, not K
+        const int nq_ = min(qn_all[qq], QPQ);
+        int ro = list;
+        float nd = qd[min(ro, QPQ - 1)];
+        int ni = (int)qj[min(ro, QPQ - 1)];
+        auto next_key = [&]() {
+            const double key = ro < nq_ ? knn_key(nd, ni) : __builtin_inf();
+            ro += 2 * CS;
+            const int rn = min(ro, QPQ - 1);
+            nd = qd[rn];
+            ni = (int)qj[rn];
+            return key;
+        };
+        bool more = __any(ro < nq_);
+        static_for<K>([&](auto t) {
+            if (more) {
+                top.template insert_first<decltype(t)::value>(next_key());
+                more = __any(ro < nq_);
+            }
+        });
+        while (more) {
+            top.insert(next_key());
+            more = __any(ro < nq_);
+        }
+    } else {
+        // a queue overflowed somewhere in this workgroup: the plain scan (every candidate through the sorted insert)
+        for (int t = cs; t < ntiles; t += CS) {
+            tile(t);
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                top.insert(knn_key(acc[e], t * KM_TILE + 4 * half + (e & 3) + 8 * (e >> 2)));      // (rows past n are +inf)
+        }
+    }
+
+    // merge the sorted key lists of every query (K keys and a +inf behind them), through the query tile's share of the
+    // queue area; the merging lanes of the four query tiles sit in waves 0, 5, 10, 15: one per SIMD
+    __syncthreads();
+    double *mk = reinterpret_cast<double *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6));
+    constexpr int KL = K + 1;
+    constexpr bool ONE_STAGE = 2 * CS * KL * 32 * 8 <= 32 * QPQ * 6;
+    constexpr int LISTS = ONE_STAGE ? 2 * CS : CS;
+    static_assert(LISTS * KL * 32 * 8 <= 32 * QPQ * 6, "key lists must fit a query tile's queues");
+    if constexpr (ONE_STAGE) {
+#pragma unroll
+        for (int p = 0; p < K; ++p)
+            mk[(list * KL + p) * 32 + col] = top.key[p];
+        mk[(list * KL + K) * 32 + col] = __builtin_inf();
+        __syncthreads();
+    } else {
+        // first the two lane halves of a wave: the upper half's list goes through LDS into the lower half's
+        if (half == 1) {
+#pragma unroll
+            for (int p = 0; p < K; ++p)
+                mk[(cs * KL + p) * 32 + col] = top.key[p];
+        }
+        __syncthreads();
+        if (half == 0) {
+            for (int p = 0; p < K; ++p)
+                top.insert(mk[(cs * KL + p) * 32 + col]);
+        }
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int p = 0; p < K; ++p)
+                mk[(cs * KL + p) * 32 + col] = top.key[p];
+            mk[(cs * KL + K) * 32 + col] = __builtin_inf();
+        }
+        __syncthreads();
+    }
+    if (cs == qt && half == 0 && qvalid) {
+        const double *hp[LISTS];
+#pragma unroll
+        for (int l = 0; l < LISTS; ++l)
+            hp[l] = mk + l * KL * 32 + col;
+        int *dst = nn_idx + ((size_t)cloud * n + qi0) * k;
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            if (p < k) {
+                double hk[LISTS];
+#pragma unroll
+                for (int l = 0; l < LISTS; ++l)
+                    hk[l] = *hp[l];
+                double best = hk[0];
+#pragma unroll
+                for (int l = 1; l < LISTS; ++l)
+                    asm("v_min_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(hk[l]));
+#pragma unroll
+                for (int l = 0; l < LISTS; ++l)
+                    hp[l] += hk[l] == best ? 32 : 0;     // (keys are unique: a candidate is in one list)
+                dst[p] = best < __builtin_inf() ? knn_key_low16(best) : 0;
+            }
+        }
+    }
+}
+
+template <int K, int QPQ>
+static hipError_t launch_knn3_wide_q(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
+{
+    const size_t lds = knn3_wide_lds_bytes(n, K);
+    static bool raised[64] = {};
+    if (hipError_t e = raise_lds_limit(&knn3_wide_kernel<K, QPQ>, raised); e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL((knn3_wide_kernel<K, QPQ>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s, n, ld, k, x, nn_idx);
+    return hipSuccess;
+}
+template <int K>
+static hipError_t launch_knn3_wide(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
+{
+    const int q = knn3_wide_qpq(n, K);
+    return q == 144   ? launch_knn3_wide_q<K, 144>(b, n, ld, k, x, nn_idx, s)
+           : q == 124 ? launch_knn3_wide_q<K, 124>(b, n, ld, k, x, nn_idx, s)
+                      : launch_knn3_wide_q<K, 112>(b, n, ld, k, x, nn_idx, s);
+}
+static bool knn3_wide_fits(int n, int k) { return k <= 20 && n >= 256 && knn3_wide_lds_bytes(n, k <= 10 ? 10 : 20) <= 160 * 1024; }
+
 // ---- C = 3, second generation: the selection split into filter + queued drain ------------------
 // knn3_kernel above runs the sorted insert for every candidate of every lane (a wave executes it
 // whenever ANY lane needs it, i.e. always): ~45 instructions per candidate against 8 for the
@@ -1430,6 +1692,14 @@ static hipError_t launch_knn(int b, int n, int c, int ld, int k, const float *x,
     const bool vec = ld % 4 == 0 && ((uintptr_t)x & 15) == 0;
     if (c == 3 && K <= 20 && n <= 6144 && !first_gen) {
         if constexpr (K <= 20) {
+            // the matrix-core form from 64 workgroups (of 128 queries, one per CU) up; knob CLOUDAAE_KNN3_WIDE = 0 / 1
+            // forces the choice (the tests cover both).  Measured, n = 1024, k = 10, continuous coordinates, wide / scan:
+            // B = 8 24 / 40 us, B = 32 24 / 47, B = 128 91 / 104, B = 256 180 / 201; [32, 4096, k = 20] 354 / 639.  (Clouds
+            // made of a few distinct points overflow the queues and pay the rescan: 48 us at B = 32 -- the scan kernel's time.)
+            const bool wide = CLOUDAAE_KNOB_SET("CLOUDAAE_KNN3_WIDE") ? CLOUDAAE_KNOB("CLOUDAAE_KNN3_WIDE", 0) != 0
+                                                                        : (long long)ceil_div(n, 128) * b >= 64;
+            if (wide && knn3_wide_fits(n, K))
+                return launch_knn3_wide<K>(b, n, ld, k, x, nn_idx, s);
             // candidate ranges per query tile: as few as still give every SIMD two waves (fewer ranges = fewer lists to
             // fill: measured, n = 1024, k = 10, ranges 4 / 2 / 1: B = 32 47 / 55 / - us, B = 64 89 / 67 / - us,
             // B = 128 170 / 127 / 105 us, B = 256 - / 243 / 202 us)

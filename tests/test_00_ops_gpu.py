@@ -270,6 +270,39 @@ def test_knn_c64_bound_kernel_adversarial(hip, oracle, knobs, mode, k, case):
     assert np.array_equal(want, got.cpu().numpy())
 
 
+@pytest.mark.parametrize("wide", [1, 0])
+@pytest.mark.parametrize("b,n,ld,k,case", [(2, 300, 24, 10, "dup"), (3, 1024, 24, 10, "dup"), (2, 1000, 3, 20, "dup"),
+                                            (2, 4096, 24, 20, "dup"), (1, 2500, 3, 7, "dup"), (5, 257, 24, 1, "dup"),
+                                            (2, 1024, 24, 10, "all_equal"), (2, 1024, 24, 20, "lattice"),
+                                            (2, 1024, 24, 10, "far_cluster"), (2, 1024, 3, 10, "large_finite")])
+def test_knn_c3_kernel_choices_vs_oracle(hip, oracle, knobs, wide, b, n, ld, k, case):
+    """C = 3 (layer 1): knn3_wide_kernel (three MFMAs per 32 x 32 tile, bound pass + queues; CLOUDAAE_KNN3_WIDE=1) and
+    knn3_scan_kernel (=0) keep the same bit-exact contract, also where (nearly) every candidate ties with the k-th
+    distance (the queues overflow: flagged rescan), where the sampled tiles are unrepresentative and where distances are huge."""
+    from cloudaae_amd import _lib
+    knobs("CLOUDAAE_KNN3_WIDE", wide)
+    rng = np.random.default_rng(n + k + ld)
+    if case == "dup":
+        x = np.maximum(rng.standard_normal((b, n, ld)), -0.5) * 0.1
+        x[:, n // 2:n // 2 + 30] = x[:, :30]      # duplicates -> exact ties
+    elif case == "all_equal":
+        x = np.tile(rng.standard_normal((b, 1, ld)), (1, n, 1))
+    elif case == "lattice":
+        x = rng.integers(0, 3, (b, n, ld)).astype(np.float64)         # exact small-integer distances: ties everywhere
+    elif case == "large_finite":
+        x = rng.standard_normal((b, n, ld)) * 1e15
+    else:
+        x = rng.standard_normal((b, n, ld)) * 0.01
+        x[:, ::128] += 50.0                                          # every sampled tile starts with an outlier
+        x[:, 32:64] += 100.0                                         # and a whole unsampled tile sits far away
+    x = x.astype(np.float32)
+    want = oracle.knn(x, k, channels=3, threads=8)
+    xd = _dev(x)
+    got = torch.full((b, n, k), -1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().cloudaae_knn(b, n, 3, ld, k, _lib.ptr(xd), _lib.ptr(got), _lib.stream()), "knn")
+    assert np.array_equal(want, got.cpu().numpy())
+
+
 # ---- ProbSample (tf_sampling_g.cu:7-104) -----------------------------------------------------
 @pytest.mark.parametrize("b,n,m", [(1, 1, 5), (2, 7, 50), (3, 21, 1000), (2, 4096, 300), (1, 8192 + 37, 500),
                                    (2, 20000, 700)])

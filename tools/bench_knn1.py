@@ -6,7 +6,9 @@ L = _lib.lib()
 b, n, c, ld, k = (int(a) for a in sys.argv[1:6])
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 10
 g = torch.Generator(device="cuda").manual_seed(1)
-x = torch.relu(torch.randn((b, n, ld), device="cuda", generator=g))     # post-ReLU features, like net1..net3
+x = torch.randn((b, n, ld), device="cuda", generator=g)
+if c != 3:
+    x = torch.relu(x)                                                    # post-ReLU features, like net1..net3 (xyz: as drawn)
 out = torch.empty((b, n, k), dtype=torch.int32, device="cuda")
 go = lambda: _lib.check(L.cloudaae_knn(b, n, c, ld, k, x.data_ptr(), out.data_ptr(), _lib.stream()), "knn")
 import time
