@@ -782,7 +782,7 @@ struct MinK {                        // the K smallest values seen, ascending
 static int knn_wide_qpq(int n) { return n <= 3328 ? 144 : 128; }
 static size_t knn_wide_lds_bytes(int n)
 {
-    return sizeof(float) * (4 * KM_TILE * 68 + (size_t)ceil_div(n, KM_TILE) * KM_TILE + 4 + 32 + 128) +
+    return sizeof(float) * (4 * KM_TILE * 68 + (size_t)ceil_div(n, KM_TILE) * KM_TILE + 4 + 128 + (size_t)ceil_div(n, KM_TILE)) +
            (sizeof(float) + sizeof(unsigned short)) * 128 * (size_t)knn_wide_qpq(n) + sizeof(int) * 128;
 }
 
@@ -810,7 +810,13 @@ static size_t knn_wide_lds_bytes(int n)
 // REUSE (the launcher sets it when pass A is at most two rounds: K <= 10, n <= 1024): the sampled tiles' distances stay
 // in registers until tau is known, go through the filter then, and pass B covers only the tiles that were NOT sampled:
 // 1.0 x the N x N x 64 products instead of 1.25 x, two rounds fewer.
-template <int K, int QPQ, bool REUSE>
+// TWO (every other launch): the bound in two stages.  The sample's even slots give a first bound (pass A1); the odd slots
+// are scanned WITH it (pass A2: their candidates at or below it go to the queues, their unit minima join the lists), the
+// K-th smallest over both halves is the final bound, and pass B leaves A2's tiles out: 1.25 x the products instead of
+// 1.5 x for K = 20 (half of the tiles sampled), 1.125 x instead of 1.25 x for K = 10.  The second merge finds the queue
+// area occupied, so its lists (the 8 smallest of every lane: the K-th over fewer values is still a bound) go through the
+// tile buffers, which are idle at that point.
+template <int K, int QPQ, bool REUSE, bool TWO>
 __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, const float *__restrict__ x,
                                                           int *__restrict__ nn_idx)
 {
@@ -820,7 +826,7 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     // QPQ: queue slots per query (its 8 lanes share them)
     extern __shared__ __attribute__((aligned(16))) char kw_smem[];
     // layout: tile[CS][TILE_FLOATS] | queue d[128 queries][QPQ] (fp32) | queue j, same shape (u16) | queue lengths [128] |
-    //         sq[ntiles * 32] | 1.0 | overflow flag | (pad) | REUSE: pass B's tile list [32] | tau [128 queries]
+    //         sq[ntiles * 32] | 1.0 | overflow flag | (pad) | tau [128 queries] | REUSE / TWO: pass B's tile list [ntiles]
     float *tiles = reinterpret_cast<float *>(kw_smem);
     float *qd_all = tiles + CS * TILE_FLOATS;
     unsigned short *qj_all = reinterpret_cast<unsigned short *>(qd_all + QW * 32 * QPQ);
@@ -848,18 +854,25 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     // pass A's sample: S tiles, every stride-th one (a quarter of the tiles; half of them for K > 10)
     const int S = min(ntiles, max((ntiles + (K > 10 ? 1 : 3)) / (K > 10 ? 2 : 4), 4));
     const int stride = ntiles / S;
-    // REUSE: pass B's tile list = the tiles pass A did not take, ascending: below S * stride the non-multiples of stride,
-    // then the rest
-    // (a table in LDS: computed where it is needed, the two integer divisions cost every wave ~45 vector instructions
-    // per round, and a vector instruction costs matrix time here -- see the round below)
-    const int nB = REUSE ? ntiles - S : ntiles;
-    int *tile_list = reinterpret_cast<int *>(sq + ntiles * KM_TILE + 4);
-    if (REUSE && tid < 32) {
-        const int sm1 = stride - 1, below = S * sm1;
-        tile_list[tid] = tid < below ? (tid / max(sm1, 1)) * stride + 1 + tid % max(sm1, 1) : S * stride + (tid - below);
+    static_assert(!(REUSE && TWO), "one or the other");
+    const int SA1 = TWO ? (S + 1) / 2 : S, SA2 = TWO ? S / 2 : 0;         // sample slots of pass A1 (TWO: the even ones) / A2
+    // pass B's tile list = the tiles whose distances are not kept, ascending: all but the sample (REUSE) / all but A2's
+    // tiles (TWO).  (A table in LDS: computed where it is needed, the integer divisions cost every wave ~45 vector
+    // instructions per round, and a vector instruction costs matrix time here -- see the round below)
+    const int nB = REUSE ? ntiles - S : ntiles - SA2;
+    float *tauv = sq + ntiles * KM_TILE + 4;
+    int *tile_list = reinterpret_cast<int *>(tauv + 128);
+    if (REUSE || TWO) {
+        for (int t = tid; t < ntiles; t += THREADS) {
+            const int below = min((t + stride - 1) / stride, S);          // sample slots in front of tile t
+            const bool sampled = t % stride == 0 && t / stride < S;
+            const bool kept = sampled && (REUSE || ((t / stride) & 1));  // its distances are kept: not pass B's
+            if (!kept)
+                tile_list[t - (REUSE ? below : below / 2)] = t;
+        }
     }
-    auto tile_b = [&](int u, bool uniform) {               // u < 32
-        return !REUSE ? u : uniform ? __builtin_amdgcn_readfirstlane(tile_list[u]) : tile_list[u];
+    auto tile_b = [&](int u, bool uniform) {               // u < nB
+        return !(REUSE || TWO) ? u : uniform ? __builtin_amdgcn_readfirstlane(tile_list[u]) : tile_list[u];
     };
 
     // staging: a round = CS tiles of 32 rows; a wave brings 8 rows, each with ONE global_load_lds_dword: lane l fetches
@@ -868,12 +881,13 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     // end repeat row n - 1: their |x|^2 reads +inf, so their distances are +inf.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int chan = 2 * col + half;
-    // first row of the tile in slot `slot` of round r.  what: 0 = pass B's tiles, 1 = pass A's sample, 2 = the query
-    // tiles, 3 = every tile in order (the fallback scan)
+    // first row of the tile in slot `slot` of round r.  what: 0 = pass B's tiles, 1 = pass A's (A1's) sample, 2 = the
+    // query tiles, 3 = every tile in order (the fallback scan), 4 = pass A2's sample
     auto tile_row0 = [&](int what, int slot, bool uniform) {
-        return what == 1   ? (slot < S ? slot * stride * KM_TILE : n)
+        return what == 1   ? (slot < SA1 ? (TWO ? 2 * slot : slot) * stride * KM_TILE : n)
+               : what == 4 ? (slot < SA2 ? (2 * slot + 1) * stride * KM_TILE : n)
                : what == 2 ? (qgroup * QW + slot) * KM_TILE
-               : what == 0 ? (slot < nB ? tile_b(REUSE ? min(slot, 31) : slot, uniform) * KM_TILE : n)
+               : what == 0 ? (slot < nB ? tile_b(slot, uniform) * KM_TILE : n)
                            : slot * KM_TILE;
     };
     float *qstage = qd_all;                                // the query tiles are staged in the (still unused) queue area
@@ -963,7 +977,7 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     };
 
     // ---------------- pass A: tau ----------------
-    const int roundsA = (S + CS - 1) / CS;
+    const int roundsA = (SA1 + CS - 1) / CS;
     stage_rows(2, 0);                                      // the workgroup's 4 query tiles, staged like candidate tiles
     stage_rows(1, 0);                                      // (the first sample tiles travel with them)
     staged();
@@ -981,76 +995,7 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     }
     __syncthreads();                                       // the query norms are in sq
     bx = half ? 1.0f : sq[qs];
-    MinK<K> um;
-    um.init();
-    // REUSE: the sampled tiles' distances are kept for the filter: the last round's in `acc`, the round before in the
-    // part of the query tile's queue area that the scratch lists below leave free ([16 values][4 waves x 64 lanes])
-    float *svl = reinterpret_cast<float *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6) + 2 * CS * K * 32 * 4) +
-                 cs * 64 + lane;
-    static_assert(!REUSE || 2 * CS * K * 32 * 4 + 16 * CS * 64 * 4 <= 32 * QPQ * 6, "saved distances must fit beside the lists");
-    for (int r = 0; r < roundsA; ++r) {
-        const int slot = r * CS + cs;
-        round(1, r, roundsA, slot < S ? slot * stride * KM_TILE : ntiles * KM_TILE - KM_TILE);
-        const bool live = slot < S;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {                      // units: the lane's rows 8 g + 4 half + (0..3)
-            const float m = fminf(fminf(acc[4 * g], acc[4 * g + 1]), fminf(acc[4 * g + 2], acc[4 * g + 3]));
-            um.insert(live ? m : __builtin_inff());
-        }
-        if constexpr (REUSE) {
-            if (r + 1 < roundsA) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    svl[e * CS * 64] = acc[e];
-            }
-        }
-    }
-    // K-th smallest unit minimum over the query's 2*CS lists, through the query tile's share of the queue area
-    float *md = reinterpret_cast<float *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6));
-    static_assert(2 * CS * K * 32 * 4 <= 32 * QPQ * 6 && (32 * QPQ * 6) % 8 == 0,
-                  "scratch lists must fit the queue area of one query tile");
-    const int list = cs * 2 + half;
-    __syncthreads();
-    int slot0 = list * K * 32 + col;                       // (opaque: keeps the compiler from deriving these K addresses
-    asm volatile("" : "+v"(slot0));                        //  before the scan loop and spilling them across it)
-#pragma unroll
-    for (int p = 0; p < K; ++p)
-        md[slot0 + p * 32] = um.d[p];
-    const int roundsB = (nB + CS - 1) / CS;
-    if (roundsB > 0)
-        stage_rows(0, 0);                                  // pass B's first tiles travel during the merge below
-    __syncthreads();
-    // K-th smallest over the query's lists: ONE wave per query tile merges (waves 0, 5, 10, 15: one per SIMD), the bound
-    // reaches the other lanes through LDS after the next barrier
-    float *tauv = sq + ntiles * KM_TILE + 4 + 32;
-    if (cs == qt) {
-        float t = __builtin_inff();
-        // K steps of "smallest head, advance it" over the 2*CS sorted lists.  Equal heads advance together, which can
-        // only make the bound larger (it stays valid).
-        int head[2 * CS];
-#pragma unroll
-        for (int l = 0; l < 2 * CS; ++l)
-            head[l] = (l * K) * 32 + col;
-#pragma unroll
-        for (int p = 0; p < K; ++p) {
-            float hv[2 * CS];
-#pragma unroll
-            for (int l = 0; l < 2 * CS; ++l)
-                hv[l] = md[head[l]];                       // (a head moves at most once per step: never past its list)
-            float m = hv[0];
-#pragma unroll
-            for (int l = 1; l < 2 * CS; ++l)
-                m = fminf(m, hv[l]);
-#pragma unroll
-            for (int l = 0; l < 2 * CS; ++l)
-                head[l] += hv[l] == m ? 32 : 0;
-            t = m;
-        }
-        if (half == 0)
-            tauv[qt * 32 + col] = fminf(t, 3.4028234664e38f);                 // rows past the end (+inf) never pass
-    }
-
-    // ---------------- pass B: everything at or below tau goes to the query's queue ----------------
+    // the queues (pass A2 of the two-stage bound and pass B fill them)
     const int qq = qt * 32 + col;
     float *qd = qd_all + qq * QPQ;
     unsigned short *qj = qj_all + qq * QPQ;
@@ -1094,6 +1039,185 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
             }
         }
     };
+    MinK<K> um;
+    um.init();
+    // REUSE: the sampled tiles' distances are kept for the filter: the last round's in `acc`, the round before in the
+    // part of the query tile's queue area that the scratch lists below leave free ([16 values][4 waves x 64 lanes])
+    float *svl = reinterpret_cast<float *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6) + 2 * CS * K * 32 * 4) +
+                 cs * 64 + lane;
+    static_assert(!REUSE || 2 * CS * K * 32 * 4 + 16 * CS * 64 * 4 <= 32 * QPQ * 6, "saved distances must fit beside the lists");
+    for (int r = 0; r < roundsA; ++r) {
+        const int slot = r * CS + cs;
+        round(1, r, roundsA, slot < SA1 ? (TWO ? 2 * slot : slot) * stride * KM_TILE : ntiles * KM_TILE - KM_TILE);
+        const bool live = slot < SA1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                      // units: the lane's rows 8 g + 4 half + (0..3)
+            const float m = fminf(fminf(acc[4 * g], acc[4 * g + 1]), fminf(acc[4 * g + 2], acc[4 * g + 3]));
+            um.insert(live ? m : __builtin_inff());
+        }
+        if constexpr (REUSE) {
+            if (r + 1 < roundsA) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    svl[e * CS * 64] = acc[e];
+            }
+        }
+    }
+    // K-th smallest unit minimum over the query's 2*CS lists, through the query tile's share of the queue area
+    float *md = reinterpret_cast<float *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6));
+    static_assert(2 * CS * K * 32 * 4 <= 32 * QPQ * 6 && (32 * QPQ * 6) % 8 == 0,
+                  "scratch lists must fit the queue area of one query tile");
+    const int list = cs * 2 + half;
+    __syncthreads();
+    int slot0 = list * K * 32 + col;                       // (opaque: keeps the compiler from deriving these K addresses
+    asm volatile("" : "+v"(slot0));                        //  before the scan loop and spilling them across it)
+#pragma unroll
+    for (int p = 0; p < K; ++p)
+        md[slot0 + p * 32] = um.d[p];
+    const int roundsB = (nB + CS - 1) / CS;
+    const int roundsA2 = (SA2 + CS - 1) / CS;
+    if (TWO ? roundsA2 > 0 : roundsB > 0)
+        stage_rows(TWO ? 4 : 0, 0);                        // the next pass's first tiles travel during the merge below
+    __syncthreads();
+    // K-th smallest over the query's lists: ONE wave per query tile merges (waves 0, 5, 10, 15: one per SIMD), the bound
+    // reaches the other lanes through LDS after the next barrier
+    if (cs == qt) {
+        float t = __builtin_inff();
+        // K steps of "smallest head, advance it" over the 2*CS sorted lists.  Equal heads advance together, which can
+        // only make the bound larger (it stays valid).
+        int head[2 * CS];
+#pragma unroll
+        for (int l = 0; l < 2 * CS; ++l)
+            head[l] = (l * K) * 32 + col;
+#pragma unroll
+        for (int p = 0; p < K; ++p) {
+            float hv[2 * CS];
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l)
+                hv[l] = md[head[l]];                       // (a head moves at most once per step: never past its list)
+            float m = hv[0];
+#pragma unroll
+            for (int l = 1; l < 2 * CS; ++l)
+                m = fminf(m, hv[l]);
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l)
+                head[l] += hv[l] == m ? 32 : 0;
+            t = m;
+        }
+        if (half == 0)
+            tauv[qt * 32 + col] = fminf(t, 3.4028234664e38f);                 // rows past the end (+inf) never pass
+    }
+
+    if constexpr (TWO) {
+        // ---------------- pass A2: the sample's odd slots, scanned with the first bound ----------------
+        // (the scratch lists are consumed and the bounds written before the first round's second barrier; the queues
+        //  are only appended to after it)
+        for (int r = 0; r < roundsA2; ++r) {
+            const int slot = r * CS + cs;
+            const int c0 = slot < SA2 ? (2 * slot + 1) * stride * KM_TILE : ntiles * KM_TILE - KM_TILE;
+            round(4, r, roundsA2, c0);
+            if (r == 0)
+                tau = tauv[qq];
+            const bool live = slot < SA2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float m = fminf(fminf(acc[4 * g], acc[4 * g + 1]), fminf(acc[4 * g + 2], acc[4 * g + 3]));
+                um.insert(live ? m : __builtin_inff());
+            }
+            if (live)
+                push_tile(acc, c0 + 4 * half);
+        }
+        // the final bound: K-th smallest over the lists of both halves.  The queue area is in use, the tile buffers are
+        // not (every wave is past the last round's second barrier, nothing is in flight): the 8 smallest of every lane
+        // ([list][8][32 queries] per query tile), merged as above with the heads checked against the end of their lists
+        constexpr int LP = 8;
+        static_assert(QW * 2 * CS * LP * 32 <= CS * TILE_FLOATS && LP <= K, "second-stage lists must fit the tile buffers");
+        float *m2 = tiles + qt * (2 * CS * LP * 32);
+#pragma unroll
+        for (int p = 0; p < LP; ++p)
+            m2[(list * LP + p) * 32 + col] = um.d[p];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (and pass A2's queue writes, for the clean-up below)
+        __syncthreads();
+        if (cs == qt) {
+            float t = __builtin_inff();
+            int hd[2 * CS];
+#pragma unroll
+            for (int l = 0; l < 2 * CS; ++l)
+                hd[l] = 0;
+#pragma unroll
+            for (int p = 0; p < K; ++p) {
+                float hv[2 * CS];
+#pragma unroll
+                for (int l = 0; l < 2 * CS; ++l) {
+                    const float v = m2[(l * LP + min(hd[l], LP - 1)) * 32 + col];
+                    hv[l] = hd[l] < LP ? v : __builtin_inff();
+                }
+                float m = hv[0];
+#pragma unroll
+                for (int l = 1; l < 2 * CS; ++l)
+                    m = fminf(m, hv[l]);
+#pragma unroll
+                for (int l = 0; l < 2 * CS; ++l)
+                    hd[l] += hv[l] == m ? 1 : 0;
+                t = m;
+            }
+            if (half == 0)
+                tauv[qt * 32 + col] = fminf(tauv[qt * 32 + col], t);          // (both are bounds; the first one is finite)
+        }
+        __syncthreads();                                   // the lists are consumed: the tile buffers may fill again
+        tau = tauv[qq];
+        if (roundsB > 0)
+            stage_rows(0, 0);
+        // Pass A2 queued by the FIRST bound; what lies above the final one only takes slots (and overflows the queues on
+        // clustered features: measured in the config-5 step, layer 4: 1635 us against 1461 without the second stage).
+        // Clean-up in place: a query = eight neighbouring lanes of one wave (queries 8 w .. 8 w + 7), every lane reads its
+        // share of the entries (i = sub, sub + 8, ...) into registers, keeps those at or below the final bound and writes
+        // them back behind the kept entries of the lanes before it (nobody else touches these queues before the next
+        // round's first barrier).
+        {
+            constexpr int PER = (QPQ + 7) / 8;
+            const int ql = wave * 8 + (lane >> 3), sub = lane & 7;
+            const int have = qn_all[ql];
+            const float t2 = tauv[ql];
+            float *qdl = qd_all + ql * QPQ;
+            unsigned short *qjl = qj_all + ql * QPQ;
+            float dv[PER];
+            unsigned short jv[PER];
+            int mine = 0;
+            if (have <= QPQ) {                             // (an overflowed queue stays as it is: the flag will be raised)
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                    const int i = sub + 8 * u;
+                    dv[u] = qdl[min(i, QPQ - 1)];
+                    jv[u] = qjl[min(i, QPQ - 1)];
+                    mine += (i < have && dv[u] <= t2) ? 1 : 0;
+                }
+            }
+            int before = mine;                             // inclusive prefix over the eight lanes
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                const int v = __shfl_up(before, o, 8);
+                before += sub >= o ? v : 0;
+            }
+            const int total = __shfl(before, 7, 8);
+            if (have <= QPQ) {
+                int at = before - mine;
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                    const int i = sub + 8 * u;
+                    if (i < have && dv[u] <= t2) {
+                        qdl[at] = dv[u];
+                        qjl[at] = jv[u];
+                        ++at;
+                    }
+                }
+                if (sub == 0)
+                    qn_all[ql] = total;
+            }
+        }
+    }
+
+    // ---------------- pass B: everything at or below tau goes to the query's queue ----------------
     if constexpr (REUSE) {
         f32x16 sv;
         if (roundsA > 1) {
@@ -1108,13 +1232,13 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
         if ((roundsA - 1) * CS + cs < S)
             push_tile(acc, ((roundsA - 1) * CS + cs) * stride * KM_TILE + 4 * half);
     }
-    // (not REUSE: the scratch lists are consumed and the bounds written before the first round's second barrier; the
-    //  queues are only appended to after it)
+    // (neither REUSE nor TWO: the scratch lists are consumed and the bounds written before the first round's second
+    //  barrier; the queues are only appended to after it)
     for (int r = 0; r < roundsB; ++r) {
         const int slot = r * CS + cs;
         const int c0 = tile_b(min(slot, nB - 1), true) * KM_TILE;
         round(0, r, roundsB, c0);
-        if (!REUSE && r == 0)
+        if (!REUSE && !TWO && r == 0)
             tau = tauv[qq];                                // (written before this round's barriers)
         if (slot < nB)
             push_tile(acc, c0 + 4 * half);
@@ -1237,15 +1361,15 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     }
 }
 
-template <int K, int QPQ, bool REUSE>
+template <int K, int QPQ, bool REUSE, bool TWO>
 static hipError_t launch_knn_wide_q(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
     const size_t lds = knn_wide_lds_bytes(n);
     static bool raised[64] = {};
-    if (hipError_t e = raise_lds_limit(&knn64_wide_kernel<K, QPQ, REUSE>, raised); e != hipSuccess)
+    if (hipError_t e = raise_lds_limit(&knn64_wide_kernel<K, QPQ, REUSE, TWO>, raised); e != hipSuccess)
         return e;
-    hipLaunchKernelGGL((knn64_wide_kernel<K, QPQ, REUSE>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s, n, ld, k,
-                       x, nn_idx);
+    hipLaunchKernelGGL((knn64_wide_kernel<K, QPQ, REUSE, TWO>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s, n, ld,
+                       k, x, nn_idx);
     return hipSuccess;
 }
 template <int K>
@@ -1254,10 +1378,14 @@ static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, i
     if constexpr (K <= 10) {
         // pass A of at most two rounds (n <= 1024): its distances are kept and pass B skips the sampled tiles
         if (ceil_div(n, KM_TILE) <= 32 && CLOUDAAE_KNOB("CLOUDAAE_KNN_REUSE", 1) != 0)
-            return launch_knn_wide_q<K, 144, true>(b, n, ld, k, x, nn_idx, s);
+            return launch_knn_wide_q<K, 144, true, false>(b, n, ld, k, x, nn_idx, s);
     }
-    return knn_wide_qpq(n) == 144 ? launch_knn_wide_q<K, 144, false>(b, n, ld, k, x, nn_idx, s)
-                                  : launch_knn_wide_q<K, 128, false>(b, n, ld, k, x, nn_idx, s);
+    // otherwise the bound in two stages (knob CLOUDAAE_KNN_TWO = 0: one stage, the sample scanned twice)
+    if (CLOUDAAE_KNOB("CLOUDAAE_KNN_TWO", 1) != 0)
+        return knn_wide_qpq(n) == 144 ? launch_knn_wide_q<K, 144, false, true>(b, n, ld, k, x, nn_idx, s)
+                                      : launch_knn_wide_q<K, 128, false, true>(b, n, ld, k, x, nn_idx, s);
+    return knn_wide_qpq(n) == 144 ? launch_knn_wide_q<K, 144, false, false>(b, n, ld, k, x, nn_idx, s)
+                                  : launch_knn_wide_q<K, 128, false, false>(b, n, ld, k, x, nn_idx, s);
 }
 
 // ---- C = 3 on the matrix cores: the bound pass + filtered scan of knn64_wide_kernel without its rounds ----------------

@@ -239,14 +239,15 @@ def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, knobs, b, n, k, mode):
     assert np.array_equal(want, got.cpu().numpy())
 
 
-@pytest.mark.parametrize("mode,k", [(1, 10), (5, 10), (5, 20)])
+@pytest.mark.parametrize("mode,k,two", [(1, 10, 1), (5, 10, 1), (5, 20, 1), (5, 20, 0)])
 @pytest.mark.parametrize("case", ["all_equal", "few_distinct", "lattice", "large_finite", "far_cluster"])
-def test_knn_c64_bound_kernel_adversarial(hip, oracle, knobs, mode, k, case):
+def test_knn_c64_bound_kernel_adversarial(hip, oracle, knobs, mode, k, two, case):
     """The bound kernel's correctness must not depend on its bound being tight: clouds where (nearly) every
     candidate ties with the k-th distance (the queue overflows and is drained over and over), where the sampled
     tiles are unrepresentative, and where distances are huge."""
     from cloudaae_amd import _lib
     knobs("CLOUDAAE_KNN_SCAN", mode)
+    knobs("CLOUDAAE_KNN_TWO", two)          # the bound in two stages (default) / one
     rng = np.random.default_rng(7)
     b, n = 3, 1024
     if case == "all_equal":
