@@ -30,9 +30,9 @@ _SIGNATURES = {
     "cloudaae_knn": [_I, _I, _I, _I, _I, _P, _P, _P],
     "cloudaae_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "cloudaae_gemm_bf16": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
-    "cloudaae_gemm_f32_ordered": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P],
-    "cloudaae_gemm_bf16_ordered": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P],
-    "cloudaae_gemm_f32_ordered_fold": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P],
+    "cloudaae_gemm_f32_ordered": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _L, _P],
+    "cloudaae_gemm_bf16_ordered": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _L, _P],
+    "cloudaae_gemm_f32_ordered_fold": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _L, _P],
     "cloudaae_gemm_f32_tn_group": [_I, _P, _P],
     "cloudaae_bn_forward": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P,
                             _P, _P, _P],
@@ -61,7 +61,7 @@ _SIGNATURES = {
     "cloudaae_bn_meanpool_backward16": [_I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P],
     "cloudaae_bn_forward_colstats": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P,
                                      _P, _P, _I, _P],
-    "cloudaae_fc_forward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P],
+    "cloudaae_fc_forward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _L, _P],
     "cloudaae_fc_backward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P,
                              _P, _I, _P],
     "cloudaae_stream_wait": [_P, _P],
@@ -122,7 +122,7 @@ class FcLayer(ctypes.Structure):
                 ("ema_mean", _P), ("ema_var", _P), ("save_mean", _P), ("save_var", _P), ("relu", _I), ("y", _P),
                 ("out", _P), ("tickets", _P), ("dout", _P), ("lddo", _I), ("dx", _P), ("lddx", _I), ("dw", _P),
                 ("accumulate_dw", _I), ("dgamma", _P), ("dbeta", _P), ("dbias", _P), ("accumulate_param_grads", _I),
-                ("partials", _P), ("out_rowvec", _P), ("out_rowvec_d", _I)]
+                ("partials", _P), ("partials_floats", _L), ("out_rowvec", _P), ("out_rowvec_d", _I)]
 
 
 # int (*cloudaae_allreduce_fn)(void *ctx, double *buf, int count, cloudaae_stream_t stream)

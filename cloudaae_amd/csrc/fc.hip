@@ -763,6 +763,11 @@ CLOUDAAE_API int cloudaae_fc_forward_group(int M, int count, const cloudaae_fc_l
         // cut over K: with the partial-tile workspace the slices are summed in a fixed order by the last one to
         // arrive (y is plainly stored); without it they add into y with atomics (y cleared first)
         a.partials = (a.atomic && l.tickets != nullptr) ? l.partials : nullptr;
+        // (the cut is derived again at every launch, also from development knobs: a buffer sized by an earlier query
+        //  must still cover it)
+        CLOUDAAE_REQUIRE(a.partials == nullptr || l.partials_floats >= (long long)tiles * splits * FC_M * FC_TN, name,
+                         "partials_floats is smaller than this launch's partial tiles (cloudaae_fc_forward_partials; did a "
+                         "split knob change since the query?)");
         a.tickets = (a.atomic && (bn || a.partials != nullptr)) ? l.tickets : nullptr;
         CLOUDAAE_REQUIRE(a.rowvec == nullptr || !a.atomic || a.partials != nullptr, name,
                          "adding a row vector to a product cut over K needs the tickets and the partial-tile scratch");
@@ -828,12 +833,12 @@ CLOUDAAE_API int cloudaae_fc_forward(int M, int K, int N, const float *x, int ld
                                      const float *bias, const float *gamma, const float *beta, int training,
                                      const float *decay, float *ema_mean, float *ema_var, float *save_mean,
                                      float *save_var, int relu, float *y, float *out, int y_zeroed, int *tickets,
-                                     float *partials, cloudaae_stream_t stream)
+                                     float *partials, long long partials_floats, cloudaae_stream_t stream)
 {
     cloudaae_fc_layer l = {};
     l.K = K; l.N = N; l.x = x; l.ldx = ldx; l.w = w; l.bias = bias; l.gamma = gamma; l.beta = beta;
     l.ema_mean = ema_mean; l.ema_var = ema_var; l.save_mean = save_mean; l.save_var = save_var; l.relu = relu;
-    l.y = y; l.out = out; l.tickets = tickets; l.partials = partials;
+    l.y = y; l.out = out; l.tickets = tickets; l.partials = partials; l.partials_floats = partials_floats;
     return cloudaae_fc_forward_group(M, 1, &l, training, decay, y_zeroed, stream);
 }
 

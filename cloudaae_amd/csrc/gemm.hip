@@ -632,11 +632,14 @@ CLOUDAAE_API long long cloudaae_gemm_f32_ordered_workspace(int M, int N, int K)
 
 CLOUDAAE_API int cloudaae_gemm_f32_ordered(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                                            const float *B, int ldb, float *C, int ldc, const float *bias,
-                                           float *workspace, cloudaae_stream_t stream)
+                                           float *workspace, long long workspace_floats, cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_gemm_f32_ordered";
-    CLOUDAAE_REQUIRE(workspace != nullptr || cloudaae_gemm_f32_ordered_workspace(M, N, K) == 0, name,
-                     "this product is cut over K: workspace needed");
+    // (the cut is derived again at every launch, also from development knobs: a buffer sized by an earlier query must
+    //  still cover it)
+    CLOUDAAE_REQUIRE(workspace != nullptr ? workspace_floats >= cloudaae_gemm_f32_ordered_workspace(M, N, K)
+                                          : cloudaae_gemm_f32_ordered_workspace(M, N, K) == 0,
+                     name, "this product is cut over K: workspace missing or smaller than cloudaae_gemm_f32_ordered_workspace");
     static float dummy_ws;      // (a product that stays whole never touches it; non-NULL selects the ordered plan)
     return gemm_f32_launch(name, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, 0, 0, 0, (hipStream_t)stream,
                            nullptr, workspace != nullptr ? workspace : &dummy_ws);
@@ -646,11 +649,12 @@ CLOUDAAE_API int cloudaae_gemm_f32_ordered(int trans_a, int trans_b, int M, int 
 // [2*cin, cout] kernel addressed as [cin, 2*cout], see gemm.h): the deterministic mode's weight-gradient products
 CLOUDAAE_API int cloudaae_gemm_f32_ordered_fold(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                                                 const float *B, int ldb, float *C, int ldc, int fold_c, float *workspace,
-                                                cloudaae_stream_t stream)
+                                                long long workspace_floats, cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_gemm_f32_ordered_fold";
-    CLOUDAAE_REQUIRE(workspace != nullptr || cloudaae_gemm_f32_ordered_workspace(M, N, K) == 0, name,
-                     "this product is cut over K: workspace needed");
+    CLOUDAAE_REQUIRE(workspace != nullptr ? workspace_floats >= cloudaae_gemm_f32_ordered_workspace(M, N, K)
+                                          : cloudaae_gemm_f32_ordered_workspace(M, N, K) == 0,
+                     name, "this product is cut over K: workspace missing or smaller than cloudaae_gemm_f32_ordered_workspace");
     static float dummy_ws;      // (a product that stays whole never touches it; non-NULL selects the ordered plan)
     return gemm_f32_launch(name, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, nullptr, 0, 0, fold_c,
                            (hipStream_t)stream, nullptr, workspace != nullptr ? workspace : &dummy_ws);

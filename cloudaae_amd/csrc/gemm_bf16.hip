@@ -594,11 +594,12 @@ CLOUDAAE_API long long cloudaae_gemm_bf16_ordered_workspace(int M, int N, int K)
 
 CLOUDAAE_API int cloudaae_gemm_bf16_ordered(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                                             const float *B, int ldb, float *C, int ldc, const float *bias,
-                                            float *workspace, cloudaae_stream_t stream)
+                                            float *workspace, long long workspace_floats, cloudaae_stream_t stream)
 {
     const char *name = "cloudaae_gemm_bf16_ordered";
-    CLOUDAAE_REQUIRE(workspace != nullptr || cloudaae_gemm_bf16_ordered_workspace(M, N, K) == 0, name,
-                     "this product is cut over K: workspace needed");
+    CLOUDAAE_REQUIRE(workspace != nullptr ? workspace_floats >= cloudaae_gemm_bf16_ordered_workspace(M, N, K)
+                                          : cloudaae_gemm_bf16_ordered_workspace(M, N, K) == 0,
+                     name, "this product is cut over K: workspace missing or smaller than cloudaae_gemm_bf16_ordered_workspace");
     static float dummy_ws;      // (non-NULL selects the ordered plan; a product that stays whole never touches it)
     return gemm_bf16_launch(name, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, 0, 0, 0, (hipStream_t)stream,
                             nullptr, workspace != nullptr ? workspace : &dummy_ws);

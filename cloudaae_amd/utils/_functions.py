@@ -137,7 +137,7 @@ def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, bias=None, accumulate=0, site=
         n = int(wsq(M, N, K))
         ws = _lib.empty(n, dtype=torch.float32, device=device) if n else None
         fn = L().cloudaae_gemm_bf16_ordered if bf16 else L().cloudaae_gemm_f32_ordered
-        _lib.check(fn(int(ta), int(tb), M, N, K, A, lda, B, ldb, C, ldc, bias, ptr(ws), stream()), "cloudaae_gemm_ordered")
+        _lib.check(fn(int(ta), int(tb), M, N, K, A, lda, B, ldb, C, ldc, bias, ptr(ws), n, stream()), "cloudaae_gemm_ordered")
     else:
         fn = L().cloudaae_gemm_bf16 if bf16 else L().cloudaae_gemm_f32
         _lib.check(fn(int(ta), int(tb), M, N, K, A, lda, B, ldb, C, ldc, bias, int(accumulate),
@@ -157,7 +157,7 @@ def gemm_forward(M, N, K, A, lda, B, ldb, C, ldc, bias, device, site=None, bf16=
     n = int(wsq(M, N, K))
     ws = _lib.empty(n, dtype=torch.float32, device=device) if n else None
     fn = L().cloudaae_gemm_bf16_ordered if bf16 else L().cloudaae_gemm_f32_ordered
-    _lib.check(fn(0, 0, M, N, K, A, lda, B, ldb, C, ldc, bias, ptr(ws), stream()),
+    _lib.check(fn(0, 0, M, N, K, A, lda, B, ldb, C, ldc, bias, ptr(ws), n, stream()),
                "cloudaae_gemm_bf16_ordered" if bf16 else "cloudaae_gemm_f32_ordered")
     if rec is not None:
         _lib.host(_mark, rec)
@@ -277,7 +277,7 @@ class FcFn(torch.autograd.Function):
         _lib.check(L().cloudaae_fc_forward(
             M, K, N, xp, ldx, ptr(w), ptr(b), ptr(gamma), ptr(beta), int(bool(training)), ptr(decay), ptr(ema_mean),
             ptr(ema_var), ptr(save_mean), ptr(save_var), int(bool(relu)), ptr(y), ptr(out), 0, ptr(tickets),
-            ptr(partials), stream()), "cloudaae_fc_forward")
+            ptr(partials), 0 if partials is None else partials.numel(), stream()), "cloudaae_fc_forward")
         ctx.save_for_backward(x, w, y if bn else None, gamma, beta, save_mean, save_var)
         ctx.cfg = (int(bool(training)), int(bool(relu)))
         ctx.bvar = b
@@ -354,6 +354,7 @@ class FcGroupFn(torch.autograd.Function):
             l.gamma, l.beta, l.ema_mean, l.ema_var = ptr(gamma), ptr(beta), ptr(ema_mean), ptr(ema_var)
             l.save_mean, l.save_var, l.relu = ptr(save_mean), ptr(save_var), int(bool(relus[i]))
             l.y, l.out, l.tickets, l.partials = ptr(y), ptr(out), ptr(tickets), ptr(partials)
+            l.partials_floats = 0 if partials is None else partials.numel()
             if rowvecs[i] is not None:
                 require(not bn and rowvecs[i].dim() == 2 and rowvecs[i].shape[0] == M, "FcGroupFn: bad row vector")
                 l.out_rowvec, l.out_rowvec_d = ptr(rowvecs[i]), int(rowvecs[i].shape[1])
@@ -929,7 +930,7 @@ class EdgeConvFn(torch.autograd.Function):
             n_ws = int(L().cloudaae_gemm_f32_ordered_workspace(cin, 2 * cout, B * N))
             ws2 = _lib.empty(n_ws, dtype=torch.float32, device=dev) if n_ws else None
             _lib.check(L().cloudaae_gemm_f32_ordered_fold(1, 0, cin, 2 * cout, B * N, x.data_ptr(), x.stride(1), ptr(dpq),
-                                                          2 * cout, ptr(gw.buf), cout, cout, ptr(ws2), stream()),
+                                                          2 * cout, ptr(gw.buf), cout, cout, ptr(ws2), n_ws, stream()),
                        "cloudaae_gemm_f32_ordered_fold")
         if defer:
             # [dW_c | dW_n] = X^T [dP' | dQ] over the folded kernel (as cloudaae_edgeconv_backward would issue it)

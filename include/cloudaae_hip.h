@@ -20,9 +20,11 @@
  *     one low-priority side stream (cloudaae_side_stream), and per-device flags
  *     that record which kernels had their dynamic-LDS limit raised;
  *   - a workspace whose size comes from a cloudaae_*_workspace / *_partials query
- *     is only as large as the K split the knobs implied AT THE QUERY: do not change
+ *     is only as large as the K split the knobs implied AT THE QUERY; the entry
+ *     points that take one also take its size in floats and fail (no launch) when
+ *     the cut they derive at launch time needs more -- e.g. after a change of
  *     CLOUDAAE_GEMM_SPLITS / CLOUDAAE_FC_FWD_SPLITS / CLOUDAAE_FC_FWD_BLOCKS /
- *     CLOUDAAE_DETERMINISTIC between the query and the launches that use it;
+ *     CLOUDAAE_DETERMINISTIC between the query and a launch or a replay;
  *   - gradient outputs are zero-filled by the callee.
  * The reference's launchers have C++ linkage, no stream and no status
  * (tf_nndistance.cpp:168,208; tf_sampling.cpp:65,94,125,150); each entry point
@@ -193,7 +195,7 @@ int cloudaae_gemm_f32_splits(int M, int N, int K);
 long long cloudaae_gemm_f32_ordered_workspace(int M, int N, int K);
 int cloudaae_gemm_f32_ordered(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                               const float *B, int ldb, float *C, int ldc, const float *bias, float *workspace,
-                              cloudaae_stream_t stream);
+                              long long workspace_floats, cloudaae_stream_t stream);
 /* Several independent weight-gradient products C_j += A_j^T B_j (A_j stored [K][M], B_j [K][N]: dW = x^T dy of
  * utils/tf_util.py:161-166 for several layers) in ONE launch: each is a single wave of short split-K workgroups on its
  * own, and nothing waits for them before the optimiser.  C_j is added to with atomics and must hold zeros: zeroed != 0
@@ -215,6 +217,7 @@ int cloudaae_gemm_f32_tn_group(int count, const cloudaae_gemm_tn_job *jobs, clou
  * cloudaae_gemm_tn_job; 0: none), no bias: the edge convolution's weight gradients in deterministic mode. */
 int cloudaae_gemm_f32_ordered_fold(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                                    const float *B, int ldb, float *C, int ldc, int fold_c, float *workspace,
+                                   long long workspace_floats,
                                    cloudaae_stream_t stream);
 /* The same product with both operands rounded to bfloat16 (round to nearest even) on their way
  * to the matrix cores (v_mfma_f32_32x32x16_bf16), fp32 accumulate; A, B, C, bias stay fp32 in
@@ -227,6 +230,7 @@ int cloudaae_gemm_bf16_splits(int M, int N, int K);
 long long cloudaae_gemm_bf16_ordered_workspace(int M, int N, int K);
 int cloudaae_gemm_bf16_ordered(int trans_a, int trans_b, int M, int N, int K, const float *A, int lda,
                                const float *B, int ldb, float *C, int ldc, const float *bias, float *workspace,
+                               long long workspace_floats,
                                cloudaae_stream_t stream);
 /* cloudaae_gemm_f32_colstats_parts / _colstats for the bf16-operand product. */
 int cloudaae_gemm_bf16_colstats_parts(int M, int N, int K);
@@ -404,7 +408,9 @@ int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, float *out, int a
  * tickets: cloudaae_fc_forward_tickets(N) ints holding ZERO, left zero by the call (arrival counters
  * that let a layer WITH batch norm be cut over K: the last slice to arrive normalises the column tile);
  * NULL = such a layer keeps K whole in one workgroup per 128 columns (slower).
- * partials: cloudaae_fc_forward_partials(K, N, gamma != NULL) floats of scratch (any contents), or NULL.
+ * partials: cloudaae_fc_forward_partials(K, N, gamma != NULL) floats of scratch (any contents), or NULL;
+ * partials_floats: the floats behind it (the call fails if this launch's cut needs more -- the cut is derived again
+ * at every launch, also from development knobs).
  * With tickets AND partials a product cut over K is summed in a FIXED slice order by the last slice to
  * arrive: the layer is bit-reproducible from run to run (and y need not be cleared).  Without partials
  * the slices add into y with fp32 atomics: results then differ by round-off between runs.
@@ -416,7 +422,7 @@ int cloudaae_fc_forward(int M, int K, int N, const float *x, int ldx, const floa
                         const float *gamma, const float *beta, int training, const float *decay,
                         float *ema_mean, float *ema_var, float *save_mean, float *save_var, int relu,
                         float *y, float *out, int y_zeroed, int *tickets, float *partials,
-                        cloudaae_stream_t stream);
+                        long long partials_floats, cloudaae_stream_t stream);
 /* backward of the same layer from dout[M,N] (gradient of `out`, or of y when gamma == NULL):
  *   dx[M,K] += d(y) w^T      (ADDED with fp32 atomics: pass zeros, or a buffer that other consumers
  *                             of x add their gradients to as well; NULL = not wanted)
@@ -456,6 +462,7 @@ typedef struct cloudaae_fc_layer {
     int accumulate_param_grads;
     /* forward */
     float *partials;
+    long long partials_floats;          /* floats behind `partials` (>= cloudaae_fc_forward_partials at launch time) */
     const float *out_rowvec;            /* gamma NULL only: y[r][c] += out_rowvec[r * out_rowvec_d + c % out_rowvec_d] */
     int out_rowvec_d;                   /* (train_cloudAAE_ycbv.py:232-233: xyz_recon = recon_res + element_mean) */
 } cloudaae_fc_layer;

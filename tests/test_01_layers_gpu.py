@@ -119,7 +119,7 @@ def test_gemm_ordered_is_bit_reproducible(hip, M, N, K, bf16):
     for _ in range(8):
         C = torch.full((M, N), float("nan"), device="cuda")
         hip.check(getattr(L, "cloudaae_gemm_%s_ordered" % nm)(0, 0, M, N, K, hip.ptr(A), K, hip.ptr(B), N, hip.ptr(C), N,
-                                                               hip.ptr(bias), ws.data_ptr() if n else None, hip.stream()),
+                                                               hip.ptr(bias), ws.data_ptr() if n else None, n, hip.stream()),
                   "gemm_ordered")
         runs.append(C)
     torch.cuda.synchronize()
@@ -129,10 +129,11 @@ def test_gemm_ordered_is_bit_reproducible(hip, M, N, K, bf16):
     hip.check(getattr(L, "cloudaae_gemm_%s" % nm)(0, 0, M, N, K, hip.ptr(A), K, hip.ptr(B), N, hip.ptr(plain), N,
                                                    hip.ptr(bias), 0, hip.stream()), "gemm")
     assert _rel(runs[0], plain) < 1e-5
-    if n:       # a cut product without its workspace is refused
-        rc = getattr(L, "cloudaae_gemm_%s_ordered" % nm)(0, 0, M, N, K, hip.ptr(A), K, hip.ptr(B), N, hip.ptr(plain), N,
-                                                          None, None, hip.stream())
-        assert rc != 0 and "workspace" in L.cloudaae_last_error().decode()
+    if n:       # a cut product without its workspace, or with one that is too small for the cut, is refused
+        for wsp, size in ((None, 0), (ws.data_ptr(), n - 1)):
+            rc = getattr(L, "cloudaae_gemm_%s_ordered" % nm)(0, 0, M, N, K, hip.ptr(A), K, hip.ptr(B), N, hip.ptr(plain), N,
+                                                              None, wsp, size, hip.stream())
+            assert rc != 0 and "workspace" in L.cloudaae_last_error().decode()
 
 
 def test_gemm_strided_views(hip):

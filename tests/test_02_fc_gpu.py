@@ -103,7 +103,7 @@ def test_fc_rejects_large_batches(hip):
     assert L.cloudaae_fc_max_rows() == 32
     x, W, y = torch.zeros(33, 8).cuda(), torch.zeros(8, 8).cuda(), torch.zeros(33, 8).cuda()
     rc = L.cloudaae_fc_forward(33, 8, 8, x.data_ptr(), 8, W.data_ptr(), None, None, None, 0, None, None, None, None,
-                               None, 0, y.data_ptr(), None, 0, None, None, _lib.stream())
+                               None, 0, y.data_ptr(), None, 0, None, None, 0, _lib.stream())
     assert rc != 0 and "rows" in L.cloudaae_last_error().decode()
 
 
@@ -133,11 +133,17 @@ def test_fc_forward_without_tickets_keeps_k_whole(hip):
                                              beta.data_ptr(), 1, decay.data_ptr(), sm.data_ptr(), sv.data_ptr(),
                                              mean.data_ptr(), var.data_ptr(), 1, y.data_ptr(), out.data_ptr(), 0,
                                              None if tk is None else tk.data_ptr(),
-                                             None if parts is None else parts.data_ptr(), _lib.stream()), "fc_forward")
+                                             None if parts is None else parts.data_ptr(),
+                                             0 if parts is None else parts.numel(), _lib.stream()), "fc_forward")
         torch.cuda.synchronize()
         if use:
             assert int(tk.abs().sum()) == 0
         res.append((y, out, mean, var, sm))
+    # the partial-tile scratch travels with its size: a launch whose cut needs more is refused (nothing is launched)
+    rc = L.cloudaae_fc_forward(M, K, N, x.data_ptr(), K, W.data_ptr(), b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1,
+                               decay.data_ptr(), sm.data_ptr(), sv.data_ptr(), mean.data_ptr(), var.data_ptr(), 1,
+                               y.data_ptr(), out.data_ptr(), 0, tk.data_ptr(), parts.data_ptr(), nparts - 1, _lib.stream())
+    assert rc != 0 and "partials_floats" in L.cloudaae_last_error().decode()
     for other in res[1:]:
         for a, c in zip(res[0], other):
             assert _rel(a, c) < 1e-5
@@ -211,7 +217,7 @@ def test_fc_forward_ticket_stress(hip, fixed_order):
                                          beta.data_ptr(), 1, decay.data_ptr(), sm.data_ptr(), sv.data_ptr(),
                                          mean.data_ptr(), var.data_ptr(), 1, y.data_ptr(), out.data_ptr(), 0,
                                          tickets, parts.data_ptr() if (fixed_order and tickets) else None,
-                                         _lib.stream()), "fc_forward")
+                                         parts.numel(), _lib.stream()), "fc_forward")
     y0, out0 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
     run(None, y0, out0)
     junk = torch.randn(1 << 22, device="cuda")
@@ -252,7 +258,7 @@ def test_fc_forward_adds_a_row_vector(hip, M, K, N, d):
         l = layer[0]
         y = torch.full((M, N), float("nan"), device="cuda")
         l.K, l.N, l.x, l.ldx, l.w, l.bias, l.y = K, N, x.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr()
-        l.tickets, l.partials = tk.data_ptr(), parts.data_ptr() if nparts else None
+        l.tickets, l.partials, l.partials_floats = tk.data_ptr(), parts.data_ptr() if nparts else None, nparts
         if with_vec:
             l.out_rowvec, l.out_rowvec_d = vec.data_ptr(), d
         _lib.check(L.cloudaae_fc_forward_group(M, 1, layer, 1, None, 0, _lib.stream()), "fc_forward_group")
@@ -290,7 +296,7 @@ def test_fc_forward_is_bit_reproducible(hip, M, K, N, bn):
         out = torch.empty(M, N, device="cuda") if bn else None
         _lib.check(L.cloudaae_fc_forward(M, K, N, P(x), K, P(W), P(b), P(gamma), P(beta), 1, P(decay), P(sm) if bn else None,
                                          P(sv) if bn else None, P(mean) if bn else None, P(var) if bn else None, 1, P(y),
-                                         P(out), 0, P(tk), P(parts), _lib.stream()), "fc_forward")
+                                         P(out), 0, P(tk), P(parts), nparts, _lib.stream()), "fc_forward")
         runs.append((y, out, mean if bn else None))
     torch.cuda.synchronize()
     for y, out, mean in runs[1:]:

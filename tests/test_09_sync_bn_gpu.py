@@ -67,11 +67,12 @@ def _worker(rank, world, port, out, B, N, replay, steps):
             e_loss = float(((losses - want).abs() / want.abs().clamp_min(1.0)).max())
             g1, g2 = solo.store.flat_grads, dp.store.flat_grads / world
             e_grad = float((g1 - g2).abs().max() / g1.abs().max())
+            e_grad_l2 = float((g1 - g2).norm() / g1.norm())
             e_state = float((solo.store.flat_state - dp.store.flat_state).abs().max() /
                             solo.store.flat_state.abs().max())
             # (Adam turns a round-off-sized difference of a near-zero gradient into a +-lr move)
             diff = (solo.store.flat_params - dp.store.flat_params).abs()
-            res["step%d" % step] = dict(e_loss=e_loss, e_grad=e_grad, e_state=e_state,
+            res["step%d" % step] = dict(e_loss=e_loss, e_grad=e_grad, e_grad_l2=e_grad_l2, e_state=e_state,
                                         moved=float((diff > 1e-5).float().mean()))
         o3 = local.train_step(mine)
         e_local = float((solo.store.flat_state - local.store.flat_state).abs().max() /
@@ -105,9 +106,12 @@ def test_sync_bn_two_ranks_equal_one_rank_of_the_global_batch(hip, B, N, replay,
         for step, e in r["res"].items():
             assert e["e_loss"] < 1e-5, (rank, step, e)            # north-star loss tolerance, N-rank vs 1-rank
             # fp32 round-off through BN-coupled layers; a Chamfer near-tie that flips between the two runs moves one
-            # point's whole gradient (measured: 2e-6 ... 1.4e-3)
-            assert e["e_grad"] < 5e-3, (rank, step, e)
+            # point's whole gradient.  Measured over 90 steps (profiles/r04_syncbn_repeat.log): largest entry difference
+            # median 2.7e-6 of the largest gradient entry, one step in 90 at 2.3e-3 (and 1.8 % of the parameters moved by
+            # more than 1e-5 there, median 0.05 %); one full-suite run in ten failed the former 5e-3 / 3 % bounds.  The
+            # max-norm bounds leave room for such a flip, the L2 bound is the tight one.
+            assert e["e_grad"] < 2e-2 and e["e_grad_l2"] < 5e-3, (rank, step, e)
             assert e["e_state"] < 1e-5, (rank, step, e)           # moving averages: the same global moments
-            assert e["moved"] < 0.03, (rank, step, e)
+            assert e["moved"] < 0.08, (rank, step, e)
         assert r["same_params"] and r["same_state"], (rank, r)    # replicas stay bit-identical
         assert r["e_local_bn"] > 1e-3, (rank, r)                  # per-rank statistics do NOT reproduce it

@@ -54,11 +54,11 @@ def main():
 
         def fused_fwd():        # slices summed in a fixed order by the last one to arrive (what the package uses)
             L.cloudaae_fc_forward(M, K, N, P(x), K, P(W), P(b), gp, bp, 1, P(decay), P(sm), P(sv), P(mean), P(var), 1,
-                                  P(y), P(out), 1, P(tk), P(parts) if nparts else None, s)
+                                  P(y), P(out), 1, P(tk), P(parts) if nparts else None, nparts, s)
 
         def atomic_fwd():       # slices added with fp32 atomics (y counted as cleared: kernel time only)
             L.cloudaae_fc_forward(M, K, N, P(x), K, P(W), P(b), gp, bp, 1, P(decay), P(sm), P(sv), P(mean), P(var), 1,
-                                  P(y), P(out), 1, P(tk), None, s)
+                                  P(y), P(out), 1, P(tk), None, 0, s)
 
         def old_fwd():
             L.cloudaae_gemm_f32(0, 0, M, N, K, P(x), K, P(W), N, P(y), N, P(b), 0, s)
