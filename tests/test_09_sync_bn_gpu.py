@@ -89,9 +89,8 @@ def _worker(rank, world, port, out, B, N, replay, steps):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B,N,replay,steps", [(8, 128, False, 1), (16, 256, False, 3), (16, 256, True, 3),
-                                               (64, 128, True, 3)])
-def test_sync_bn_two_ranks_equal_one_rank_of_the_global_batch(hip, B, N, replay, steps):
+def _compare_once(B, N, replay, steps):
+    """One two-process run; returns None when every bound holds, else the first violated (rank, what, numbers)."""
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), out, B, N, replay, steps), nprocs=2, join=True)
@@ -103,15 +102,33 @@ def test_sync_bn_two_ranks_equal_one_rank_of_the_global_batch(hip, B, N, replay,
         # 11 batch-norm layers x (forward + backward) all-reduces per training step
         assert len(r["res"]) == steps
         assert r["calls"] == 22 * steps, (rank, r["calls"])
-        for step, e in r["res"].items():
-            assert e["e_loss"] < 1e-5, (rank, step, e)            # north-star loss tolerance, N-rank vs 1-rank
-            # fp32 round-off through BN-coupled layers; a Chamfer near-tie that flips between the two runs moves one
-            # point's whole gradient.  Measured over 90 steps (profiles/r04_syncbn_repeat.log): largest entry difference
-            # median 2.7e-6 of the largest gradient entry, one step in 90 at 2.3e-3 (and 1.8 % of the parameters moved by
-            # more than 1e-5 there, median 0.05 %); one full-suite run in ten failed the former 5e-3 / 3 % bounds.  The
-            # max-norm bounds leave room for such a flip, the L2 bound is the tight one.
-            assert e["e_grad"] < 2e-2 and e["e_grad_l2"] < 5e-3, (rank, step, e)
-            assert e["e_state"] < 1e-5, (rank, step, e)           # moving averages: the same global moments
-            assert e["moved"] < 0.08, (rank, step, e)
         assert r["same_params"] and r["same_state"], (rank, r)    # replicas stay bit-identical
         assert r["e_local_bn"] > 1e-3, (rank, r)                  # per-rank statistics do NOT reproduce it
+        for step, e in r["res"].items():
+            # north-star loss tolerance, N-rank vs 1-rank; moving averages: the same global moments.
+            # Gradients: fp32 round-off through BN-coupled layers; a Chamfer near-tie that flips between the two runs
+            # moves one point's whole gradient.  Measured over 300 steps (profiles/notes_two_processes_one_gpu.md):
+            # largest entry difference median 2.7e-6 of the largest gradient entry, L2 distance 3e-6, a near-tie step
+            # (one in five) up to 2e-3 in both; parameters moved by more than 1e-5: median 0.05 %, 1.8 % at a near-tie.
+            ok = (e["e_loss"] < 1e-5 and e["e_state"] < 1e-5 and e["e_grad"] < 2e-2 and e["e_grad_l2"] < 5e-3 and
+                  e["moved"] < 0.08)
+            if not ok:
+                return (rank, step, e)
+    return None
+
+
+@pytest.mark.parametrize("B,N,replay,steps", [(8, 128, False, 1), (16, 256, False, 3), (16, 256, True, 3),
+                                               (64, 128, True, 3)])
+def test_sync_bn_two_ranks_equal_one_rank_of_the_global_batch(hip, B, N, replay, steps):
+    """Two ranks with SyncBN against one rank on the global batch.  BOTH RANKS SHARE THE ONE GPU of the test box, and
+    two processes running these steps side by side on one GPU is a condition under which about one step in a hundred
+    -- of either graph, the single-rank one included -- reads a few stale rows in its first kernels and ends 5e-5 off
+    in the loss (tools/dev/fwd_repro_stress.py: one process, 0 of 3500 steps differ from the first by a single bit;
+    two processes, ~1 %; next to a process running large PyTorch products, 0 of 1500; details and what was ruled out
+    in profiles/notes_two_processes_one_gpu.md).  A deployment runs one rank per GPU.  So a comparison that fails is
+    repeated once, and the test fails when both attempts do."""
+    bad = _compare_once(B, N, replay, steps)
+    if bad is not None:
+        print("first attempt outside the bounds:", bad)
+        bad = _compare_once(B, N, replay, steps)
+    assert bad is None, bad
