@@ -246,7 +246,11 @@ __global__ __launch_bounds__(HS_THREADS) void hpr_sort_kernel(int n1, const floa
 // to n1: a permutation of [0, n1) whose every prefix is spread evenly over the (spatially sorted) cloud -- what
 // Seidel's expected O(n) needs.  (Round 2 walked the bit-reversal sequence over [0, 2^bits) and skipped what fell
 // outside [0, n1): for the reference's 2449 / 2049-point clouds 40-50 % of the positions of every scan.)
-constexpr int HPR_NEAR = 192;
+// (neighbourhood size by cloud size, measured per batch of 32 with two hulls each: 2449-point clouds 96 / 128 / 192 / 256 / 512
+// neighbours 1.69 / 1.56 / 1.52 / 1.51 / 1.74 ms; 8593-point clouds 128 / 192 / 256 / 384 / 512 / 768 / 1536 neighbours
+// 13.0 / 11.75 / 11.0 / 10.47 / 10.54 / 10.49 / 11.1 ms)
+constexpr int HPR_NEAR_SMALL = 192, HPR_NEAR_LARGE = 512;      // clouds one workgroup of 8 / 16 waves holds (hull_vertex_kernel)
+template <int HPR_NEAR>
 __device__ __forceinline__ int hpr_seq(int pos, int self, int n1, int stride)
 {
     if (pos < HPR_NEAR) {
@@ -326,6 +330,7 @@ __device__ __forceinline__ double dpp_f64(double v)
 }
 __device__ __forceinline__ bool frac_less(const Frac &x, const Frac &y) { return x.num * y.den < y.num * x.den; }
 
+template <int HPR_NEAR>
 __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, int stride, const Frame &fr, int lane)
 {
     double vx = HPR_TAN, vy = HPR_TAN;
@@ -374,7 +379,7 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
             dd = min(dd, n1 - dd);
             q = (p2 < n1 && !(dd >= 1 && dd <= HPR_NEAR / 2)) ? qraw : n1;
         } else {
-            q = pos < span ? hpr_seq(pos, self, n1, stride) : n1;
+            q = pos < span ? hpr_seq<HPR_NEAR>(pos, self, n1, stride) : n1;
         }
         const bool valid = q < n1 && q != self;
         bool viol = false;
@@ -422,7 +427,7 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
             add(lane == 0 ? 1.0 : (lane == 1 ? -1.0 : 0.0), lane == 2 ? 1.0 : (lane == 3 ? -1.0 : 0.0), HPR_TAN);
         const int upto = i + first;            // sequence positions [0, upto) were already accepted
         for (int jpos = lane; jpos < upto; jpos += 64) {
-            const int r = hpr_seq(jpos, self, n1, stride);
+            const int r = hpr_seq<HPR_NEAR>(jpos, self, n1, stride);
             if (r >= n1 || r == self)
                 continue;
             const Cons m = hpr_constraint(pts, r, fr);
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, con
             f.wx = ry * uz - rz * uy;
             f.wy = rz * ux - rx * uz;
             f.wz = rx * uy - ry * ux;
-            vertex = hpr_lp2d_wave(pts, n1, j, stride, f, lane);
+            vertex = hpr_lp2d_wave<(HPR_WAVES > 8 ? HPR_NEAR_LARGE : HPR_NEAR_SMALL)>(pts, n1, j, stride, f, lane);
         }
         if (lane == 0)     // `points` is the spatially sorted cloud: the flag goes back to the original index
             flags[(size_t)blockIdx.y * n1 + perm[(size_t)blockIdx.y * n1 + j]] = vertex ? 1 : 0;
