@@ -1789,13 +1789,13 @@ static hipError_t launch_knn3_scan(int b, int n, int ld, int k, const float *x, 
 }
 
 // Which C = 64 kernel for `tiles` 32-query tiles (measured, B x N = 1024 points, k = 10, us):
-//   tiles      knn64_mfma   scan, 1 wave/tile   scan, 2 waves/tile   wide (bound pass, 16 waves)
-//    256 (B=8)      55            152                100                  73
-//    512 (B=16)     66            152                101                  74
-//    640 (B=20)     85                                                    75
-//   1024 (B=32)    138            134                102                  76
-//   4096 (B=128)                  414                397                 289
-//   8192 (B=256)   780            631                788                 571
+//   tiles      knn64_mfma   scan, 1 wave/tile   scan, 2 waves/tile   wide (bound pass, 16 waves; round 3 -> end of round 4)
+//    256 (B=8)      55            152                100                  73 -> 58
+//    512 (B=16)     66            152                101                  74 -> 58
+//    640 (B=20)     85                                                    75 -> 59
+//   1024 (B=32)    138            134                102                  76 -> 58
+//   4096 (B=128)                  414                397                 289 -> 228
+//   8192 (B=256)   780            631                788                 571 -> 455
 // Return value / knob CLOUDAAE_KNN_SCAN (forces a choice; the tests cover all of them): 0 = knn64_mfma_kernel,
 // 1 / 2 = knn64_scan_kernel with one / two waves per query tile, 5 = knn64_wide_kernel (where it applies: see
 // knn_wide_fits; otherwise 5 means 1).  (3 / 4 were the 8-wave bound kernel of round 2, superseded by the wide one.)
@@ -1808,7 +1808,10 @@ static int knn_scan_waves(long long tiles, int n, int k)
 {
     if (CLOUDAAE_KNOB_SET("CLOUDAAE_KNN_SCAN"))
         return CLOUDAAE_KNOB("CLOUDAAE_KNN_SCAN", 0);
-    if (tiles > 512 && knn_wide_fits(n, k))
+    // (re-measured at the end of round 4, k = 10, wide / first generation: 256 tiles 57.7 / 59.3 us at n = 1024, 22.5 / 23.6 at
+    //  n = 256, 35.4 / 35.1 at n = 512; 512 tiles 58.2 / 70.1, 22.7 / 27.6, 35.7 / 42.9, 114.8 / 117.4 at n = 2048; 128 tiles
+    //  57.5 / 53.5)
+    if (tiles >= 256 && knn_wide_fits(n, k))
         return 5;
     return tiles >= 4096 ? 1 : tiles >= 1024 ? 2 : 0;
 }
