@@ -1823,12 +1823,12 @@ static hipError_t launch_knn(int b, int n, int c, int ld, int k, const float *x,
     const bool vec = ld % 4 == 0 && ((uintptr_t)x & 15) == 0;
     if (c == 3 && K <= 20 && n <= 6144 && !first_gen) {
         if constexpr (K <= 20) {
-            // the matrix-core form from 64 workgroups (of 128 queries, one per CU) up; knob CLOUDAAE_KNN3_WIDE = 0 / 1
-            // forces the choice (the tests cover both).  Measured, n = 1024, k = 10, continuous coordinates, wide / scan:
-            // B = 8 24 / 40 us, B = 32 24 / 47, B = 128 91 / 104, B = 256 180 / 201; [32, 4096, k = 20] 354 / 639.  (Clouds
-            // made of a few distinct points overflow the queues and pay the rescan: 48 us at B = 32 -- the scan kernel's time.)
-            const bool wide = CLOUDAAE_KNOB_SET("CLOUDAAE_KNN3_WIDE") ? CLOUDAAE_KNOB("CLOUDAAE_KNN3_WIDE", 0) != 0
-                                                                        : (long long)ceil_div(n, 128) * b >= 64;
+            // the matrix-core form wherever it fits (n >= 256, the cloud and the queues in LDS); knob CLOUDAAE_KNN3_WIDE = 0
+            // / 1 forces the choice (the tests cover both).  Measured, k = 10, continuous coordinates, wide / scan: n = 1024:
+            // B = 1 23 / 39 us, B = 8 24 / 40, B = 32 24 / 47, B = 128 91 / 104, B = 256 180 / 201; n = 256: B = 16 ... 64
+            // 12 / 21; n = 512: 17 / 29; [2, 4096] 61 / 88; [32, 4096, k = 20] 354 / 639.  (Clouds made of a few distinct
+            // points overflow the queues and pay the rescan: 48 us at B = 32 -- the scan kernel's time.)
+            const bool wide = CLOUDAAE_KNOB_SET("CLOUDAAE_KNN3_WIDE") ? CLOUDAAE_KNOB("CLOUDAAE_KNN3_WIDE", 0) != 0 : true;
             if (wide && knn3_wide_fits(n, K))
                 return launch_knn3_wide<K>(b, n, ld, k, x, nn_idx, s);
             // candidate ranges per query tile: as few as still give every SIMD two waves (fewer ranges = fewer lists to
