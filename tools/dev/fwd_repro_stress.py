@@ -11,7 +11,13 @@ def work(rank, steps, B, N):
     from cloudaae_amd import train_cloudAAE_ycbv as T
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    g = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, process_group=False, seed=9)
+    if os.environ.get("RCCL") == "1":          # one rank, the collectives really issued (CLOUDAAE_FORCE_COLLECTIVES=1)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29700 + rank))
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        g = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, seed=9, sync_bn=os.environ.get("SYNCBN") == "1")
+    else:
+        g = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, process_group=False, seed=9)
     el = T.synthetic_element(B, N, dev, seed=21)
     el["noise"] = torch.randn((B, N, 3), generator=torch.Generator(device=dev).manual_seed(3), device=dev) * 0.001
     snap = [t.clone() for t in (g.store.flat_params, g.store.flat_state, g.adam_m, g.adam_v, g.batch, g.beta1_power,
