@@ -202,6 +202,26 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_stats_kernel(EcArgs a, 
 #pragma unroll
     for (int e = 0; e < CPL; ++e)
         s[e] = s2[e] = 0.0;
+    if constexpr (CPL * KCAP >= 40) {
+        // 128 channels x 20 neighbours: two points at a time are 80 edge values per lane -- under the 128 registers of a
+        // 16-wave workgroup the pair form spilled 200 of them (467 us for [32, 4096], layer 4 of BASELINE configs[4]).
+        // One point at a time: forty gathers in flight per lane are enough, and the sums take the same order.
+        ec_for_each_point<EC_STAT_WAVES>(a, wave, [&](int pt) {
+            EcPoint<CPL, KCAP> p;
+            p.load(a, pt, lane);
+#pragma unroll
+            for (int j = 0; j < KCAP; ++j)
+                if (j < a.k) {
+#pragma unroll
+                    for (int e = 0; e < CPL; ++e) {
+                        s[e] += (double)p.y[j][e];
+                        s2[e] += (double)p.y[j][e] * (double)p.y[j][e];
+                    }
+                }
+        });
+        ec_block_reduce_store<CPL>(s, s2, partial, a.cout, lane, wave);
+        return;
+    }
     ec_for_each_pair<EC_STAT_WAVES>(a, wave, [&](int pt0, int pt1) {
         EcPoint<CPL, KCAP> p0, p1;
         ec_load_pair(a, pt0, pt1 >= 0 ? pt1 : pt0, lane, p0, p1);
