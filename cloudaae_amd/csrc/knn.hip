@@ -1039,13 +1039,17 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
             }
         }
     };
-    MinK<K> um;
+    // the lane's unit minima: its UL smallest (UL = 12 for K = 20: the K-th smallest over the union of shorter lists is still a
+    // bound, and looser only if one of a query's eight lanes held more than 12 of the 20 smallest; eight registers and sixteen
+    // vector instructions per insert less where this kernel spills)
+    constexpr int UL = K > 12 ? 12 : K;
+    MinK<UL> um;
     um.init();
     // REUSE: the sampled tiles' distances are kept for the filter: the last round's in `acc`, the round before in the
     // part of the query tile's queue area that the scratch lists below leave free ([16 values][4 waves x 64 lanes])
-    float *svl = reinterpret_cast<float *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6) + 2 * CS * K * 32 * 4) +
+    float *svl = reinterpret_cast<float *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6) + 2 * CS * (UL + 1) * 32 * 4) +
                  cs * 64 + lane;
-    static_assert(!REUSE || 2 * CS * K * 32 * 4 + 16 * CS * 64 * 4 <= 32 * QPQ * 6, "saved distances must fit beside the lists");
+    static_assert(!REUSE || 2 * CS * (UL + 1) * 32 * 4 + 16 * CS * 64 * 4 <= 32 * QPQ * 6, "saved distances must fit beside the lists");
     for (int r = 0; r < roundsA; ++r) {
         const int slot = r * CS + cs;
         round(1, r, roundsA, slot < SA1 ? (TWO ? 2 * slot : slot) * stride * KM_TILE : ntiles * KM_TILE - KM_TILE);
@@ -1065,15 +1069,17 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     }
     // K-th smallest unit minimum over the query's 2*CS lists, through the query tile's share of the queue area
     float *md = reinterpret_cast<float *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6));
-    static_assert(2 * CS * K * 32 * 4 <= 32 * QPQ * 6 && (32 * QPQ * 6) % 8 == 0,
+    // (UL values and a +inf behind them per list: a head that has taken a whole list reads the sentinel)
+    static_assert(2 * CS * (UL + 1) * 32 * 4 <= 32 * QPQ * 6 && (32 * QPQ * 6) % 8 == 0,
                   "scratch lists must fit the queue area of one query tile");
     const int list = cs * 2 + half;
     __syncthreads();
-    int slot0 = list * K * 32 + col;                       // (opaque: keeps the compiler from deriving these K addresses
+    int slot0 = list * (UL + 1) * 32 + col;                // (opaque: keeps the compiler from deriving these addresses
     asm volatile("" : "+v"(slot0));                        //  before the scan loop and spilling them across it)
 #pragma unroll
-    for (int p = 0; p < K; ++p)
+    for (int p = 0; p < UL; ++p)
         md[slot0 + p * 32] = um.d[p];
+    md[slot0 + UL * 32] = __builtin_inff();
     const int roundsB = (nB + CS - 1) / CS;
     const int roundsA2 = (SA2 + CS - 1) / CS;
     if (TWO ? roundsA2 > 0 : roundsB > 0)
@@ -1088,13 +1094,14 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
         int head[2 * CS];
 #pragma unroll
         for (int l = 0; l < 2 * CS; ++l)
-            head[l] = (l * K) * 32 + col;
+            head[l] = (l * (UL + 1)) * 32 + col;
 #pragma unroll
         for (int p = 0; p < K; ++p) {
             float hv[2 * CS];
 #pragma unroll
             for (int l = 0; l < 2 * CS; ++l)
-                hv[l] = md[head[l]];                       // (a head moves at most once per step: never past its list)
+                hv[l] = md[head[l]];                       // (a head stops at its list's sentinel: +inf is never the minimum
+                                                           //  unless every list is exhausted, and then it stays the answer)
             float m = hv[0];
 #pragma unroll
             for (int l = 1; l < 2 * CS; ++l)
@@ -1131,7 +1138,7 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
         // not (every wave is past the last round's second barrier, nothing is in flight): the 8 smallest of every lane
         // ([list][8][32 queries] per query tile), merged as above with the heads checked against the end of their lists
         constexpr int LP = 8;
-        static_assert(QW * 2 * CS * LP * 32 <= CS * TILE_FLOATS && LP <= K, "second-stage lists must fit the tile buffers");
+        static_assert(QW * 2 * CS * LP * 32 <= CS * TILE_FLOATS && LP <= UL, "second-stage lists must fit the tile buffers");
         float *m2 = tiles + qt * (2 * CS * LP * 32);
 #pragma unroll
         for (int p = 0; p < LP; ++p)
