@@ -205,7 +205,8 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_stats_kernel(EcArgs a, 
     if constexpr (CPL * KCAP >= 40) {
         // 128 channels x 20 neighbours: two points at a time are 80 edge values per lane -- under the 128 registers of a
         // 16-wave workgroup the pair form spilled 200 of them (467 us for [32, 4096], layer 4 of BASELINE configs[4]).
-        // One point at a time: forty gathers in flight per lane are enough, and the sums take the same order.
+        // One point at a time: forty gathers in flight per lane are enough, and the sums take the same order.  (At 64
+        // channels x 20 neighbours the pair form stays: 86 against 96 us.)
         ec_for_each_point<EC_STAT_WAVES>(a, wave, [&](int pt) {
             EcPoint<CPL, KCAP> p;
             p.load(a, pt, lane);
@@ -317,6 +318,17 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
             }
         }
     };
+    if constexpr (KCAP >= 20) {
+        // one point at a time from 20 neighbours up: twenty or forty gathers per lane are in flight anyway, and the pair
+        // form needs 113 / 135 registers (64 / 128 channels: four / three waves per SIMD).  Measured at [32, 4096, k = 20]:
+        // 103 -> 86 us (64 channels), 215 -> 169 us (128); at k = 10 the pair form stays (16.7 against 17.7 us at [32, 1024])
+        ec_for_each_point<EC_WAVES>(a, wave, [&](int pt) {
+            EcPoint<CPL, KCAP> p;
+            p.load(a, pt, lane);
+            finish(p, pt, true);
+        });
+        return;
+    }
     ec_for_each_pair<EC_WAVES>(a, wave, [&](int pt0, int pt1) {
         EcPoint<CPL, KCAP> p0, p1;
         ec_load_pair(a, pt0, pt1 >= 0 ? pt1 : pt0, lane, p0, p1);
