@@ -55,10 +55,10 @@ __device__ __forceinline__ size_t fold_off(int r, int c, int ld, Fold f)
 // One operand panel: ROWS "outer" indices (m for A, n for B) x BK k-values.
 // KC = true : memory is [outer][k] (k contiguous)   -> LDS [ROWS][BK+1]
 // KC = false: memory is [k][outer] (outer contiguous)-> LDS [BK][ROWS]
-template <int ROWS, bool KC>
+template <int ROWS, bool KC, int BK = GEMM_BK>
 struct Panel {
-    static constexpr int LDS_FLOATS = KC ? ROWS * (GEMM_BK + 1) : GEMM_BK * ROWS;
-    static constexpr int VECS = ROWS * GEMM_BK / 4;           // float4 per slab
+    static constexpr int LDS_FLOATS = KC ? ROWS * (BK + 1) : BK * ROWS;
+    static constexpr int VECS = ROWS * BK / 4;           // float4 per slab
     static constexpr int PER_THREAD = (VECS + GEMM_THREADS - 1) / GEMM_THREADS;
 
     float4v reg[PER_THREAD];
@@ -77,13 +77,13 @@ struct Panel {
             if (FAST) {
                 if (VECS % GEMM_THREADS != 0 && v >= VECS)
                     break;
-                const size_t off = KC ? fold_off(outer0 + v / (GEMM_BK / 4), k0 + (v % (GEMM_BK / 4)) * 4, ld, fold)
+                const size_t off = KC ? fold_off(outer0 + v / (BK / 4), k0 + (v % (BK / 4)) * 4, ld, fold)
                                       : fold_off(k0 + v / (ROWS / 4), outer0 + (v % (ROWS / 4)) * 4, ld, fold);
                 reg[it] = *reinterpret_cast<const float4v *>(P + off);
                 continue;
             } else if (VECS % GEMM_THREADS == 0 || v < VECS) {
                 if (KC) {
-                    const int o = v / (GEMM_BK / 4), kq = v % (GEMM_BK / 4);
+                    const int o = v / (BK / 4), kq = v % (BK / 4);
                     const int go = outer0 + o, gk = k0 + kq * 4;
                     if (go < nouter) {
                         const float *src = P + fold_off(go, gk, ld, fold);
@@ -124,8 +124,8 @@ struct Panel {
             const int v = it * GEMM_THREADS + (int)threadIdx.x;
             if (VECS % GEMM_THREADS == 0 || v < VECS) {
                 if (KC) {
-                    const int o = v / (GEMM_BK / 4), kq = v % (GEMM_BK / 4);
-                    float *dst = lds + o * (GEMM_BK + 1) + kq * 4;
+                    const int o = v / (BK / 4), kq = v % (BK / 4);
+                    float *dst = lds + o * (BK + 1) + kq * 4;
                     dst[0] = reg[it].x;
                     dst[1] = reg[it].y;
                     dst[2] = reg[it].z;
@@ -141,14 +141,14 @@ struct Panel {
     // MFMA operand of this lane: element (outer, kk) of the staged slab
     static __device__ __forceinline__ float frag(const float *__restrict__ lds, int outer, int kk)
     {
-        return KC ? lds[outer * (GEMM_BK + 1) + kk] : lds[kk * ROWS + outer];
+        return KC ? lds[outer * (BK + 1) + kk] : lds[kk * ROWS + outer];
     }
 };
 
 // C[M,N] (+)= op(A)[M,K] * op(B)[K,N] (+ bias[N])
 // TA: A is stored [K][M] (lda >= M); else [M][K].  TB: B is stored [N][K]; else [K][N].
 // The tile (m0, n0) of K slice `slice` (what one workgroup computes).
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool FAST>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool FAST, int BK = GEMM_BK>
 __device__ __forceinline__ void gemm_f32_tile(
     int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
     float *__restrict__ C, int ldc, const float *__restrict__ bias, int epilogue, int kchunk,
@@ -156,8 +156,8 @@ __device__ __forceinline__ void gemm_f32_tile(
 {
     static_assert(WM * WN * 64 == GEMM_THREADS, "4 waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;   // 32x32 tiles per wave
-    typedef Panel<BM, !TA> PA;
-    typedef Panel<BN, TB> PB;
+    typedef Panel<BM, !TA, BK> PA;
+    typedef Panel<BN, TB, BK> PB;
     __shared__ float ldsA[PA::LDS_FLOATS];
     __shared__ float ldsB[PB::LDS_FLOATS];
 
@@ -182,14 +182,14 @@ __device__ __forceinline__ void gemm_f32_tile(
     pb.template load<FAST>(B, ldb, n0, N, kbeg, kend, vecB != 0, foldB);
 
     const int fr = lane & 31, fk = lane >> 5;
-    for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();            // previous slab fully consumed
         pa.stage(ldsA);
         pb.stage(ldsB);
         __syncthreads();
-        if (k0 + GEMM_BK < kend) {  // prefetch the next slab behind the MFMAs
-            pa.template load<FAST>(A, lda, m0, M, k0 + GEMM_BK, kend, vecA != 0, nofold);
-            pb.template load<FAST>(B, ldb, n0, N, k0 + GEMM_BK, kend, vecB != 0, foldB);
+        if (k0 + BK < kend) {  // prefetch the next slab behind the MFMAs
+            pa.template load<FAST>(A, lda, m0, M, k0 + BK, kend, vecA != 0, nofold);
+            pb.template load<FAST>(B, ldb, n0, N, k0 + BK, kend, vecB != 0, foldB);
         }
         // operand fragments are read one k-step ahead of the MFMAs that consume them
         float a[2][TM], b[2][TN];
@@ -200,9 +200,9 @@ __device__ __forceinline__ void gemm_f32_tile(
         for (int j = 0; j < TN; ++j)
             b[0][j] = PB::frag(ldsB, (wn * TN + j) * 32 + fr, fk);
 #pragma unroll
-        for (int s = 0; s < GEMM_BK / 2; ++s) {
+        for (int s = 0; s < BK / 2; ++s) {
             const int c = s & 1, n = c ^ 1;
-            if (s + 1 < GEMM_BK / 2) {
+            if (s + 1 < BK / 2) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     a[n][i] = PA::frag(ldsA, (wm * TM + i) * 32 + fr, 2 * (s + 1) + fk);
@@ -273,6 +273,24 @@ __device__ __forceinline__ void gemm_f32_tile(
         const float bv = add_bias ? bias[col] : 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            if (epilogue == EPI_ACCUM) {
+                // all sixteen old values first, then the sums: written as "*dst = *dst + v" per element every load waits
+                // behind the previous store (the compiler cannot tell the rows apart), sixteen memory round trips in a row --
+                // 7 of the 20 us of the edge convolution's dX product into the concat gradient
+                float old[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    old[r] = (FAST || row < M) ? C[fold_off(row, col, ldc, foldC)] : 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                    if (FAST || row < M)
+                        C[fold_off(row, col, ldc, foldC)] = old[r] + (acc[i][j][r] + bv);
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
@@ -281,8 +299,6 @@ __device__ __forceinline__ void gemm_f32_tile(
                     const float v = acc[i][j][r] + bv;
                     if (epilogue == EPI_STORE)
                         *dst = v;
-                    else if (epilogue == EPI_ACCUM)
-                        *dst = *dst + v;
                     else
                         atomicAdd(dst, v);
                 }
@@ -293,7 +309,7 @@ __device__ __forceinline__ void gemm_f32_tile(
 
 // C[M,N] (+)= op(A)[M,K] * op(B)[K,N] (+ bias[N])
 // TA: A is stored [K][M] (lda >= M); else [M][K].  TB: B is stored [N][K]; else [K][N].
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool FAST>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool FAST, int BK = GEMM_BK>
 __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
     int M, int N, int K, const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
     float *__restrict__ C, int ldc, const float *__restrict__ bias, int epilogue, int kchunk,
@@ -319,7 +335,7 @@ __global__ __launch_bounds__(GEMM_THREADS) GEMM_ATTR void gemm_f32_kernel(
         slice = blockIdx.z;
     }
     // cslice != 0: every K slice stores its own copy of C (summed in slice order by gemm_slices_sum_kernel)
-    gemm_f32_tile<BM, BN, WM, WN, TA, TB, FAST>(M, N, K, A, lda, B, ldb, C + (size_t)slice * (size_t)cslice, ldc, bias, epilogue, kchunk, vecA, vecB, foldB,
+    gemm_f32_tile<BM, BN, WM, WN, TA, TB, FAST, BK>(M, N, K, A, lda, B, ldb, C + (size_t)slice * (size_t)cslice, ldc, bias, epilogue, kchunk, vecA, vecB, foldB,
                                                 foldC, colstats, (vid / (int)gridDim.x) * BM, (vid % (int)gridDim.x) * BN,
                                                 slice);
 }

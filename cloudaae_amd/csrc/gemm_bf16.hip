@@ -351,14 +351,24 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_bf16_kernel(int M, int N, int
             const float bv = add_bias ? bias[col] : 0.0f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                if (epilogue == GB_ACCUM) {
+                    // the sixteen old values first, then the sums (see gemm.hip: per element every load waits behind the
+                    // previous store)
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        old[r] = c0[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        c0[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc] = old[r] + (acc[i][j][r] + bv);
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float *dst = c0 + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc;
                     const float v = acc[i][j][r] + bv;
                     if (epilogue == GB_STORE)
                         *dst = v;
-                    else if (epilogue == GB_ACCUM)
-                        *dst = *dst + v;
                     else
                         atomicAdd(dst, v);
                 }
