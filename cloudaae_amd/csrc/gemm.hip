@@ -718,10 +718,14 @@ CLOUDAAE_API int cloudaae_gemm_f32_tn_group(int count, const cloudaae_gemm_tn_jo
         j.foldC.rows = q.M;
         j.tiles_x = ceil_div(q.N, 128);
         j.tiles = j.tiles_x * ceil_div(q.M, 64);
-        // K slices: one wave of workgroups for the whole group (5 resident per CU), >= 64 k each, whole slices per XCD
-        int splits = (256 * 5 / count) / j.tiles;
-        if (splits > q.K / 64)
-            splits = q.K / 64;
+        // K slices: one wave of workgroups for the whole group (5 resident per CU), >= 256 k each, whole slices per XCD.
+        // (every slice adds its whole tile to the same 32 KB with atomics: at K = 32768 the 320 slices of 112 k that fill
+        //  the chip take 53 us, 128 of 256 k 44 us (step 1.590 -> 1.582 ms); at K = 131072 320 slices of 416 k stay best:
+        //  profiles/notes_gemm_f32.md)
+        const int kmin = CLOUDAAE_KNOB("CLOUDAAE_GEMM_GROUP_KMIN", 256);
+        int splits = (CLOUDAAE_KNOB("CLOUDAAE_GEMM_GROUP_WGS", 256 * 5) / count) / j.tiles;
+        if (splits > q.K / kmin)
+            splits = q.K / kmin;
         if (splits > 8)
             splits = splits / 8 * 8;
         if (splits < 1 || CLOUDAAE_KNOB("CLOUDAAE_DETERMINISTIC", 0) != 0)
