@@ -98,14 +98,16 @@ int cloudaae_nn_distance_prefix(int b, int n, const float *xyz1, int m, const fl
  *   const float* xyz2,const float* grad_dist1,const int* idx1,const float* grad_dist2,
  *   const int* idx2,float* grad_xyz1,float* grad_xyz2)
  *   (tf_nndistance.cpp:208, tf_nndistance_g.cu:152-157; CPU loops tf_nndistance.cpp:126-163).
- * Either gradient output may be NULL (not wanted). */
+ * Either gradient output may be NULL (not wanted).  The terms of a point are added in no fixed order (atomics, in LDS per
+ * 2048-point chunk of an output; the reference's own GPU kernel adds with global atomics): fp32 round-off apart from the
+ * sequential sweep.  Every element of a wanted output is written. */
 int cloudaae_nn_distance_grad(int b, int n, const float *xyz1, int m, const float *xyz2,
                               const float *grad_dist1, const int *idx1, const float *grad_dist2,
                               const int *idx2, float *grad_xyz1, float *grad_xyz2,
                               cloudaae_stream_t stream);
 /* The same gradients accumulated in the ORDER of the reference's sequential CPU loops (tf_nndistance.cpp:126-163:
  * sweep over xyz1, then over xyz2), without atomics: bit-identical to that sweep and reproducible from run to run
- * (the atomic kernels above agree with it to fp32 round-off only, as the reference's own GPU kernel does).
+ * (the atomic kernel above agrees with it to fp32 round-off only, as the reference's own GPU kernel does).
  * uniform != NULL: every distance has the upstream gradient uniform[0] * uniform_scale (the mean of
  * losses/chamfer_loss.py:13-14) and grad_dist1 / grad_dist2 are not read.  O(n m) index comparisons per cloud:
  * about ten times the time of the atomic kernel -- the deterministic mode's choice. */
@@ -114,8 +116,9 @@ int cloudaae_nn_distance_grad_ordered(int b, int n, const float *xyz1, int m, co
                                       const int *idx2, const float *uniform, float uniform_scale,
                                       float *grad_xyz1, float *grad_xyz2, cloudaae_stream_t stream);
 /* The same when every distance has the SAME upstream gradient grad[0] * scale (the Chamfer loss is a mean
- * over them, losses/chamfer_loss.py:13-14): no per-point gradient arrays.  outputs_zeroed != 0: the caller
- * provides zero-filled outputs (otherwise the call clears them, as above). */
+ * over them, losses/chamfer_loss.py:13-14): no per-point gradient arrays.  outputs_zeroed: only read by the
+ * global-atomic development form (CLOUDAAE_NND_GRAD_LDS=0), which adds into its outputs (!= 0: the caller zero-filled
+ * them, else the call clears them first); the default form stores every output element. */
 int cloudaae_nn_distance_grad_uniform(int b, int n, const float *xyz1, int m, const float *xyz2, const float *grad,
                                       float scale, const int *idx1, const int *idx2, float *grad_xyz1,
                                       float *grad_xyz2, int outputs_zeroed, cloudaae_stream_t stream);

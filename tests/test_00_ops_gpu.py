@@ -90,6 +90,33 @@ def test_nn_distance_vs_oracle(hip, oracle, b, n, m, kernel, knobs):
         assert np.array_equal(w, g_.cpu().numpy())
 
 
+@pytest.mark.parametrize("lds", [1, 0])
+@pytest.mark.parametrize("case", ["random-2x2048x2048", "collapsed-2x4096x4096", "ragged-3x700x5461", "long-2x6000x100", "one-1x1x1", "config5-2x4096x16384"])
+def test_nn_distance_grad_forms_vs_oracle(hip, oracle, knobs, case, lds):
+    """The Chamfer gradient with its additions in LDS (one workgroup per cloud and 2048 points of an output array, the
+    default) and with global atomics (CLOUDAAE_NND_GRAD_LDS=0) against the oracle's sequential sweep
+    (tf_nndistance.cpp:126-163): unordered fp32 additions either way -> fp32 tolerance.  'collapsed': nearly every target
+    point names one of a few predicted points (a decoder at initialisation) -- thousands of additions per address."""
+    from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
+    knobs("CLOUDAAE_NND_GRAD_LDS", lds)
+    b, n, m = (int(x) for x in case.split("-")[-1].split("x"))
+    rng = np.random.default_rng(n + m)
+    a = rng.standard_normal((b, n, 3)).astype(np.float32)
+    c = rng.standard_normal((b, m, 3)).astype(np.float32)
+    if case.startswith("collapsed"):
+        a *= np.float32(1e-3)
+        a[:, :8] *= np.float32(1e3)
+    d1, i1, d2, i2 = tf_nndistance.nn_distance(_dev(a), _dev(c))
+    w1 = rng.standard_normal((b, n)).astype(np.float32)
+    w2 = rng.standard_normal((b, m)).astype(np.float32)
+    g1, g2 = tf_nndistance.nn_distance_grad(_dev(a), _dev(c), _dev(w1), i1, _dev(w2), i2)
+    want1, want2 = oracle.nn_distance_grad(a, c, w1, i1.cpu().numpy(), w2, i2.cpu().numpy())
+    # (sums of up to thousands of terms in another order: the tolerance scales with the largest sum)
+    tol = 5e-5 * max(1.0, float(np.abs(want1).max()), float(np.abs(want2).max()))
+    np.testing.assert_allclose(g1.cpu().numpy(), want1, rtol=1e-4, atol=tol)
+    np.testing.assert_allclose(g2.cpu().numpy(), want2, rtol=1e-4, atol=tol)
+
+
 def test_nn_distance_autograd_and_empty(hip, oracle):
     from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
     rng = np.random.default_rng(11)
