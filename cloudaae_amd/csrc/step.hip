@@ -17,6 +17,7 @@ namespace cloudaae {
 // :217 as a pure function of (seed, step counter, cloud, point) -- Philox4x32-10 + Box-Muller -- so a recorded step
 // draws fresh noise at every replay without a generator kernel in front of it.
 constexpr int IA_THREADS = 1024, IA_KEEP = 4;      // a thread keeps its first IA_KEEP points in registers
+constexpr int IA_LDS_N = 4096;                     // clouds up to this many points assemble their rows through LDS
 __global__ __launch_bounds__(IA_THREADS) void input_assemble_kernel(int P, int N, int num_class,
                                                                    const float *__restrict__ visible,
                                                                    const float *__restrict__ noise,
@@ -28,6 +29,7 @@ __global__ __launch_bounds__(IA_THREADS) void input_assemble_kernel(int P, int N
     constexpr int NWV = IA_THREADS / 64;
     __shared__ float red[3][NWV];
     __shared__ float mu[3];
+    __shared__ float sxyz[3][IA_LDS_N];
     const int b = blockIdx.x, t = threadIdx.x;
     const float *V = visible + (size_t)b * P * 3;
     const float *Z = noise ? noise + (size_t)b * N * 3 : nullptr;
@@ -93,6 +95,54 @@ __global__ __launch_bounds__(IA_THREADS) void input_assemble_kernel(int P, int N
     __syncthreads();
     const int C = 3 + num_class;
     const long long cls = class_id ? class_id[b] : -1;
+    if (N <= IA_LDS_N) {
+        // rows of C = 3 + num_class floats written by their point's thread are 96-byte strided stores, 24 per thread,
+        // each touching 48 cache lines (9 of this kernel's 12 us); the centred coordinates go through LDS instead and the
+        // cloud's [N, C] block leaves as whole 16-byte pieces in address order
+        it = 0;
+        for (int j = t; j < N; j += IA_THREADS, ++it) {
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (it < IA_KEEP) {
+#pragma unroll
+                for (int u = 0; u < IA_KEEP; ++u)
+                    if (u == it) {
+                        x = kx[u];
+                        y = ky[u];
+                        z = kz[u];
+                    }
+            } else {
+                point(j, x, y, z);
+            }
+            if (noisy) {
+                noisy[((size_t)b * N + j) * 3 + 0] = x;
+                noisy[((size_t)b * N + j) * 3 + 1] = y;
+                noisy[((size_t)b * N + j) * 3 + 2] = z;
+            }
+            sxyz[0][j] = x - mu[0];
+            sxyz[1][j] = y - mu[1];
+            sxyz[2][j] = z - mu[2];
+        }
+        __syncthreads();
+        float *rows = pc + (size_t)b * N * C;
+        const int total = N * C;
+        auto value = [&](int j, int c) { return c < 3 ? sxyz[c][j] : ((long long)(c - 3) == cls ? 1.0f : 0.0f); };
+        if ((C & 3) == 0 && ((uintptr_t)rows & 15) == 0) {
+            for (int e = 4 * t; e < total; e += 4 * IA_THREADS) {      // (C % 4 == 0: the four lie in one row)
+                const int j = e / C, c = e - j * C;
+                float4v v;
+                v.x = value(j, c);
+                v.y = value(j, c + 1);
+                v.z = value(j, c + 2);
+                v.w = value(j, c + 3);
+                *reinterpret_cast<float4v *>(rows + e) = v;
+            }
+        } else {
+            for (int e = t; e < total; e += IA_THREADS) {
+                const int j = e / C;
+                rows[e] = value(j, e - j * C);
+            }
+        }
+    } else {
     it = 0;
     for (int j = t; j < N; j += IA_THREADS, ++it) {
         float x = 0.f, y = 0.f, z = 0.f;
@@ -118,6 +168,7 @@ __global__ __launch_bounds__(IA_THREADS) void input_assemble_kernel(int P, int N
         row[2] = z - mu[2];
         for (int c = 0; c < num_class; ++c)
             row[3 + c] = (c == cls) ? 1.0f : 0.0f;
+    }
     }
     if (draw && draws != nullptr && t == 0) {
         if (atomicAdd(&draws[1], 1ull) == (unsigned long long)gridDim.x - 1ull) {

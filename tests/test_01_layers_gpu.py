@@ -342,6 +342,25 @@ def test_step_kernels(hip):
                                         hip.ptr(dmean), hip.ptr(dnoisy), hip.stream()), "assemble")
     assert _rel(dmean, mean) < 1e-6 and torch.equal(dnoisy.cpu(), noisy)
     assert float((dpc.cpu() - pc).abs().max()) < 1e-6 and torch.equal(dpc.cpu()[:, :, 3:], pc[:, :, 3:])
+    # the same rows at other shapes of the kernel: rows that are not whole 16-byte pieces (C = 3 + 2), more than one point
+    # per thread (N = 1500), and a cloud above the 4096 points whose rows go through LDS (the per-point row stores)
+    for nb, P, N, ncls in [(3, 1600, 1500, 2), (2, 5000, 4200, 21), (2, 4096, 4096, 21)]:
+        gg = torch.Generator().manual_seed(N)
+        vis = torch.randn((nb, P, 3), generator=gg)
+        nz = torch.randn((nb, N, 3), generator=gg) * 0.01
+        cls = torch.randint(0, ncls, (nb,), generator=gg)
+        dpc2 = torch.empty((nb, N, 3 + ncls), device="cuda")
+        dmean2, dnoisy2 = torch.empty((nb, 3), device="cuda"), torch.empty((nb, N, 3), device="cuda")
+        dvis2, dnz2, dcls2 = vis.cuda(), nz.cuda(), cls.cuda()       # (held: the call only sees their addresses)
+        hip.check(L.cloudaae_input_assemble(nb, P, N, ncls, hip.ptr(dvis2), hip.ptr(dnz2), hip.ptr(dcls2),
+                                            hip.ptr(dpc2), hip.ptr(dmean2), hip.ptr(dnoisy2), hip.stream()), "assemble")
+        torch.cuda.synchronize()
+        want_noisy = vis[:, :N] + nz
+        assert torch.equal(dnoisy2.cpu(), want_noisy)
+        # (the kernel's mean is a fixed-order fp32 tree: compare the rows with ITS mean, the mean itself to round-off)
+        assert float((dmean2.cpu() - want_noisy.double().mean(dim=1).float()).abs().max()) < 1e-6
+        assert torch.equal(dpc2.cpu()[:, :, :3], want_noisy - dmean2.cpu()[:, None, :])
+        assert torch.equal(dpc2.cpu()[:, :, 3:], torch.nn.functional.one_hot(cls, ncls).float()[:, None, :].expand(nb, N, ncls))
     # Adam (TF ApplyAdam form) over 3 steps on a ragged length
     g = torch.Generator().manual_seed(1)
     n = 1003
