@@ -69,6 +69,8 @@ _SIGNATURES = {
     "cloudaae_fc_backward_group": [_I, _I, _P, _I, _P],
     "cloudaae_edgeconv_forward": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P,
                                   _P, _P, _P, _I, _P, _P, _I, _P, _P],
+    "cloudaae_edgeconv_forward_b16out": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P,
+                                         _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P],
     "cloudaae_edgeconv_backward": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P,
                                    _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P],
     "cloudaae_edgeconv_revlists": [_I, _I, _I, _I, _P, _P, _P],

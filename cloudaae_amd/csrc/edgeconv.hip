@@ -45,7 +45,18 @@ struct EcArgs {
     const float *dout;     // [P][lddo]
     int lddo;
     int training;
+    unsigned short *out16;     // forward, optional: the pooled output once more as bfloat16 (round to nearest even) ...
+    int ldo16;                 // ... rows ldo16 elements apart: the concat's bf16 twin (configs[2]: no separate conversion pass)
 };
+
+// fp32 -> bfloat16 bits, round to nearest even (NaN stays NaN): the conversion of cloudaae_to_bf16 (gemm_b16.hip)
+__device__ __forceinline__ unsigned short ec_bf16_bits(float v)
+{
+    const __bf16 b = (__bf16)v;
+    unsigned short w;
+    __builtin_memcpy(&w, &b, 2);
+    return w;
+}
 
 // all k pre-activation rows of one point, for this lane's CPL channels
 // US: the P' half of pq already holds U = P' - Q + bias (true in the backward kernels: every forward
@@ -300,7 +311,10 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
             return;
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
-            out[(size_t)pt * ldo + lane + 64 * e] = POOL == 2 ? acc[e] : acc[e] / (float)a.k;
+            const float o = POOL == 2 ? acc[e] : acc[e] / (float)a.k;
+            out[(size_t)pt * ldo + lane + 64 * e] = o;
+            if (a.out16 != nullptr)
+                a.out16[(size_t)pt * a.ldo16 + lane + 64 * e] = ec_bf16_bits(o);
             if (POOL == 2 && ties != nullptr)
                 ties[(size_t)pt * a.cout + lane + 64 * e] = cnt[e];
             if (stats) {
@@ -898,11 +912,13 @@ static int ec_forward_impl(const char *name, int b, int n, int k, int cin, int c
                            const float *decay, float *ema_mean, float *ema_var,
                            int pool_mode, float *pq, float *save_mean, float *save_var,
                            float *out, int ldo, float *tie_count, float *edge_stats,
-                           int gemm_bf16, void *workspace, const cloudaae_bn_sync *sync, cloudaae_stream_t stream)
+                           int gemm_bf16, void *workspace, const cloudaae_bn_sync *sync, cloudaae_stream_t stream,
+                           void *out16 = nullptr, int ldo16 = 0)
 {
     if (int rc = ec_check(name, b, n, k, cin, cout, pool_mode))
         return rc;
     CLOUDAAE_REQUIRE(training || (ema_mean && ema_var), name, "inference needs the EMA statistics");
+    CLOUDAAE_REQUIRE(out16 == nullptr || ldo16 >= cout, name, "bfloat16 output rows too short");
     CLOUDAAE_REQUIRE(pool_mode != 2 || tie_count != nullptr, name, "max pool needs the tie_count output");
     hipStream_t s = (hipStream_t)stream;
     const int P = b * n;
@@ -916,6 +932,7 @@ static int ec_forward_impl(const char *name, int b, int n, int k, int cin, int c
     a.P = P; a.N = n; a.k = k; a.cout = cout; a.ldpq = 2 * cout;
     a.pq = pq; a.bias = biases; a.nn_idx = nn_idx; a.scale_shift = scale_shift;
     a.save_mean = save_mean; a.save_var = save_var;
+    a.out16 = (unsigned short *)out16; a.ldo16 = ldo16;
     float *es = (training && pool_mode == 1) ? edge_stats : nullptr;
     const int cpl = cout / 64, kcap = k <= 10 ? 10 : (k <= 20 ? 20 : 32);
     const int grid = ec_stat_grid(P), agrid = ec_apply_grid(P);
@@ -960,6 +977,22 @@ CLOUDAAE_API int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cou
     return ec_forward_impl("cloudaae_edgeconv_forward", b, n, k, cin, cout, x, ldx, nn_idx, weights, biases, gamma, beta,
                            training, decay, ema_mean, ema_var, pool_mode, pq, save_mean, save_var, out, ldo, tie_count,
                            edge_stats, gemm_bf16, workspace, nullptr, stream);
+}
+
+CLOUDAAE_API int cloudaae_edgeconv_forward_b16out(int b, int n, int k, int cin, int cout, const float *x, int ldx,
+                                                  const int *nn_idx, const float *weights, const float *biases,
+                                                  const float *gamma, const float *beta, int training,
+                                                  const float *decay, float *ema_mean, float *ema_var,
+                                                  int pool_mode, float *pq, float *save_mean, float *save_var,
+                                                  float *out, int ldo, float *tie_count, float *edge_stats,
+                                                  int gemm_bf16, void *workspace, void *out_bf16, int ldo_bf16,
+                                                  cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_edgeconv_forward_b16out";
+    CLOUDAAE_REQUIRE(out_bf16 != nullptr, name, "null argument");
+    return ec_forward_impl(name, b, n, k, cin, cout, x, ldx, nn_idx, weights, biases, gamma, beta, training, decay, ema_mean,
+                           ema_var, pool_mode, pq, save_mean, save_var, out, ldo, tie_count, edge_stats, gemm_bf16, workspace,
+                           nullptr, stream, out_bf16, ldo_bf16);
 }
 
 CLOUDAAE_API int cloudaae_edgeconv_forward_sync(int b, int n, int k, int cin, int cout, const float *x, int ldx,

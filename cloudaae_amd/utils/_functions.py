@@ -96,6 +96,8 @@ BN_SYNC = None
 # products see the values they would have rounded to anyway; the one new rounding point is the stored y.  Off in
 # deterministic mode and under SyncBN (those take the fp32-storage kernels).
 ACT_BF16 = os.environ.get("CLOUDAAE_ACT_BF16", "1") != "0"
+# ... and the edge-conv layers store the bfloat16 copy of the concat themselves (0: one conversion pass in front of the product)
+CONCAT_BF16 = os.environ.get("CLOUDAAE_CONCAT_BF16", "1") != "0"
 
 
 def to_bf16(t):
@@ -445,6 +447,10 @@ class ConcatSlot(object):
     def __init__(self, buf):
         self.buf = buf
         self.dcat = None
+        # bfloat16 twin of buf (activations kept in bfloat16, BASELINE configs[2]): each edge-conv layer stores its slice
+        # there too, and the aggregation product reads it instead of converting the whole concat (cols16: columns written)
+        self.buf16 = None
+        self.cols16 = 0
         # (nn_idx, reverse-list buffer) of every edge-conv layer writing into this slot: the first backward
         # call builds all their reverse neighbour lists with one launch
         self.revs = []
@@ -521,8 +527,12 @@ class ConcatLinearFn(torch.autograd.Function):
                 L().cloudaae_gemm_b16_supported(0, 1, M, Ktot, N) and L().cloudaae_gemm_b16_supported(1, 0, Ktot, N, M)):
             # activations in bf16: x, W rounded once, y stored as bf16, column sums from the fp32 accumulators
             parts = int(L().cloudaae_gemm_b16_colstats_parts(M, N, Ktot))
-            x16 = _lib.empty((M, Ktot), dtype=torch.bfloat16, device=w.device)
-            _lib.check(L().cloudaae_to_bf16(M * Ktot, xp, x16.data_ptr(), stream()), "cloudaae_to_bf16")
+            if (isinstance(slot, ConcatSlot) and slot.buf16 is not None and slot.cols16 == Ktot and adjacent and
+                    xp == slot.buf.data_ptr() and slot.buf16.numel() == M * Ktot):
+                x16 = slot.buf16.view(M, Ktot)      # every layer stored its bfloat16 slice already (EdgeConvFn)
+            else:
+                x16 = _lib.empty((M, Ktot), dtype=torch.bfloat16, device=w.device)
+                _lib.check(L().cloudaae_to_bf16(M * Ktot, xp, x16.data_ptr(), stream()), "cloudaae_to_bf16")
             w16 = to_bf16(w)
             y = _lib.empty((M, N), dtype=torch.bfloat16, device=w.device)
             ws = _lib.empty(parts * 2 * N, dtype=torch.float64, device=w.device)
@@ -812,6 +822,13 @@ class EdgeConvFn(torch.autograd.Function):
             require(tuple(out.shape) == (B, N, cout) and out.stride(2) == 1 and
                     out.stride(0) == N * out.stride(1), "EdgeConvFn: bad output slot")
         ldo = out.stride(1)
+        slot16 = None
+        if (CONCAT_BF16 and out_slot is not None and isinstance(out_slot[0], ConcatSlot) and BN_SYNC is None and gemm_is_bf16() and ACT_BF16
+                and not DETERMINISTIC and out_slot[0].buf.dim() == 3 and out_slot[0].buf.is_contiguous()):
+            slot16 = out_slot[0]
+            if slot16.buf16 is None:
+                slot16.buf16 = _lib.empty(tuple(slot16.buf.shape), dtype=torch.bfloat16, device=dev)
+                slot16.cols16 = 0
         pq = _lib.empty((B * N, 2 * cout), dtype=torch.float32, device=dev)
         save_mean = _lib.empty(cout, dtype=torch.float32, device=dev)
         save_var = _lib.empty(cout, dtype=torch.float32, device=dev)
@@ -829,6 +846,14 @@ class EdgeConvFn(torch.autograd.Function):
                 int(training), ptr(decay), ptr(ema_mean), ptr(ema_var), int(pool_mode), ptr(pq), ptr(save_mean),
                 ptr(save_var), out.data_ptr(), ldo, ptr(ties), ptr(estats), int(gemm_is_bf16()), ptr(ws),
                 ctx.sync.arg(cout, dev), stream()), "cloudaae_edgeconv_forward_sync")
+        elif slot16 is not None:
+            ctot = slot16.buf.shape[2]
+            _lib.check(L().cloudaae_edgeconv_forward_b16out(
+                B, N, k, cin, cout, x.data_ptr(), ldx, ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),
+                int(training), ptr(decay), ptr(ema_mean), ptr(ema_var), int(pool_mode), ptr(pq), ptr(save_mean),
+                ptr(save_var), out.data_ptr(), ldo, ptr(ties), ptr(estats), int(gemm_is_bf16()), ptr(ws),
+                slot16.buf16.data_ptr() + 2 * out_slot[1], ctot, stream()), "cloudaae_edgeconv_forward_b16out")
+            slot16.cols16 += cout
         else:
             _lib.check(L().cloudaae_edgeconv_forward(
                 B, N, k, cin, cout, x.data_ptr(), ldx, ptr(nn_idx), ptr(w), ptr(b), ptr(gamma), ptr(beta),

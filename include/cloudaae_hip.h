@@ -500,6 +500,16 @@ int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cout, const floa
                               float *ema_mean, float *ema_var, int pool_mode, float *pq, float *save_mean,
                               float *save_var, float *out, int ldo, float *tie_count, float *edge_stats,
                               int gemm_bf16, void *workspace, cloudaae_stream_t stream);
+/* The same, the pooled output stored once more as bfloat16 (round to nearest even, the conversion of cloudaae_to_bf16):
+ * out_bf16 [b*n] rows ldo_bf16 elements apart -- a column slice of the bfloat16 twin of the concat buffer the aggregation
+ * product reads when activations are kept in bfloat16 (BASELINE configs[2]): no conversion pass over the concat. */
+int cloudaae_edgeconv_forward_b16out(int b, int n, int k, int cin, int cout, const float *x, int ldx,
+                                     const int *nn_idx, const float *weights, const float *biases,
+                                     const float *gamma, const float *beta, int training, const float *decay,
+                                     float *ema_mean, float *ema_var, int pool_mode, float *pq, float *save_mean,
+                                     float *save_var, float *out, int ldo, float *tie_count, float *edge_stats,
+                                     int gemm_bf16, void *workspace, void *out_bf16, int ldo_bf16,
+                                     cloudaae_stream_t stream);
 /* Reverse neighbour lists (for every point m: the points that have m among their k neighbours) of up to 8
  * layers in one launch: rev_scratch[i] (b*(n+1) + b*n*k ints, the buffer later passed to
  * cloudaae_edgeconv_backward with rev_ready = 1) from nn_idx[i] ([b,n,k]).  The encoder's layers all have
