@@ -217,3 +217,36 @@ def test_bf16_mode_builders_with_and_without_bf16_storage(hip, name, N):
     for i, (a, b) in enumerate(zip(*outs)):
         assert torch.isfinite(a).all() and torch.isfinite(b).all()
         assert _rel(a, b) < (0.25 if i else (3e-2 if expect16 else 1e-6))
+
+
+def test_concat_bf16_twin_is_the_conversion_pass(hip, monkeypatch):
+    """BASELINE configs[2] arithmetic (bf16 dense-layer operands, activations kept in bf16): the edge-conv layers store the
+    bfloat16 twin of the concat themselves (cloudaae_edgeconv_forward_b16out) instead of one cloudaae_to_bf16 pass in front
+    of the aggregation product -- the same roundings of the same values, so the forward results of a step are bit-identical
+    either way (the backward pass differs from run to run by the order of its fp32 atomics in both)."""
+    from cloudaae_amd import train_cloudAAE_ycbv as T
+    from cloudaae_amd.utils import _functions as F
+    B, N = 8, 256
+    outs, conversions = [], []
+    for twin in (True, False):
+        monkeypatch.setattr(F, "CONCAT_BF16", twin)
+        g = T.TrainGraph({"num_point": N, "gpu": 0}, {}, {"batch_size": B}, gemm_dtype="bf16", replay=True)
+        if outs:
+            with torch.no_grad():
+                g.store.flat_params.copy_(outs[0][0])
+                g.store.flat_state.copy_(outs[0][1])
+        p0, s0 = g.store.flat_params.clone(), g.store.flat_state.clone()
+        el = T.synthetic_element(B, N, g.device, seed=77)
+        el["noise"] = torch.zeros((B, N, 3), device="cuda")
+        o = g.train_step(el)
+        torch.cuda.synchronize()
+        outs.append((p0, s0, float(o["total_loss"]), o["xyz_recon"].detach().clone()))
+        names = [e[2] for e in g._plan.entries]
+        # the recorded step: four edge-conv layers through the twin-writing entry point and only the weights converted,
+        # or the plain entry point and one more conversion (the concat)
+        assert names.count("cloudaae_edgeconv_forward_b16out") == (4 if twin else 0)
+        assert names.count("cloudaae_edgeconv_forward") == (0 if twin else 4)
+        conversions.append(names.count("cloudaae_to_bf16"))
+    assert conversions[1] == conversions[0] + 1
+    assert outs[0][2] == outs[1][2]
+    assert torch.equal(outs[0][3], outs[1][3])
