@@ -523,10 +523,11 @@ struct EcRevJobs {
 // grid (clouds, layers): the neighbour lists of every layer of the encoder exist once its forward pass
 // is over, so the backward pass builds all their reverse lists with ONE launch (four ~11 us launches of
 // 32 workgroups each otherwise).
-__global__ __launch_bounds__(512) void ec_revlist_kernel(int B, int N, int k, EcRevJobs jobs, int sorted)
+constexpr int EC_REV_THREADS = 1024;    // (512: 14.2 us at [32, 1024, k = 10] x 4 layers, 135 us at [32, 4096, k = 20])
+__global__ __launch_bounds__(EC_REV_THREADS) void ec_revlist_kernel(int B, int N, int k, EcRevJobs jobs, int sorted)
 {
     extern __shared__ int cnt[];
-    __shared__ int wsum[8];
+    __shared__ int wsum[EC_REV_THREADS / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int *nn_idx = jobs.nn_idx[blockIdx.y];
     int *rev_off = jobs.rev[blockIdx.y], *rev_src = rev_off + (size_t)B * (N + 1);
@@ -534,25 +535,25 @@ __global__ __launch_bounds__(512) void ec_revlist_kernel(int B, int N, int k, Ec
     int *off = rev_off + (size_t)blockIdx.x * (N + 1);
     int *src = rev_src + (size_t)blockIdx.x * N * k;
     const int E = N * k;
-    for (int m = t; m < N; m += 512)
+    for (int m = t; m < N; m += EC_REV_THREADS)
         cnt[m] = 0;
     __syncthreads();
     // the index loads are issued eight at a time ahead of the LDS atomics that consume them: one global
     // round trip per batch instead of one per edge (a loop of load -> atomic pairs costs the latency
-    // E/512 times over)
+    // E / threads times over)
     constexpr int RU = 8;
-    for (int e0 = t; e0 < E; e0 += 512 * RU) {
+    for (int e0 = t; e0 < E; e0 += EC_REV_THREADS * RU) {
         int v[RU];
 #pragma unroll
         for (int u = 0; u < RU; ++u)
-            v[u] = e0 + 512 * u < E ? idx[e0 + 512 * u] : -1;
+            v[u] = e0 + EC_REV_THREADS * u < E ? idx[e0 + EC_REV_THREADS * u] : -1;
 #pragma unroll
         for (int u = 0; u < RU; ++u)
             if (v[u] >= 0)
                 atomicAdd(&cnt[v[u]], 1);
     }
     __syncthreads();
-    const int per = (N + 511) / 512;
+    const int per = (N + EC_REV_THREADS - 1) / EC_REV_THREADS;
     const int lo = min(N, t * per), hi = min(N, lo + per);
     int local = 0;
     for (int m = lo; m < hi; ++m)
@@ -580,23 +581,23 @@ __global__ __launch_bounds__(512) void ec_revlist_kernel(int B, int N, int k, Ec
     if (t == 0)
         off[N] = E;
     __syncthreads();
-    for (int e0 = t; e0 < E; e0 += 512 * RU) {
+    for (int e0 = t; e0 < E; e0 += EC_REV_THREADS * RU) {
         int v[RU];
 #pragma unroll
         for (int u = 0; u < RU; ++u)
-            v[u] = e0 + 512 * u < E ? idx[e0 + 512 * u] : -1;
+            v[u] = e0 + EC_REV_THREADS * u < E ? idx[e0 + EC_REV_THREADS * u] : -1;
 #pragma unroll
         for (int u = 0; u < RU; ++u)
             if (v[u] >= 0) {
                 const int pos = atomicAdd(&cnt[v[u]], 1);
-                src[pos] = (e0 + 512 * u) / k;
+                src[pos] = (e0 + EC_REV_THREADS * u) / k;
             }
     }
     if (sorted) {
         // deterministic mode: the slots of a list were handed out in arrival order; sorted by source point the list --
         // and with it the summation order of the backward gather -- is the same in every run
         __syncthreads();
-        for (int mpt = t; mpt < N; mpt += 512) {
+        for (int mpt = t; mpt < N; mpt += EC_REV_THREADS) {
             const int a = off[mpt], e = (mpt + 1 < N) ? off[mpt + 1] : E;
             for (int i = a + 1; i < e; ++i) {
                 const int v = src[i];
@@ -878,7 +879,7 @@ static int ec_launch_revlists(const char *name, int count, int b, int n, int k, 
     if (lds > 48 * 1024)
         CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)ec_revlist_kernel,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
-    hipLaunchKernelGGL(ec_revlist_kernel, dim3(b, count), dim3(512), lds, s, b, n, k, jobs,
+    hipLaunchKernelGGL(ec_revlist_kernel, dim3(b, count), dim3(EC_REV_THREADS), lds, s, b, n, k, jobs,
                        CLOUDAAE_KNOB("CLOUDAAE_DETERMINISTIC", 0) != 0 ? 1 : 0);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
