@@ -18,8 +18,12 @@ collectives, the same 128-cloud batch -- the honest denominator for a scaling ef
 Inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
-  roofline     : the dominant kernel (the dgcnn_agg forward GEMM on the matrix cores),
-                 timed live with HIP events on the launch stream over the timed region
+  roofline     : the dominant kernel = the top row of the step's kernel trace: the kNN over 64 feature
+                 channels (knn64_wide_kernel, three launches per step), algorithmic flops 2 B N^2 64 against the
+                 fp32 matrix pipe; timed live with HIP events on the launch stream over the timed region
+  roofline_agg_fwd : the dgcnn_agg forward product, algorithmic flops (frac, frac_algorithmic) kept apart
+                 from the bf16 pipe's utilisation by the six issued piece products (frac_issued)
+  roofline_edgeconv: the four edge-convolution blocks, forward + backward, against HBM
   cpu_baseline : the CPU oracle's train step timed on this box's host cores on a bounded
                  sample (rank 0, N=1 only)
   comm (N > 1) : ranks_seen (an RCCL all-reduce of ones), allreduce_exposed_ms (HIP events on the
@@ -41,6 +45,7 @@ import torch.distributed as dist
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense (the headline figure with 2:1 sparsity is never used)
 
 
 def cpu_baseline(num_point, sample_batch, steps=1):
@@ -404,7 +409,11 @@ def main():
         sys.stdout.flush()
         stdout_fd = os.dup(1)
         os.dup2(2, 1)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # a rank that never shows up (or a communicator that cannot form) is a non-zero exit after two minutes with
+        # the rendezvous error on stderr, not a hang for the length of the driver's own limit
+        import datetime
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local),
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("CLOUDAAE_PG_TIMEOUT_S", "120"))))
 
     from cloudaae_amd import train_cloudAAE_ycbv as T
     from cloudaae_amd.utils import _functions as F
@@ -521,50 +530,55 @@ def main():
                        "global_batch": B * world, "per_gpu_batch": B, "num_point": N, "parallelism": "dp%d" % world,
                        "step_issue": "recorded step replay" if graph.replay else "eager",
                        "final_total_loss": round(loss, 4)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128,2,2> dgcnn_agg forward "
-                                                     "[%d x 320] x [320 x 1024]" % M,
-                         "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": measured_traffic(B, N, "agg_fwd") if args.gemm_dtype == "f32" else None,
-                         "launch_ms": round(k_ms, 4), "launches_timed": k_n},
         }
-        if args.gemm_dtype == "bf16x3":
-            # the split product issues six bf16 MFMAs where the fp32 kernel issues eight fp32 ones: priced on the bf16
-            # matrix pipe (2.5 PFLOP/s dense) with the flops it really issues (6 x the algorithmic ones)
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_x3s_kernel dgcnn_agg forward [%d x 320] x "
-                                                          "[320 x 1024] as 3 x bf16 splits (6 piece products)" % M,
-                                "achieved": round(6.0 * achieved, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                                "frac": round(6.0 * achieved / 2500.0, 4), "traffic": measured_traffic(B, N, "agg_fwd_x3"),
-                                "algorithmic_tflops": round(achieved, 2), "launch_ms": round(k_ms, 4),
-                                "launches_timed": k_n}
-        if args.gemm_dtype == "bf16":
+        # `roofline`: the DOMINANT kernel = the top row of the step's kernel trace at every batch size
+        # (profiles/r0N_trainstep_*_kernel_stats.csv): the kNN over 64 feature channels, three launches per step
+        # (layers 2-4, tf_util.py:597-632).  Algorithmic flops = the N x N x 64 inner products of every cloud
+        # (2 B N^2 C) against the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s); the selection
+        # that follows the products is what keeps the kernel from that bound.
+        q_ms, q_n = site_ms(events["knn64"])
+        qf = 2.0 * B * N * N * 64 / (q_ms * 1e-3) / 1e12 if q_ms > 0 else 0.0
+        line["roofline"] = {"bound": "mfma", "kernel": "knn64_wide_kernel (cloudaae_knn, C=64, k=%d) [%d x %d x %d], "
+                                                        "3 launches per step" % (args.k, B, N, N),
+                            "achieved": round(qf, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(qf / FP32_MFMA_PEAK_TFLOPS, 4),
+                            "traffic": measured_traffic(B, N, "knn64"),
+                            "algorithmic_flops_per_launch": int(2.0 * B * N * N * 64),
+                            "launch_ms": round(q_ms, 4), "launches_timed": q_n}
+        # second entry: the dgcnn_agg forward product [B N x 320] x [320 x 1024] (tf_util.py:161-166).  ALGORITHMIC flops
+        # 2 M N K whatever the arithmetic.  f32: on the fp32 matrix pipe.  bf16x3: six bf16 piece products are ISSUED per
+        # algorithmic product, so the line carries frac_issued (6 x flops / 2.5 PFLOP/s: how busy the bf16 pipe is -- a
+        # utilisation figure, NOT a roofline fraction) next to frac_algorithmic against both pipes (vs the bf16 pipe
+        # it runs on; vs the fp32 pipe an fp32 kernel would be bound by: > 1 means it beats every fp32-MFMA kernel).
+        agg = {"bound": "mfma", "algorithmic_tflops": round(achieved, 3), "launch_ms": round(k_ms, 4), "launches_timed": k_n,
+               "algorithmic_flops_per_launch": int(flops)}
+        if args.gemm_dtype == "f32":
+            agg.update({"kernel": "gemm_f32_kernel dgcnn_agg forward [%d x 320] x [320 x 1024]" % M,
+                        "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": measured_traffic(B, N, "agg_fwd")})
+        elif args.gemm_dtype == "bf16x3":
+            agg.update({"kernel": "gemm_x3s_kernel dgcnn_agg forward [%d x 320] x [320 x 1024] as 3 x bf16 splits "
+                                  "(6 piece products issued per product)" % M,
+                        "achieved": round(achieved, 3), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                        "frac_algorithmic": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                        "frac_algorithmic_vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "frac_issued": round(6.0 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
+                        "issued_tflops": round(6.0 * achieved, 2), "traffic": measured_traffic(B, N, "agg_fwd_x3")})
+        else:
             # with bf16 operands the same product leaves the matrix pipe (2.5 PFLOP/s dense) and is bound by
             # HBM.  Activations kept as bfloat16 (F.ACT_BF16, the default): x (M x 320) and W in as bf16, y
             # (M x 1024) out as bf16; else fp32 tensors in and out (rounded on the way into LDS)
-            from cloudaae_amd.utils import _functions as F_
-            act16 = bool(F_.ACT_BF16) and M % 128 == 0 and not args.sync_bn
+            act16 = bool(F.ACT_BF16) and M % 128 == 0 and not args.sync_bn
             esz = 2.0 if act16 else 4.0
             nbytes = esz * (M * K + K * Nn + M * Nn) + 4.0 * Nn
             gbs = nbytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-            kname = ("gemm_b16_kernel<128,128,2,2> (bf16 x, W in; bf16 y out)" if act16 else
-                     "gemm_bf16_kernel<128,128,2,2> (fp32 in / out)")
-            line["roofline"] = {"bound": "hbm", "kernel": kname + " dgcnn_agg forward [%d x 320] x [320 x 1024]" % M,
-                                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                "traffic": measured_traffic(B, N, "agg_fwd_b16" if act16 else "agg_fwd_bf16"),
-                                "launch_ms": round(k_ms, 4), "launches_timed": k_n}
-        # second roofline entry: the kNN over 64 feature channels (layers 2-4), the kernel furthest below its
-        # bound.  Algorithmic flops = the N x N x 64 inner products of every cloud (2 N^2 C B), on the fp32
-        # matrix pipe (the selection that follows is what keeps it from that bound)
-        q_ms, q_n = site_ms(events["knn64"])
-        if q_n:
-            qf = 2.0 * B * N * N * 64 / (q_ms * 1e-3) / 1e12
-            line["roofline_knn64"] = {"bound": "mfma", "kernel": "knn64 (cloudaae_knn, C=64, k=%d) [%d x %d x %d]"
-                                                                   % (args.k, B, N, N),
-                                      "achieved": round(qf, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": round(qf / FP32_MFMA_PEAK_TFLOPS, 4),
-                                      "traffic": measured_traffic(B, N, "knn64"),
-                                      "launch_ms": round(q_ms, 4), "launches_timed": q_n}
+            kname = ("gemm_b16 (bf16 x, W in; bf16 y out)" if act16 else "gemm_bf16_kernel<128,128,2,2> (fp32 in / out)")
+            agg.update({"bound": "hbm", "kernel": kname + " dgcnn_agg forward [%d x 320] x [320 x 1024]" % M,
+                        "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(nbytes),
+                        "traffic": measured_traffic(B, N, "agg_fwd_b16" if act16 else "agg_fwd_bf16")})
+        line["roofline_agg_fwd"] = agg
         # third entry: the four edge-convolution blocks, forward and backward (the calls cloudaae_edgeconv_forward /
         # _backward: their products, statistics, finalise and apply / gather kernels; the grouped weight-gradient
         # launch that follows backward is not inside).  HBM-bound by construction (the k-fold edge tensor never
