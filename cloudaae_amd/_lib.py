@@ -61,11 +61,11 @@ _SIGNATURES = {
     "cloudaae_bn_meanpool_backward16": [_I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P],
     "cloudaae_bn_forward_colstats": [_I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P,
                                      _P, _P, _I, _P],
-    "cloudaae_fc_forward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _L, _P],
+    "cloudaae_fc_forward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _P],
     "cloudaae_fc_backward": [_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P,
                              _P, _I, _P],
     "cloudaae_stream_wait": [_P, _P],
-    "cloudaae_fc_forward_group": [_I, _I, _P, _I, _P, _I, _P],
+    "cloudaae_fc_forward_group": [_I, _I, _P, _I, _P, _P],
     "cloudaae_fc_backward_group": [_I, _I, _P, _I, _P],
     "cloudaae_edgeconv_forward": [_I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P,
                                   _P, _P, _P, _I, _P, _P, _I, _P, _P],
@@ -139,6 +139,9 @@ class BnSyncStruct(ctypes.Structure):
 _LONGLONG_RESULTS = ["cloudaae_x3_planes_bytes", "cloudaae_loss_tail_workspace_bytes", "cloudaae_bn_workspace_bytes", "cloudaae_edgeconv_workspace_bytes",
                      "cloudaae_mean_workspace_bytes", "cloudaae_gemm_f32_ordered_workspace",
                      "cloudaae_gemm_bf16_ordered_workspace"]
+
+
+ABI_VERSION = 500     # CLOUDAAE_ABI_VERSION of include/cloudaae_hip.h (tests/test_capi_symbols.py compares the two)
 
 
 class HipLibraryError(RuntimeError):
@@ -303,6 +306,14 @@ def lib():
                 "or `make -C cloudaae_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
         cdll = ctypes.CDLL(LIB_PATH)
         cdll.cloudaae_last_error.restype = ctypes.c_char_p
+        # the signature table below describes ONE revision of the C ABI (CLOUDAAE_ABI_VERSION of include/cloudaae_hip.h):
+        # a library of another revision would take these calls with shifted arguments and corrupt memory
+        cdll.cloudaae_version.argtypes = []
+        cdll.cloudaae_version.restype = ctypes.c_int
+        have = int(cdll.cloudaae_version())
+        if have != ABI_VERSION:
+            raise HipLibraryError("%s speaks ABI revision %d, this package expects %d: rebuild it (`make -C cloudaae_amd/csrc`)"
+                                  % (LIB_PATH, have, ABI_VERSION))
         for fn, sig in _SIGNATURES.items():
             f = getattr(cdll, fn)
             f.argtypes = sig
@@ -339,10 +350,10 @@ def lib():
             getattr(cdll, q).restype = ctypes.c_int
         cdll.cloudaae_side_stream.argtypes = []
         cdll.cloudaae_side_stream.restype = ctypes.c_void_p
-        cdll.cloudaae_fc_forward_tickets.argtypes = [_I]
+        cdll.cloudaae_fc_forward_tickets.argtypes = [_I, _I]
         cdll.cloudaae_fc_forward_tickets.restype = ctypes.c_int
         cdll.cloudaae_loss_tail_workspace_bytes.argtypes = []
-        cdll.cloudaae_fc_forward_partials.argtypes = [_I, _I, _I]
+        cdll.cloudaae_fc_forward_partials.argtypes = [_I, _I, _I, _I]
         cdll.cloudaae_fc_forward_partials.restype = ctypes.c_longlong
         cdll.cloudaae_edgeconv_workspace_bytes.argtypes = [_I]
         for q in ("cloudaae_set_knob", "cloudaae_unset_knob"):

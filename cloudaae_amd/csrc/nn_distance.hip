@@ -55,21 +55,29 @@ __device__ __forceinline__ int prefix_rows(const long long *count2, int cloud, i
     return c > 0 && c < m ? (int)c : m;
 }
 
-// results of the copies: row j >= count2[cloud] of xyz2 is a copy of row row_src[j] < count2[cloud]
+// results of the copies: row j >= count2[cloud] of xyz2 is a copy of row row_src[j] < count2[cloud].  EVERY such row is
+// written: a row whose row_src is not a distinct row (< 0 or >= count2[cloud] -- a caller that shuffled, truncated or
+// augmented the target after the synthesis broke the contract) gets dist = NaN, idx = 0, i.e. a loss that says so and an
+// index the gradient kernels may follow, instead of whatever the output buffer held.  verify (development knob
+// CLOUDAAE_NN_PREFIX_VERIFY): the row must also BE its original, bit for bit, else the same NaN.
 __global__ __launch_bounds__(256) void nn_distance_expand_kernel(int m, const long long *__restrict__ count2,
-                                                               const int *__restrict__ row_src, float *__restrict__ dist2,
-                                                               int *__restrict__ idx2)
+                                                               const int *__restrict__ row_src, const float *__restrict__ xyz2,
+                                                               int verify, float *__restrict__ dist2, int *__restrict__ idx2)
 {
     const int cloud = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
     const int m_eff = prefix_rows(count2, cloud, m);
     if (j < m_eff || j >= m)
         return;
     const size_t base = (size_t)cloud * m;
-    const int r = row_src[base + j];
-    if (r >= 0 && r < m_eff) {
-        dist2[base + j] = dist2[base + r];
-        idx2[base + j] = idx2[base + r];
+    const int r = row_src != nullptr ? row_src[base + j] : -1;
+    bool good = r >= 0 && r < m_eff;
+    if (good && verify) {
+        const unsigned *a = reinterpret_cast<const unsigned *>(xyz2 + (base + j) * 3);
+        const unsigned *c = reinterpret_cast<const unsigned *>(xyz2 + (base + r) * 3);
+        good = a[0] == c[0] && a[1] == c[1] && a[2] == c[2];
     }
+    dist2[base + j] = good ? dist2[base + r] : __uint_as_float(0x7fc00000u);
+    idx2[base + j] = good ? idx2[base + r] : 0;
 }
 
 template <int Q>
@@ -882,7 +890,8 @@ static int nn_distance_impl(const char *name, int b, int n, const float *xyz1, i
             hipLaunchKernelGGL(nn_distance_unpack_kernel, dim3(ceil_div((long long)c2, 256)), dim3(256), 0, s,
                                (long long)c2, k2, dist2, idx2);
         if (count2 != nullptr && m > 0)
-            hipLaunchKernelGGL(nn_distance_expand_kernel, dim3(ceil_div(m, 256), b), dim3(256), 0, s, m, count2, row_src2, dist2, idx2);
+            hipLaunchKernelGGL(nn_distance_expand_kernel, dim3(ceil_div(m, 256), b), dim3(256), 0, s, m, count2, row_src2, xyz2,
+                               CLOUDAAE_KNOB("CLOUDAAE_NN_PREFIX_VERIFY", 0), dist2, idx2);
         CLOUDAAE_CHECK_LAUNCH(name);
         if (keys != nullptr)
             CLOUDAAE_CHECK_HIP(hipFreeAsync(keys, s), name);
@@ -909,7 +918,8 @@ static int nn_distance_impl(const char *name, int b, int n, const float *xyz1, i
         hipLaunchKernelGGL(nn_distance_kernel<1>, grid, block, 0, s, n, m, xyz1, xyz2, dist1, idx1,
                            dist2, idx2, t1, count2);
     if (count2 != nullptr && m > 0)
-        hipLaunchKernelGGL(nn_distance_expand_kernel, dim3(ceil_div(m, 256), b), dim3(256), 0, s, m, count2, row_src2, dist2, idx2);
+        hipLaunchKernelGGL(nn_distance_expand_kernel, dim3(ceil_div(m, 256), b), dim3(256), 0, s, m, count2, row_src2, xyz2,
+                               CLOUDAAE_KNOB("CLOUDAAE_NN_PREFIX_VERIFY", 0), dist2, idx2);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }

@@ -15,7 +15,7 @@ void set_error(const char *fmt, ...)
 }
 } // namespace cloudaae
 
-CLOUDAAE_API int cloudaae_version(void) { return 300; }
+CLOUDAAE_API int cloudaae_version(void) { return CLOUDAAE_ABI_VERSION; }
 
 // ---- development knobs (common.h) ---------------------------------------------------------------------
 #include <stdlib.h>

@@ -248,7 +248,10 @@ class TrainGraph(object):
         # whose sum needs n == m, exactly as in the reference)
         visiblePoints_org_final = org[:, 0:N * 4, :].contiguous()
         # the on-line synthesis says which rows of the target are distinct points and which are re-draws of them
-        # (hidden_point_removal.py:38-43): the nearest-neighbour search then visits the distinct points only
+        # (hidden_point_removal.py:38-43): the nearest-neighbour search then visits the distinct points only.  The two
+        # keys must still describe 'visiblePoints_org' as it is here: a pipeline that reorders or perturbs the target
+        # after hidden_point_removal_org drops them (a row whose source is not a distinct row comes back as a NaN
+        # distance; CLOUDAAE_NN_PREFIX_VERIFY=1 also compares every copy with its original)
         count2 = row_src2 = None
         if element.get('visiblePoints_org_src') is not None and element.get('num_vis_point_org') is not None:
             count2 = element['num_vis_point_org'].to(torch.int64).contiguous()
@@ -292,7 +295,7 @@ class TrainGraph(object):
     def _step(self, element):
         L = _lib.lib()
         s = stream()
-        # gradients of the fully connected stack are stored whole by its grouped kernels (batch <= 32):
+        # gradients of the fully connected stack are stored whole by its grouped kernels (batch <= 128):
         # only the encoder's slots (split-K products add into them) are cleared
         self.store.begin_step(zero_grads=True, zero_limit=self._zero_limit)
         if self.bn_sync is not None:

@@ -243,20 +243,21 @@ def fc_max_group():
     return int(L().cloudaae_fc_max_group())
 
 
-def _fc_scratch(K, N, bn, dev):
-    """(tickets, partials) of one forward layer of csrc/fc.hip: arrival counters of its column tiles (zero before
-    and after every launch) and room for the partial tiles of its K slices, which the last slice to arrive sums
-    in slice order -- the forward pass is bit-reproducible from run to run.  (None, None) when K stays whole."""
-    n = int(L().cloudaae_fc_forward_partials(int(K), int(N), int(bool(bn))))
+def _fc_scratch(M, K, N, bn, dev):
+    """(tickets, partials) of one forward layer of csrc/fc.hip: arrival counters of its column / row tiles (zero before
+    and after every launch) and room for the partial tiles of its K slices and row tiles, which the last to arrive sums
+    in a fixed order -- the forward pass is bit-reproducible from run to run.  (None, None) when one workgroup per
+    column tile finishes the layer."""
+    n = int(L().cloudaae_fc_forward_partials(int(M), int(K), int(N), int(bool(bn))))
     if n == 0:
         return None, None
-    return (_lib.zeros(L().cloudaae_fc_forward_tickets(int(N)), dtype=torch.int32, device=dev),
+    return (_lib.zeros(L().cloudaae_fc_forward_tickets(int(M), int(N)), dtype=torch.int32, device=dev),
             _lib.empty(n, dtype=torch.float32, device=dev))
 
 
 class FcFn(torch.autograd.Function):
     """tf_util.fully_connected as a whole (utils/tf_util.py:321-365): matmul + bias [+ batch norm + ReLU]
-    for a batch of at most 32 rows, one launch forward and one backward (csrc/fc.hip)."""
+    for a batch of at most 128 rows, one launch forward and one backward (csrc/fc.hip)."""
 
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, ema_mean, ema_var, decay, training, relu):
@@ -274,11 +275,11 @@ class FcFn(torch.autograd.Function):
             save_var = _lib.empty(N, dtype=torch.float32, device=dev)
         # a product cut over K is summed in slice order by its last slice (bit-reproducible forward pass):
         # arrival counters of the column tiles (zero before and after every launch) + the slices' partial tiles
-        tickets, partials = _fc_scratch(K, N, bn, dev)
+        tickets, partials = _fc_scratch(M, K, N, bn, dev)
         y = _lib.empty((M, N), dtype=torch.float32, device=dev)
         _lib.check(L().cloudaae_fc_forward(
             M, K, N, xp, ldx, ptr(w), ptr(b), ptr(gamma), ptr(beta), int(bool(training)), ptr(decay), ptr(ema_mean),
-            ptr(ema_var), ptr(save_mean), ptr(save_var), int(bool(relu)), ptr(y), ptr(out), 0, ptr(tickets),
+            ptr(ema_var), ptr(save_mean), ptr(save_var), int(bool(relu)), ptr(y), ptr(out), ptr(tickets),
             ptr(partials), 0 if partials is None else partials.numel(), stream()), "cloudaae_fc_forward")
         ctx.save_for_backward(x, w, y if bn else None, gamma, beta, save_mean, save_var)
         ctx.cfg = (int(bool(training)), int(bool(relu)))
@@ -317,7 +318,7 @@ class FcFn(torch.autograd.Function):
 
 
 class FcGroupFn(torch.autograd.Function):
-    """Several independent fully connected layers of one batch (<= 32 rows) in ONE launch per direction
+    """Several independent fully connected layers of one batch (<= 128 rows) in ONE launch per direction
     (cloudaae_fc_forward_group / _backward_group): depth by depth, the decoder and the two pose heads
     (models/pointnet_ycb_23_decoder_4.py:413-455).
 
@@ -350,7 +351,7 @@ class FcGroupFn(torch.autograd.Function):
                 save_mean = _lib.empty(N, dtype=torch.float32, device=dev)
                 save_var = _lib.empty(N, dtype=torch.float32, device=dev)
             # a product cut over K is summed in slice order by its last slice (see _fc_scratch)
-            tickets, partials = _fc_scratch(K, N, bn, dev)
+            tickets, partials = _fc_scratch(M, K, N, bn, dev)
             l = layers[i]
             l.K, l.N, l.x, l.ldx, l.w, l.bias = K, N, xp, ldx, ptr(w), ptr(b)
             l.gamma, l.beta, l.ema_mean, l.ema_var = ptr(gamma), ptr(beta), ptr(ema_mean), ptr(ema_var)
@@ -362,7 +363,7 @@ class FcGroupFn(torch.autograd.Function):
                 l.out_rowvec, l.out_rowvec_d = ptr(rowvecs[i]), int(rowvecs[i].shape[1])
             outs.append(out if bn else y)
             keep.append((y if bn else None, save_mean, save_var, tickets, partials))
-        _lib.check(L().cloudaae_fc_forward_group(M, len(per), layers, int(bool(training)), ptr(decay), 0, stream()),
+        _lib.check(L().cloudaae_fc_forward_group(M, len(per), layers, int(bool(training)), ptr(decay), stream()),
                    "cloudaae_fc_forward_group")
         ctx.cfg, ctx.xs, ctx.per, ctx.keep, ctx.fwd_layers = cfg, xs, per, keep, layers
         return tuple(outs)

@@ -71,7 +71,10 @@ def hidden_point_removal(x, seed=0, rows=None):
 
 def hidden_point_removal_org(x, seed=0, rows=None):
     # (+ 'visiblePoints_org_src': the row each row of the Chamfer target equals -- an extra key the train step hands
-    #  to the nearest-neighbour search, which then looks at the distinct points only)
+    #  to the nearest-neighbour search, which then looks at the distinct points only.  The key describes THESE rows:
+    #  a pipeline that shuffles, subsamples or perturbs 'visiblePoints_org' afterwards must drop the key (or the
+    #  Chamfer loss is computed against rows that no longer are what the key says; CLOUDAAE_NN_PREFIX_VERIFY=1 makes
+    #  cloudaae_nn_distance_prefix check every copy against its original and return NaN distances on a mismatch))
     x['visiblePoints_org'], x['num_vis_point_org'], x['visiblePoints_org_src'] = convexHull(
         x['flippedPoints_org'], x['orgPoints_org'], seed + 1, rows=rows, return_src=True)
     return x

@@ -197,7 +197,7 @@ def fully_connected(inputs,
     weights, biases, gamma, beta, ema_mean, ema_var = _fc_variables(
         scope, inputs.shape[-1], num_outputs, bn, use_xavier=use_xavier, stddev=stddev, weight_decay=weight_decay,
         trainable=trainable)
-    # a batch of <= 32 clouds: the whole layer is one launch (not with SyncBN in training mode: the moments
+    # a batch of <= 128 clouds (cloudaae_fc_max_rows): the whole layer is one launch (not with SyncBN in training mode: the moments
     # leave for the other ranks between the product and the normalisation)
     if F.fc_fits(inputs.shape[0]) and not (bn and is_training and F.BN_SYNC is not None):
         require(bn or not act, "fully_connected: ReLU without batch norm does not occur in CloudAAE")
@@ -237,7 +237,7 @@ def _fc_variables(scope, num_inputs, num_outputs, bn, use_xavier=True, stddev=1e
 def fully_connected_chains(inputs, chains, bn_decay=None, is_training=None, point_outputs=None):
     """Several independent chains of fully_connected layers over one input -- the decoder and the two
     pose heads of models/pointnet_ycb_23_decoder_4.py:413-455 -- evaluated depth by depth: with a batch of
-    <= 32 clouds the layers of one depth share a launch per direction (F.FcGroupFn), otherwise each layer
+    <= 128 clouds the layers of one depth share a launch per direction (F.FcGroupFn), otherwise each layer
     runs as fully_connected() does.  chains: list of chains; a chain is a list of
     (scope, num_outputs, bn) with ReLU exactly on the bn layers.  Variables are created chain by chain,
     i.e. in the order separate fully_connected() calls would create them.  Returns the chain outputs.

@@ -160,7 +160,7 @@ class VariableStore(object):
         fill, so that the split-K weight-gradient products of the step can add into it directly
         instead of each clearing its own output first (a dozen tiny fills per step).  zero_limit: clear
         only the first zero_limit elements -- the slots beyond belong to layers whose gradient kernels
-        store every element (the fully connected stack at batch <= 32: 63 of the 65 MB)."""
+        store every element (the fully connected stack at batch <= 128: 63 of the 65 MB)."""
         zeroed = bool(zero_grads) and self.flat_grads is not None
         limit = self.flat_grads.numel() if (zeroed and zero_limit is None) else (int(zero_limit) if zeroed else 0)
         if zeroed and limit > 0:

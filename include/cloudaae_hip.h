@@ -41,6 +41,11 @@ extern "C" {
 
 typedef void *cloudaae_stream_t; /* hipStream_t */
 
+/* The ABI revision this header describes: argument lists and struct layouts.  A caller built against another
+ * revision must not call in -- check cloudaae_version() == CLOUDAAE_ABI_VERSION after loading (the Python host
+ * does, cloudaae_amd/_lib.py).  500: round 5 (fully connected entry points take up to 128 rows; tickets / partials
+ * queries take M; no y_zeroed argument). */
+#define CLOUDAAE_ABI_VERSION 500
 int cloudaae_version(void);
 const char *cloudaae_last_error(void);
 /* Development knobs (kernel A/B choices and launch shapes for tests and sweeps; none is needed in normal use):
@@ -88,7 +93,10 @@ int cloudaae_nn_distance(int b, int n, const float *xyz1, int m, const float *xy
  * row j >= count2[c], the row < count2[c] it is a bitwise copy of (cloudaae_hidden_point_removal_rows writes both).
  * Results are those of cloudaae_nn_distance bit for bit ("first index wins" puts every answer among the originals; a
  * copy's own answer is its original's), at the cost of the distinct points only.  count2[c] outside (0, m]: all m rows
- * are searched.  Both NULL: cloudaae_nn_distance. */
+ * are searched.  Both NULL: cloudaae_nn_distance.  A copy row whose row_src2 is not a distinct row (< 0, >= count2[c]) gets
+ * dist2 = NaN and idx2 = 0 -- every output element is written; the development knob CLOUDAAE_NN_PREFIX_VERIFY = 1 also
+ * compares every copy with its original bit for bit (NaN on a mismatch): the hint is only valid for targets that are still
+ * what cloudaae_hidden_point_removal_rows wrote (no shuffle, slice beyond the rows, or augmentation in between). */
 int cloudaae_nn_distance_prefix(int b, int n, const float *xyz1, int m, const float *xyz2, const long long *count2,
                                 const int *row_src2, float *dist1, int *idx1, float *dist2, int *idx2,
                                 cloudaae_stream_t stream);
@@ -401,30 +409,29 @@ int cloudaae_colsum_f32(int M, int C, const float *x, int ldx, float *out, int a
 
 /* tf_util.fully_connected (utils/tf_util.py:321-365: tf.matmul :351, bias_add :352, batch_norm_for_fc
  * :355, activation :358) as ONE launch per direction when the rows are the clouds of a batch of at
- * most cloudaae_fc_max_rows() (= 32): the decoder and pose heads of
+ * most cloudaae_fc_max_rows() (= 128: four 32-row MFMA tiles): the decoder and pose heads of
  * models/pointnet_ycb_23_decoder_4.py:413-455.  Larger batches take cloudaae_gemm_f32 + cloudaae_bn_*.
  *
  * forward: y[M,N] = x[M,K] w[K,N] + bias (bias may be NULL); with gamma != NULL also the batch norm of
  * y (arguments as cloudaae_bn_forward) into out[M,N], y keeping the pre-normalisation values the
- * backward needs.  gamma == NULL: no batch norm, only y is written.  y_zeroed != 0: y is known to hold
- * zeros (a product cut over K adds its slices into it; otherwise the call clears it first).
- * tickets: cloudaae_fc_forward_tickets(N) ints holding ZERO, left zero by the call (arrival counters
- * that let a layer WITH batch norm be cut over K: the last slice to arrive normalises the column tile);
- * NULL = such a layer keeps K whole in one workgroup per 128 columns (slower).
- * partials: cloudaae_fc_forward_partials(K, N, gamma != NULL) floats of scratch (any contents), or NULL;
+ * backward needs.  gamma == NULL: no batch norm, only y is written.
+ * tickets: cloudaae_fc_forward_tickets(M, N) ints holding ZERO, left zero by the call (arrival counters:
+ * the product is cut over K -- and over 32-row tiles of the batch -- across workgroups; the last to
+ * arrive at a column tile sums the pieces and, with batch norm, normalises the column tile);
+ * partials: cloudaae_fc_forward_partials(M, K, N, gamma != NULL) floats of scratch (any contents);
  * partials_floats: the floats behind it (the call fails if this launch's cut needs more -- the cut is derived again
  * at every launch, also from development knobs).
- * With tickets AND partials a product cut over K is summed in a FIXED slice order by the last slice to
- * arrive: the layer is bit-reproducible from run to run (and y need not be cleared).  Without partials
- * the slices add into y with fp32 atomics: results then differ by round-off between runs.
+ * The pieces are summed in a FIXED order by the last to arrive: the layer is bit-reproducible from run
+ * to run.  With tickets or partials NULL a layer keeps K whole in one workgroup per column tile and
+ * row tile (slower; batch norm over more than 32 rows is then refused).
  * Two calls in flight at the same time (different streams) need separate counters and scratch. */
 int cloudaae_fc_max_rows(void);
-int cloudaae_fc_forward_tickets(int N);
-long long cloudaae_fc_forward_partials(int K, int N, int batch_norm);
+int cloudaae_fc_forward_tickets(int M, int N);
+long long cloudaae_fc_forward_partials(int M, int K, int N, int batch_norm);
 int cloudaae_fc_forward(int M, int K, int N, const float *x, int ldx, const float *w, const float *bias,
                         const float *gamma, const float *beta, int training, const float *decay,
                         float *ema_mean, float *ema_var, float *save_mean, float *save_var, int relu,
-                        float *y, float *out, int y_zeroed, int *tickets, float *partials,
+                        float *y, float *out, int *tickets, float *partials,
                         long long partials_floats, cloudaae_stream_t stream);
 /* backward of the same layer from dout[M,N] (gradient of `out`, or of y when gamma == NULL):
  *   dx[M,K] += d(y) w^T      (ADDED with fp32 atomics: pass zeros, or a buffer that other consumers
@@ -471,7 +478,7 @@ typedef struct cloudaae_fc_layer {
 } cloudaae_fc_layer;
 int cloudaae_fc_max_group(void);
 int cloudaae_fc_forward_group(int M, int count, const cloudaae_fc_layer *layers, int training,
-                              const float *decay, int y_zeroed, cloudaae_stream_t stream);
+                              const float *decay, cloudaae_stream_t stream);
 int cloudaae_fc_backward_group(int M, int count, const cloudaae_fc_layer *layers, int training,
                                cloudaae_stream_t stream);
 

@@ -504,3 +504,44 @@ def test_nn_distance_filter_kernel_adversarial(hip, oracle, case, knobs):
     got = tf_nndistance.nn_distance(_dev(a), _dev(c))
     for w, g_ in zip(want, got):
         assert np.array_equal(w, g_.cpu().numpy())
+
+
+def test_nn_distance_prefix_broken_hint_is_loud(hip, knobs):
+    """A caller that breaks the contract of cloudaae_nn_distance_prefix: a copy row whose row_src is not a
+    distinct row gets dist2 = NaN, idx2 = 0 -- never the output buffer's old contents, never an index the gradient
+    kernels could follow out of bounds; with CLOUDAAE_NN_PREFIX_VERIFY = 1 a copy that is not bitwise its original
+    (a target shuffled after the synthesis) is flagged the same way."""
+    from cloudaae_amd import _lib
+    L = _lib.lib()
+    b, n, m, k = 2, 512, 640, 200
+    rng = np.random.default_rng(9)
+    base = rng.standard_normal((b, k, 3)).astype(np.float32)
+    pick = rng.integers(0, k, (b, m - k))
+    target = np.concatenate([base, np.take_along_axis(base, pick[:, :, None].repeat(3, 2), 1)], 1)
+    src = np.concatenate([np.tile(np.arange(k), (b, 1)), pick], 1).astype(np.int32)
+    src[0, k + 3], src[1, k + 7], src[1, m - 1] = -1, k, m + 100          # not distinct rows
+    pred = rng.standard_normal((b, n, 3)).astype(np.float32)
+    p, t, sd = _dev(pred), _dev(target), torch.from_numpy(src).cuda()
+    count = torch.full((b,), k, dtype=torch.int64, device="cuda")
+    d1 = torch.empty((b, n), device="cuda"); i1 = torch.empty((b, n), dtype=torch.int32, device="cuda")
+
+    def run():
+        d2 = torch.full((b, m), 123.0, device="cuda"); i2 = torch.full((b, m), 1 << 30, dtype=torch.int32, device="cuda")
+        _lib.check(L.cloudaae_nn_distance_prefix(b, n, p.data_ptr(), m, t.data_ptr(), count.data_ptr(), sd.data_ptr(),
+                                                 d1.data_ptr(), i1.data_ptr(), d2.data_ptr(), i2.data_ptr(), _lib.stream()),
+                   "nn_distance_prefix")
+        return d2.cpu().numpy(), i2.cpu().numpy()
+    d2, i2 = run()
+    bad = np.zeros((b, m), dtype=bool)
+    bad[0, k + 3] = bad[1, k + 7] = bad[1, m - 1] = True
+    assert np.isnan(d2[bad]).all() and (i2[bad] == 0).all()
+    assert not np.isnan(d2[~bad]).any() and (i2 >= 0).all() and (i2 < n).all()
+    # a copy that is no longer its original
+    t[0, k + 11] += 1.0
+    d2, _ = run()
+    assert not np.isnan(d2[0, k + 11])                    # (trusted without the knob)
+    knobs("CLOUDAAE_NN_PREFIX_VERIFY", 1)
+    d2, i2 = run()
+    bad[0, k + 11] = True
+    assert np.isnan(d2[bad]).all() and (i2[bad] == 0).all() and not np.isnan(d2[~bad]).any()
+
