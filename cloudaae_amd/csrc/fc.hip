@@ -659,7 +659,9 @@ struct FcBwdGroup {
 };
 
 // One workgroup (four waves) = (128-column slice of the output, group of 32-row tiles of W), all RT row tiles of the batch.
-// parts = 1: a wave does both products of a tile (fewest atomics: the wide output layer);
+// parts = 1: a wave does both products of a tile (the wide output layer);
+// parts = 2: the same tiles, but waves 0, 1 write dW and waves 2, 3 gather dX: the two streams (W read + atomics, dW
+//            written) run side by side on different SIMDs instead of one after the other in every wave;
 // parts = 4: the four waves share a tile -- dW columns 0..63 | 64..127, dX over columns 0..63 | 64..127 --
 //            for the layers whose whole backward is a few hundred tiles (one tile per workgroup, every
 //            workgroup resident at once).
@@ -676,15 +678,19 @@ __device__ __forceinline__ void fc_bwd_body(const FcBwdArgs &a, int slice_x, int
     const int t_end = min(ktiles, (group_y + 1) * a.tiles_per_block);
     // one row tile, a tile per wave, W in whole quads: the first tile's operands are requested NOW
     constexpr bool STAGED = VEC && RT == 1;
-    const bool ahead = STAGED && a.parts == 1;
-    const int t_first = group_y * a.tiles_per_block + wv;
+    const bool ahead = STAGED && a.parts <= 2;
+    // parts = 2: waves 0, 1 write dW and waves 2, 3 gather dX, each pair over the workgroup's tiles alternately
+    const int role = a.parts == 2 ? wv >> 1 : -1;       // -1: both products
+    const int t_first = group_y * a.tiles_per_block + (a.parts == 2 ? (wv & 1) : wv);
+    const int t_step = a.parts == 2 ? 2 : 4;
+    const bool do_dw = a.dw != nullptr && role != 1, do_dx = a.dx != nullptr && role != 0;
     float4v wq[STAGED ? 2 : 1][8];
     float xa0[16 * RT];
     if constexpr (STAGED) {
         if (ahead && t_first < t_end) {
-            if (a.dx != nullptr)
+            if (do_dx)
                 fc_bwd_w_load(a, t_first * 32, n0, lane, wq);
-            if (a.dw != nullptr)
+            if (do_dw)
                 fc_bwd_dw_load<RT>(a, t_first * 32, r32, half, xa0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -795,21 +801,21 @@ __device__ __forceinline__ void fc_bwd_body(const FcBwdArgs &a, int slice_x, int
     }
     FC_STAMP(1);
 
-    if (a.parts == 1) {
-        for (int t = t_first; t < t_end; t += 4) {
+    if (a.parts <= 2) {
+        for (int t = t_first; t < t_end; t += t_step) {
             if constexpr (STAGED) {
                 if (t != t_first) {
-                    if (a.dx != nullptr)
+                    if (do_dx)
                         fc_bwd_w_load(a, t * 32, n0, lane, wq);
-                    if (a.dw != nullptr)
+                    if (do_dw)
                         fc_bwd_dw_load<RT>(a, t * 32, r32, half, xa0);
                 }
-                if (a.dw != nullptr)
+                if (do_dw)
                     fc_bwd_dw<VEC, 4, RT>(a, dyl, t * 32, n0 + 4 * r32, 4 * r32, half, xa0);
-                if (a.dx != nullptr)
+                if (do_dx)
                     fc_bwd_dx_staged(a, dyl, patches + wv * (FC_ROWS * FC_WLD), t * 32, r32, half, lane, wq);
             } else {
-                if (a.dw != nullptr) {
+                if (do_dw) {
                     fc_bwd_dw_load<RT>(a, t * 32, r32, half, xa0);
                     fc_bwd_dw<VEC, 4, RT>(a, dyl, t * 32, n0 + 4 * r32, 4 * r32, half, xa0);
                 }
@@ -817,7 +823,7 @@ __device__ __forceinline__ void fc_bwd_body(const FcBwdArgs &a, int slice_x, int
                 // and the second workgroup of the CU hides the trip to memory better than they would)
                 if (RT > 1)
                     __builtin_amdgcn_sched_barrier(0);
-                if (a.dx != nullptr)
+                if (do_dx)
                     fc_bwd_dx<VEC, 16, RT>(a, dyl, t * 32, n0, 0, r32, half);
                 if (RT > 1)
                     __builtin_amdgcn_sched_barrier(0);
@@ -870,10 +876,11 @@ static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 
 // Column tiles, row tiles and K slices of one forward layer.  Four waves per workgroup, each with at least sixteen
-// k; K is cut into slices until the chip is covered.  These products are short chains of load -> MFMA: what they need
-// is every load of the layer in flight at once, i.e. many workgroups -- but every slice costs the last arrival of its
-// column tile one more partial tile to read back, so a layer with batch norm (whose last arrival finishes ALL rows of
-// the column tile) takes 64-column tiles and fewer slices.
+// k.  These products are short chains of load -> MFMA: what they need is every load of the layer in flight at once,
+// i.e. many workgroups -- but every slice costs its column tile a publish / ticket / read-back episode of 5-7 us
+// (profiles/r05_fc_phases_first.log) whose length grows with the slices, so K is cut sparingly: a layer with batch
+// norm (whose last arrival finishes ALL rows of the column tile) takes 64-column tiles and about 64 workgroups, the
+// wide output layer 128-column tiles and about 256 (measured: profiles/r05_fc_fwd_block_sweep.log).
 struct FcFwdPlan {
     int cq, tiles, rts, splits, kslice, units, blocks, combine;
 };
@@ -883,7 +890,7 @@ static FcFwdPlan fc_fwd_plan(int M, int K, int N, bool bn, bool no_scratch)
     p.rts = ceil_div(M, FC_ROWS);
     p.cq = bn ? CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_CQ_BN", 2) : CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_CQ_PLAIN", 4);
     p.cq = p.cq == 2 ? 2 : 4;
-    const int want = bn ? CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_BLOCKS_BN", 128) : CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_BLOCKS", 512);
+    const int want = bn ? CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_BLOCKS_BN", 64) : CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_BLOCKS", 256);
     const int forced = CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_SPLITS", 0);
     p.tiles = ceil_div(N, 32 * p.cq);
     int splits = want / (p.tiles * p.rts);
@@ -1029,7 +1036,7 @@ CLOUDAAE_API int cloudaae_fc_backward_group(int M, int count, const cloudaae_fc_
         FcBwdArgs &a = g.p[i];
         a.M = M; a.K = l.K; a.N = l.N; a.ldx = l.ldx; a.lddo = l.lddo; a.lddx = l.lddx; a.tiles_per_block = tpb;
         a.acc_dw = l.accumulate_dw; a.acc_pg = l.accumulate_param_grads; a.training = training; a.relu = l.relu;
-        a.block0 = blocks; a.slices = slices; a.parts = fine ? 4 : 1;
+        a.block0 = blocks; a.slices = slices; a.parts = fine ? 4 : (CLOUDAAE_KNOB("CLOUDAAE_FC_BWD_ROLES", 1) ? 2 : 1);
         a.vec = l.N % 4 == 0 && aligned16(l.w) && (l.dw == nullptr || aligned16(l.dw));
         a.x = l.x; a.w = l.w; a.y = l.y; a.gamma = l.gamma; a.beta = l.beta; a.save_mean = l.save_mean;
         a.save_var = l.save_var; a.dout = l.dout; a.dx = l.dx; a.dw = l.dw; a.dgamma = l.dgamma;

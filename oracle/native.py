@@ -37,7 +37,7 @@ _ref = None
 def lib():
     global _lib
     if _lib is None:
-        p = os.path.join(_HERE, "liboracle.so")
+        p = os.environ.get("CLOUDAAE_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")   # (env: the sanitizer build)
         if not os.path.exists(p):
             build()
         _lib = ctypes.CDLL(p)
