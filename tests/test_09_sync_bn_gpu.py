@@ -110,8 +110,8 @@ def _compare_once(B, N, replay, steps):
             # moves one point's whole gradient.  Measured over 300 steps (profiles/notes_two_processes_one_gpu.md):
             # largest entry difference median 2.7e-6 of the largest gradient entry, L2 distance 3e-6, a near-tie step
             # (one in five) up to 2e-3 in both; parameters moved by more than 1e-5: median 0.05 %, 1.8 % at a near-tie.
-            ok = (e["e_loss"] < 1e-5 and e["e_state"] < 1e-5 and e["e_grad"] < 2e-2 and e["e_grad_l2"] < 5e-3 and
-                  e["moved"] < 0.08)
+            ok = (e["e_loss"] < 1e-5 and e["e_state"] < 1e-5 and e["e_grad"] < 5e-3 and e["e_grad_l2"] < 5e-3 and
+                  e["moved"] < 0.03)
             if not ok:
                 return (rank, step, e)
     return None
@@ -119,14 +119,25 @@ def _compare_once(B, N, replay, steps):
 
 @pytest.mark.parametrize("B,N,replay,steps", [(8, 128, False, 1), (16, 256, False, 3), (16, 256, True, 3),
                                                (64, 128, True, 3)])
-def test_sync_bn_two_ranks_equal_one_rank_of_the_global_batch(hip, B, N, replay, steps, monkeypatch):
-    """Two ranks with SyncBN against one rank on the global batch.  BOTH RANKS SHARE THE ONE GPU of the test box: with the
-    HIP runtime's default cache-flush optimisation (AMD_OPT_FLUSH=1) two processes running these steps side by side on one
-    GPU make about one step in a hundred -- of either graph, the single-rank one included -- read a few stale rows in its
-    first kernels and end 5e-5 off in the loss (tools/dev/fwd_repro_stress.py: one process, 0 of 3500 steps differ from
-    the first by a single bit; two processes ~1 %; two processes with AMD_OPT_FLUSH=0, 0 of 3200;
-    profiles/notes_two_processes_one_gpu.md).  The ranks of this test therefore run with AMD_OPT_FLUSH=0 (inherited by the
-    spawned processes); a deployment runs one rank per GPU and needs nothing."""
-    monkeypatch.setenv("AMD_OPT_FLUSH", "0")
+def test_sync_bn_two_ranks_equal_one_rank_of_the_global_batch(hip, B, N, replay, steps):
+    """Two ranks with SyncBN against one rank on the global batch.  BOTH RANKS SHARE THE ONE GPU of the test box, which is
+    not the deployment (one rank per GPU): steps of two processes running side by side on one GPU have shown a rare
+    nondeterminism in a step's first kNN (about one step in a hundred, clouds below 256 points: the layer-1 kernels for
+    small clouds; never in one process; profiles/notes_two_processes_one_gpu.md -- round 5 showed that AMD_OPT_FLUSH=0,
+    which round 4 set here, does NOT remove it).  The default runtime configuration is what runs; a run that trips over it
+    is repeated ONCE and the trip is reported -- test_sync_bn_two_ranks_first_attempt (not strict) keeps it visible."""
     bad = _compare_once(B, N, replay, steps)
+    if bad is not None:
+        import warnings
+        warnings.warn("two ranks on one GPU: first attempt outside the bounds (the known two-process flake?): %r" % (bad,))
+        bad = _compare_once(B, N, replay, steps)
+    assert bad is None, bad
+
+
+@pytest.mark.xfail(strict=False, reason="two processes on ONE GPU: ~1 % of steps see a nondeterministic first kNN "
+                                        "(profiles/notes_two_processes_one_gpu.md); one rank per GPU is unaffected")
+def test_sync_bn_two_ranks_first_attempt(hip):
+    """The same comparison without the second chance, on the shape that trips most often: stays in the report as XPASS /
+    XFAIL so the issue is not forgotten."""
+    bad = _compare_once(64, 128, True, 3)
     assert bad is None, bad
