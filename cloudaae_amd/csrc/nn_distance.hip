@@ -217,13 +217,74 @@ __global__ __launch_bounds__(NN_THREADS) void nn_distance_kernel(
 //     NaN: every comparison false) still take that full scan.
 // Results are the reference's bit for bit; 2 MFMA + ~13 VALU instructions per 1024 pairs instead of
 // ~140.
+//
+// Round 5: the scores on the BF16 matrix pipe (template SPLIT).  v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate and
+// shares its datapath with the vector ALU: the digest of a tile (the minima, the top three) ADDS to the matrix time
+// (profiles/r05_mfma_valu_overlap.txt).  v_mfma_f32_32x32x16_bf16 is its own pipe -- vector instructions of the same wave
+// overlap it -- and does sixteen products per output element in half the cycles.  Every centred coordinate is split
+// exactly into three bfloat16 pieces v = h + m + l (round to nearest even; 3 x 8 significand bits), the query pieces
+// pre-multiplied by -2 (exact), and a score is the sum over 21 of the 32 K-slots of two such MFMAs:
+//     MFMA 1:  Ch.Qh  Ch.Qm  Cm.Qh  Cm.Qm  (3 coordinates each)   |b'|^2 as its three pieces x 1
+//     MFMA 2:  Ch.Ql  Cl.Qh
+// i.e. every piece product of weight >= 2^-16; each product of two bfloat16 is exact in fp32.  What a score can be off the
+// exact |b'|^2 - 2 a'.b' of the centred fp32 values: the dropped pieces (m.l, l.m, l.l: <= 2^-22 |a'||b'| <= 1 unit of
+// 2^-24 R), the rounding of |b'|^2 itself (3 units), and the accumulation inside the two MFMAs -- 21 non-zero terms and
+// the carried sum; charged here with ONE FULL ULP of R per K-slot (truncating alignment, 2 units each: 64 units), which is
+// far above what the hardware shows (tests/test_00_ops_gpu.py::test_nn_distance_split_score_error measures <= 4 units).
+// With the translation (4) and the reference's own rounding (4) two candidates whose scores differ by more than
+// 2 * (1 + 3 + 64 + 4 + 4) = 152 units are ordered the same way by the reference: M = 160 * 2^-24 * R (five times the
+// fp32 form's margin: still ~1e-6 of R against neighbour gaps of 1e-4 R, the second pass stays a rarity).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 nf_bf16x8 __attribute__((ext_vector_type(8)));
+
+// v = h + m + l exactly (|v| below the overflow threshold of bfloat16; infinities and NaN give non-finite pieces and
+// scores, which take the full scan)
+__device__ __forceinline__ void nf_split3(float v, __bf16 &h, __bf16 &m, __bf16 &l)
+{
+    h = (__bf16)v;
+    const float r1 = v - (float)h;
+    m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    l = (__bf16)r2;
+}
+// K-slots of MFMA 1:  0-2 Ch.Qh | 3-5 Ch.Qm | 6-8 Cm.Qh | 9-11 Cm.Qm | 12-14 the pieces of |b'|^2 x 1 | 15 nothing
+// K-slots of MFMA 2:  0-2 Ch.Ql | 3-5 Cl.Qh | 6-15 nothing
+// A operands of a candidate row (centred x, y, z and |b'|^2): a1lo / a1hi = k 0-7 / 8-15 of MFMA 1, a2lo = k 0-7 of MFMA 2
+__device__ __forceinline__ void nf_split_candidate(float x, float y, float z, float bb, bool padding, nf_bf16x8 &a1lo,
+                                                   nf_bf16x8 &a1hi, nf_bf16x8 &a2lo)
+{
+    __bf16 xh, xm, xl, yh, ym, yl, zh, zm, zl, nh, nm, nl;
+    nf_split3(x, xh, xm, xl);
+    nf_split3(y, yh, ym, yl);
+    nf_split3(z, zh, zm, zl);
+    nf_split3(bb, nh, nm, nl);
+    const __bf16 zero = (__bf16)0.0f;
+    if (padding) {      // (|b'|^2 = +inf: inf - inf would make its lower pieces NaN)
+        nm = zero;
+        nl = zero;
+    }
+    a1lo = nf_bf16x8{xh, yh, zh, xh, yh, zh, xm, ym};
+    a1hi = nf_bf16x8{zm, xm, ym, zm, nh, nm, nl, zero};
+    a2lo = nf_bf16x8{xh, yh, zh, xl, yl, zl, zero, zero};
+}
+// B operands of a query (centred a'): this lane's k = 8 half .. 8 half + 7 of the two MFMAs
+__device__ __forceinline__ void nf_split_query(float ax, float ay, float az, int half, nf_bf16x8 &b1, nf_bf16x8 &b2)
+{
+    __bf16 xh, xm, xl, yh, ym, yl, zh, zm, zl;
+    nf_split3(-2.0f * ax, xh, xm, xl);
+    nf_split3(-2.0f * ay, yh, ym, yl);
+    nf_split3(-2.0f * az, zh, zm, zl);
+    const __bf16 one = (__bf16)1.0f, zero = (__bf16)0.0f;
+    b1 = half ? nf_bf16x8{zh, xm, ym, zm, one, one, one, zero} : nf_bf16x8{xh, yh, zh, xm, ym, zm, xh, yh};
+    b2 = half ? nf_bf16x8{zero, zero, zero, zero, zero, zero, zero, zero} : nf_bf16x8{xl, yl, zl, xh, yh, zh, zero, zero};
+}
 
 constexpr int NF_QT = 2;            // query tiles (32 queries each) per wave (4: 208 VGPRs, two waves per SIMD, 116 us at
                                     // [32,4096]^2 and 186 us at [32,16384]x[32,1024]; 2: 109 VGPRs, four waves: 111 / 149 us; 1: 115 us)
 constexpr int NF_WAVES = 4;
 constexpr int NF_QBLOCK = NF_WAVES * NF_QT * 32;   // queries per workgroup
 constexpr int NF_CHUNK = 2048;      // candidates per LDS chunk: 64 tiles x 64 lanes x 8 bytes = 32 KiB
+constexpr int NF_CHUNK_SPLIT = 1024; // the split form stages 48 bytes per candidate: 32 tiles x (64 + 32) lanes x 16 bytes = 48 KiB
 
 __device__ __forceinline__ bool key_less(unsigned d, int i, unsigned bd, int bi)
 {
@@ -281,6 +342,7 @@ struct NfTop {
     }
 };
 
+template <bool SPLIT>
 __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
     int n, int m, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
     float *__restrict__ dist1, int *__restrict__ idx1, float *__restrict__ dist2,
@@ -293,7 +355,13 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
     // order like the values, and equal distances resolve to the lower index, the reference's first-wins rule.
     // A cloud pair of very unequal sizes (the reference's own benchmark: 16384 x 1024 points) otherwise leaves
     // the few workgroups that own the short side's queries scanning the whole long side alone.
-    __shared__ float2v cand[NF_CHUNK / 32 + 1][64];     // (+1: the pipeline reads one tile ahead)
+    constexpr int CHUNK = SPLIT ? NF_CHUNK_SPLIT : NF_CHUNK;
+    // fp32 form: float2 per lane and tile; split form: the A operands of MFMA 1 (64 lanes) and of MFMA 2 (its k = 8 .. 15
+    // are zeros: 32 lanes), 16 bytes each.  (+1 tile: the pipeline reads one ahead)
+    __shared__ __attribute__((aligned(16))) char cand_raw[SPLIT ? (CHUNK / 32 + 1) * 96 * 16 : (CHUNK / 32 + 1) * 64 * 8];
+    float2v (*cand)[64] = reinterpret_cast<float2v (*)[64]>(cand_raw);
+    nf_bf16x8 (*cand2)[32] = reinterpret_cast<nf_bf16x8 (*)[32]>(cand_raw);
+    nf_bf16x8 (*cand1)[64] = reinterpret_cast<nf_bf16x8 (*)[64]>(cand_raw + (CHUNK / 32 + 1) * 32 * 16);
     __shared__ float bmax_s[NF_WAVES];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -317,13 +385,14 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
     if (blk * NF_QBLOCK >= nq)
         return;                                         // (a query block of copies only)
     // this workgroup's candidate range
-    const int range = ((nc + split - 1) / split + NF_CHUNK - 1) / NF_CHUNK * NF_CHUNK;
+    const int range = ((nc + split - 1) / split + NF_CHUNK - 1) / NF_CHUNK * NF_CHUNK;     // (the host's cut: multiples of NF_CHUNK)
     const int cbeg = min(part * range, nc), cend = min(cbeg + range, nc);
     if (cbeg >= cend)
         return;                                         // (an empty trailing range)
 
     const float cx = to[0], cy = to[1], cz = to[2];
     float qx[NF_QT], qy[NF_QT], qz[NF_QT], b0[NF_QT], b1[NF_QT], a2[NF_QT];
+    nf_bf16x8 B1[NF_QT], B2[NF_QT];      // split form: the B operands (this lane's k = 8 half .. 8 half + 7)
     NfTop top[NF_QT];
 #pragma unroll
     for (int q = 0; q < NF_QT; ++q) {
@@ -335,11 +404,31 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
         a2[q] = ax * ax + ay * ay + az * az;
         b0[q] = half ? -2.0f * ay : -2.0f * ax;
         b1[q] = half ? 1.0f : -2.0f * az;
+        if (SPLIT)
+            nf_split_query(ax, ay, az, half, B1[q], B2[q]);
         top[q].init();
     }
 
     // scores of one candidate tile for the wave's NF_QT query tiles: 2 MFMAs each
     auto issue = [&](f32x16 (&acc)[NF_QT], int t) {
+        if (SPLIT) {
+            const nf_bf16x8 A1 = cand1[t][lane];
+            nf_bf16x8 A2 = cand2[t][c32];
+            if (half)
+                A2 = nf_bf16x8{(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
+#pragma unroll
+            for (int q = 0; q < NF_QT; ++q) {
+                f32x16 zero;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    zero[r] = 0.0f;
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1[q], zero, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < NF_QT; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2[q], acc[q], 0, 0, 0);
+            return;
+        }
         const float2v A = cand[t][lane];
 #pragma unroll
         for (int q = 0; q < NF_QT; ++q) {
@@ -353,16 +442,9 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
         for (int q = 0; q < NF_QT; ++q)
             acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, b1[q], acc[q], 0, 0, 0);
     };
-    // The digest of a tile (8 v_min3 per query tile; the insertion into the top three once per PAIR of
-    // tiles) is NOT hidden behind the MFMAs of the next one: measured, the loop costs the matrix time
-    // (78 us at B=32, 4096^2, 70 % of the pipe) PLUS the VALU time whether the two are interleaved by
-    // hand, left to two waves per SIMD, or both -- so the VALU work is what gets minimised.
-    float run[NF_QT];
+    // one chunk of candidates into LDS as MFMA A operands (lane r of a tile: row r; padding rows never win)
     float bmax2 = 0.0f;
-    for (int c0 = cbeg; c0 < cend; c0 += NF_CHUNK) {
-        const int cnt = min(NF_CHUNK, cend - c0);
-        const int padded = (cnt + 31) & ~31;
-        __syncthreads();
+    auto stage = [&](int c0, int cnt, int padded, bool track) {
         for (int k = tid; k < padded + 32; k += NF_WAVES * 64) {
             float x = 0.0f, y = 0.0f, z = 0.0f, bb = __builtin_inff();     // padding never wins
             if (k < cnt) {
@@ -371,25 +453,61 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
                 y = p[1] - cy;
                 z = p[2] - cz;
                 bb = x * x + y * y + z * z;
-                bmax2 = fmaxf(bmax2, bb);
+                if (track)
+                    bmax2 = fmaxf(bmax2, bb);
             }
-            // MFMA A operand: lane r holds k = 0 of row r, lane 32 + r holds k = 1
-            cand[k >> 5][k & 31] = float2v{x, z};
-            cand[k >> 5][32 + (k & 31)] = float2v{y, bb};
+            if (SPLIT) {
+                nf_bf16x8 lo, hi, lo2;
+                nf_split_candidate(x, y, z, bb, !(k < cnt), lo, hi, lo2);
+                cand1[k >> 5][k & 31] = lo;
+                cand1[k >> 5][32 + (k & 31)] = hi;
+                cand2[k >> 5][k & 31] = lo2;
+            } else {
+                // MFMA A operand: lane r holds k = 0 of row r, lane 32 + r holds k = 1
+                cand[k >> 5][k & 31] = float2v{x, z};
+                cand[k >> 5][32 + (k & 31)] = float2v{y, bb};
+            }
         }
+    };
+    // The digest of a tile (8 v_min3 per query tile; the insertion into the top three once per PAIR of
+    // tiles) is NOT hidden behind the MFMAs of the next one: measured, the loop costs the matrix time
+    // (78 us at B=32, 4096^2, 70 % of the pipe) PLUS the VALU time whether the two are interleaved by
+    // hand, left to two waves per SIMD, or both -- so the VALU work is what gets minimised.
+    float run[NF_QT];
+    for (int c0 = cbeg; c0 < cend; c0 += CHUNK) {
+        const int cnt = min(CHUNK, cend - c0);
+        const int padded = (cnt + 31) & ~31;
+        __syncthreads();
+        stage(c0, cnt, padded, true);
         __syncthreads();
         const int ntile = padded >> 5, t0 = c0 >> 5;
         f32x16 accA[NF_QT], accB[NF_QT];
         issue(accA, 0);
         for (int t = 0; t < ntile; t += 2) {
             issue(accB, t + 1);             // (tile ntile is all padding: inf scores)
+            // SPLIT: nf_min3 is inline assembly, which the compiler's hazard recogniser does not see: it neither counts the
+            // wait states an XDL result needs before a vector instruction may read it (v_mfma_f32_32x32x16_bf16: 11) nor
+            // keeps its scheduler from putting the v_min3 of an accumulator right behind the MFMA that writes it -- which
+            // it did: stale reads, a few wrong answers per thousand, different in every launch.  (The fp32 matrix
+            // instruction of the other form is not an XDL operation and is interlocked.)  The order is pinned here: the
+            // minima of one accumulator pair are taken after the 2 NF_QT MFMAs of the OTHER pair have been issued, i.e. at
+            // least three MFMA issue slots (96 cycles) after its own last MFMA; the digest still overlaps the matrix pipe
+            // through the other waves of the SIMD.
+            if (SPLIT)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < NF_QT; ++q)
                 run[q] = nf_min16(__builtin_inff(), accA[q]);
+            if (SPLIT)
+                __builtin_amdgcn_sched_barrier(0);
             issue(accA, min(t + 2, ntile));
+            if (SPLIT)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < NF_QT; ++q)
                 top[q].push(nf_min16(run[q], accB[q]), (t0 + t) >> 1);
+            if (SPLIT)
+                __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -425,7 +543,7 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
         const float r = sqrtf(a2[q]) + rb;
         // (+ an absolute floor: below ~1e-37 the matrix cores may flush denormal terms, so relative bounds
         // mean nothing there and such clouds always take the full scan)
-        const float margin = 32.0f * 5.9604645e-8f * (r * r) + 1e-36f;
+        const float margin = (SPLIT ? 160.0f : 32.0f) * 5.9604645e-8f * (r * r) + 1e-36f;
         // only the two best units can hold a candidate within the margin of the best score?
         const bool decided = g.s3 > g.s1 + margin;      // false for NaN / overflow as well
 
@@ -482,27 +600,21 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
                 theta[q] = -__builtin_inff();
             }
         } else {
-            for (int c0 = cbeg; c0 < cend; c0 += NF_CHUNK) {
-                const int cnt = min(NF_CHUNK, cend - c0);
+            for (int c0 = cbeg; c0 < cend; c0 += CHUNK) {
+                const int cnt = min(CHUNK, cend - c0);
                 const int padded = (cnt + 31) & ~31;
                 __syncthreads();
-                for (int k = tid; k < padded + 32; k += NF_WAVES * 64) {
-                    float x = 0.0f, y = 0.0f, z = 0.0f, bb = __builtin_inff();
-                    if (k < cnt) {
-                        const float *p = to + (size_t)(c0 + k) * 3;
-                        x = p[0] - cx;
-                        y = p[1] - cy;
-                        z = p[2] - cz;
-                        bb = x * x + y * y + z * z;
-                    }
-                    cand[k >> 5][k & 31] = float2v{x, z};
-                    cand[k >> 5][32 + (k & 31)] = float2v{y, bb};
-                }
+                stage(c0, cnt, padded, false);
                 __syncthreads();
                 const int ntile = padded >> 5;
                 for (int t = 0; t < ntile; ++t) {
                     f32x16 acc[NF_QT];
                     issue(acc, t);              // the same instructions on the same operands: the same scores
+                    if (SPLIT) {                // (the wait states of the XDL results, by hand: see the first pass)
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_nop 15");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
 #pragma unroll
                     for (int q = 0; q < NF_QT; ++q) {
                         const float tm = nf_min16(__builtin_inff(), acc[q]);
@@ -589,6 +701,47 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
                 idx[j] = ki;
             }
         }
+    }
+}
+
+// Development / test entry (cloudaae_dev_nn_split_scores): the split scores of up to 32 queries against up to 32 candidates,
+// built by the SAME operand functions and MFMAs as nn_distance_filter_kernel<true>, next to R = (|a'| + max |b'|)^2 per
+// query -- what tests/test_00_ops_gpu.py compares with float64 to show how far inside the margin's accumulation charge
+// the hardware stays.
+__global__ __launch_bounds__(64) void nn_split_scores_kernel(int nq, int nc, const float *__restrict__ from,
+                                                             const float *__restrict__ to, float *__restrict__ scores,
+                                                             float *__restrict__ R)
+{
+    const int lane = threadIdx.x, c32 = lane & 31, half = lane >> 5;
+    const float cx = to[0], cy = to[1], cz = to[2];
+    // candidate row c32 (A operand), query column c32 (B operand)
+    const int kc = min(c32, nc - 1), jq = min(c32, nq - 1);
+    const float x = to[3 * kc] - cx, y = to[3 * kc + 1] - cy, z = to[3 * kc + 2] - cz;
+    const float bb = c32 < nc ? x * x + y * y + z * z : __builtin_inff();
+    nf_bf16x8 a1lo, a1hi, a2lo, b1, b2;
+    nf_split_candidate(c32 < nc ? x : 0.0f, c32 < nc ? y : 0.0f, c32 < nc ? z : 0.0f, bb, !(c32 < nc), a1lo, a1hi, a2lo);
+    const float ax = from[3 * jq] - cx, ay = from[3 * jq + 1] - cy, az = from[3 * jq + 2] - cz;
+    nf_split_query(ax, ay, az, half, b1, b2);
+    const nf_bf16x8 zero8 = {(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        acc[r] = 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(half ? a1hi : a1lo, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(half ? zero8 : a2lo, b2, acc, 0, 0, 0);
+    float bmax = c32 < nc ? bb : 0.0f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        bmax = fmaxf(bmax, __shfl_xor(bmax, off, 64));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;      // candidate
+        if (row < nc && c32 < nq)
+            scores[c32 * 32 + row] = acc[r];
+    }
+    if (half == 0 && c32 < nq) {
+        const float rr = sqrtf(ax * ax + ay * ay + az * az) + sqrtf(bmax);
+        R[c32] = rr * rr;
     }
 }
 
@@ -881,8 +1034,13 @@ static int nn_distance_impl(const char *name, int b, int n, const float *xyz1, i
             k1 = keys;
             k2 = keys + c1;
         }
-        hipLaunchKernelGGL(nn_distance_filter_kernel, dim3(t1 * s1 + t2 * s2, b), dim3(NF_WAVES * 64), 0, s, n, m, xyz1,
-                           xyz2, dist1, idx1, dist2, idx2, t1 * s1, s1, s2, k1, k2, count2);
+        // scores on the bf16 matrix pipe (three-piece split, round 5) unless the knob asks for the fp32 matrix instruction
+        if (CLOUDAAE_KNOB("CLOUDAAE_NN_SPLIT_SCORES", 1) != 0)
+            hipLaunchKernelGGL(nn_distance_filter_kernel<true>, dim3(t1 * s1 + t2 * s2, b), dim3(NF_WAVES * 64), 0, s, n, m, xyz1,
+                               xyz2, dist1, idx1, dist2, idx2, t1 * s1, s1, s2, k1, k2, count2);
+        else
+            hipLaunchKernelGGL(nn_distance_filter_kernel<false>, dim3(t1 * s1 + t2 * s2, b), dim3(NF_WAVES * 64), 0, s, n, m, xyz1,
+                               xyz2, dist1, idx1, dist2, idx2, t1 * s1, s1, s2, k1, k2, count2);
         if (c1)
             hipLaunchKernelGGL(nn_distance_unpack_kernel, dim3(ceil_div((long long)c1, 256)), dim3(256), 0, s,
                                (long long)c1, k1, dist1, idx1);
@@ -920,6 +1078,16 @@ static int nn_distance_impl(const char *name, int b, int n, const float *xyz1, i
     if (count2 != nullptr && m > 0)
         hipLaunchKernelGGL(nn_distance_expand_kernel, dim3(ceil_div(m, 256), b), dim3(256), 0, s, m, count2, row_src2, xyz2,
                                CLOUDAAE_KNOB("CLOUDAAE_NN_PREFIX_VERIFY", 0), dist2, idx2);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+CLOUDAAE_API int cloudaae_dev_nn_split_scores(int nq, int nc, const float *queries, const float *candidates, float *scores,
+                                              float *R, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_dev_nn_split_scores";
+    CLOUDAAE_REQUIRE(nq >= 1 && nq <= 32 && nc >= 1 && nc <= 32 && queries && candidates && scores && R, name, "1 .. 32 points each");
+    hipLaunchKernelGGL(nn_split_scores_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, nq, nc, queries, candidates, scores, R);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;
 }

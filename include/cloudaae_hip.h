@@ -101,6 +101,13 @@ int cloudaae_nn_distance_prefix(int b, int n, const float *xyz1, int m, const fl
                                 const int *row_src2, float *dist1, int *idx1, float *dist2, int *idx2,
                                 cloudaae_stream_t stream);
 
+/* Development / test entry: the search scores of cloudaae_nn_distance's large-cloud kernel (|b'|^2 - 2 a'.b' of coordinates
+ * centred on candidates[0], as error-free three-piece bfloat16 split products on the bf16 matrix pipe) for nq <= 32 queries
+ * [nq,3] against nc <= 32 candidates [nc,3]: scores[q * 32 + c], and R[q] = (|a'_q| + max_c |b'_c|)^2, the quantity the
+ * kernel's decision margin 160 * 2^-24 * R is stated in.  Same operand construction and instructions as the kernel. */
+int cloudaae_dev_nn_split_scores(int nq, int nc, const float *queries, const float *candidates, float *scores, float *R,
+                                 cloudaae_stream_t stream);
+
 /* NnDistanceGrad.
  * Replaces: void NmDistanceGradKernelLauncher(int b,int n,const float* xyz1,int m,
  *   const float* xyz2,const float* grad_dist1,const int* idx1,const float* grad_dist2,

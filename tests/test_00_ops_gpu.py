@@ -1,6 +1,8 @@
 """GPU: tf_ops custom operators and kNN grouping through the C-ABI vs the oracle."""
 import os
 
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -544,4 +546,42 @@ def test_nn_distance_prefix_broken_hint_is_loud(hip, knobs):
     d2, i2 = run()
     bad[0, k + 11] = True
     assert np.isnan(d2[bad]).all() and (i2[bad] == 0).all() and not np.isnan(d2[~bad]).any()
+
+
+@pytest.mark.parametrize("scale,offset", [(0.05, (0.1, -0.2, 0.9)), (1.0, (0.0, 0.0, 0.0)), (1e-3, (5.0, -3.0, 40.0)),
+                                          (300.0, (1e3, 2e3, -5e2))])
+def test_nn_distance_split_score_error(hip, scale, offset):
+    """The large-cloud Chamfer kernel searches with scores |b'|^2 - 2 a'.b' computed as error-free three-piece bfloat16
+    split products on the bf16 matrix pipe (csrc/nn_distance.hip, round 5) and decides with a margin of 160 units of
+    2^-24 R, R = (|a'| + max |b'|)^2, of which 64 + 1 + 3 per score are charged to the arithmetic of the score.  Here the
+    scores of the same operand construction and instructions (cloudaae_dev_nn_split_scores) are compared with float64 on
+    the centred fp32 coordinates: the hardware must stay inside that charge -- it stays far inside (a few units)."""
+    from cloudaae_amd import _lib
+    L = _lib.lib()
+    L._cdll.cloudaae_dev_nn_split_scores.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5
+    rng = np.random.default_rng(int(scale * 1000) % 997)
+    worst = 0.0
+    for rep in range(40):
+        q = (rng.standard_normal((32, 3)) * scale + offset).astype(np.float32)
+        c = (rng.standard_normal((32, 3)) * scale + offset).astype(np.float32)
+        if rep % 4 == 1:
+            c[5:9] = q[5:9]                     # exact hits
+        if rep % 4 == 2:
+            c[:, 2] = c[0, 2]                   # a flat cloud
+        qd, cd = _dev(q), _dev(c)
+        sc = torch.full((32, 32), float("nan"), device="cuda")
+        R = torch.empty(32, device="cuda")
+        _lib.check(L._cdll.cloudaae_dev_nn_split_scores(32, 32, qd.data_ptr(), cd.data_ptr(), sc.data_ptr(), R.data_ptr(),
+                                                         _lib.stream()), "dev_nn_split_scores")
+        torch.cuda.synchronize()
+        a = (q - c[0]).astype(np.float64)       # the centred fp32 values, exactly (fp32 subtraction, then widened)
+        b = (c - c[0]).astype(np.float64)
+        want = (b * b).sum(1)[None, :] - 2.0 * a @ b.T
+        Rw = (np.sqrt((a * a).sum(1)) + np.sqrt((b * b).sum(1)).max()) ** 2
+        got, Rg = sc.cpu().numpy().astype(np.float64), R.cpu().numpy().astype(np.float64)
+        assert np.allclose(Rg, Rw, rtol=1e-5)
+        units = np.abs(got - want) / (2.0 ** -24 * Rw[:, None])
+        worst = max(worst, float(units.max()))
+    print("largest score error: %.2f units of 2^-24 R" % worst)
+    assert worst <= 8.0, worst                   # (charged in the margin: 68)
 
