@@ -409,6 +409,26 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
         top[q].init();
     }
 
+    // split form, in halves (the first pass interleaves the digest of the other accumulator pair with the second half)
+    auto issue_first = [&](f32x16 (&acc)[NF_QT], int t) {
+        const nf_bf16x8 A1 = cand1[t][lane];
+#pragma unroll
+        for (int q = 0; q < NF_QT; ++q) {
+            f32x16 zero;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                zero[r] = 0.0f;
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1[q], zero, 0, 0, 0);
+        }
+    };
+    auto issue_second = [&](f32x16 (&acc)[NF_QT], int t) {
+        nf_bf16x8 A2 = cand2[t][c32];
+        if (half)
+            A2 = nf_bf16x8{(__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f, (__bf16)0.0f};
+#pragma unroll
+        for (int q = 0; q < NF_QT; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2[q], acc[q], 0, 0, 0);
+    };
     // scores of one candidate tile for the wave's NF_QT query tiles: 2 MFMAs each
     auto issue = [&](f32x16 (&acc)[NF_QT], int t) {
         if (SPLIT) {
@@ -483,31 +503,43 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
         const int ntile = padded >> 5, t0 = c0 >> 5;
         f32x16 accA[NF_QT], accB[NF_QT];
         issue(accA, 0);
+        if (SPLIT)
+            __builtin_amdgcn_sched_barrier(0);
         for (int t = 0; t < ntile; t += 2) {
-            issue(accB, t + 1);             // (tile ntile is all padding: inf scores)
-            // SPLIT: nf_min3 is inline assembly, which the compiler's hazard recogniser does not see: it neither counts the
-            // wait states an XDL result needs before a vector instruction may read it (v_mfma_f32_32x32x16_bf16: 11) nor
-            // keeps its scheduler from putting the v_min3 of an accumulator right behind the MFMA that writes it -- which
-            // it did: stale reads, a few wrong answers per thousand, different in every launch.  (The fp32 matrix
-            // instruction of the other form is not an XDL operation and is interlocked.)  The order is pinned here: the
-            // minima of one accumulator pair are taken after the 2 NF_QT MFMAs of the OTHER pair have been issued, i.e. at
-            // least three MFMA issue slots (96 cycles) after its own last MFMA; the digest still overlaps the matrix pipe
-            // through the other waves of the SIMD.
-            if (SPLIT)
+            if (SPLIT) {
+                // nf_min3 is inline assembly, which the compiler's hazard recogniser does not see: it neither counts the
+                // wait states an XDL result needs before a vector instruction may read it (v_mfma_f32_32x32x16_bf16: 11)
+                // nor keeps its scheduler from putting the v_min3 of an accumulator right behind the MFMA that writes it
+                // -- which it did: stale reads, a few wrong answers per thousand, different in every launch.  (The fp32
+                // matrix instruction of the other form is not an XDL operation and is interlocked.)  The order is pinned
+                // in four groups; inside a group the scheduler is free, and what a group reads was written at least one
+                // whole group of NF_QT independent MFMAs (>= 64 cycles) earlier:
+                //   1  first MFMAs of B          2  second MFMAs of B  |  minima of A (last written in group 4)
+                //   3  first MFMAs of the next A  4  second MFMAs of A  |  minima of B (last written in group 2), push
+                issue_first(accB, t + 1);       // (tile ntile is all padding: inf scores)
                 __builtin_amdgcn_sched_barrier(0);
+                issue_second(accB, t + 1);
+#pragma unroll
+                for (int q = 0; q < NF_QT; ++q)
+                    run[q] = nf_min16(__builtin_inff(), accA[q]);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_first(accA, min(t + 2, ntile));
+                __builtin_amdgcn_sched_barrier(0);
+                issue_second(accA, min(t + 2, ntile));
+#pragma unroll
+                for (int q = 0; q < NF_QT; ++q)
+                    top[q].push(nf_min16(run[q], accB[q]), (t0 + t) >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
+            issue(accB, t + 1);             // (tile ntile is all padding: inf scores)
 #pragma unroll
             for (int q = 0; q < NF_QT; ++q)
                 run[q] = nf_min16(__builtin_inff(), accA[q]);
-            if (SPLIT)
-                __builtin_amdgcn_sched_barrier(0);
             issue(accA, min(t + 2, ntile));
-            if (SPLIT)
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < NF_QT; ++q)
                 top[q].push(nf_min16(run[q], accB[q]), (t0 + t) >> 1);
-            if (SPLIT)
-                __builtin_amdgcn_sched_barrier(0);
         }
     }
 

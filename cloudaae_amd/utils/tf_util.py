@@ -252,6 +252,8 @@ def fully_connected_chains(inputs, chains, bn_decay=None, is_training=None, poin
             for scope, num_outputs, bn in chain:
                 net, _, _ = fully_connected(net, num_outputs, scope, bn=bn, is_training=is_training,
                                             bn_decay=bn_decay, activation_fn=relu if bn else None)
+                if FC_TAP is not None:
+                    FC_TAP[scope] = net
             outs.append(net)
         return outs
     variables = []
@@ -291,7 +293,15 @@ def fully_connected_chains(inputs, chains, bn_decay=None, is_training=None, poin
         outs = F.FcGroupFn.apply(cfg, decay, *(xs + flat))
         for i, o in zip(members, outs):
             nets[i] = o
+            if FC_TAP is not None:
+                FC_TAP[chains[i][d][0]] = o
     return nets
+
+
+# Debugging / test aid: a dict that fully_connected_chains fills with scope -> output of every layer it evaluates (the
+# tensors the next layer reads: arena buffers of a recorded step stay valid afterwards).  tests/test_03_configs_gpu.py
+# takes the activation pattern of the fully connected stack from it; None (the default) = nothing is kept.
+FC_TAP = None
 
 
 def _relu_rows(x):

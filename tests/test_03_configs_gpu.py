@@ -129,7 +129,13 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype, kn):
                     scalars=[float(graph.batch), float(graph.beta1_power), float(graph.beta2_power),
                              float(graph.bn_decay)])
 
-    rec = run()                                   # the recording pass (eager issue, arena buffers)
+    from cloudaae_amd.utils import tf_util
+    tf_util.FC_TAP = {}
+    try:
+        rec = run()                               # the recording pass (eager issue, arena buffers)
+        fc_on = {scope: (t.detach() > 0).cpu() for scope, t in tf_util.FC_TAP.items()}
+    finally:
+        tf_util.FC_TAP = None
     assert graph.replay and graph._plan is not None and not graph._plan.foreign_ops, "step not replayable"
     _restore(graph, start)
     rep = run()                                   # the replayed pass: what bench.py times
@@ -176,10 +182,25 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype, kn):
     # ---- the oracle's iteration, grouped on the GPU's indices ----
     p0 = {n: p.detach().clone() for n, p in V.p.items()}
     MO.GEMM_BF16 = MO.ACT_BF16 = bf16       # (bf16 mode: dgcnn_agg's y is stored as bfloat16, F.ACT_BF16)
+    # ... and, for the units of the fully connected stack that sit on the ReLU's corner (|normalised value| < 1e-4: a coin
+    # toss between two correct fp32 implementations, worth 1 / B of a column's gradient each -- found at B = 128: one unit
+    # of dgcnn_rot_fc2, column 237 3.6 % off and every other column at 1e-7, tools/dev/chk_cfg3_rot.py), on the GPU's side
+    # of the corner; everywhere else the two activation patterns must be equal (the oracle asserts it)
+    MO.RELU_OVERRIDE = {s_: m for s_, m in fc_on.items() if s_ + "/bn/gamma" in V.p}
+    MO.RELU_REPORT = []
+    tie0 = MO.RELU_TIE
+    if bf16:
+        MO.RELU_TIE = 3e-2          # (bf16 operands below the stack: its inputs agree to ~1e-3, not to round-off)
     try:
         ref, grads = MO.train_step(batch, V, opt, STEP0, N, B, k=kn, nn_override=rep["idx"])
+        took = [(s_, a_, c_) for s_, a_, c_ in MO.RELU_REPORT if c_]
+        print("%s: fully connected units within %.0e of the ReLU corner: %d, of which the oracle took the GPU's side: %s"
+              % (name, MO.RELU_TIE, sum(a_ for _, a_, _ in MO.RELU_REPORT), took or "none"))
+        assert len(MO.RELU_REPORT) >= 6, MO.RELU_REPORT          # the six batch-normalised layers were compared
     finally:
         MO.GEMM_BF16 = MO.ACT_BF16 = False
+        MO.RELU_OVERRIDE = MO.RELU_REPORT = None
+        MO.RELU_TIE = tie0
 
     ltol = 2e-3 if bf16 else 1e-5             # north star: fp32 Chamfer / pose losses within 1e-5
     for k in ("xyz_loss", "trans_loss", "axag_loss"):

@@ -57,3 +57,37 @@ def test_free_running_neighbour_sets_move_the_losses():
     assert flips > 0                          # a 1-ulp change flips near-ties of the grouping
     assert pinned < 2e-6, pinned
     assert free > 1e-5, free                  # more than the north-star tolerance: compare on the same neighbour sets
+
+
+def test_a_unit_on_the_relu_corner_moves_its_column():
+    """tf_util.fully_connected (utils/tf_util.py:321-365) = matmul + batch norm + ReLU over the B rows of the batch.  A unit
+    whose normalised value is within round-off of zero is a coin toss between two correct fp32 implementations; switching
+    it changes its column's bias-side gradient (d beta) by that unit's upstream gradient -- 1 / B of the column's sum, not
+    a round-off -- while d gamma (weighted by the normalised value, ~0) does not notice.  Shown on the oracle: the same
+    layer with one pre-activation moved from +1e-7 to -1e-7."""
+    B, K, N = 128, 64, 32
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, K, generator=g)
+    up = torch.randn(B, N, generator=g)
+
+    def grads(side):
+        V = MO.Vars(seed=2)
+        z = MO.fully_connected(x, N, "s", V, bn=True, is_training=True, bn_decay=0.5, relu=False)
+        # the same layer with the unit of column 7 that is nearest to the corner sitting at side * 1e-7 (a constant
+        # offset: the derivative is untouched)
+        r = int(z[:, 7].detach().abs().argmin())
+        delta = torch.zeros_like(z)
+        delta[r, 7] = float(side * 1e-7 - z[r, 7])
+        out = torch.relu(z + delta)
+        (out * up).sum().backward()
+        return V.p["s/bn/beta"].grad.clone(), V.p["s/bn/gamma"].grad.clone(), V.p["s/weights"].grad.clone(), r
+
+    bp, gp, wp, r = grads(+1.0)
+    bm, gm, wm, _ = grads(-1.0)
+    d_beta = (bp - bm).abs()
+    assert float(d_beta[7]) > 0.5 * abs(float(up[r, 7]))            # the unit's whole upstream gradient ...
+    others = torch.cat([d_beta[:7], d_beta[8:]])
+    assert float(others.max()) < 1e-4 * float(d_beta[7])            # ... in that column only
+    assert float((gp - gm).abs()[7]) < 0.05 * float(d_beta[7])      # and nearly invisible in d gamma (weighted by x_hat ~ 0)
+    col = (wp - wm).abs().max(0).values / wp.abs().max()
+    assert float(col[7]) > 1e-3 and float(torch.cat([col[:7], col[8:]]).max()) < 1e-6   # percent-level in ONE weight column
