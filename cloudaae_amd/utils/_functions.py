@@ -112,6 +112,20 @@ def gemm_is_bf16():
     return GEMM_DTYPE == "bf16"
 
 
+_X3_FALLBACKS = set()
+
+
+def _note_x3_fallback(M, N, K):
+    """gemm_dtype='bf16x3' is a request: a shape the split-product kernels do not serve (rows not a multiple of their
+    tiles, unaligned operands) runs on the fp32 matrix cores instead -- same accuracy class, but not what the run's label
+    says.  Said once per shape."""
+    if (M, N, K) not in _X3_FALLBACKS:
+        _X3_FALLBACKS.add((M, N, K))
+        import warnings
+        warnings.warn("cloudaae_amd: gemm_dtype='bf16x3' not available for the dgcnn_agg product [%d x %d] x [%d x %d]: "
+                      "using the fp32 matrix cores (cloudaae_gemm_f32)" % (M, K, K, N), RuntimeWarning)
+
+
 def gemm_is_x3():
     """GEMM_DTYPE "bf16x3" (TrainGraph's default): fp32 everywhere, but the three dgcnn_agg products run as split products on the bf16
     matrix cores (csrc/gemm_x3.hip: every operand element = three bfloat16 pieces, six piece products, fp32 accumulate --
@@ -554,6 +568,8 @@ class ConcatLinearFn(torch.autograd.Function):
                   bool(L().cloudaae_gemm_bf16x3p_supported(M, N, Ktot)) and
                   bool(L().cloudaae_gemm_bf16x3p_supported(M, Ktot, N)) and
                   bool(L().cloudaae_gemm_bf16x3_supported(1, 0, Ktot, N, M)))
+        if gemm_is_x3() and not ctx.x3:
+            _note_x3_fallback(M, N, Ktot)
         if ctx.x3:
             # the weight is split into its bfloat16 planes ONCE per step, for the forward and the input-gradient product
             pbytes = int(L().cloudaae_x3_planes_bytes(N, Ktot))

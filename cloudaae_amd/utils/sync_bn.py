@@ -53,9 +53,12 @@ class BnSync(object):
             # first BnSync over these ranks (ranks outside `group` included), in the same order relative to other
             # new_group calls.  Later BnSyncs over the same ranks reuse the communicator: no further collective, no leak.
             ranks = tuple(dist.get_process_group_ranks(group) if group is not None else range(dist.get_world_size()))
-            if ranks not in _OWN_GROUPS:
-                _OWN_GROUPS[ranks] = dist.new_group(ranks=list(ranks))
-            group = _OWN_GROUPS[ranks]
+            # (keyed by the default group as well: after destroy_process_group + init_process_group in one process --
+            # tests, notebooks, an elastic restart -- a handle made under the old default group is dead)
+            key = (id(dist.group.WORLD), ranks)
+            if key not in _OWN_GROUPS:
+                _OWN_GROUPS[key] = dist.new_group(ranks=list(ranks))
+            group = _OWN_GROUPS[key]
         self.group = group
         self.calls = 0               # all-reduces issued (tests and bench read it)
         self.error = None            # exception raised inside the callback (ctypes cannot propagate it)
