@@ -180,7 +180,69 @@ __device__ __forceinline__ void fc_fwd_body(const FcFwdArgs &a, int tile_x, int 
     };
 
     // two operand sets: the loads of one are in flight behind the MFMAs of the other
-    if (kw0 < kw1) {
+    if (VEC && kw0 < kw1) {
+        // The X operand in WHOLE LINES.  The fragment-shaped load above (a lane: 16 bytes of ITS row) touches 64 lines per
+        // instruction for 1 KB of operand -- eight times the bytes cross the L2 -> L1 path, and at 128 rows that is more
+        // traffic than W itself.  Here a wave brings 32 k of its 32 rows as four loads of 8 rows x 128 bytes, parks them in
+        // its own LDS patch (its slot of the partial-tile area, which is only written after the loop: wave-private, program
+        // order and the LDS counter are all the synchronisation needed) and takes the MFMA operand from there.
+        constexpr int XLD = 32 + 4;                  // floats per patch row
+        float *patch = tile + (size_t)wv * FC_ROWS * LD;
+        const int xr = lane >> 3, xc = 4 * (lane & 7);
+        const float *xline = a.x + (size_t)min(row0 + xr, a.M - 1) * a.ldx;
+        const size_t xstep = (size_t)8 * a.ldx;      // (rows past M: the last row again, never written)
+        const int rows_left = a.M - 1 - min(row0 + xr, a.M - 1);
+        auto xload = [&](float4v (&r)[4], int k) {
+            const int kq = min(k + xc, kw1 - 4);     // (a quad past the run: the run's last one, zeroed where it is consumed)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                r[i] = *reinterpret_cast<const float4v *>(xline + (8 * i <= rows_left ? i * xstep : (size_t)rows_left * a.ldx) + kq);
+        };
+        auto xpark = [&](const float4v (&r)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float4v *>(patch + (xr + 8 * i) * XLD + xc) = r[i];
+        };
+        auto loadw = [&](Set &st, int k) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ka = k + 8 * u + 4 * half;
+                const bool in = k + 8 * u < kw1;
+                const int kc = in ? ka : kb0;
+                st.in[u] = in;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    st.g[u].b[j] = fc_loadq<CQ, VEC>(wcol + (size_t)(kc + j) * a.N, wvalid, a.w);
+            }
+        };
+        auto frag = [&](Set &st, int klocal) {       // klocal: 0 or 16 inside the parked slab
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                st.g[u].a = *reinterpret_cast<const float4v *>(patch + r32 * XLD + klocal + 8 * u + 4 * half);
+        };
+        Set s0, s1;
+        float4v x0[4], x1[4];
+        xload(x0, kw0);
+        loadw(s0, kw0);
+        for (int k = kw0; k < kw1; k += 32) {
+            loadw(s1, k + 16);
+            xload(x1, k + 32);
+            __builtin_amdgcn_sched_barrier(0);
+            xpark(x0);
+            frag(s0, 0);
+            frag(s1, 16);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(s0);
+            __builtin_amdgcn_sched_barrier(0);
+            loadw(s0, k + 32);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(s1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                x0[i] = x1[i];
+        }
+    } else if (kw0 < kw1) {
         Set s0, s1;
         load(s0, kw0);
         for (int k = kw0; k < kw1; k += 32) {

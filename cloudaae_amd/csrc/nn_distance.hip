@@ -391,6 +391,8 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
         return;                                         // (an empty trailing range)
 
     const float cx = to[0], cy = to[1], cz = to[2];
+    // whole quads of candidates can be read as three 16-byte pieces (rows of 12 bytes: every fourth row starts one)
+    const bool to_quads = ((uintptr_t)to & 15) == 0 && (sc & 3) == 0;
     float qx[NF_QT], qy[NF_QT], qz[NF_QT], b0[NF_QT], b1[NF_QT], a2[NF_QT];
     nf_bf16x8 B1[NF_QT], B2[NF_QT];      // split form: the B operands (this lane's k = 8 half .. 8 half + 7)
     NfTop top[NF_QT];
@@ -585,16 +587,48 @@ __global__ __launch_bounds__(NF_WAVES * 64, 2) void nn_distance_filter_kernel(
         int ki = 0x7fffffff;
         const int unit = half ? g.u2 : g.u1;
         const int base = (unit >> 1) * 64 + 4 * (unit & 1);
+        if (to_quads) {
+            // four consecutive candidates are 48 contiguous, 16-byte aligned bytes: three dwordx4 loads per quad, four quads
+            // in flight (the scalar form below is 96 dependent-latency loads per unit in batches of twelve: measured, the
+            // exact evaluation was a quarter of the kernel)
+#pragma unroll
+            for (int g0 = 0; g0 < 8; g0 += 4) {
+                float4v v[4][3];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int kq = base + 8 * (g0 + g);
+                    const float4v *p = reinterpret_cast<const float4v *>(to + 3 * (size_t)(kq < cend ? kq : 0));
+                    v[g][0] = p[0];
+                    v[g][1] = p[1];
+                    v[g][2] = p[2];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float f[12] = {v[g][0].x, v[g][0].y, v[g][0].z, v[g][0].w, v[g][1].x, v[g][1].y, v[g][1].z, v[g][1].w,
+                                         v[g][2].x, v[g][2].y, v[g][2].z, v[g][2].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = base + 8 * (g0 + g) + e;
+                        const unsigned u = __float_as_uint(sqdist(f[3 * e], f[3 * e + 1], f[3 * e + 2], qx[q], qy[q], qz[q]));
+                        if (k < cend && u < kb) {       // ascending k: the first minimum stays
+                            kb = u;
+                            ki = k;
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll 4
-        for (int s = 0; s < 32; ++s) {
-            const int k = base + (s & 3) + 8 * (s >> 2);
-            if (k < cend) {
-                const float d = sqdist(to[3 * (size_t)k], to[3 * (size_t)k + 1], to[3 * (size_t)k + 2], qx[q],
-                                       qy[q], qz[q]);
-                const unsigned u = __float_as_uint(d);
-                if (u < kb) {       // ascending k: the first minimum stays
-                    kb = u;
-                    ki = k;
+            for (int s = 0; s < 32; ++s) {
+                const int k = base + (s & 3) + 8 * (s >> 2);
+                if (k < cend) {
+                    const float d = sqdist(to[3 * (size_t)k], to[3 * (size_t)k + 1], to[3 * (size_t)k + 2], qx[q],
+                                           qy[q], qz[q]);
+                    const unsigned u = __float_as_uint(d);
+                    if (u < kb) {       // ascending k: the first minimum stays
+                        kb = u;
+                        ki = k;
+                    }
                 }
             }
         }
