@@ -215,7 +215,11 @@ def test_batch_norm_pool(hip, pool):
 
 @pytest.mark.parametrize("B,N,cin,cout,k,pool", [(2, 256, 24, 64, 10, "mean"), (2, 200, 64, 64, 10, "mean"),
                                                  (3, 128, 64, 128, 10, "mean"), (2, 130, 64, 64, 20, "max"),
-                                                 (2, 100, 24, 128, 5, "max"), (1, 64, 64, 64, 32, "mean")])
+                                                 (2, 100, 24, 128, 5, "max"), (1, 64, 64, 64, 32, "mean"),
+                                                 # (clouds on every XCD / the model's N and k = 20; much larger cases put
+                                                 # single edges on the ReLU corner, where the two sides may differ by a
+                                                 # whole edge's gradient: tools/dev/chk_edgeconv_shapes.py counts them)
+                                                 (8, 512, 64, 64, 20, "mean"), (1, 1024, 64, 128, 20, "mean")])
 def test_edge_conv_fwd_bwd(hip, oracle, B, N, cin, cout, k, pool):
     from cloudaae_amd.utils import _functions as F
     from oracle import model_oracle as MO
