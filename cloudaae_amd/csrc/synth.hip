@@ -241,6 +241,111 @@ __global__ __launch_bounds__(HS_THREADS) void hpr_sort_kernel(int n1, const floa
     }
 }
 
+// The same counting sort on a 32 x 32 x 32 grid over the cloud's bounding box, cells in Morton order (round 5): consecutive
+// sorted points are neighbours in SPACE, whatever the shape of the cloud.  The cube map above sorts by direction from the
+// centroid; a flipped cloud is a thin, almost flat patch of a huge sphere (radius 10^2.5 x its distance) with its centroid
+// inside, so nearly all of its directions fall into the two rows of cells next to the patch's plane and a cell is a long
+// radial sliver -- fine as "some neighbours first", useless as a bounding volume (hpr_lp2d_wave_culled below).
+constexpr int HG_BITS = 5, HG_CELLS = 1 << (3 * HG_BITS);
+
+__device__ __forceinline__ unsigned hg_spread(unsigned v)          // 5 bits -> every third bit
+{
+    v &= 0x1fu;
+    v = (v | (v << 8)) & 0x100fu;
+    v = (v | (v << 4)) & 0x10c3u;
+    v = (v | (v << 2)) & 0x1249u;
+    return v;
+}
+
+__global__ __launch_bounds__(HS_THREADS) void hpr_sort_grid_kernel(int n1, const float *__restrict__ points,
+                                                                   float *__restrict__ sorted, int *__restrict__ perm)
+{
+    extern __shared__ int cell_cnt[];         // HG_CELLS counters
+    __shared__ float box[6][HS_THREADS / 64];
+    __shared__ int wsum[HS_THREADS / 64];
+    const float *P = points + (size_t)blockIdx.x * n1 * 3;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int q = t; q < n1; q += HS_THREADS)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = fminf(lo[c], P[3 * q + c]);
+            hi[c] = fmaxf(hi[c], P[3 * q + c]);
+        }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = fminf(lo[c], __shfl_xor(lo[c], off, 64));
+            hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], off, 64));
+        }
+    if (lane == 0)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            box[c][wave] = lo[c];
+            box[3 + c][wave] = hi[c];
+        }
+    for (int c = t; c < HG_CELLS; c += HS_THREADS)
+        cell_cnt[c] = 0;
+    __syncthreads();
+    float scale[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        for (int w = 0; w < HS_THREADS / 64; ++w) {
+            lo[c] = fminf(lo[c], box[c][w]);
+            hi[c] = fmaxf(hi[c], box[3 + c][w]);
+        }
+        const float ext = hi[c] - lo[c];
+        scale[c] = ext > 0.0f ? (float)(1 << HG_BITS) / ext : 0.0f;
+    }
+    auto cell_of = [&](int q) {
+        unsigned code = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int i = min((1 << HG_BITS) - 1, max(0, (int)((P[3 * q + c] - lo[c]) * scale[c])));
+            code |= hg_spread((unsigned)i) << c;
+        }
+        return (int)code;
+    };
+    for (int q = t; q < n1; q += HS_THREADS)
+        atomicAdd(&cell_cnt[cell_of(q)], 1);
+    __syncthreads();
+    // exclusive prefix over the cells: HG_CELLS / HS_THREADS consecutive cells per thread
+    constexpr int PER = HG_CELLS / HS_THREADS;
+    int local = 0;
+    for (int c = 0; c < PER; ++c)
+        local += cell_cnt[t * PER + c];
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d)
+            incl += o;
+    }
+    if (lane == 63)
+        wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - local;
+    for (int w = 0; w < wave; ++w)
+        run += wsum[w];
+    for (int c = 0; c < PER; ++c) {
+        const int n = cell_cnt[t * PER + c];
+        cell_cnt[t * PER + c] = run;
+        run += n;
+    }
+    __syncthreads();
+    float *S = sorted + (size_t)blockIdx.x * n1 * 3;
+    int *PM = perm + (size_t)blockIdx.x * n1;
+    for (int q = t; q < n1; q += HS_THREADS) {
+        const int pos = atomicAdd(&cell_cnt[cell_of(q)], 1);
+        PM[pos] = q;
+        S[3 * pos] = P[3 * q];
+        S[3 * pos + 1] = P[3 * q + 1];
+        S[3 * pos + 2] = P[3 * q + 2];
+    }
+}
+
 // constraint sequence of point `self` (sorted position): HPR_NEAR neighbours in sorted order, alternating
 // sides, then all OTHER positions in the order q = (p * stride) mod n1, stride ~ n1 / golden ratio and coprime
 // to n1: a permutation of [0, n1) whose every prefix is spread evenly over the (spatially sorted) cloud -- what
@@ -463,21 +568,319 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
     return true;
 }
 
+// ---- the same LP, the full scan replaced by CULLED verification passes (round 5) -----------------------------------
+// hpr_lp2d_wave pays n1 / 64 iterations of ~75 vector instructions for the scan behind the local problem -- per point,
+// although the plane it verifies is (almost always) already final and cuts a cap of the shell that only p's surroundings
+// come near.  Here the sorted cloud is cut into GROUPS of 64 consecutive points with their bounding boxes (hpr_group_boxes:
+// the spatial sort makes them compact).  After the local problem over the working set W = {the HPR_NEAR sorted-order
+// neighbours}:
+//   pass : every group's box against the plane under test, a lane per group: max over the box of d.(q - p) in fp32 at or
+//          below the (negative) margin of the point test proves every point of the group satisfied -- the group is culled.
+//          The points of the other groups take the point test of the scan above (fp32 with a margin, fp64 inside it),
+//          a lane per point, consecutive LDS addresses, no sequence arithmetic.
+//   a violated point q outside W: W += {q}, the optimum moves onto q's line by the 1-D problem over W (Seidel's step: the
+//          optimum of W + {q} lies on q's line; the members of W are never re-tested, as in the scan above: the optimum sits
+//          exactly on its binding constraints), and the pass starts again.  A pass without a violation proves the plane.
+// This is Seidel's algorithm with the constraints that never mattered left out of the 1-D problems: the optimum over W only
+// is what the passes verify against EVERY point, W only grows, and the answer (feasible or not) is that of the full LP.  At
+// most HPR_EXTRA points join W behind the neighbours; a point that needs more goes through hpr_lp2d_wave instead.
+#ifdef CLOUDAAE_HPR_STATS
+__device__ unsigned long long hpr_stats[8];   // points, local re-solves, passes, box iterations, groups scanned, joined, fallbacks, vertices
+#define HPR_COUNT(slot, v) do { if (lane == 0) atomicAdd(&hpr_stats[slot], (unsigned long long)(v)); } while (0)
+#else
+#define HPR_COUNT(slot, v) do { } while (0)
+#endif
+constexpr int HPR_GROUP = 64;
+constexpr int HPR_MAX_GROUPS = 12800 / HPR_GROUP;     // (150 KB of points: the entry point's limit)
+constexpr int HPR_EXTRA = 32;
+
+// Bounding volume of a group: a slab piece.  With m the group's mean and n a unit vector (the direction from the viewpoint
+// -- the normal of the flip sphere there; ANY n keeps the bound valid), every point of the group is m + h n + t with
+// h in [hlo, hhi] and t perpendicular to n, |t| <= rad: thin along n (relief + the patch's own sagitta), wide across.  For a
+// plane normal d:  max d.(q - m) <= max(hlo d.n, hhi d.n) + rad |d - (d.n) n|.  An axis-aligned box does not do: its top
+// corner stands above a tilted patch by slope x width, more than the cap a supporting plane cuts off a few groups away
+// (measured: 54 of 135 boxes survived a pass; the slabs: see profiles/notes_hull_vertex.md).
+struct HprGroups {              // LDS
+    float m[3][HPR_MAX_GROUPS], n[3][HPR_MAX_GROUPS], rad[HPR_MAX_GROUPS], hlo[HPR_MAX_GROUPS], hhi[HPR_MAX_GROUPS],
+        rmax[HPR_MAX_GROUPS];
+};
+
+template <int HPR_WAVES>
+__device__ __forceinline__ void hpr_group_slabs(const float *__restrict__ pts, int n1, int viewpoint, HprGroups &gb)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int groups = (n1 + HPR_GROUP - 1) / HPR_GROUP;
+    const float vx = pts[3 * viewpoint], vy = pts[3 * viewpoint + 1], vz = pts[3 * viewpoint + 2];
+    for (int g = wave; g < groups; g += HPR_WAVES) {
+        const int q = min(g * HPR_GROUP + lane, n1 - 1);       // (a short last group repeats its last point)
+        const float x = pts[3 * q], y = pts[3 * q + 1], z = pts[3 * q + 2];
+        float sx = x, sy = y, sz = z;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            sx += __shfl_xor(sx, off, 64);
+            sy += __shfl_xor(sy, off, 64);
+            sz += __shfl_xor(sz, off, 64);
+        }
+        const float mx = sx * (1.0f / 64.0f), my = sy * (1.0f / 64.0f), mz = sz * (1.0f / 64.0f);
+        float nx = mx - vx, ny = my - vy, nz = mz - vz;
+        const float len = sqrtf((nx * nx + ny * ny) + nz * nz);
+        if (len > 0.0f) {
+            nx /= len; ny /= len; nz /= len;
+        } else {
+            nx = 0.0f; ny = 0.0f; nz = 1.0f;
+        }
+        const float ex = x - mx, ey = y - my, ez = z - mz;
+        const float h = (nx * ex + ny * ey) + nz * ez;
+        const float r2 = (ex * ex + ey * ey) + ez * ez;
+        float t2 = r2 - h * h, r2max = r2, hmin = h, hmax = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            t2 = fmaxf(t2, __shfl_xor(t2, off, 64));
+            r2max = fmaxf(r2max, __shfl_xor(r2max, off, 64));
+            hmin = fminf(hmin, __shfl_xor(hmin, off, 64));
+            hmax = fmaxf(hmax, __shfl_xor(hmax, off, 64));
+        }
+        // rounded quantities, so every bound is widened: 1e-5 of the group's radius covers the fp32 evaluation of h and t
+        const float rmax = sqrtf(r2max) * 1.001f;
+        if (lane == 0) {
+            gb.m[0][g] = mx; gb.m[1][g] = my; gb.m[2][g] = mz;
+            gb.n[0][g] = nx; gb.n[1][g] = ny; gb.n[2][g] = nz;
+            gb.rmax[g] = rmax;
+            gb.rad[g] = sqrtf(fmaxf(t2, 0.0f) + 1e-5f * r2max) * 1.001f;
+            gb.hlo[g] = hmin - 1e-5f * rmax;
+            gb.hhi[g] = hmax + 1e-5f * rmax;
+        }
+    }
+}
+
+// returns 1 = vertex, 0 = not a vertex, -1 = more than HPR_EXTRA points joined the working set (the caller runs the scan)
+template <int HPR_NEAR>
+__device__ int hpr_lp2d_wave_culled(const float *__restrict__ pts, const HprGroups &gb, int *__restrict__ extras, int n1,
+                                    int self, const Frame &fr, int lane)
+{
+    double vx = HPR_TAN, vy = HPR_TAN;
+    const float pxf = (float)fr.px, pyf = (float)fr.py, pzf = (float)fr.pz;     // exact: p is a float
+    double dx, dy, dz;
+    float dxf, dyf, dzf, slack, ddf;
+    auto set_plane = [&]() {
+        dx = (fr.rx + vx * fr.ux) + vy * fr.wx;
+        dy = (fr.ry + vx * fr.uy) + vy * fr.wy;
+        dz = (fr.rz + vx * fr.uz) + vy * fr.wz;
+        dxf = (float)dx;
+        dyf = (float)dy;
+        dzf = (float)dz;
+        slack = -4e-6f * ((fabsf(dxf) + fabsf(dyf)) + fabsf(dzf));
+        ddf = (dxf * dxf + dyf * dyf) + dzf * dzf;
+    };
+    set_plane();
+    int n_extra = 0;
+    // member `pos` of the working set: the neighbours in sorted order, alternating sides, then the points that joined
+    auto member = [&](int pos) {
+        if (pos < HPR_NEAR) {
+            const int d = (pos >> 1) + 1;
+            int q = (pos & 1) ? self - d : self + d;
+            q = q < 0 ? q + n1 : (q >= n1 ? q - n1 : q);
+            return (q < 0 || q >= n1) ? n1 : q;             // (clouds smaller than the neighbourhood)
+        }
+        return extras[pos - HPR_NEAR];
+    };
+    // the point test of the scan: fp32 with a margin, fp64 inside it (see hpr_lp2d_wave)
+    double excess = 0.0;                        // of the last violated point: d.g + eps |g| (> 0)
+    auto violated = [&](int q) {
+        const float qx = pts[3 * q], qy = pts[3 * q + 1], qz = pts[3 * q + 2];
+        const float gxf = qx - pxf, gyf = qy - pyf, gzf = qz - pzf;
+        const float nrmf = (fabsf(gxf) + fabsf(gyf)) + fabsf(gzf);
+        const float v32 = (dxf * gxf + dyf * gyf) + dzf * gzf;
+        bool viol = false;
+        if (v32 > slack * nrmf) {
+            const double gx = (double)qx - fr.px, gy = (double)qy - fr.py, gz = (double)qz - fr.pz;
+            const double nrm = (fabs(gx) + fabs(gy)) + fabs(gz);
+            const double v = (dx * gx + dy * gy) + dz * gz;
+            viol = v > -HPR_EPS * nrm;
+            excess = v + HPR_EPS * nrm;
+        }
+        return viol;
+    };
+    // Seidel's step: the optimum moves onto the line of the violated constraint of point qv, by the 1-D problem over the
+    // first `upto` members of the working set; false = infeasible
+    auto resolve = [&](int qv, int upto) {
+        const Cons kf = hpr_constraint(pts, qv, fr);
+        const double ka = kf.a, kb = kf.b, kc = kf.c;
+        const double nn = ka * ka + kb * kb;
+        if (nn == 0.0)
+            return false;
+        const double p0x = ka * kc / nn, p0y = kb * kc / nn, ux = -kb, uy = ka;
+        Frac lo = {-1e300, 1.0}, hi = {1e300, 1.0};
+        bool bad = false;
+        auto add = [&](double ca, double cb, double cc) {
+            const double den = ca * ux + cb * uy, num = cc - (ca * p0x + cb * p0y);
+            if (den > 0.0) {
+                const Frac f = {num, den};
+                if (frac_less(f, hi))
+                    hi = f;
+            } else if (den < 0.0) {
+                const Frac f = {-num, -den};
+                if (frac_less(lo, f))
+                    lo = f;
+            } else if (num < 0.0) {
+                bad = true;
+            }
+        };
+        if (lane < 4)      // the box |x| <= HPR_TAN, |y| <= HPR_TAN
+            add(lane == 0 ? 1.0 : (lane == 1 ? -1.0 : 0.0), lane == 2 ? 1.0 : (lane == 3 ? -1.0 : 0.0), HPR_TAN);
+        for (int jpos = lane; jpos < upto; jpos += 64) {
+            const int r = member(jpos);
+            if (r >= n1 || r == self)
+                continue;
+            const Cons m = hpr_constraint(pts, r, fr);
+            add(m.a, m.b, m.c);
+        }
+        auto fold = [&](Frac ol, Frac oh) {
+            if (frac_less(lo, ol))
+                lo = ol;
+            if (frac_less(oh, hi))
+                hi = oh;
+        };
+        fold(Frac{dpp_f64<0xB1>(lo.num), dpp_f64<0xB1>(lo.den)}, Frac{dpp_f64<0xB1>(hi.num), dpp_f64<0xB1>(hi.den)});
+        fold(Frac{dpp_f64<0x4E>(lo.num), dpp_f64<0x4E>(lo.den)}, Frac{dpp_f64<0x4E>(hi.num), dpp_f64<0x4E>(hi.den)});
+        fold(Frac{dpp_f64<0x141>(lo.num), dpp_f64<0x141>(lo.den)}, Frac{dpp_f64<0x141>(hi.num), dpp_f64<0x141>(hi.den)});
+        fold(Frac{dpp_f64<0x140>(lo.num), dpp_f64<0x140>(lo.den)}, Frac{dpp_f64<0x140>(hi.num), dpp_f64<0x140>(hi.den)});
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1)
+            fold(Frac{__shfl_xor(lo.num, off, 64), __shfl_xor(lo.den, off, 64)},
+                 Frac{__shfl_xor(hi.num, off, 64), __shfl_xor(hi.den, off, 64)});
+        if (__ballot(bad) != 0ull || frac_less(hi, lo))
+            return false;
+        const Frac pick = (ux + 0.5 * uy) > 0.0 ? hi : lo;
+        const double tt = pick.num / pick.den;
+        vx = p0x + tt * ux;
+        vy = p0y + tt * uy;
+        set_plane();
+        return true;
+    };
+
+    // ---- the local problem: the neighbours in sequence (Seidel over W's first HPR_NEAR members) ----
+    int i = 0;
+    while (i < HPR_NEAR) {
+        const int q = member(i + lane);
+        const bool viol = (i + lane < HPR_NEAR && q < n1 && q != self) ? violated(q) : false;
+        const unsigned long long mask = __ballot(viol);
+        if (mask == 0ull) {
+            i += 64;
+            continue;
+        }
+        const int first = __ffsll((long long)mask) - 1;
+        HPR_COUNT(1, 1);
+        if (!resolve(__shfl(q, first, 64), i + first))
+            return 0;
+        i += first + 1;
+    }
+
+    // ---- verification passes ----
+    const int groups = (n1 + HPR_GROUP - 1) / HPR_GROUP;
+    const float slack_g = 2.5f * slack;         // -1e-5 |d|_1: the margin of the slab test
+    for (;;) {
+        // the MOST violated point of the pass joins (by d.g + eps |g|: the plane's own measure); every lane keeps its worst
+        double worst = 0.0;
+        int worst_q = -1;
+        HPR_COUNT(2, 1);
+        for (int g0 = 0; g0 < groups; g0 += 64) {
+            HPR_COUNT(3, 1);
+            // a lane per group: can a point of its slab violate?
+            unsigned long long open;
+            {
+                const int g = min(g0 + lane, groups - 1);
+                const float ex = gb.m[0][g] - pxf, ey = gb.m[1][g] - pyf, ez = gb.m[2][g] - pzf;
+                const float dm = (dxf * ex + dyf * ey) + dzf * ez;
+                const float dn = (dxf * gb.n[0][g] + dyf * gb.n[1][g]) + dzf * gb.n[2][g];
+                const float perp = sqrtf(fmaxf(ddf - dn * dn, 0.0f) + 1e-6f * ddf);    // |d - (d.n) n|, rounded up
+                const float rm = gb.rmax[g];
+                const float top = (dm + fmaxf(gb.hlo[g] * dn, gb.hhi[g] * dn)) + gb.rad[g] * perp;
+                const float far = ((fabsf(ex) + fabsf(ey)) + fabsf(ez)) + 2.0f * rm;
+                // culled: top <= -1e-5 |d|_1 far -- the fp32 evaluation of top is off by < 1e-6 |d|_1 far, the fp32 copy of d
+                // by less still, and what has to hold for every point is only d.g <= -1e-12 |g|_1
+                open = __ballot(g0 + lane < groups && !(top <= slack_g * far));
+            }
+            while (open != 0ull) {
+                const int gi = __ffsll((long long)open) - 1;
+                open &= open - 1ull;
+                HPR_COUNT(4, 1);
+                const int q = (g0 + gi) * HPR_GROUP + lane;
+                bool viol = q < n1 ? violated(q) : false;
+                if (__ballot(viol) == 0ull)
+                    continue;
+                // (rare) members of W are not re-tested: the neighbours by their distance in sorted order, the joined ones
+                // by the list
+                if (viol) {
+                    int dd = q - self;
+                    dd = dd < 0 ? -dd : dd;
+                    dd = min(dd, n1 - dd);
+                    viol = dd > HPR_NEAR / 2;
+                    for (int e = 0; e < n_extra; ++e)
+                        viol = viol && extras[e] != q;
+                    if (viol && (worst_q < 0 || excess > worst)) {
+                        worst = excess;
+                        worst_q = q;
+                    }
+                }
+            }
+        }
+        if (__ballot(worst_q >= 0) == 0ull) {
+            HPR_COUNT(7, 1);
+            return 1;
+        }
+        if (n_extra == HPR_EXTRA) {
+            HPR_COUNT(6, 1);
+            return -1;
+        }
+        HPR_COUNT(5, 1);
+        if (worst_q < 0)
+            worst = -1.0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double ov = __shfl_xor(worst, off, 64);
+            const int oq = __shfl_xor(worst_q, off, 64);
+            if (ov > worst || (ov == worst && oq > worst_q)) {
+                worst = ov;
+                worst_q = oq;
+            }
+        }
+        if (!resolve(worst_q, HPR_NEAR + n_extra))
+            return 0;
+        if (lane == 0)
+            extras[n_extra] = worst_q;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        ++n_extra;
+    }
+}
+
 // flags[h][j] = 1 iff point j of cloud h (n1 points, the last one is the viewpoint) is a
 // vertex of the convex hull.  One wave per point; a workgroup (8 waves; 16 when the cloud is so large that a CU
 // holds one workgroup anyway) keeps the cloud in dynamic LDS and walks points j = blockIdx.x*W + wave, + W*gridDim.x, ...
 template <int HPR_WAVES>
 __global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, const float *__restrict__ points,
-                                                                    const int *__restrict__ perm, int stride,
+                                                                    const int *__restrict__ perm, int stride, int culled,
                                                                     unsigned char *__restrict__ flags)
 {
     extern __shared__ float pts[];
     __shared__ double cen[3][HPR_WAVES];
+    __shared__ HprGroups gb;
+    __shared__ int extras[HPR_WAVES][HPR_EXTRA];
     const float *P = points + (size_t)blockIdx.y * n1 * 3;
     for (int f = threadIdx.x; f < n1 * 3; f += 64 * HPR_WAVES)
         pts[f] = P[f];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (culled) {
+        // the viewpoint (the cloud's last point) in sorted order: the slabs' normals point away from it
+        __shared__ int viewpoint;
+        for (int j = threadIdx.x; j < n1; j += 64 * HPR_WAVES)
+            if (perm[(size_t)blockIdx.y * n1 + j] == n1 - 1)
+                viewpoint = j;
+        __syncthreads();
+        hpr_group_slabs<HPR_WAVES>(pts, n1, viewpoint, gb);
+    }
     // centroid of the cloud (strictly inside its hull)
     double sx = 0.0, sy = 0.0, sz = 0.0;
     for (int q = threadIdx.x; q < n1; q += 64 * HPR_WAVES) {
@@ -534,7 +937,12 @@ __global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, con
             f.wx = ry * uz - rz * uy;
             f.wy = rz * ux - rx * uz;
             f.wz = rx * uy - ry * ux;
-            vertex = hpr_lp2d_wave<(HPR_WAVES > 8 ? HPR_NEAR_LARGE : HPR_NEAR_SMALL)>(pts, n1, j, stride, f, lane);
+            constexpr int NEAR = HPR_WAVES > 8 ? HPR_NEAR_LARGE : HPR_NEAR_SMALL;
+            int verdict = -1;
+            HPR_COUNT(0, 1);
+            if (culled)
+                verdict = hpr_lp2d_wave_culled<NEAR>(pts, gb, extras[wave], n1, j, f, lane);
+            vertex = verdict >= 0 ? verdict == 1 : hpr_lp2d_wave<NEAR>(pts, n1, j, stride, f, lane);
         }
         if (lane == 0)     // `points` is the spatially sorted cloud: the flag goes back to the original index
             flags[(size_t)blockIdx.y * n1 + perm[(size_t)blockIdx.y * n1 + j]] = vertex ? 1 : 0;
@@ -627,6 +1035,19 @@ static int hpr_stride(int n)
 
 using namespace cloudaae;
 
+#ifdef CLOUDAAE_HPR_STATS
+CLOUDAAE_API int cloudaae_hpr_stats_read(unsigned long long *out, int reset)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(hpr_stats), sizeof(hpr_stats));
+    if (reset) {
+        unsigned long long z[8] = {};
+        hipMemcpyToSymbol(HIP_SYMBOL(hpr_stats), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
+
 CLOUDAAE_API int cloudaae_transform_object_model(int b, int npts, int nmodels, const float *models,
                                                  const long long *class_id, const double *rot, const float *trans,
                                                  float *out, cloudaae_stream_t stream)
@@ -697,10 +1118,21 @@ CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *
     const size_t pts = (size_t)b * n1;
     float *sorted = (float *)(flags + (pts + 15) / 16 * 16);
     int *perm = (int *)(sorted + pts * 3);
-    hipLaunchKernelGGL(hpr_sort_kernel, dim3(b), dim3(HS_THREADS), 0, s, n1, flipped, sorted, perm);
+    // spatial order of every cloud: the 3-D grid in Morton order (knob CLOUDAAE_HPR_SORT = 0: the cube map of directions)
+    if (CLOUDAAE_KNOB("CLOUDAAE_HPR_SORT", 1) != 0) {
+        static bool raised = false;
+        if (!raised) {
+            CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)hpr_sort_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)(HG_CELLS * sizeof(int))), name);
+            raised = true;
+        }
+        hipLaunchKernelGGL(hpr_sort_grid_kernel, dim3(b), dim3(HS_THREADS), HG_CELLS * sizeof(int), s, n1, flipped, sorted, perm);
+    } else {
+        hipLaunchKernelGGL(hpr_sort_kernel, dim3(b), dim3(HS_THREADS), 0, s, n1, flipped, sorted, perm);
+    }
     const size_t lds = (size_t)n1 * 3 * sizeof(float);
     // a cloud of more than ~6800 points leaves room for ONE workgroup per CU: it then takes 16 waves instead of 8
-    const bool wide = lds > 80 * 1024;
+    const bool wide = lds > 74 * 1024;          // (6 KB of group boxes and working-set lists next to the cloud)
     const int waves = wide ? 16 : 8;
     if (lds > 48 * 1024)
         CLOUDAAE_CHECK_HIP(hipFuncSetAttribute(wide ? (const void *)hull_vertex_kernel<16> : (const void *)hull_vertex_kernel<8>,
@@ -721,10 +1153,14 @@ CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *
             }
         }
     }
+    // the scan behind the local problem as culled verification passes (knob CLOUDAAE_HPR_CULL = 0: the full strided scan)
+    const int culled = CLOUDAAE_KNOB("CLOUDAAE_HPR_CULL", 1) != 0 ? 1 : 0;
     if (wide)
-        hipLaunchKernelGGL(hull_vertex_kernel<16>, dim3(gx, b), dim3(64 * 16), lds, s, n1, sorted, perm, hpr_stride(n1), flags);
+        hipLaunchKernelGGL(hull_vertex_kernel<16>, dim3(gx, b), dim3(64 * 16), lds, s, n1, sorted, perm, hpr_stride(n1), culled,
+                           flags);
     else
-        hipLaunchKernelGGL(hull_vertex_kernel<8>, dim3(gx, b), dim3(64 * 8), lds, s, n1, sorted, perm, hpr_stride(n1), flags);
+        hipLaunchKernelGGL(hull_vertex_kernel<8>, dim3(gx, b), dim3(64 * 8), lds, s, n1, sorted, perm, hpr_stride(n1), culled,
+                           flags);
     hipLaunchKernelGGL(hpr_gather_kernel, dim3(b), dim3(512), (size_t)n1 * sizeof(int), s, n1, flags, org, seed,
                        visible, num_vis, visible_id, row_src, rows);
     CLOUDAAE_CHECK_LAUNCH(name);
