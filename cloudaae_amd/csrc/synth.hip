@@ -155,8 +155,11 @@ __device__ __forceinline__ unsigned hs_morton8(unsigned x, unsigned y)     // 4 
 
 // sorted[h][pos] = points[h][perm[h][pos]]; one workgroup per cloud, counting sort on the cell id
 __global__ __launch_bounds__(HS_THREADS) void hpr_sort_kernel(int n1, const float *__restrict__ points,
-                                                              float *__restrict__ sorted, int *__restrict__ perm)
+                                                              float *__restrict__ sorted, int *__restrict__ perm,
+                                                              int *__restrict__ next_point)
 {
+    if (threadIdx.x == 0)
+        next_point[blockIdx.x] = 0;         // (the hull kernel's queue of this cloud)
     __shared__ int cell_cnt[HS_CELLS];
     __shared__ double cen[3][HS_THREADS / 64];
     __shared__ int wsum[HS_THREADS / 64];
@@ -258,8 +261,11 @@ __device__ __forceinline__ unsigned hg_spread(unsigned v)          // 5 bits -> 
 }
 
 __global__ __launch_bounds__(HS_THREADS) void hpr_sort_grid_kernel(int n1, const float *__restrict__ points,
-                                                                   float *__restrict__ sorted, int *__restrict__ perm)
+                                                                   float *__restrict__ sorted, int *__restrict__ perm,
+                                                                   int *__restrict__ next_point)
 {
+    if (threadIdx.x == 0)
+        next_point[blockIdx.x] = 0;         // (the hull kernel's queue of this cloud)
     extern __shared__ int cell_cnt[];         // HG_CELLS counters
     __shared__ float box[6][HS_THREADS / 64];
     __shared__ int wsum[HS_THREADS / 64];
@@ -354,7 +360,13 @@ __global__ __launch_bounds__(HS_THREADS) void hpr_sort_grid_kernel(int n1, const
 // (neighbourhood size by cloud size, measured per batch of 32 with two hulls each: 2449-point clouds 96 / 128 / 192 / 256 / 512
 // neighbours 1.69 / 1.56 / 1.52 / 1.51 / 1.74 ms; 8593-point clouds 128 / 192 / 256 / 384 / 512 / 768 / 1536 neighbours
 // 13.0 / 11.75 / 11.0 / 10.47 / 10.54 / 10.49 / 11.1 ms)
-constexpr int HPR_NEAR_SMALL = 192, HPR_NEAR_LARGE = 512;      // clouds one workgroup of 8 / 16 waves holds (hull_vertex_kernel)
+#ifndef HPR_NEAR_SMALL_V
+#define HPR_NEAR_SMALL_V 192
+#endif
+#ifndef HPR_NEAR_LARGE_V
+#define HPR_NEAR_LARGE_V 512
+#endif
+constexpr int HPR_NEAR_SMALL = HPR_NEAR_SMALL_V, HPR_NEAR_LARGE = HPR_NEAR_LARGE_V;      // clouds one workgroup of 8 / 16 waves holds (hull_vertex_kernel)
 template <int HPR_NEAR>
 __device__ __forceinline__ int hpr_seq(int pos, int self, int n1, int stride)
 {
@@ -861,11 +873,18 @@ __device__ int hpr_lp2d_wave_culled(const float *__restrict__ pts, const HprGrou
 template <int HPR_WAVES>
 __global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, const float *__restrict__ points,
                                                                     const int *__restrict__ perm, int stride, int culled,
+                                                                    int *__restrict__ next_point,
                                                                     unsigned char *__restrict__ flags)
 {
     extern __shared__ float pts[];
     __shared__ double cen[3][HPR_WAVES];
     __shared__ HprGroups gb;
+    __shared__ int queue_at;
+    if (threadIdx.x == 0)
+        queue_at = next_point ? __hip_atomic_load(&next_point[blockIdx.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    __syncthreads();
+    if (queue_at >= n1)
+        return;                              // (every point of this cloud has a wave already; the whole workgroup leaves)
     __shared__ int extras[HPR_WAVES][HPR_EXTRA];
     const float *P = points + (size_t)blockIdx.y * n1 * 3;
     for (int f = threadIdx.x; f < n1 * 3; f += 64 * HPR_WAVES)
@@ -906,7 +925,20 @@ __global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, con
     cx /= (double)n1;
     cy /= (double)n1;
     cz /= (double)n1;
-    for (int j = blockIdx.x * HPR_WAVES + wave; j < n1; j += HPR_WAVES * gridDim.x) {
+    // the cloud's points are handed out one at a time (a counter per cloud, zeroed by the sort kernel): a hull vertex costs
+    // its wave several passes, an interior point leaves inside the local problem -- with a fixed share per wave the
+    // workgroup waited for its unluckiest wave
+    for (int turn = 0;; ++turn) {
+        int j = 0;
+        if (next_point != nullptr) {
+            if (lane == 0)
+                j = atomicAdd(&next_point[blockIdx.y], 1);
+            j = __builtin_amdgcn_readfirstlane(j);      // (uniform for the compiler as well: with __shfl(j, 0) the kernel hung)
+        } else {                             // (knob CLOUDAAE_HPR_QUEUE = 0: a fixed share per wave)
+            j = blockIdx.x * HPR_WAVES + wave + turn * HPR_WAVES * gridDim.x;
+        }
+        if (j >= n1)
+            break;
         Frame f;
         f.px = pts[3 * j];
         f.py = pts[3 * j + 1];
@@ -1087,11 +1119,11 @@ CLOUDAAE_API int cloudaae_spherical_flip(int b, int na, const float *a, int nb, 
     return 0;
 }
 
-// flags [b*n1] bytes (padded to 16) | sorted points [b*n1*3] floats | permutation [b*n1] ints
+// flags [b*n1] bytes (padded to 16) | sorted points [b*n1*3] floats | permutation [b*n1] ints | point queues [b] ints
 CLOUDAAE_API long long cloudaae_hpr_workspace_bytes(int b, int n1)
 {
     const long long pts = (long long)b * n1;
-    return (pts + 15) / 16 * 16 + pts * 12 + pts * 4;
+    return (pts + 15) / 16 * 16 + pts * 12 + pts * 4 + (long long)b * 4;
 }
 
 CLOUDAAE_API int cloudaae_hidden_point_removal(int b, int n1, const float *flipped, const float *org,
@@ -1118,6 +1150,7 @@ CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *
     const size_t pts = (size_t)b * n1;
     float *sorted = (float *)(flags + (pts + 15) / 16 * 16);
     int *perm = (int *)(sorted + pts * 3);
+    int *next_point = perm + pts;
     // spatial order of every cloud: the 3-D grid in Morton order (knob CLOUDAAE_HPR_SORT = 0: the cube map of directions)
     if (CLOUDAAE_KNOB("CLOUDAAE_HPR_SORT", 1) != 0) {
         static bool raised = false;
@@ -1126,9 +1159,10 @@ CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *
                                                    (int)(HG_CELLS * sizeof(int))), name);
             raised = true;
         }
-        hipLaunchKernelGGL(hpr_sort_grid_kernel, dim3(b), dim3(HS_THREADS), HG_CELLS * sizeof(int), s, n1, flipped, sorted, perm);
+        hipLaunchKernelGGL(hpr_sort_grid_kernel, dim3(b), dim3(HS_THREADS), HG_CELLS * sizeof(int), s, n1, flipped, sorted, perm,
+                           next_point);
     } else {
-        hipLaunchKernelGGL(hpr_sort_kernel, dim3(b), dim3(HS_THREADS), 0, s, n1, flipped, sorted, perm);
+        hipLaunchKernelGGL(hpr_sort_kernel, dim3(b), dim3(HS_THREADS), 0, s, n1, flipped, sorted, perm, next_point);
     }
     const size_t lds = (size_t)n1 * 3 * sizeof(float);
     // a cloud of more than ~6800 points leaves room for ONE workgroup per CU: it then takes 16 waves instead of 8
@@ -1137,11 +1171,17 @@ CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *
     if (lds > 48 * 1024)
         CLOUDAAE_CHECK_HIP(hipFuncSetAttribute(wide ? (const void *)hull_vertex_kernel<16> : (const void *)hull_vertex_kernel<8>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
-    // workgroups per cloud: the kernel holds 108 VGPRs, i.e. two 8-wave workgroups per CU, 512 on the chip (256 of
-    // the 16-wave form); a grid of 640 ran as one full round plus a quarter-full one.  Pick the split whose (rounds x
-    // points per wave) is smallest -- e.g. 16 x 32 clouds = 512 workgroups of 20 points per wave for the 2449-point hull.
+    // workgroups per cloud: two 8-wave workgroups fit a CU (512 on the chip), one of the 16-wave form (256).  The points of a
+    // cloud come from its queue, so a workgroup lives as long as its cloud has points: exactly the resident number is launched.
+    // (knob CLOUDAAE_HPR_WG_ROUNDS: 2 / 3 / 4 x as many -- late workgroups joining the clouds that still have points -- cost
+    // more in set-up than they balance: 4.18 / 4.52 / 6.56 / 7.64 ms per config-5 batch; a fixed share per wave 6.55 ms.)
     int gx = 1;
-    {
+    const bool queue = CLOUDAAE_KNOB("CLOUDAAE_HPR_QUEUE", 1) != 0;
+    if (queue) {
+        const long long resident = wide ? 256 : 512;
+        const long long rounds = std::max(1, CLOUDAAE_KNOB("CLOUDAAE_HPR_WG_ROUNDS", 1));
+        gx = (int)std::min<long long>(std::max<long long>(1, (rounds * resident + b - 1) / b), ceil_div(n1, waves * 2));
+    } else {                                 // a fixed share per wave: the split whose (rounds x points per wave) is smallest
         const long long resident = wide ? 256 : 512;
         long long best = -1;
         for (int cand = ceil_div(n1, waves * 32); cand <= ceil_div(n1, waves * 4); ++cand) {
@@ -1157,10 +1197,10 @@ CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *
     const int culled = CLOUDAAE_KNOB("CLOUDAAE_HPR_CULL", 1) != 0 ? 1 : 0;
     if (wide)
         hipLaunchKernelGGL(hull_vertex_kernel<16>, dim3(gx, b), dim3(64 * 16), lds, s, n1, sorted, perm, hpr_stride(n1), culled,
-                           flags);
+                           queue ? next_point : nullptr, flags);
     else
         hipLaunchKernelGGL(hull_vertex_kernel<8>, dim3(gx, b), dim3(64 * 8), lds, s, n1, sorted, perm, hpr_stride(n1), culled,
-                           flags);
+                           queue ? next_point : nullptr, flags);
     hipLaunchKernelGGL(hpr_gather_kernel, dim3(b), dim3(512), (size_t)n1 * sizeof(int), s, n1, flags, org, seed,
                        visible, num_vis, visible_id, row_src, rows);
     CLOUDAAE_CHECK_LAUNCH(name);
