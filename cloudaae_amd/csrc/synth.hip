@@ -597,7 +597,7 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
 // is what the passes verify against EVERY point, W only grows, and the answer (feasible or not) is that of the full LP.  At
 // most HPR_EXTRA points join W behind the neighbours; a point that needs more goes through hpr_lp2d_wave instead.
 #ifdef CLOUDAAE_HPR_STATS
-__device__ unsigned long long hpr_stats[8];   // points, local re-solves, passes, box iterations, groups scanned, joined, fallbacks, vertices
+__device__ unsigned long long hpr_stats[16];   // points, local re-solves, passes, box iterations, groups scanned, joined, fallbacks, vertices
 #define HPR_COUNT(slot, v) do { if (lane == 0) atomicAdd(&hpr_stats[slot], (unsigned long long)(v)); } while (0)
 #else
 #define HPR_COUNT(slot, v) do { } while (0)
@@ -747,24 +747,28 @@ __device__ int hpr_lp2d_wave_culled(const float *__restrict__ pts, const HprGrou
             const Cons m = hpr_constraint(pts, r, fr);
             add(m.a, m.b, m.c);
         }
-        auto fold = [&](Frac ol, Frac oh) {
-            if (frac_less(lo, ol))
-                lo = ol;
-            if (frac_less(oh, hi))
-                hi = oh;
-        };
-        fold(Frac{dpp_f64<0xB1>(lo.num), dpp_f64<0xB1>(lo.den)}, Frac{dpp_f64<0xB1>(hi.num), dpp_f64<0xB1>(hi.den)});
-        fold(Frac{dpp_f64<0x4E>(lo.num), dpp_f64<0x4E>(lo.den)}, Frac{dpp_f64<0x4E>(hi.num), dpp_f64<0x4E>(hi.den)});
-        fold(Frac{dpp_f64<0x141>(lo.num), dpp_f64<0x141>(lo.den)}, Frac{dpp_f64<0x141>(hi.num), dpp_f64<0x141>(hi.den)});
-        fold(Frac{dpp_f64<0x140>(lo.num), dpp_f64<0x140>(lo.den)}, Frac{dpp_f64<0x140>(hi.num), dpp_f64<0x140>(hi.den)});
+        // the wave's lo (max) and hi (min): every lane's pair as quotients (one division each -- the lanes' own lists were
+        // compared as fractions, without one), then a min / max butterfly: DPP inside a row of 16 lanes (quad swaps, then the
+        // half-row and row mirrors: after the quad steps a quad is uniform, so the mirrors act as "xor 4" and "xor 8"), the two
+        // cross-row steps through the LDS crossbar.  (Round 4 folded the FRACTIONS, by cross multiplication: 150 of a
+        // re-solve's ~280 vector instructions.)
+        double tlo = lo.num / lo.den, thi = hi.num / hi.den;
+        tlo = fmax(tlo, dpp_f64<0xB1>(tlo));
+        thi = fmin(thi, dpp_f64<0xB1>(thi));
+        tlo = fmax(tlo, dpp_f64<0x4E>(tlo));
+        thi = fmin(thi, dpp_f64<0x4E>(thi));
+        tlo = fmax(tlo, dpp_f64<0x141>(tlo));
+        thi = fmin(thi, dpp_f64<0x141>(thi));
+        tlo = fmax(tlo, dpp_f64<0x140>(tlo));
+        thi = fmin(thi, dpp_f64<0x140>(thi));
 #pragma unroll
-        for (int off = 16; off <= 32; off <<= 1)
-            fold(Frac{__shfl_xor(lo.num, off, 64), __shfl_xor(lo.den, off, 64)},
-                 Frac{__shfl_xor(hi.num, off, 64), __shfl_xor(hi.den, off, 64)});
-        if (__ballot(bad) != 0ull || frac_less(hi, lo))
+        for (int off = 16; off <= 32; off <<= 1) {
+            tlo = fmax(tlo, __shfl_xor(tlo, off, 64));
+            thi = fmin(thi, __shfl_xor(thi, off, 64));
+        }
+        if (__ballot(bad) != 0ull || thi < tlo)
             return false;
-        const Frac pick = (ux + 0.5 * uy) > 0.0 ? hi : lo;
-        const double tt = pick.num / pick.den;
+        const double tt = (ux + 0.5 * uy) > 0.0 ? thi : tlo;
         vx = p0x + tt * ux;
         vy = p0y + tt * uy;
         set_plane();
@@ -783,8 +787,13 @@ __device__ int hpr_lp2d_wave_culled(const float *__restrict__ pts, const HprGrou
         }
         const int first = __ffsll((long long)mask) - 1;
         HPR_COUNT(1, 1);
-        if (!resolve(__shfl(q, first, 64), i + first))
+        HPR_COUNT(8, (i + first + 63) / 64);             // 64-constraint iterations of the local re-solves
+        HPR_COUNT(9 + min(3, (i + first) / 128), 1);    // where they happen: [0,128) [128,256) [256,384) [384,512)
+        if (!resolve(__shfl(q, first, 64), i + first)) {
+            HPR_COUNT(13, 1);                            // rejected inside the local problem
+            HPR_COUNT(14, i + first);
             return 0;
+        }
         i += first + 1;
     }
 
@@ -1073,7 +1082,7 @@ CLOUDAAE_API int cloudaae_hpr_stats_read(unsigned long long *out, int reset)
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out, HIP_SYMBOL(hpr_stats), sizeof(hpr_stats));
     if (reset) {
-        unsigned long long z[8] = {};
+        unsigned long long z[16] = {};
         hipMemcpyToSymbol(HIP_SYMBOL(hpr_stats), z, sizeof(z));
     }
     return 0;

@@ -15,11 +15,13 @@ x = T.get_object_model(x, models); x = T.get_rotation_matrix(x); x = T.transform
 x = generate_occluder.get_random_spherical_occluder(x, 'ycbv', seed=1)
 x = hpr.sphericalFlip(x, None, 0.8 * math.pi)
 cd = _lib.lib()._cdll
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 16)()
 cd.cloudaae_hpr_stats_read(out, 1)
 v, n = hpr.convexHull(x['flippedPoints'], x['orgPoints'], 1)
 cd.cloudaae_hpr_stats_read(out, 1)
-names = ["points", "local re-solves", "passes", "box iterations", "groups scanned", "joined", "fallbacks", "vertices"]
+names = ["points", "local re-solves", "passes", "box iterations", "groups scanned", "joined", "fallbacks", "vertices",
+         "local re-solve iterations", "re-solves at [0,128)", "at [128,256)", "at [256,384)", "at [384,512)", "rejected locally",
+         "sum of reject positions", "-"]
 pts = max(out[0], 1)
 for k, c in zip(names, out):
     print("%-16s %10d  %.3f per point" % (k, c, c / pts))
