@@ -818,8 +818,15 @@ static size_t knn_wide_lds_bytes(int n)
 // tile buffers, which are idle at that point.
 template <int K, int QPQ, bool REUSE, bool TWO>
 __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, const float *__restrict__ x,
-                                                          int *__restrict__ nn_idx)
+                                                          int *__restrict__ nn_idx, const unsigned char *__restrict__ only)
 {
+    // only != nullptr: the launch repairs the query groups knn64_split_kernel flagged (a byte per workgroup of this grid)
+    if (only != nullptr) {
+        int qg, cl;
+        xcd_cloud_tile(qg, cl);
+        if (only[cl * gridDim.x + qg] == 0)
+            return;
+    }
     constexpr int QW = 4, CS = 4, THREADS = 1024;
     constexpr int KS_LD = 68;                              // staged row: [32 even channels | 32 odd | 4 pad]
     constexpr int TILE_FLOATS = KM_TILE * KS_LD;
@@ -1369,30 +1376,32 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
 }
 
 template <int K, int QPQ, bool REUSE, bool TWO>
-static hipError_t launch_knn_wide_q(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
+static hipError_t launch_knn_wide_q(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s,
+                                    const unsigned char *only = nullptr)
 {
     const size_t lds = knn_wide_lds_bytes(n);
     static bool raised[64] = {};
     if (hipError_t e = raise_lds_limit(&knn64_wide_kernel<K, QPQ, REUSE, TWO>, raised); e != hipSuccess)
         return e;
     hipLaunchKernelGGL((knn64_wide_kernel<K, QPQ, REUSE, TWO>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s, n, ld,
-                       k, x, nn_idx);
+                       k, x, nn_idx, only);
     return hipSuccess;
 }
 template <int K>
-static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
+static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s,
+                                  const unsigned char *only = nullptr)
 {
     if constexpr (K <= 10) {
         // pass A of at most two rounds (n <= 1024): its distances are kept and pass B skips the sampled tiles
         if (ceil_div(n, KM_TILE) <= 32 && CLOUDAAE_KNOB("CLOUDAAE_KNN_REUSE", 1) != 0)
-            return launch_knn_wide_q<K, 144, true, false>(b, n, ld, k, x, nn_idx, s);
+            return launch_knn_wide_q<K, 144, true, false>(b, n, ld, k, x, nn_idx, s, only);
     }
     // otherwise the bound in two stages (knob CLOUDAAE_KNN_TWO = 0: one stage, the sample scanned twice)
     if (CLOUDAAE_KNOB("CLOUDAAE_KNN_TWO", 1) != 0)
-        return knn_wide_qpq(n) == 144 ? launch_knn_wide_q<K, 144, false, true>(b, n, ld, k, x, nn_idx, s)
-                                      : launch_knn_wide_q<K, 128, false, true>(b, n, ld, k, x, nn_idx, s);
-    return knn_wide_qpq(n) == 144 ? launch_knn_wide_q<K, 144, false, false>(b, n, ld, k, x, nn_idx, s)
-                                  : launch_knn_wide_q<K, 128, false, false>(b, n, ld, k, x, nn_idx, s);
+        return knn_wide_qpq(n) == 144 ? launch_knn_wide_q<K, 144, false, true>(b, n, ld, k, x, nn_idx, s, only)
+                                      : launch_knn_wide_q<K, 128, false, true>(b, n, ld, k, x, nn_idx, s, only);
+    return knn_wide_qpq(n) == 144 ? launch_knn_wide_q<K, 144, false, false>(b, n, ld, k, x, nn_idx, s, only)
+                                  : launch_knn_wide_q<K, 128, false, false>(b, n, ld, k, x, nn_idx, s, only);
 }
 
 // ---- C = 3 on the matrix cores: the bound pass + filtered scan of knn64_wide_kernel without its rounds ----------------
@@ -1795,6 +1804,534 @@ static hipError_t launch_knn3_scan(int b, int n, int ld, int k, const float *x, 
     return hipSuccess;
 }
 
+// ---- C = 64, fourth generation: the scan on the bf16 matrix pipe, the oracle's arithmetic only where it decides -------------
+// knn64_wide_kernel computes every one of the N x N distances the way the oracle defines them (a k-ordered fp32 fma chain =
+// v_mfma_f32_32x32x2_f32, 33 steps of 64 cycles per 32 x 32 tile) and is bound by exactly that: the fp32 matrix rate.  But
+// the oracle's arithmetic is needed only to ORDER candidates whose distances are closer together than a cheaper evaluation
+// can tell apart.  Here:
+//   planes  : every point once as two bf16 pieces per channel, h = bf16(x), m = bf16(x - h) (x - h - m is below 2^-18 |x|),
+//             its norm |x|^2 in the oracle's order (fp32, exact) and -|x|^2 / 2 as two bf16 pieces (knn64_planes_kernel).
+//   scores  : s~_ij = x_i.x_j - (|x_i|^2 + |x_j|^2) / 2 = -d_ij / 2 from 13 v_mfma_f32_32x32x16_bf16 per tile (h.h, h.m, m.h
+//             over four blocks of 16 channels, and one block that adds the norms): 416 matrix cycles instead of 2112.
+//             |s~ - s| <= E_i = 4e-5 (|x_i|^2 + max_j |x_j|^2) for the s the oracle's arithmetic gives (the dropped piece
+//             products are below 1.2e-5 |x_i| |x_j|, the fp32 accumulation of the matrix pipe and the oracle's own rounding
+//             below that again).
+//   pass A  : every second candidate tile; per lane the maxima of its four units of four rows go into a sorted list of K
+//             values; the k-th largest over the query's two lanes is tau~ (k DISTINCT candidates score at least that).
+//   pass B  : every tile; a candidate with s~ >= tau~ - 2 E_i goes to its query's queue in LDS (score and index: about 2k
+//             of them).  Every candidate the oracle ranks among the k nearest is in the queue: its s is >= the oracle's
+//             k-th largest >= tau~ - E_i.
+//   select  : the queue's K + 4 best by s~ (sorted keys, a lane pair per query).  Two neighbours of that list closer than
+//             4 E_i in distance cannot be ordered by s~: those -- a few per cent -- get the oracle's distance (the fma chain
+//             over the 64 channels, (|x_i|^2 + -2 inner) + |x_j|^2) and are ordered by it (ties by index); everything else is
+//             separated from its neighbours by more than both evaluations can differ, so the order of s~ IS the oracle's.
+//   A queue that overflows, or an undecided chain that reaches the end of the K + 4 list, flags the query group; a gated
+//   launch of knn64_wide_kernel (workgroups leave at once unless flagged) recomputes those: correctness never depends on
+//   the margins being small, only on E_i being a bound.
+constexpr int KSP_T = 2;             // candidate tiles per round
+constexpr int KSP_NB = 4;            // ring of round buffers: the tiles of round r + 3 travel while round r computes
+constexpr int KSP_TILE_BYTES = KM_TILE * 256;
+constexpr int KSP_X = 4;             // list slots behind the K-th
+typedef __bf16 ksp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned ksp_u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned ksp_bf16_rne(float v)           // finite v
+{
+    const unsigned u = __float_as_uint(v);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+struct KspScratch {                  // one call's scratch (scratch_alloc): offsets in bytes
+    size_t flags, rows, ext, sqx, total;
+    int npad, gq;                    // rows per cloud in the planes (whole 256-query workgroups); 128-query groups per cloud
+};
+static KspScratch ksp_layout(int b, int n)
+{
+    KspScratch L;
+    L.gq = ceil_div(n, 4 * KM_TILE);
+    L.npad = ceil_div(n, 256) * 256;
+    L.flags = 0;
+    L.rows = ((size_t)b * L.gq + 255) / 256 * 256;
+    L.ext = L.rows + (size_t)b * L.npad * 256;
+    L.sqx = L.ext + (size_t)b * L.npad * 4;
+    L.total = L.sqx + (size_t)b * L.npad * 4;
+    return L;
+}
+
+// grid (npad / 32, b), 256 threads: thread (row r = t / 8, unit u = t % 8) splits channels 8u .. 8u + 7 of its row.  The norm in
+// the oracle's order (squares rounded, then summed channel by channel) is a chain through the row's eight threads: thread u
+// continues the sum where thread u - 1 stopped (eight steps of eight additions; every thread runs all of them, one keeps
+// the result).  Also clears the flag bytes of the query groups (a byte per 128 rows).
+__global__ __launch_bounds__(256) void knn64_planes_kernel(int n, int ld, int npad, int gq, const float *__restrict__ x,
+                                                          unsigned char *__restrict__ rows, unsigned *__restrict__ ext,
+                                                          float *__restrict__ sqx, unsigned char *__restrict__ flags)
+{
+    const int cloud = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    const int row = blockIdx.x * KM_TILE + (t >> 3), u = t & 7;
+    const float *X = x + (size_t)cloud * n * ld;
+    if (t == 0 && (blockIdx.x & 3) == 0 && (int)(blockIdx.x >> 2) < gq)
+        flags[cloud * gq + (blockIdx.x >> 2)] = 0;
+    unsigned h[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0};
+    float v2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < n) {
+        const float4v a = *reinterpret_cast<const float4v *>(X + (size_t)row * ld + 8 * u);
+        const float4v c = *reinterpret_cast<const float4v *>(X + (size_t)row * ld + 8 * u + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned hb = ksp_bf16_rne(v[e]);
+            const unsigned mb = ksp_bf16_rne(v[e] - __uint_as_float(hb << 16));      // (the difference is exact)
+            h[e >> 1] |= hb << (16 * (e & 1));
+            m[e >> 1] |= mb << (16 * (e & 1));
+            v2[e] = v[e] * v[e];
+        }
+    }
+    unsigned char *R = rows + ((size_t)cloud * npad + row) * 256;
+    *reinterpret_cast<ksp_u4 *>(R + 16 * u) = ksp_u4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<ksp_u4 *>(R + 128 + 16 * u) = ksp_u4{m[0], m[1], m[2], m[3]};
+    float sq = 0.0f;
+#pragma unroll
+    for (int step = 0; step < 8; ++step) {
+        float c = sq;                                       // (step 0: the chain starts from +0, like the oracle's)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            c = c + v2[e];
+        sq = __shfl(c, (lane & ~7) | step, 64);             // what the row's thread `step` computed goes on
+    }
+    if (u == 0) {
+        unsigned e = 0xff80u;                               // (-inf, 0): a row past the end never scores
+        if (row < n) {
+            const float hs = -0.5f * sq;
+            const unsigned a0 = ksp_bf16_rne(hs);
+            const unsigned a1 = ksp_bf16_rne(hs - __uint_as_float(a0 << 16));
+            e = a0 | (a1 << 16);
+        }
+        ext[(size_t)cloud * npad + row] = e;
+        sqx[(size_t)cloud * npad + row] = row < n ? sq : __builtin_inff();
+    }
+}
+
+template <int K>
+struct MaxK {                        // the K largest values seen, descending
+    float d[K];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int p = 0; p < K; ++p)
+            d[p] = -__builtin_inff();
+    }
+    __device__ __forceinline__ void insert(float nd)
+    {
+        d[K - 1] = fmaxf(d[K - 1], nd);
+#pragma unroll
+        for (int p = K - 1; p > 0; --p) {
+            const float a = d[p - 1], b = d[p];
+            d[p - 1] = fmaxf(a, b);
+            d[p] = fminf(a, b);
+        }
+    }
+};
+
+// queue slots per LANE (a query's two lanes keep their own: no counters in LDS, no atomics) + one slot that takes every write
+// that is not a hit
+constexpr int KSP_QH = 24;
+template <int QW>
+static size_t ksp_lds_bytes()
+{
+    return KSP_NB * KSP_T * KSP_TILE_BYTES + KSP_NB * KSP_T * 64 * 4 + 64 * QW * (size_t)(KSP_QH + 1) * 6 + 64 * 4 + 16;
+}
+
+// the distance bits of an orderable key (knn_key)
+__device__ __forceinline__ float ksp_key_dist(double key)
+{
+    const unsigned u = (unsigned)__builtin_trunc(__builtin_ldexp(key, -16));
+    const unsigned b = (u & 0x80000000u) ? (u ^ 0x80000000u) : ~u;
+    return __uint_as_float(b);
+}
+
+// QW waves per workgroup, a 32-query tile each (8 where that still fills the chip: two waves per SIMD, and the cloud passes
+// through LDS half as often; every workgroup streams the whole cloud through its own LDS either way)
+template <int K, int QW>
+__global__ __launch_bounds__(64 * QW) void knn64_split_kernel(int n, int ld, int k, int npad, int gq,
+                                                             const float *__restrict__ x,
+                                                             const unsigned char *__restrict__ rows,
+                                                             const unsigned *__restrict__ ext, const float *__restrict__ sqx,
+                                                             unsigned char *__restrict__ flags, int *__restrict__ nn_idx)
+{
+    constexpr int QH = KSP_QH, KK = K + KSP_X, T = KSP_T, NB = KSP_NB, NQ = 32 * QW;
+    extern __shared__ __attribute__((aligned(16))) char ksp_smem[];
+    char *tiles = ksp_smem;                                               // [NB][T][32 rows x 256 bytes], units XOR-swizzled
+    unsigned *extb = reinterpret_cast<unsigned *>(tiles + NB * T * KSP_TILE_BYTES);   // [NB][T][64]
+    float *qs = reinterpret_cast<float *>(extb + NB * T * 64);            // [64 QW lanes][QH + 1] scores
+    unsigned short *qj = reinterpret_cast<unsigned short *>(qs + 64 * QW * (QH + 1));   // same shape: indices
+    float *red = reinterpret_cast<float *>(qj + 64 * QW * (QH + 1));      // [64]
+    int *flag = reinterpret_cast<int *>(red + 64);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    int wg, cloud;
+    xcd_cloud_tile(wg, cloud);
+    const int ntiles = (n + KM_TILE - 1) / KM_TILE;
+    const unsigned char *R = rows + (size_t)cloud * npad * 256;
+    const unsigned *EX = ext + (size_t)cloud * npad;
+    const float *SQ = sqx + (size_t)cloud * npad;
+    if (tid == 0)
+        *flag = 0;
+    // the largest norm of the cloud (the error bound of a score needs it)
+    float sqmax = 0.0f;
+    for (int j = tid; j < n; j += 64 * QW)
+        sqmax = fmaxf(sqmax, SQ[j]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+        sqmax = fmaxf(sqmax, __shfl_xor(sqmax, off, 64));
+    if (lane == 0)
+        red[wave] = sqmax;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < QW; ++w)
+        sqmax = fmaxf(sqmax, red[w]);
+
+    const int qrow = wg * NQ + wave * 32 + col;             // (< npad)
+    const bool qvalid = qrow < n;
+    // B operands: the query's pieces (this lane's half of every block of 16 channels), and the block that adds the norms
+    ksp_u4 bh[4], bm[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        bh[kb] = *reinterpret_cast<const ksp_u4 *>(R + (size_t)qrow * 256 + 16 * (2 * kb + half));
+        bm[kb] = *reinterpret_cast<const ksp_u4 *>(R + (size_t)qrow * 256 + 128 + 16 * (2 * kb + half));
+    }
+    const ksp_u4 bext = half == 0 ? ksp_u4{0x3f803f80u, EX[qrow], 0u, 0u} : ksp_u4{0u, 0u, 0u, 0u};
+    const float sq_i = SQ[qrow];
+    // |s~ - s| <= 1.3e-5 (|x_i|^2 + |x_j|^2): dropped piece products 1.15e-5 |x_i| |x_j| (m.m', r.x', x.r' with |m| <= 2^-9 |x|,
+    // |r| <= 2^-18 |x| per channel), the norms' pieces 2^-19 each, the matrix pipe's fp32 accumulation (13 instructions, taken
+    // as 4 ulp of the running magnitude each: 3e-6), the oracle's own fma chain and sums (64 ulp of |x_i| |x_j|: 2e-6)
+    const float Es = 1.5e-5f * ((qvalid ? sq_i : 0.0f) + sqmax);
+
+    // staging: a tile = 32 rows of 256 bytes = 8 wave instructions of 1 KB (global_load_lds, 16 bytes per lane, lane-linear
+    // in LDS).  The rows are read back a row per lane, so the 16-byte units of a row are XOR-swizzled with the row number: the
+    // lane that fills physical unit p of row r fetches logical unit p ^ (r & 15).
+    auto stage = [&](auto tile_of, int slot0, int nslots, int buf) {
+#pragma unroll
+        for (int mth = 0; mth < T * 8 / QW; ++mth) {
+            const int ii = wave + QW * mth, t = ii >> 3, part = ii & 7;
+            const int tile = tile_of(min(slot0 + t, nslots - 1));
+            const int r = part * 4 + (lane >> 4), pu = lane & 15;
+            const unsigned char *src = R + ((size_t)(tile * KM_TILE + r) * 256 + 16 * (pu ^ (r & 15)));
+            __builtin_amdgcn_global_load_lds(src, tiles + (buf * T + t) * KSP_TILE_BYTES + part * 1024, 16, 0, 0);
+        }
+        static_assert(T <= 2 && QW >= 2, "a wave per tile brings the norms' pieces");
+        if (wave < T) {
+            const int tile = tile_of(min(slot0 + wave, nslots - 1));
+            __builtin_amdgcn_global_load_lds(EX + tile * KM_TILE + col, extb + (buf * T + wave) * 64, 4, 0, 0);
+        }
+    };
+    struct Ops {
+        ksp_u4 a[9];                                        // the norms' block, then (h, m) of the four blocks of 16 channels
+    };
+    auto operands = [&](int buf, int t) {
+        const char *tb = tiles + (buf * T + t) * KSP_TILE_BYTES + col * 256;
+        Ops o;
+        o.a[0] = half == 0 ? ksp_u4{extb[(buf * T + t) * 64 + col], 0x3f803f80u, 0u, 0u} : ksp_u4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            o.a[1 + 2 * kb] = *reinterpret_cast<const ksp_u4 *>(tb + 16 * ((2 * kb + half) ^ (col & 15)));
+            o.a[2 + 2 * kb] = *reinterpret_cast<const ksp_u4 *>(tb + 16 * ((8 + 2 * kb + half) ^ (col & 15)));
+        }
+        return o;
+    };
+    auto mm = [](const ksp_u4 &a, const ksp_u4 &b, const f32x16 &c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ksp_bf16x8, a), __builtin_bit_cast(ksp_bf16x8, b), c, 0, 0, 0);
+    };
+    // matrix instruction `step` (0 .. 12) of a tile: the norms, then h.h, h.m, m.h of every block
+    auto mstep = [&](const Ops &o, auto step, const f32x16 &c) {
+        constexpr int st = decltype(step)::value;
+        if constexpr (st == 0)
+            return mm(o.a[0], bext, c);
+        else {
+            constexpr int kb = (st - 1) / 3, w = (st - 1) % 3;
+            return w == 0 ? mm(o.a[1 + 2 * kb], bh[kb], c) : w == 1 ? mm(o.a[1 + 2 * kb], bm[kb], c) : mm(o.a[2 + 2 * kb], bh[kb], c);
+        }
+    };
+    // A pass: `nslots` tiles in rounds of T through a ring of NB round buffers.  One barrier per round: behind it the round's
+    // tiles have landed (every wave waited for its own part) and nobody reads the buffer of the round before any more -- the
+    // tiles of round r + NB - 1 travel into it; the loads of the NB - 2 rounds in between stay in flight (loads are issued for
+    // rounds past the end as well -- the last tile again -- so the count a wave may leave outstanding never changes).
+    // A wave alone on its SIMD issues in order: an accumulating matrix instruction waits ~32 cycles for the one before it,
+    // and nothing else of the wave issues meanwhile.  So the visitor's work on tile t - 1 is cut into 13 pieces that sit
+    // BETWEEN the 13 matrix instructions of tile t in program order (pinned by scheduling barriers).
+    constexpr int LPR = T * 8 / QW;                         // a wave's loads per round (+ 1 for the waves that bring the norms)
+    f32x16 zero16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        zero16[e] = 0.0f;
+    asm volatile("" : "+v"(zero16));                        // (opaque: not rebuilt in front of every tile)
+    auto pass = [&](auto tile_of, int nslots, auto piece) {
+        const int rounds = (nslots + T - 1) / T;
+#pragma unroll
+        for (int r = 0; r < NB - 1; ++r)
+            stage(tile_of, r * T, nslots, r);
+        f32x16 cur = zero16;
+        int cur_tile = 0;
+        bool cur_valid = false;
+        for (int r = 0; r < rounds; ++r) {
+            if (wave < T)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * (LPR + 1)) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * LPR) : "memory");
+            __syncthreads();
+            stage(tile_of, (r + NB - 1) * T, nslots, (r + NB - 1) % NB);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const Ops o = operands(r % NB, t);
+                f32x16 nxt = zero16;                      // (a register set that stays zero: the first instruction's addend)
+                static_for<13>([&](auto st) {
+                    nxt = mstep(o, st, nxt);
+                    piece(cur, cur_tile, cur_valid, st);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                cur = nxt;
+                cur_tile = tile_of(min(r * T + t, nslots - 1));
+                cur_valid = r * T + t < nslots;
+            }
+        }
+        static_for<13>([&](auto st) { piece(cur, cur_tile, cur_valid, st); });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                    // (the buffers are free for the next pass)
+    };
+
+    // ---------------- pass A: tau~ ----------------
+    // every tile once: per lane the maximum of its sixteen rows of the tile (of two blocks of eight, of four units of four,
+    // where the cloud has few tiles) goes into a sorted list of K; the k-th largest over the query's two lanes is reached by
+    // k DISTINCT candidates, and with 2 ntiles blocks to choose from it sits just below the k-th best score (about 1.2 k
+    // candidates pass it).  The pass costs a third of pass B per tile (no queue writes).
+    MaxK<K> best;
+    best.init();
+    const int units = 2 * ntiles >= 4 * K ? 1 : (4 * ntiles >= 4 * K ? 2 : 4);
+    float um[4];
+    pass([](int s) { return s; }, ntiles, [&](const f32x16 &acc, int, bool valid, auto step) {
+        constexpr int st = decltype(step)::value;
+        if constexpr (st < 4) {
+            um[st] = fmaxf(fmaxf(acc[4 * st], acc[4 * st + 1]), fmaxf(acc[4 * st + 2], acc[4 * st + 3])) +
+                     (valid ? 0.0f : -__builtin_inff());
+        } else if constexpr (st == 4) {
+            if (units <= 2) {
+                um[0] = fmaxf(um[0], um[1]);
+                um[2] = fmaxf(um[2], um[3]);
+            }
+            if (units == 1)
+                um[0] = fmaxf(um[0], um[2]);
+        } else if constexpr (st == 5) {
+            best.insert(um[0]);
+        } else if constexpr (st == 9) {
+            if (units >= 2)
+                best.insert(um[2]);
+        } else if constexpr (st == 7 || st == 11) {
+            if (units == 4)
+                best.insert(um[st == 7 ? 1 : 3]);
+        }
+    });
+    {
+        float other[K];
+#pragma unroll
+        for (int p = 0; p < K; ++p)
+            other[p] = __shfl_xor(best.d[p], 32, 64);
+#pragma unroll
+        for (int p = 0; p < K; ++p)
+            best.insert(other[p]);
+    }
+#if defined(KSP_STOP) && KSP_STOP == 1
+    if (best.d[0] > -1e30f) return;
+#endif
+    float tau = best.d[K - 1];
+#pragma unroll
+    for (int p = 0; p < K; ++p)
+        tau = p == k - 1 ? best.d[p] : tau;
+    const float thr = qvalid ? tau - 2.0f * Es : __builtin_inff();          // (a row past the end asks for nothing)
+
+    // ---------------- pass B: the candidates at or above the bound ----------------
+    // branch free: every score is written -- a hit to the lane's next queue slot, anything else to the slot behind the queue
+    float *myqs = qs + (wave * 64 + lane) * (QH + 1);
+    unsigned short *myqj = qj + (wave * 64 + lane) * (QH + 1);
+    int cnt = 0;                                            // hits so far (the queue keeps the first QH)
+    pass([](int s) { return s; }, ntiles, [&](const f32x16 &acc, int tile, bool valid, auto step) {
+        constexpr int st = decltype(step)::value;
+        const float th = valid ? thr : __builtin_inff();
+        auto one = [&](auto ee) {
+            constexpr int e = decltype(ee)::value;
+            const bool hit = acc[e] >= th;
+            const int slot = hit ? min(cnt, QH) : QH;
+            myqs[slot] = acc[e];
+            myqj[slot] = (unsigned short)(tile * KM_TILE + 4 * half + (e & 3) + 8 * (e >> 2));
+            cnt += hit ? 1 : 0;
+        };
+        one(std::integral_constant<int, st>{});
+        if constexpr (st >= 10)
+            one(std::integral_constant<int, st + 3>{});
+    });
+    const int cnt_pair = cnt + __shfl_xor(cnt, 32, 64);
+    if (qvalid && (cnt > QH || cnt_pair < k))               // (fewer than k: only NaN scores do that)
+        *flag = 1;
+#if defined(KSP_STOP) && KSP_STOP == 2
+    if (cnt >= 0) return;
+#endif
+
+    // ---------------- select: the K + 4 best by score, a lane pair per query ----------------
+    TopKey<KK> top;
+    top.init();
+    {
+        const int L = min(cnt, QH);
+        int e = 0;
+        while (__any(e < L)) {
+            const int ee = min(e, QH - 1);
+            const float sv = myqs[ee];
+            const int jv = (int)myqj[ee];
+            top.insert(e < L ? knn_key(-2.0f * sv, jv) : __builtin_inf());
+            e += 1;
+        }
+        double other[KK];
+#pragma unroll
+        for (int p = 0; p < KK; ++p)
+            other[p] = __shfl_xor(top.key[p], 32, 64);
+#pragma unroll
+        for (int p = 0; p < KK; ++p)
+            top.insert(other[p]);
+    }
+    // neighbours of the list the scores cannot order: d~ = -2 s~ is within 2 E_i of the oracle's distance, so two candidates
+    // less than 4 E_i apart (4.5: room for the subtraction) are undecided; both get the oracle's distance.  Everything
+    // undecided lies in runs of such neighbours, and a candidate outside a run is more than 4 E_i from every other.  What
+    // can still reach the first k places is within that distance of the k-th: if the LAST kept entry is, the list may be
+    // too short and the group is flagged.
+    const float gap = 4.5f * 2.0f * Es;
+    unsigned amb = 0;
+    {
+        float dprev = ksp_key_dist(top.key[0]), dk = 0.0f;
+#pragma unroll
+        for (int p = 0; p + 1 < KK; ++p) {
+            const float dnext = ksp_key_dist(top.key[p + 1]);
+            const bool close = top.key[p + 1] < __builtin_inf() && (dnext - dprev) < gap;
+            amb |= close ? (3u << p) : 0u;
+            dk = p == k - 1 ? dprev : dk;
+            dprev = dnext;
+        }
+        if (qvalid && top.key[KK - 1] < __builtin_inf() && (dprev - dk) < gap)
+            *flag = 1;
+    }
+    if (!qvalid)
+        amb = 0;
+#if defined(KSP_STOP) && KSP_STOP == 3
+    amb = 0;
+#endif
+    // the oracle's distance for those: positions of this lane's parity, one at a time
+    {
+        const float *X = x + (size_t)cloud * n * ld;
+        unsigned pend = amb & (half ? 0xaaaaaaaau : 0x55555555u);
+        while (__any(pend != 0)) {
+            const int p = pend ? __builtin_ctz(pend) : 0;
+            const bool act = pend != 0;
+            pend &= pend - 1u;
+            double key = top.key[0];
+#pragma unroll
+            for (int t = 1; t < KK; ++t)
+                key = p == t ? top.key[t] : key;
+            const int j = act ? knn_key_low16(key) : 0;
+            const float4v *xi = reinterpret_cast<const float4v *>(X + (size_t)(qvalid ? qrow : 0) * ld);
+            const float4v *xj = reinterpret_cast<const float4v *>(X + (size_t)j * ld);
+            float inner = 0.0f;
+#pragma unroll
+            for (int c4 = 0; c4 < 16; c4 += 4) {
+                float4v a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = xi[c4 + u];
+                    b[u] = xj[c4 + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    inner = __builtin_fmaf(a[u].x, b[u].x, inner);
+                    inner = __builtin_fmaf(a[u].y, b[u].y, inner);
+                    inner = __builtin_fmaf(a[u].z, b[u].z, inner);
+                    inner = __builtin_fmaf(a[u].w, b[u].w, inner);
+                }
+            }
+            const float m2 = -2.0f * inner;
+            const float tt = sq_i + m2;
+            const float d = tt + SQ[j];
+            const double nk = knn_key(d, j);
+#pragma unroll
+            for (int t = 0; t < KK; ++t)
+                top.key[t] = (act && p == t) ? nk : top.key[t];
+        }
+    }
+    // both lanes of the pair see every decided key, sort again, and the first k indices go out
+    if (__any(amb != 0)) {
+        double keys[KK];
+#pragma unroll
+        for (int p = 0; p < KK; ++p) {
+            const double o = __shfl_xor(top.key[p], 32, 64);
+            keys[p] = (p & 1) == half ? top.key[p] : o;
+        }
+        top.init();
+#pragma unroll
+        for (int p = 0; p < KK; ++p)
+            top.insert(keys[p]);
+    }
+    __syncthreads();
+    if (*flag != 0) {
+        if (tid < (NQ + 127) / 128 && (wg * NQ) / 128 + tid < gq)
+            flags[cloud * gq + (wg * NQ) / 128 + tid] = 1;
+        return;
+    }
+    if (qvalid && half == 0) {
+        int *dst = nn_idx + ((size_t)cloud * n + qrow) * k;
+#pragma unroll
+        for (int p = 0; p < K; ++p)
+            if (p < k)
+                dst[p] = knn_key_low16(top.key[p]);
+    }
+}
+
+template <int K>
+static hipError_t launch_knn_split(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
+{
+    const KspScratch L = ksp_layout(b, n);
+    void *scratch = nullptr;
+    if (hipError_t e = scratch_alloc(&scratch, L.total, s); e != hipSuccess)
+        return e;
+    unsigned char *base = (unsigned char *)scratch;
+    hipLaunchKernelGGL(knn64_planes_kernel, dim3(L.npad / KM_TILE, b), dim3(256), 0, s, n, ld, L.npad, L.gq, x, base + L.rows,
+                       (unsigned *)(base + L.ext), (float *)(base + L.sqx), base + L.flags);
+    // 256-query workgroups (two waves per SIMD, the cloud streamed through LDS half as often) where that still fills the
+    // chip; 128-query ones otherwise (knob CLOUDAAE_KNN_SPLIT_QW)
+    const long long groups = (long long)(L.npad / 128) * b;
+    const int qw = CLOUDAAE_KNOB_SET("CLOUDAAE_KNN_SPLIT_QW") ? CLOUDAAE_KNOB("CLOUDAAE_KNN_SPLIT_QW", 4) : (groups >= 1024 ? 8 : 4);
+    if (qw == 8) {
+        static bool raised[64] = {};
+        auto kern = &knn64_split_kernel<K, 8>;
+        const size_t lds = ksp_lds_bytes<8>();
+        if (hipError_t e = raise_lds_limit(kern, raised); e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL((knn64_split_kernel<K, 8>), dim3(ceil_div(L.npad, 256), b), dim3(512), lds, s, n, ld, k, L.npad,
+                           L.gq, x, base + L.rows, (const unsigned *)(base + L.ext), (const float *)(base + L.sqx), base + L.flags,
+                           nn_idx);
+    } else {
+        static bool raised[64] = {};
+        auto kern = &knn64_split_kernel<K, 4>;
+        const size_t lds = ksp_lds_bytes<4>();
+        if (hipError_t e = raise_lds_limit(kern, raised); e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL((knn64_split_kernel<K, 4>), dim3(L.npad / 128, b), dim3(256), lds, s, n, ld, k, L.npad,
+                           L.gq, x, base + L.rows, (const unsigned *)(base + L.ext), (const float *)(base + L.sqx), base + L.flags,
+                           nn_idx);
+    }
+    // the flagged query groups once more, the oracle's arithmetic throughout (a byte per workgroup of THAT grid)
+    // (development knob CLOUDAAE_KNN_SPLIT_FIXUP = 0 leaves them unwritten: tools/dev/chk_knn_split.py counts them)
+    if (CLOUDAAE_KNOB("CLOUDAAE_KNN_SPLIT_FIXUP", 1) != 0)
+        if (hipError_t e = launch_knn_wide<K>(b, n, ld, k, x, nn_idx, s, base + L.flags); e != hipSuccess)
+            return e;
+    return hipFreeAsync(scratch, s);
+}
+
+
 // Which C = 64 kernel for `tiles` 32-query tiles (measured, B x N = 1024 points, k = 10, us):
 //   tiles      knn64_mfma   scan, 1 wave/tile   scan, 2 waves/tile   wide (bound pass, 16 waves; round 3 -> end of round 4)
 //    256 (B=8)      55            152                100                  73 -> 58
@@ -1854,6 +2391,13 @@ static hipError_t launch_knn(int b, int n, int c, int ld, int k, const float *x,
             const long long tiles = (long long)ceil_div(n, KM_TILE) * b;
             const int mode = knn_scan_waves(tiles, n, K);
             if (mode == 5 && knn_wide_fits(n, K)) {
+                // the scan on the bf16 matrix pipe (knob CLOUDAAE_KNN_SPLIT = 0: the fp32 matrix pipe throughout)
+                // -- where 256-query workgroups fill the chip (two waves per SIMD); below that a wave alone on its SIMD issues
+                // the filter's instructions one at a time and the fp32 kernel is as fast (B = 32, N = 1024: 59.5 against 59 us);
+                // knob = 2 forces it
+                const int split = CLOUDAAE_KNOB("CLOUDAAE_KNN_SPLIT", 1);
+                if (n <= 65536 && k >= 2 && (split == 2 || (split == 1 && (long long)ceil_div(n, 128) * b >= 1024)))
+                    return launch_knn_split<K>(b, n, ld, k, x, nn_idx, s);
                 return launch_knn_wide<K>(b, n, ld, k, x, nn_idx, s);
             } else if (mode == 2) {
                 return launch_knn_scan<K, 4, 2>(b, n, ld, k, x, nn_idx, s);

@@ -252,12 +252,18 @@ def test_knn_vs_oracle(hip, oracle, b, n, c, ld, k):
                                           (5, 4096, 20, None), (33, 1024, 20, None), (1, 3400, 10, 5),
                                           # sampled tiles reused, pass B over the rest: tile counts 17 / 25 / 29 / 9 / 32
                                           (3, 530, 10, 5), (2, 800, 10, 5), (2, 900, 7, 5), (3, 270, 10, 5), (2, 1024, 1, 5)])
-def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, knobs, b, n, k, mode):
+@pytest.mark.parametrize("split", [2, 0])
+def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, knobs, b, n, k, mode, split):
     """All C = 64 kernels (knob CLOUDAAE_KNN_SCAN = 0: knn64_mfma, 1 / 2: whole-cloud scan with one / two waves
-    per query tile, 5: bound pass + filtered scan in 16-wave workgroups; None: the launcher's own choice) keep
-    the same bit-exact contract."""
+    per query tile, 5: bound pass + filtered scan in 16-wave workgroups; None: the launcher's own choice; where 5 applies,
+    knob CLOUDAAE_KNN_SPLIT = 2: the scan on the bf16 matrix pipe, the oracle's arithmetic for undecided neighbours (1, the
+    default: the same where 256-query workgroups fill the chip), = 0: the fp32 matrix pipe throughout) keep the same
+    bit-exact contract."""
     from cloudaae_amd import _lib
+    if split == 0 and mode not in (5, None):
+        pytest.skip("the knob only matters where the 16-wave kernel applies")
     knobs("CLOUDAAE_KNN_SCAN", mode)
+    knobs("CLOUDAAE_KNN_SPLIT", split)
     rng = np.random.default_rng(n + k)
     x = np.maximum(rng.standard_normal((b, n, 64)), -0.5).astype(np.float32) * 0.1
     x[:, n // 2:n // 2 + 30] = x[:, :30]
@@ -268,18 +274,26 @@ def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, knobs, b, n, k, mode):
     assert np.array_equal(want, got.cpu().numpy())
 
 
-@pytest.mark.parametrize("mode,k,two", [(1, 10, 1), (5, 10, 1), (5, 20, 1), (5, 20, 0)])
-@pytest.mark.parametrize("case", ["all_equal", "few_distinct", "lattice", "large_finite", "far_cluster"])
-def test_knn_c64_bound_kernel_adversarial(hip, oracle, knobs, mode, k, two, case):
+@pytest.mark.parametrize("mode,k,two,split", [(1, 10, 1, 1), (5, 10, 1, 0), (5, 20, 1, 0), (5, 20, 0, 0), (5, 10, 1, 2), (5, 20, 1, 2)])
+@pytest.mark.parametrize("case", ["all_equal", "few_distinct", "lattice", "large_finite", "far_cluster", "near_ties"])
+def test_knn_c64_bound_kernel_adversarial(hip, oracle, knobs, mode, k, two, split, case):
     """The bound kernel's correctness must not depend on its bound being tight: clouds where (nearly) every
     candidate ties with the k-th distance (the queue overflows and is drained over and over), where the sampled
     tiles are unrepresentative, and where distances are huge."""
     from cloudaae_amd import _lib
     knobs("CLOUDAAE_KNN_SCAN", mode)
     knobs("CLOUDAAE_KNN_TWO", two)          # the bound in two stages (default) / one
+    knobs("CLOUDAAE_KNN_SPLIT", split)      # the scan on the bf16 matrix pipe / the fp32 pipe throughout
     rng = np.random.default_rng(7)
     b, n = 3, 1024
-    if case == "all_equal":
+    if case == "near_ties":
+        # every point with 7 copies that differ in the last bits of a few channels: distances equal to ~1e-7 relative, the
+        # order decided by the oracle's rounding alone
+        base = rng.standard_normal((b, n // 8, 64)).astype(np.float32)
+        x = np.repeat(base, 8, axis=1)
+        jig = rng.integers(-2, 3, x.shape).astype(np.int32) * (rng.random(x.shape) < 0.1)
+        x = (x.view(np.int32) + jig).view(np.float32).astype(np.float64)
+    elif case == "all_equal":
         x = np.tile(rng.standard_normal((b, 1, 64)), (1, n, 1))
     elif case == "few_distinct":
         x = rng.standard_normal((b, 5, 64))[:, rng.integers(0, 5, n)]
