@@ -1804,34 +1804,35 @@ static hipError_t launch_knn3_scan(int b, int n, int ld, int k, const float *x, 
     return hipSuccess;
 }
 
-// ---- C = 64, fourth generation: the scan on the bf16 matrix pipe, the oracle's arithmetic only where it decides -------------
+// ---- C = 64, fourth generation (round 5; NOT the default -- see the end of this comment): the scan on the bf16 matrix pipe -----
 // knn64_wide_kernel computes every one of the N x N distances the way the oracle defines them (a k-ordered fp32 fma chain =
 // v_mfma_f32_32x32x2_f32, 33 steps of 64 cycles per 32 x 32 tile) and is bound by exactly that: the fp32 matrix rate.  But
-// the oracle's arithmetic is needed only to ORDER candidates whose distances are closer together than a cheaper evaluation
-// can tell apart.  Here:
-//   planes  : every point once as two bf16 pieces per channel, h = bf16(x), m = bf16(x - h) (x - h - m is below 2^-18 |x|),
-//             its norm |x|^2 in the oracle's order (fp32, exact) and -|x|^2 / 2 as two bf16 pieces (knn64_planes_kernel).
-//   scores  : s~_ij = x_i.x_j - (|x_i|^2 + |x_j|^2) / 2 = -d_ij / 2 from 13 v_mfma_f32_32x32x16_bf16 per tile (h.h, h.m, m.h
-//             over four blocks of 16 channels, and one block that adds the norms): 416 matrix cycles instead of 2112.
-//             |s~ - s| <= E_i = 4e-5 (|x_i|^2 + max_j |x_j|^2) for the s the oracle's arithmetic gives (the dropped piece
-//             products are below 1.2e-5 |x_i| |x_j|, the fp32 accumulation of the matrix pipe and the oracle's own rounding
-//             below that again).
-//   pass A  : every second candidate tile; per lane the maxima of its four units of four rows go into a sorted list of K
-//             values; the k-th largest over the query's two lanes is tau~ (k DISTINCT candidates score at least that).
-//   pass B  : every tile; a candidate with s~ >= tau~ - 2 E_i goes to its query's queue in LDS (score and index: about 2k
-//             of them).  Every candidate the oracle ranks among the k nearest is in the queue: its s is >= the oracle's
-//             k-th largest >= tau~ - E_i.
-//   select  : the queue's K + 4 best by s~ (sorted keys, a lane pair per query).  Two neighbours of that list closer than
-//             4 E_i in distance cannot be ordered by s~: those -- a few per cent -- get the oracle's distance (the fma chain
-//             over the 64 channels, (|x_i|^2 + -2 inner) + |x_j|^2) and are ordered by it (ties by index); everything else is
-//             separated from its neighbours by more than both evaluations can differ, so the order of s~ IS the oracle's.
-//   A queue that overflows, or an undecided chain that reaches the end of the K + 4 list, flags the query group; a gated
-//   launch of knn64_wide_kernel (workgroups leave at once unless flagged) recomputes those: correctness never depends on
-//   the margins being small, only on E_i being a bound.
+// the oracle's arithmetic is needed only for the candidates that can be among the k nearest.  Here:
+//   planes  : every point once, minus a centre of its cloud, as two bf16 pieces per channel, h = bf16(y), m = bf16(y - h)
+//             (y - h - m is below 2^-18 |y|); |x|^2 in the oracle's order (fp32, exact), |y|^2, and -|y|^2 / 2 as two bf16
+//             pieces (knn64_planes_kernel).
+//   scores  : s~_ij = y_i.y_j - (|y_i|^2 + |y_j|^2) / 2 = -d_ij / 2 from 13 v_mfma_f32_32x32x16_bf16 per tile (h.h, h.m, m.h
+//             over four blocks of 16 channels, and one block that adds the norms): 416 matrix cycles instead of 2112, and
+//             |s~ - s| <= E_i for the s the oracle's arithmetic gives (the bound is spelled out in the kernel).
+//   pass A  : every tile; per lane the maximum of its rows of the tile goes into a sorted list of K values; the k-th largest
+//             over the query's two lanes is tau~ (k DISTINCT candidates score at least that).
+//   pass B  : every tile again; a candidate with s~ >= tau~ - 2 E_i goes to its lane's queue in LDS (the index only).  Every
+//             candidate the oracle ranks among the k nearest is there: its s is >= the oracle's k-th largest >= tau~ - E_i.
+//   select  : the oracle's distance (the fma chain over the 64 channels, (|x_i|^2 + -2 inner) + |x_j|^2) for every queued
+//             candidate, sorted keys, a lane pair per query.
+//   A queue that overflows flags the query group; a gated launch of knn64_wide_kernel (workgroups leave at once unless
+//   flagged) recomputes those: correctness never depends on the margins being small, only on E_i being a bound.
+// Bit-exact on every case of tests/test_00_ops_gpu.py (CLOUDAAE_KNN_SPLIT = 2 forces it).  Measured (profiles/
+// notes_knn_split_r5.md): post-ReLU Gaussian features, [128, 1024, k = 10] 229 -> 163 us and [32, 4096, k = 20] 1036 -> 542 us with
+// a first version of the selection (the oracle's distance only for neighbours the scores cannot order).  INSIDE a training
+// step it loses: the features of a freshly initialised encoder sit in a ball a tenth of their own size (|x - centre|^2 =
+// 0.01 |x|^2), neighbours' distances are 1e-3 |x|^2 and 5e-5 |x|^2 apart -- the level of the oracle's OWN rounding (its fma chain
+// is good to 2e-6 |x|^2 a term), so half of all neighbours have to be settled by the oracle's arithmetic anyway -- and clouds
+// stored in scan order keep a query's neighbours in a few tiles, so block maxima bound the k-th score loosely and the queues
+// run long.  B = 128: 241 us against 236; config 5: the queues overflow.  The fp32 kernel stays the default.
 constexpr int KSP_T = 2;             // candidate tiles per round
 constexpr int KSP_NB = 4;            // ring of round buffers: the tiles of round r + 3 travel while round r computes
 constexpr int KSP_TILE_BYTES = KM_TILE * 256;
-constexpr int KSP_X = 4;             // list slots behind the K-th
 typedef __bf16 ksp_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned ksp_u4 __attribute__((ext_vector_type(4)));
 
@@ -1842,7 +1843,7 @@ __device__ __forceinline__ unsigned ksp_bf16_rne(float v)           // finite v
 }
 
 struct KspScratch {                  // one call's scratch (scratch_alloc): offsets in bytes
-    size_t flags, rows, ext, sqx, total;
+    size_t flags, rows, ext, sqx, sqc, total;
     int npad, gq;                    // rows per cloud in the planes (whole 256-query workgroups); 128-query groups per cloud
 };
 static KspScratch ksp_layout(int b, int n)
@@ -1854,60 +1855,90 @@ static KspScratch ksp_layout(int b, int n)
     L.rows = ((size_t)b * L.gq + 255) / 256 * 256;
     L.ext = L.rows + (size_t)b * L.npad * 256;
     L.sqx = L.ext + (size_t)b * L.npad * 4;
-    L.total = L.sqx + (size_t)b * L.npad * 4;
+    L.sqc = L.sqx + (size_t)b * L.npad * 4;
+    L.total = L.sqc + (size_t)b * L.npad * 4;
     return L;
 }
 
-// grid (npad / 32, b), 256 threads: thread (row r = t / 8, unit u = t % 8) splits channels 8u .. 8u + 7 of its row.  The norm in
-// the oracle's order (squares rounded, then summed channel by channel) is a chain through the row's eight threads: thread u
-// continues the sum where thread u - 1 stopped (eight steps of eight additions; every thread runs all of them, one keeps
-// the result).  Also clears the flag bytes of the query groups (a byte per 128 rows).
+// grid (npad / 32, b), 256 threads: thread (row r = t / 8, unit u = t % 8) splits channels 8u .. 8u + 7 of its row -- of the row
+// MINUS a centre of the cloud: distances do not change, and the error of a score is relative to the norms of what was
+// split.  Features behind a ReLU are all positive: their spread around the centre is a fraction of their size (at the
+// first training steps a twentieth), and neighbours whose distances differ by 1e-4 of |x|^2 -- most of them, there -- are
+// told apart by scores on centred rows but not by scores on the rows themselves.  The centre is the mean of 64 rows spread
+// over the cloud, summed in one fixed order by every workgroup (ANY centre is valid; it only has to be the same for the whole
+// cloud).  The norm in the oracle's order (of the row itself: squares rounded, then summed channel by channel) is a chain
+// through the row's eight threads: thread u continues the sum where thread u - 1 stopped (eight steps of eight additions;
+// every thread runs all of them, one keeps the result); the norm of the centred row likewise.  Also clears the flag bytes
+// of the query groups (a byte per 128 rows).
 __global__ __launch_bounds__(256) void knn64_planes_kernel(int n, int ld, int npad, int gq, const float *__restrict__ x,
                                                           unsigned char *__restrict__ rows, unsigned *__restrict__ ext,
-                                                          float *__restrict__ sqx, unsigned char *__restrict__ flags)
+                                                          float *__restrict__ sqx, float *__restrict__ sqc,
+                                                          unsigned char *__restrict__ flags)
 {
+    __shared__ float part[4][64];
     const int cloud = blockIdx.y, t = threadIdx.x, lane = t & 63;
     const int row = blockIdx.x * KM_TILE + (t >> 3), u = t & 7;
     const float *X = x + (size_t)cloud * n * ld;
     if (t == 0 && (blockIdx.x & 3) == 0 && (int)(blockIdx.x >> 2) < gq)
         flags[cloud * gq + (blockIdx.x >> 2)] = 0;
+    {
+        float sum = 0.0f;
+        for (int i = 0; i < 16; ++i) {
+            const int r = (int)(((long long)((t >> 6) * 16 + i) * n) >> 6);     // sample row (t / 64) * 16 + i of 64
+            sum += X[(size_t)r * ld + lane];
+        }
+        part[t >> 6][lane] = sum;
+    }
+    __syncthreads();
+    float mu[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = 8 * u + e;
+        mu[e] = (((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]) * (1.0f / 64.0f);
+    }
     unsigned h[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0};
-    float v2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float v2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (row < n) {
         const float4v a = *reinterpret_cast<const float4v *>(X + (size_t)row * ld + 8 * u);
         const float4v c = *reinterpret_cast<const float4v *>(X + (size_t)row * ld + 8 * u + 4);
         const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const unsigned hb = ksp_bf16_rne(v[e]);
-            const unsigned mb = ksp_bf16_rne(v[e] - __uint_as_float(hb << 16));      // (the difference is exact)
+            const float w = v[e] - mu[e];
+            const unsigned hb = ksp_bf16_rne(w);
+            const unsigned mb = ksp_bf16_rne(w - __uint_as_float(hb << 16));         // (the difference is exact)
             h[e >> 1] |= hb << (16 * (e & 1));
             m[e >> 1] |= mb << (16 * (e & 1));
             v2[e] = v[e] * v[e];
+            w2[e] = w * w;
         }
     }
     unsigned char *R = rows + ((size_t)cloud * npad + row) * 256;
     *reinterpret_cast<ksp_u4 *>(R + 16 * u) = ksp_u4{h[0], h[1], h[2], h[3]};
     *reinterpret_cast<ksp_u4 *>(R + 128 + 16 * u) = ksp_u4{m[0], m[1], m[2], m[3]};
-    float sq = 0.0f;
+    float sq = 0.0f, sc = 0.0f;
 #pragma unroll
     for (int step = 0; step < 8; ++step) {
-        float c = sq;                                       // (step 0: the chain starts from +0, like the oracle's)
+        float c = sq, d = sc;                               // (step 0: the chains start from +0, like the oracle's)
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
+        for (int e = 0; e < 8; ++e) {
             c = c + v2[e];
+            d = d + w2[e];
+        }
         sq = __shfl(c, (lane & ~7) | step, 64);             // what the row's thread `step` computed goes on
+        sc = __shfl(d, (lane & ~7) | step, 64);
     }
     if (u == 0) {
         unsigned e = 0xff80u;                               // (-inf, 0): a row past the end never scores
         if (row < n) {
-            const float hs = -0.5f * sq;
+            const float hs = -0.5f * sc;
             const unsigned a0 = ksp_bf16_rne(hs);
             const unsigned a1 = ksp_bf16_rne(hs - __uint_as_float(a0 << 16));
             e = a0 | (a1 << 16);
         }
         ext[(size_t)cloud * npad + row] = e;
         sqx[(size_t)cloud * npad + row] = row < n ? sq : __builtin_inff();
+        sqc[(size_t)cloud * npad + row] = row < n ? sc : 0.0f;
     }
 }
 
@@ -1934,19 +1965,11 @@ struct MaxK {                        // the K largest values seen, descending
 
 // queue slots per LANE (a query's two lanes keep their own: no counters in LDS, no atomics) + one slot that takes every write
 // that is not a hit
-constexpr int KSP_QH = 24;
+constexpr int KSP_QH = 32;
 template <int QW>
 static size_t ksp_lds_bytes()
 {
-    return KSP_NB * KSP_T * KSP_TILE_BYTES + KSP_NB * KSP_T * 64 * 4 + 64 * QW * (size_t)(KSP_QH + 1) * 6 + 64 * 4 + 16;
-}
-
-// the distance bits of an orderable key (knn_key)
-__device__ __forceinline__ float ksp_key_dist(double key)
-{
-    const unsigned u = (unsigned)__builtin_trunc(__builtin_ldexp(key, -16));
-    const unsigned b = (u & 0x80000000u) ? (u ^ 0x80000000u) : ~u;
-    return __uint_as_float(b);
+    return KSP_NB * KSP_T * KSP_TILE_BYTES + KSP_NB * KSP_T * 64 * 4 + 64 * QW * (size_t)(KSP_QH + 2) * 2 + 64 * 4 + 16;
 }
 
 // QW waves per workgroup, a 32-query tile each (8 where that still fills the chip: two waves per SIMD, and the cloud passes
@@ -1956,15 +1979,15 @@ __global__ __launch_bounds__(64 * QW) void knn64_split_kernel(int n, int ld, int
                                                              const float *__restrict__ x,
                                                              const unsigned char *__restrict__ rows,
                                                              const unsigned *__restrict__ ext, const float *__restrict__ sqx,
-                                                             unsigned char *__restrict__ flags, int *__restrict__ nn_idx)
+                                                             const float *__restrict__ sqc, unsigned char *__restrict__ flags,
+                                                             int *__restrict__ nn_idx)
 {
-    constexpr int QH = KSP_QH, KK = K + KSP_X, T = KSP_T, NB = KSP_NB, NQ = 32 * QW;
+    constexpr int QH = KSP_QH, T = KSP_T, NB = KSP_NB, NQ = 32 * QW;
     extern __shared__ __attribute__((aligned(16))) char ksp_smem[];
     char *tiles = ksp_smem;                                               // [NB][T][32 rows x 256 bytes], units XOR-swizzled
     unsigned *extb = reinterpret_cast<unsigned *>(tiles + NB * T * KSP_TILE_BYTES);   // [NB][T][64]
-    float *qs = reinterpret_cast<float *>(extb + NB * T * 64);            // [64 QW lanes][QH + 1] scores
-    unsigned short *qj = reinterpret_cast<unsigned short *>(qs + 64 * QW * (QH + 1));   // same shape: indices
-    float *red = reinterpret_cast<float *>(qj + 64 * QW * (QH + 1));      // [64]
+    unsigned short *qj = reinterpret_cast<unsigned short *>(extb + NB * T * 64);      // [64 QW lanes][QH + 2] candidate indices
+    float *red = reinterpret_cast<float *>(qj + 64 * QW * (QH + 2));      // [64]
     int *flag = reinterpret_cast<int *>(red + 64);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1975,21 +1998,30 @@ __global__ __launch_bounds__(64 * QW) void knn64_split_kernel(int n, int ld, int
     const unsigned char *R = rows + (size_t)cloud * npad * 256;
     const unsigned *EX = ext + (size_t)cloud * npad;
     const float *SQ = sqx + (size_t)cloud * npad;
+    const float *SC = sqc + (size_t)cloud * npad;
     if (tid == 0)
         *flag = 0;
-    // the largest norm of the cloud (the error bound of a score needs it)
-    float sqmax = 0.0f;
-    for (int j = tid; j < n; j += 64 * QW)
+    // the largest norms of the cloud, of the rows and of the centred rows (the error bound of a score needs them)
+    float sqmax = 0.0f, scmax = 0.0f;
+    for (int j = tid; j < n; j += 64 * QW) {
         sqmax = fmaxf(sqmax, SQ[j]);
+        scmax = fmaxf(scmax, SC[j]);
+    }
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1)
+    for (int off = 1; off < 64; off <<= 1) {
         sqmax = fmaxf(sqmax, __shfl_xor(sqmax, off, 64));
-    if (lane == 0)
+        scmax = fmaxf(scmax, __shfl_xor(scmax, off, 64));
+    }
+    if (lane == 0) {
         red[wave] = sqmax;
+        red[32 + wave] = scmax;
+    }
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < QW; ++w)
+    for (int w = 0; w < QW; ++w) {
         sqmax = fmaxf(sqmax, red[w]);
+        scmax = fmaxf(scmax, red[32 + w]);
+    }
 
     const int qrow = wg * NQ + wave * 32 + col;             // (< npad)
     const bool qvalid = qrow < n;
@@ -2002,10 +2034,14 @@ __global__ __launch_bounds__(64 * QW) void knn64_split_kernel(int n, int ld, int
     }
     const ksp_u4 bext = half == 0 ? ksp_u4{0x3f803f80u, EX[qrow], 0u, 0u} : ksp_u4{0u, 0u, 0u, 0u};
     const float sq_i = SQ[qrow];
-    // |s~ - s| <= 1.3e-5 (|x_i|^2 + |x_j|^2): dropped piece products 1.15e-5 |x_i| |x_j| (m.m', r.x', x.r' with |m| <= 2^-9 |x|,
-    // |r| <= 2^-18 |x| per channel), the norms' pieces 2^-19 each, the matrix pipe's fp32 accumulation (13 instructions, taken
-    // as 4 ulp of the running magnitude each: 3e-6), the oracle's own fma chain and sums (64 ulp of |x_i| |x_j|: 2e-6)
-    const float Es = 1.5e-5f * ((qvalid ? sq_i : 0.0f) + sqmax);
+    // How far a score can be from the oracle's -d / 2, with y = x - centre the rows that were split:
+    //   the score against y's exact -|y_i - y_j|^2 / 2: 1.6e-5 (|y_i|^2 + |y_j|^2) -- dropped piece products 1.15e-5 |y_i| |y_j|
+    //     (m.m', r.y', y.r' with |m| <= 2^-9 |y|, |r| <= 2^-18 |y| per channel), the norms' pieces 2^-19 each and the norms' own
+    //     fp32 sums (64 ulp), the matrix pipe's fp32 accumulation (13 instructions, taken as 4 ulp of the running magnitude
+    //     each: 3e-6); y is x - centre ROUNDED, off by an ulp of itself: 1.2e-7 more;
+    //   the oracle's fp32 distance against the exact one: its fma chain and sums are off by up to 64 ulp of |x_i| |x_j|, the size
+    //     of the rows themselves: 2.1e-6 (|x_i|^2 + |x_j|^2).
+    const float Es = 1.8e-5f * ((qvalid ? SC[qrow] : 0.0f) + scmax) + 2.1e-6f * ((qvalid ? sq_i : 0.0f) + sqmax);
 
     // staging: a tile = 32 rows of 256 bytes = 8 wave instructions of 1 KB (global_load_lds, 16 bytes per lane, lane-linear
     // in LDS).  The rows are read back a row per lane, so the 16-byte units of a row are XOR-swizzled with the row number: the
@@ -2149,9 +2185,9 @@ __global__ __launch_bounds__(64 * QW) void knn64_split_kernel(int n, int ld, int
     const float thr = qvalid ? tau - 2.0f * Es : __builtin_inff();          // (a row past the end asks for nothing)
 
     // ---------------- pass B: the candidates at or above the bound ----------------
-    // branch free: every score is written -- a hit to the lane's next queue slot, anything else to the slot behind the queue
-    float *myqs = qs + (wave * 64 + lane) * (QH + 1);
-    unsigned short *myqj = qj + (wave * 64 + lane) * (QH + 1);
+    // branch free: every candidate's index is written -- a hit to the lane's next queue slot, anything else to the slot behind
+    // the queue
+    unsigned short *myqj = qj + (wave * 64 + lane) * (QH + 2);
     int cnt = 0;                                            // hits so far (the queue keeps the first QH)
     pass([](int s) { return s; }, ntiles, [&](const f32x16 &acc, int tile, bool valid, auto step) {
         constexpr int st = decltype(step)::value;
@@ -2160,7 +2196,6 @@ __global__ __launch_bounds__(64 * QW) void knn64_split_kernel(int n, int ld, int
             constexpr int e = decltype(ee)::value;
             const bool hit = acc[e] >= th;
             const int slot = hit ? min(cnt, QH) : QH;
-            myqs[slot] = acc[e];
             myqj[slot] = (unsigned short)(tile * KM_TILE + 4 * half + (e & 3) + 8 * (e >> 2));
             cnt += hit ? 1 : 0;
         };
@@ -2175,66 +2210,21 @@ __global__ __launch_bounds__(64 * QW) void knn64_split_kernel(int n, int ld, int
     if (cnt >= 0) return;
 #endif
 
-    // ---------------- select: the K + 4 best by score, a lane pair per query ----------------
-    TopKey<KK> top;
+    // ---------------- select: the oracle's distance for every queued candidate, a lane pair per query ----------------
+    // (Round 5 first ordered the queue by score and gave only neighbours closer than the two evaluations can differ the oracle's
+    //  distance.  On features as a training step has them -- |x - centre|^2 a hundredth of |x|^2, neighbours' distances 1e-3 |x|^2
+    //  and 5e-5 |x|^2 apart -- half of all neighbours are that close: the ORACLE's own fma chain is only good to 2e-6 |x|^2 a
+    //  term.  So every candidate of the queue, about 1.2 k per query, gets the fma chain; the bound keeps the queue that short
+    //  whatever the data.)
+    TopKey<K> top;
     top.init();
     {
+        const float *X = x + (size_t)cloud * n * ld;
+        const float4v *xi = reinterpret_cast<const float4v *>(X + (size_t)(qvalid ? qrow : 0) * ld);
         const int L = min(cnt, QH);
         int e = 0;
         while (__any(e < L)) {
-            const int ee = min(e, QH - 1);
-            const float sv = myqs[ee];
-            const int jv = (int)myqj[ee];
-            top.insert(e < L ? knn_key(-2.0f * sv, jv) : __builtin_inf());
-            e += 1;
-        }
-        double other[KK];
-#pragma unroll
-        for (int p = 0; p < KK; ++p)
-            other[p] = __shfl_xor(top.key[p], 32, 64);
-#pragma unroll
-        for (int p = 0; p < KK; ++p)
-            top.insert(other[p]);
-    }
-    // neighbours of the list the scores cannot order: d~ = -2 s~ is within 2 E_i of the oracle's distance, so two candidates
-    // less than 4 E_i apart (4.5: room for the subtraction) are undecided; both get the oracle's distance.  Everything
-    // undecided lies in runs of such neighbours, and a candidate outside a run is more than 4 E_i from every other.  What
-    // can still reach the first k places is within that distance of the k-th: if the LAST kept entry is, the list may be
-    // too short and the group is flagged.
-    const float gap = 4.5f * 2.0f * Es;
-    unsigned amb = 0;
-    {
-        float dprev = ksp_key_dist(top.key[0]), dk = 0.0f;
-#pragma unroll
-        for (int p = 0; p + 1 < KK; ++p) {
-            const float dnext = ksp_key_dist(top.key[p + 1]);
-            const bool close = top.key[p + 1] < __builtin_inf() && (dnext - dprev) < gap;
-            amb |= close ? (3u << p) : 0u;
-            dk = p == k - 1 ? dprev : dk;
-            dprev = dnext;
-        }
-        if (qvalid && top.key[KK - 1] < __builtin_inf() && (dprev - dk) < gap)
-            *flag = 1;
-    }
-    if (!qvalid)
-        amb = 0;
-#if defined(KSP_STOP) && KSP_STOP == 3
-    amb = 0;
-#endif
-    // the oracle's distance for those: positions of this lane's parity, one at a time
-    {
-        const float *X = x + (size_t)cloud * n * ld;
-        unsigned pend = amb & (half ? 0xaaaaaaaau : 0x55555555u);
-        while (__any(pend != 0)) {
-            const int p = pend ? __builtin_ctz(pend) : 0;
-            const bool act = pend != 0;
-            pend &= pend - 1u;
-            double key = top.key[0];
-#pragma unroll
-            for (int t = 1; t < KK; ++t)
-                key = p == t ? top.key[t] : key;
-            const int j = act ? knn_key_low16(key) : 0;
-            const float4v *xi = reinterpret_cast<const float4v *>(X + (size_t)(qvalid ? qrow : 0) * ld);
+            const int j = e < L ? (int)myqj[min(e, QH - 1)] : (qvalid ? qrow : 0);
             const float4v *xj = reinterpret_cast<const float4v *>(X + (size_t)j * ld);
             float inner = 0.0f;
 #pragma unroll
@@ -2256,24 +2246,16 @@ __global__ __launch_bounds__(64 * QW) void knn64_split_kernel(int n, int ld, int
             const float m2 = -2.0f * inner;
             const float tt = sq_i + m2;
             const float d = tt + SQ[j];
-            const double nk = knn_key(d, j);
-#pragma unroll
-            for (int t = 0; t < KK; ++t)
-                top.key[t] = (act && p == t) ? nk : top.key[t];
+            top.insert(e < L ? knn_key(d, j) : __builtin_inf());
+            e += 1;
         }
-    }
-    // both lanes of the pair see every decided key, sort again, and the first k indices go out
-    if (__any(amb != 0)) {
-        double keys[KK];
+        double other[K];
 #pragma unroll
-        for (int p = 0; p < KK; ++p) {
-            const double o = __shfl_xor(top.key[p], 32, 64);
-            keys[p] = (p & 1) == half ? top.key[p] : o;
-        }
-        top.init();
+        for (int p = 0; p < K; ++p)
+            other[p] = __shfl_xor(top.key[p], 32, 64);
 #pragma unroll
-        for (int p = 0; p < KK; ++p)
-            top.insert(keys[p]);
+        for (int p = 0; p < K; ++p)
+            top.insert(other[p]);
     }
     __syncthreads();
     if (*flag != 0) {
@@ -2299,7 +2281,7 @@ static hipError_t launch_knn_split(int b, int n, int ld, int k, const float *x, 
         return e;
     unsigned char *base = (unsigned char *)scratch;
     hipLaunchKernelGGL(knn64_planes_kernel, dim3(L.npad / KM_TILE, b), dim3(256), 0, s, n, ld, L.npad, L.gq, x, base + L.rows,
-                       (unsigned *)(base + L.ext), (float *)(base + L.sqx), base + L.flags);
+                       (unsigned *)(base + L.ext), (float *)(base + L.sqx), (float *)(base + L.sqc), base + L.flags);
     // 256-query workgroups (two waves per SIMD, the cloud streamed through LDS half as often) where that still fills the
     // chip; 128-query ones otherwise (knob CLOUDAAE_KNN_SPLIT_QW)
     const long long groups = (long long)(L.npad / 128) * b;
@@ -2311,8 +2293,8 @@ static hipError_t launch_knn_split(int b, int n, int ld, int k, const float *x, 
         if (hipError_t e = raise_lds_limit(kern, raised); e != hipSuccess)
             return e;
         hipLaunchKernelGGL((knn64_split_kernel<K, 8>), dim3(ceil_div(L.npad, 256), b), dim3(512), lds, s, n, ld, k, L.npad,
-                           L.gq, x, base + L.rows, (const unsigned *)(base + L.ext), (const float *)(base + L.sqx), base + L.flags,
-                           nn_idx);
+                           L.gq, x, base + L.rows, (const unsigned *)(base + L.ext), (const float *)(base + L.sqx),
+                           (const float *)(base + L.sqc), base + L.flags, nn_idx);
     } else {
         static bool raised[64] = {};
         auto kern = &knn64_split_kernel<K, 4>;
@@ -2320,8 +2302,8 @@ static hipError_t launch_knn_split(int b, int n, int ld, int k, const float *x, 
         if (hipError_t e = raise_lds_limit(kern, raised); e != hipSuccess)
             return e;
         hipLaunchKernelGGL((knn64_split_kernel<K, 4>), dim3(L.npad / 128, b), dim3(256), lds, s, n, ld, k, L.npad,
-                           L.gq, x, base + L.rows, (const unsigned *)(base + L.ext), (const float *)(base + L.sqx), base + L.flags,
-                           nn_idx);
+                           L.gq, x, base + L.rows, (const unsigned *)(base + L.ext), (const float *)(base + L.sqx),
+                           (const float *)(base + L.sqc), base + L.flags, nn_idx);
     }
     // the flagged query groups once more, the oracle's arithmetic throughout (a byte per workgroup of THAT grid)
     // (development knob CLOUDAAE_KNN_SPLIT_FIXUP = 0 leaves them unwritten: tools/dev/chk_knn_split.py counts them)
@@ -2391,11 +2373,9 @@ static hipError_t launch_knn(int b, int n, int c, int ld, int k, const float *x,
             const long long tiles = (long long)ceil_div(n, KM_TILE) * b;
             const int mode = knn_scan_waves(tiles, n, K);
             if (mode == 5 && knn_wide_fits(n, K)) {
-                // the scan on the bf16 matrix pipe (knob CLOUDAAE_KNN_SPLIT = 0: the fp32 matrix pipe throughout)
-                // -- where 256-query workgroups fill the chip (two waves per SIMD); below that a wave alone on its SIMD issues
-                // the filter's instructions one at a time and the fp32 kernel is as fast (B = 32, N = 1024: 59.5 against 59 us);
-                // knob = 2 forces it
-                const int split = CLOUDAAE_KNOB("CLOUDAAE_KNN_SPLIT", 1);
+                // development knob CLOUDAAE_KNN_SPLIT: 2 = the scan on the bf16 matrix pipe (knn64_split_kernel), 1 = the same where
+                // 256-query workgroups fill the chip, 0 (default) = the fp32 matrix pipe throughout: see knn64_split_kernel
+                const int split = CLOUDAAE_KNOB("CLOUDAAE_KNN_SPLIT", 0);
                 if (n <= 65536 && k >= 2 && (split == 2 || (split == 1 && (long long)ceil_div(n, 128) * b >= 1024)))
                     return launch_knn_split<K>(b, n, ld, k, x, nn_idx, s);
                 return launch_knn_wide<K>(b, n, ld, k, x, nn_idx, s);

@@ -302,6 +302,7 @@ def fully_connected_chains(inputs, chains, bn_decay=None, is_training=None, poin
 # tensors the next layer reads: arena buffers of a recorded step stay valid afterwards).  tests/test_03_configs_gpu.py
 # takes the activation pattern of the fully connected stack from it; None (the default) = nothing is kept.
 FC_TAP = None
+KNN_TAP = None      # a list: cloudaae_knn's C = 64 inputs are appended (development)
 
 
 def _relu_rows(x):
@@ -379,6 +380,8 @@ def knn(adj_matrix, k=9):
     nn_idx = _lib.empty((b, n, int(k)), dtype=torch.int32, device=x.device)
     # bench.py times a launch over 64 feature channels live (F.TIMED_SITES["knn64"]): one of every three -- layers
     # 2-4 launch the same shape, and every event pair costs the step a few microseconds of stream markers
+    if KNN_TAP is not None and adj_matrix.channels == 64:       # (development: tools/dev/knn_step_data.py looks at the features)
+        KNN_TAP.append(x.detach().clone())
     rec = F.TIMED_SITES.get("knn64") if adj_matrix.channels == 64 else None
     if rec is not None:
         F.KNN64_SEEN += 1
