@@ -657,7 +657,10 @@ int cloudaae_spherical_flip(int b, int na, const float *a, int nb, const float *
  * conv(flipped[b,n1,3]) minus the two largest vertex indices (the reference's two `[:-1]`); visible
  * [b,n1,3] = org rows of the visible ids (ascending), padded with random re-draws of visible ids;
  * num_vis [b] int64; visible_id [b,n1] (optional; -1 in the padded rows).  qhull is replaced by an exact
- * per-point vertex test (2-variable LPs in fp64); workspace: cloudaae_hpr_workspace_bytes(b, n1). */
+ * per-point vertex test (2-variable LPs in fp64: a local problem over the point's neighbours in a spatial
+ * order, then verification passes over bounding volumes of 64-point groups; the points of a cloud are handed
+ * to waves from a per-cloud queue); workspace: cloudaae_hpr_workspace_bytes(b, n1) (vertex flags, the sorted
+ * cloud, its permutation, the queues -- contents undefined afterwards). */
 long long cloudaae_hpr_workspace_bytes(int b, int n1);
 int cloudaae_hidden_point_removal(int b, int n1, const float *flipped, const float *org,
                                   unsigned long long seed, float *visible, long long *num_vis, int *visible_id,

@@ -30,3 +30,31 @@ for li, x in enumerate(tf_util.KNN_TAP):
           % (li + 2, sq.mean(), sq.max(), sc.mean(), sc.max(), sc.mean() / sq.mean(), dk[..., K - 1].mean() / rel,
              gaps.median() / rel, gaps.flatten().kthvalue(int(gaps.numel() * 0.1)).values / rel,
              gaps.flatten().kthvalue(int(gaps.numel() * 0.01)).values / rel, 100.0 * (gaps == 0).double().mean()))
+
+# the kNN launch itself on these inputs, against the same shape of post-ReLU Gaussian features
+from cloudaae_amd import _lib
+L = _lib.lib()
+
+
+def time_knn(x, tag):
+    b, n, _ = x.shape
+    ld = x.stride(1)
+    out = torch.empty((b, n, K), dtype=torch.int32, device="cuda")
+    go = lambda: _lib.check(L.cloudaae_knn(b, n, 64, ld, K, x.data_ptr(), out.data_ptr(), _lib.stream()), "knn")
+    for _ in range(20):
+        go()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        go()
+    e1.record(); torch.cuda.synchronize()
+    print("  %-28s %.1f us" % (tag, e0.elapsed_time(e1) * 1e3 / 20))
+
+
+for li, x in enumerate(tf_util.KNN_TAP):
+    x = x.contiguous()
+    time_knn(x, "layer %d features" % (li + 2))
+    perm = torch.stack([torch.randperm(x.shape[1], device="cuda") for _ in range(x.shape[0])])
+    time_knn(torch.gather(x, 1, perm[..., None].expand_as(x)).contiguous(), "  ... rows shuffled")
+time_knn(torch.relu(torch.randn_like(tf_util.KNN_TAP[0])).contiguous(), "relu(randn)")
