@@ -20,6 +20,8 @@ timeout 300 bash tools/pmc_kernel.sh r05_x3s_dx gemm_x3s -- python3 "$ROOT/tools
 # SQ counters of the C = 64 kNN kernel at the headline shape and at config 5's
 timeout 300 bash tools/pmc_kernel.sh r05_knn64_wide knn64_wide -- python3 "$ROOT/tools/bench_knn1.py" 32 1024 64 320 10
 timeout 300 bash tools/pmc_kernel.sh r05_knn64_wide_k20_n4096 knn64_wide -- python3 "$ROOT/tools/bench_knn1.py" 32 4096 64 320 20 3
+# SQ counters of the hull-vertex kernel (hidden point removal, config 5's clouds)
+timeout 300 bash tools/pmc_kernel.sh r05_hull_pmc_n8593 hull_vertex -- python3 "$ROOT/tools/dev/run_hpr.py" 32 8192 1
 # the bench lines (no profiler)
 python3 bench.py > "$OUT/r05_bench_b32_n1024.json" 2> "$OUT/bench_b32.err"
 python3 bench.py --per-gpu-batch 128 --step-only > "$OUT/r05_bench_b128_n1024.json" 2>/dev/null
