@@ -1827,9 +1827,9 @@ static hipError_t launch_knn3_scan(int b, int n, int ld, int k, const float *x, 
 // a first version of the selection (the oracle's distance only for neighbours the scores cannot order).  INSIDE a training
 // step it loses: the features of a freshly initialised encoder sit in a ball a tenth of their own size (|x - centre|^2 =
 // 0.01 |x|^2), neighbours' distances are 1e-3 |x|^2 and 5e-5 |x|^2 apart -- the level of the oracle's OWN rounding (its fma chain
-// is good to 2e-6 |x|^2 a term), so half of all neighbours have to be settled by the oracle's arithmetic anyway -- and clouds
-// stored in scan order keep a query's neighbours in a few tiles, so block maxima bound the k-th score loosely and the queues
-// run long.  B = 128: 241 us against 236; config 5: the queues overflow.  The fp32 kernel stays the default.
+// is good to 2e-6 |x|^2 a term), so half of all neighbours have to be settled by the oracle's arithmetic anyway; config 5's
+// clouds repeat points (visible points re-drawn to 4096 rows), whose exact ties overflow the per-lane queues.
+// B = 128: 241 us against 236; config 5: the queues overflow.  The fp32 kernel stays the default.
 constexpr int KSP_T = 2;             // candidate tiles per round
 constexpr int KSP_NB = 4;            // ring of round buffers: the tiles of round r + 3 travel while round r computes
 constexpr int KSP_TILE_BYTES = KM_TILE * 256;
