@@ -367,16 +367,18 @@ __global__ __launch_bounds__(HS_THREADS) void hpr_sort_grid_kernel(int n1, const
 #define HPR_NEAR_LARGE_V 512
 #endif
 constexpr int HPR_NEAR_SMALL = HPR_NEAR_SMALL_V, HPR_NEAR_LARGE = HPR_NEAR_LARGE_V;      // clouds one workgroup of 8 / 16 waves holds (hull_vertex_kernel)
-template <int HPR_NEAR>
-__device__ __forceinline__ int hpr_seq(int pos, int self, int n1, int stride)
+// (`near`: the neighbours actually offered -- HPR_NEAR, or fewer in a cloud so small that the offsets +-1, +-2, ... would come round
+//  to a point a second time: a binding constraint re-tested in floating point reports round-off as a violation)
+__device__ __forceinline__ int hpr_near_of(int n1, int cap) { return min(cap, 2 * ((n1 - 1) / 2)); }
+__device__ __forceinline__ int hpr_seq(int pos, int self, int n1, int stride, int near)
 {
-    if (pos < HPR_NEAR) {
+    if (pos < near) {
         const int d = (pos >> 1) + 1;
         int q = (pos & 1) ? self - d : self + d;
         q = q < 0 ? q + n1 : (q >= n1 ? q - n1 : q);
         return q;
     }
-    const int p2 = pos - HPR_NEAR;
+    const int p2 = pos - near;
     if (p2 >= n1)
         return n1;
     // (p2 * stride) mod n1 without an integer division: quotient from a float product, off by at most one
@@ -389,7 +391,7 @@ __device__ __forceinline__ int hpr_seq(int pos, int self, int n1, int stride)
     int d = q - self;
     d = d < 0 ? -d : d;
     d = min(d, n1 - d);
-    return (d >= 1 && d <= HPR_NEAR / 2) ? n1 : q;
+    return (d >= 1 && d <= near / 2) ? n1 : q;
 }
 
 // ---- hull vertex test ---------------------------------------------------------------------
@@ -452,7 +454,8 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
 {
     double vx = HPR_TAN, vy = HPR_TAN;
     const float pxf = (float)fr.px, pyf = (float)fr.py, pzf = (float)fr.pz;     // exact: p is a float
-    const int span = HPR_NEAR + n1;
+    const int near = hpr_near_of(n1, HPR_NEAR);
+    const int span = near + n1;
     // the plane d = r + vx u + vy w under test, and its fp32 copy: recomputed only when a re-solve moved (vx, vy)
     double dx, dy, dz;
     float dxf, dyf, dzf, slack;
@@ -468,7 +471,7 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
     set_plane();
     // the strided part of the sequence advances by 64 positions per iteration: q += 64 * stride (mod n1)
     const int step64 = (int)(((long long)64 * stride) % n1);
-    int qraw = 0, qat = -1;                 // qraw = ((qat + lane - HPR_NEAR) * stride) mod n1
+    int qraw = 0, qat = -1;                 // qraw = ((qat + lane - near) * stride) mod n1
     int i = 0;
     while (i < span) {
         // the scan tests the current plane itself: with d = r + vx u + vy w the constraint of q reads
@@ -479,8 +482,8 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
         // the margin repeat the test in fp64.  The decision is therefore exactly the fp64 one.
         const int pos = i + lane;
         int q;
-        if (i >= HPR_NEAR) {                // (uniform) every lane is in the strided part
-            const int p2 = pos - HPR_NEAR;
+        if (i >= near) {                    // (uniform) every lane is in the strided part
+            const int p2 = pos - near;
             if (qat + 64 == i) {
                 qraw += step64;
                 qraw -= qraw >= n1 ? n1 : 0;
@@ -494,9 +497,9 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
             int dd = qraw - self;
             dd = dd < 0 ? -dd : dd;
             dd = min(dd, n1 - dd);
-            q = (p2 < n1 && !(dd >= 1 && dd <= HPR_NEAR / 2)) ? qraw : n1;
+            q = (p2 < n1 && !(dd >= 1 && dd <= near / 2)) ? qraw : n1;
         } else {
-            q = pos < span ? hpr_seq<HPR_NEAR>(pos, self, n1, stride) : n1;
+            q = pos < span ? hpr_seq(pos, self, n1, stride, near) : n1;
         }
         const bool valid = q < n1 && q != self;
         bool viol = false;
@@ -544,7 +547,7 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
             add(lane == 0 ? 1.0 : (lane == 1 ? -1.0 : 0.0), lane == 2 ? 1.0 : (lane == 3 ? -1.0 : 0.0), HPR_TAN);
         const int upto = i + first;            // sequence positions [0, upto) were already accepted
         for (int jpos = lane; jpos < upto; jpos += 64) {
-            const int r = hpr_seq<HPR_NEAR>(jpos, self, n1, stride);
+            const int r = hpr_seq(jpos, self, n1, stride, near);
             if (r >= n1 || r == self)
                 continue;
             const Cons m = hpr_constraint(pts, r, fr);
@@ -686,15 +689,16 @@ __device__ int hpr_lp2d_wave_culled(const float *__restrict__ pts, const HprGrou
     };
     set_plane();
     int n_extra = 0;
+    const int near = hpr_near_of(n1, HPR_NEAR);
     // member `pos` of the working set: the neighbours in sorted order, alternating sides, then the points that joined
     auto member = [&](int pos) {
-        if (pos < HPR_NEAR) {
+        if (pos < near) {
             const int d = (pos >> 1) + 1;
             int q = (pos & 1) ? self - d : self + d;
             q = q < 0 ? q + n1 : (q >= n1 ? q - n1 : q);
             return (q < 0 || q >= n1) ? n1 : q;             // (clouds smaller than the neighbourhood)
         }
-        return extras[pos - HPR_NEAR];
+        return extras[pos - near];
     };
     // the point test of the scan: fp32 with a margin, fp64 inside it (see hpr_lp2d_wave)
     double excess = 0.0;                        // of the last violated point: d.g + eps |g| (> 0)
@@ -777,9 +781,9 @@ __device__ int hpr_lp2d_wave_culled(const float *__restrict__ pts, const HprGrou
 
     // ---- the local problem: the neighbours in sequence (Seidel over W's first HPR_NEAR members) ----
     int i = 0;
-    while (i < HPR_NEAR) {
+    while (i < near) {
         const int q = member(i + lane);
-        const bool viol = (i + lane < HPR_NEAR && q < n1 && q != self) ? violated(q) : false;
+        const bool viol = (i + lane < near && q < n1 && q != self) ? violated(q) : false;
         const unsigned long long mask = __ballot(viol);
         if (mask == 0ull) {
             i += 64;
@@ -836,7 +840,7 @@ __device__ int hpr_lp2d_wave_culled(const float *__restrict__ pts, const HprGrou
                     int dd = q - self;
                     dd = dd < 0 ? -dd : dd;
                     dd = min(dd, n1 - dd);
-                    viol = dd > HPR_NEAR / 2;
+                    viol = dd > near / 2;
                     for (int e = 0; e < n_extra; ++e)
                         viol = viol && extras[e] != q;
                     if (viol && (worst_q < 0 || excess > worst)) {
@@ -866,7 +870,7 @@ __device__ int hpr_lp2d_wave_culled(const float *__restrict__ pts, const HprGrou
                 worst_q = oq;
             }
         }
-        if (!resolve(worst_q, HPR_NEAR + n_extra))
+        if (!resolve(worst_q, near + n_extra))
             return 0;
         if (lane == 0)
             extras[n_extra] = worst_q;

@@ -660,7 +660,9 @@ int cloudaae_spherical_flip(int b, int na, const float *a, int nb, const float *
  * per-point vertex test (2-variable LPs in fp64: a local problem over the point's neighbours in a spatial
  * order, then verification passes over bounding volumes of 64-point groups; the points of a cloud are handed
  * to waves from a per-cloud queue); workspace: cloudaae_hpr_workspace_bytes(b, n1) (vertex flags, the sorted
- * cloud, its permutation, the queues -- contents undefined afterwards). */
+ * cloud, its permutation, the queues -- contents undefined afterwards).  The points of a cloud are taken to be
+ * distinct (qhull reports one of several identical vertices; here an exact copy of a binding constraint tests
+ * as violated by round-off and the answer for such points is unspecified). */
 long long cloudaae_hpr_workspace_bytes(int b, int n1);
 int cloudaae_hidden_point_removal(int b, int n1, const float *flipped, const float *org,
                                   unsigned long long seed, float *visible, long long *num_vis, int *visible_id,
