@@ -671,7 +671,7 @@ __device__ __forceinline__ void hpr_group_slabs(const float *__restrict__ pts, i
 // returns 1 = vertex, 0 = not a vertex, -1 = more than HPR_EXTRA points joined the working set (the caller runs the scan)
 template <int HPR_NEAR>
 __device__ int hpr_lp2d_wave_culled(const float *__restrict__ pts, const HprGroups &gb, int *__restrict__ extras, int n1,
-                                    int self, const Frame &fr, int lane)
+                                    int self, const Frame &fr, int lane, int extra_cap)
 {
     double vx = HPR_TAN, vy = HPR_TAN;
     const float pxf = (float)fr.px, pyf = (float)fr.py, pzf = (float)fr.pz;     // exact: p is a float
@@ -854,7 +854,7 @@ __device__ int hpr_lp2d_wave_culled(const float *__restrict__ pts, const HprGrou
             HPR_COUNT(7, 1);
             return 1;
         }
-        if (n_extra == HPR_EXTRA) {
+        if (n_extra >= extra_cap) {          // (HPR_EXTRA; the tests lower it to send points through the scan)
             HPR_COUNT(6, 1);
             return -1;
         }
@@ -986,7 +986,7 @@ __global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, con
             int verdict = -1;
             HPR_COUNT(0, 1);
             if (culled)
-                verdict = hpr_lp2d_wave_culled<NEAR>(pts, gb, extras[wave], n1, j, f, lane);
+                verdict = hpr_lp2d_wave_culled<NEAR>(pts, gb, extras[wave], n1, j, f, lane, min(culled - 1, HPR_EXTRA));
             vertex = verdict >= 0 ? verdict == 1 : hpr_lp2d_wave<NEAR>(pts, n1, j, stride, f, lane);
         }
         if (lane == 0)     // `points` is the spatially sorted cloud: the flag goes back to the original index
@@ -1206,8 +1206,11 @@ CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *
             }
         }
     }
-    // the scan behind the local problem as culled verification passes (knob CLOUDAAE_HPR_CULL = 0: the full strided scan)
-    const int culled = CLOUDAAE_KNOB("CLOUDAAE_HPR_CULL", 1) != 0 ? 1 : 0;
+    // the scan behind the local problem as culled verification passes (knob CLOUDAAE_HPR_CULL = 0: the full strided scan; a value
+    // of 2 .. 32 caps the points that may join a working set -- HPR_EXTRA = 32 by default -- so that the tests can send
+    // points through the fallback, 1 = the default)
+    const int cull_knob = CLOUDAAE_KNOB("CLOUDAAE_HPR_CULL", 1);
+    const int culled = cull_knob <= 0 ? 0 : (cull_knob == 1 ? HPR_EXTRA + 1 : cull_knob - 1);    // 0 = off, else the cap + 1
     if (wide)
         hipLaunchKernelGGL(hull_vertex_kernel<16>, dim3(gx, b), dim3(64 * 16), lds, s, n1, sorted, perm, hpr_stride(n1), culled,
                            queue ? next_point : nullptr, flags);
