@@ -2175,9 +2175,6 @@ __global__ __launch_bounds__(64 * QW) void knn64_split_kernel(int n, int ld, int
         for (int p = 0; p < K; ++p)
             best.insert(other[p]);
     }
-#if defined(KSP_STOP) && KSP_STOP == 1
-    if (best.d[0] > -1e30f) return;
-#endif
     float tau = best.d[K - 1];
 #pragma unroll
     for (int p = 0; p < K; ++p)
@@ -2206,9 +2203,6 @@ __global__ __launch_bounds__(64 * QW) void knn64_split_kernel(int n, int ld, int
     const int cnt_pair = cnt + __shfl_xor(cnt, 32, 64);
     if (qvalid && (cnt > QH || cnt_pair < k))               // (fewer than k: only NaN scores do that)
         *flag = 1;
-#if defined(KSP_STOP) && KSP_STOP == 2
-    if (cnt >= 0) return;
-#endif
 
     // ---------------- select: the oracle's distance for every queued candidate, a lane pair per query ----------------
     // (Round 5 first ordered the queue by score and gave only neighbours closer than the two evaluations can differ the oracle's

@@ -586,11 +586,11 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
 // ---- the same LP, the full scan replaced by CULLED verification passes (round 5) -----------------------------------
 // hpr_lp2d_wave pays n1 / 64 iterations of ~75 vector instructions for the scan behind the local problem -- per point,
 // although the plane it verifies is (almost always) already final and cuts a cap of the shell that only p's surroundings
-// come near.  Here the sorted cloud is cut into GROUPS of 64 consecutive points with their bounding boxes (hpr_group_boxes:
+// come near.  Here the sorted cloud is cut into GROUPS of 64 consecutive points with a bounding volume each (hpr_group_slabs:
 // the spatial sort makes them compact).  After the local problem over the working set W = {the HPR_NEAR sorted-order
 // neighbours}:
-//   pass : every group's box against the plane under test, a lane per group: max over the box of d.(q - p) in fp32 at or
-//          below the (negative) margin of the point test proves every point of the group satisfied -- the group is culled.
+//   pass : every group's volume against the plane under test, a lane per group: max over the volume of d.(q - p) in fp32 at
+//          or below a (negative) margin proves every point of the group satisfied -- the group is culled.
 //          The points of the other groups take the point test of the scan above (fp32 with a margin, fp64 inside it),
 //          a lane per point, consecutive LDS addresses, no sequence arithmetic.
 //   a violated point q outside W: W += {q}, the optimum moves onto q's line by the 1-D problem over W (Seidel's step: the
