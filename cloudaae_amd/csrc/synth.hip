@@ -593,9 +593,10 @@ __device__ bool hpr_lp2d_wave(const float *__restrict__ pts, int n1, int self, i
 //          or below a (negative) margin proves every point of the group satisfied -- the group is culled.
 //          The points of the other groups take the point test of the scan above (fp32 with a margin, fp64 inside it),
 //          a lane per point, consecutive LDS addresses, no sequence arithmetic.
-//   a violated point q outside W: W += {q}, the optimum moves onto q's line by the 1-D problem over W (Seidel's step: the
-//          optimum of W + {q} lies on q's line; the members of W are never re-tested, as in the scan above: the optimum sits
-//          exactly on its binding constraints), and the pass starts again.  A pass without a violation proves the plane.
+//   the MOST violated point q of a pass outside W: W += {q}, the optimum moves onto q's line by the 1-D problem over W
+//          (Seidel's step: the optimum of W + {q} lies on q's line; the members of W are never re-tested, as in the scan
+//          above: the optimum sits exactly on its binding constraints), and another pass follows.  A pass without a
+//          violation proves the plane.
 // This is Seidel's algorithm with the constraints that never mattered left out of the 1-D problems: the optimum over W only
 // is what the passes verify against EVERY point, W only grows, and the answer (feasible or not) is that of the full LP.  At
 // most HPR_EXTRA points join W behind the neighbours; a point that needs more goes through hpr_lp2d_wave instead.
