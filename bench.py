@@ -152,11 +152,13 @@ def cpu_table(num_point):
 def chamfer_kernel_rate(batch, n, m, iters=20, distinct=None, hint=False):
     """The second half of BASELINE's metric: Chamfer nn_distance forward kernel rate.
     Algorithmic bytes = B*(n+m)*20 (12 B read + 4 B dist + 4 B idx per point): arithmetic-bound
-    by three orders of magnitude.  Large clouds take nn_distance_filter_kernel: the nearest candidate is
-    searched with scores on the matrix cores (two v_mfma_f32_32x32x2_f32 per 32 x 32 pairs) and the
-    reference's un-fused arithmetic decides among the candidates of the two best units (bit parity with
-    the CPU reference).  Its bound is the matrix pipe: 1024 pairs per 128 cycles per SIMD = 19.7 T pairs/s
-    (the first-generation kernel: 8.6 fp32 lane-operations per pair, 9.1 T pairs/s at best)."""
+    by three orders of magnitude.  Large clouds take nn_distance_filter_kernel<SPLIT>: the nearest candidate is
+    searched with scores on the bf16 matrix cores -- error-free three-piece splits, two v_mfma_f32_32x32x16_bf16
+    (32 cycles each) per 32 x 32 pairs -- and the reference's un-fused arithmetic decides among the candidates of
+    the two best units (bit parity with the CPU reference).  `frac_of_bf16_matrix_pipe_bound` prices the pipe the
+    scores run on: 1024 pairs per 64 cycles per SIMD = 39.3 T pairs/s (27 us at [32, 4096]^2); the vector digest of
+    the scores (8 v_min3 per 512 pairs, ~25 us, overlapping only partly) is what the kernel adds to it:
+    `frac_of_pipe_plus_digest_floor` prices against both."""
     from cloudaae_amd.tf_ops.nn_distance import tf_nndistance
     g = torch.Generator(device="cuda").manual_seed(100)       # tf_nndistance.py:45-46 seeds
     a = torch.randn((batch, n, 3), generator=g, device="cuda")
@@ -198,13 +200,16 @@ def chamfer_kernel_rate(batch, n, m, iters=20, distinct=None, hint=False):
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     pairs = 2.0 * batch * n * m
-    bound = 256 * 4 * 2.4e9 * 1024 / 128
+    bound = 256 * 4 * 2.4e9 * 1024 / 64             # two 32-cycle bf16 MFMAs per 1024 pairs per SIMD
+    digest = 256 * 4 * 2.4e9 * 512 / (8 * 4)        # the digest: 8 v_min3 (4 cycles each) per 512 pairs per SIMD
+    floor = 1.0 / (1.0 / bound + 1.0 / digest)
     return {"shape": "[%d,%d,3]x[%d,%d,3]%s" % (batch, n, batch, m, "" if distinct is None else
                                                  " (target = %d points + re-draws, as the reference pads%s)"
                                                  % (distinct, "; the search is told which rows are re-draws" if hint else "")),
             "us_per_launch": round(sec * 1e6, 2),
             "GB/s": round(batch * (n + m) * 20 / sec / 1e9, 3), "Tpairs/s": round(pairs / sec / 1e12, 3),
-            "clouds/s": round(batch / sec, 1), "frac_of_matrix_pipe_bound": round(pairs / sec / bound, 4)}
+            "clouds/s": round(batch / sec, 1), "frac_of_bf16_matrix_pipe_bound": round(pairs / sec / bound, 4),
+            "frac_of_pipe_plus_digest_floor": round(pairs / sec / floor, 4)}
 
 
 def fps_kernel_rate(batch, n, m, iters=5):
@@ -341,10 +346,15 @@ def timed_steps(graph, el, steps, warmup, world, sites):
     torch.cuda.synchronize()
     for k in sites:
         F.TIMED_SITES[k].clear()
+    # one HIP event per step on the launch stream: the spread of the single steps (min / median / max) goes into the
+    # line next to the mean, so that a box effect on a 30 ms timed region can be told from a regression
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(steps):
         F.TIMED_ON = i % 4 == 0          # the live kernel timings sample one step in four of the timed region
         out = graph.train_step(el)
+        marks[i + 1].record()
     F.TIMED_ON = True
     torch.cuda.synchronize()
     if world > 1:
@@ -355,7 +365,10 @@ def timed_steps(graph, el, steps, warmup, world, sites):
         t = torch.tensor([elapsed], dtype=torch.float64, device=graph.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    return elapsed, out
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    spread = {"step_ms_min": round(per_step[0], 4), "step_ms_median": round(per_step[len(per_step) // 2], 4),
+              "step_ms_max": round(per_step[-1], 4)} if per_step else {}
+    return elapsed, out, spread
 
 
 def site_ms(events):
@@ -463,7 +476,7 @@ def main():
         os.dup2(stdout_fd, 1)
         os.close(stdout_fd)
 
-    elapsed, out = timed_steps(synth if synth is not None else graph, el, args.steps, args.warmup, world, sites)
+    elapsed, out, spread = timed_steps(synth if synth is not None else graph, el, args.steps, args.warmup, world, sites)
     events = {k: F.TIMED_SITES.pop(k) for k in sites}
     loss = float(out["total_loss"])
     # the edge-convolution blocks are timed AFTER the timed region (sixteen event pairs per step would cost the
@@ -492,7 +505,7 @@ def main():
                                 {"batch_size": B, "learning_rate": 0.0008}, replay=not args.eager,
                                 gemm_dtype=args.gemm_dtype, k_neighbor=args.k, process_group=False)
             solo.reuse_staged_inputs = True
-            t1, _ = timed_steps(solo, el, args.steps, args.warmup, 1, [])
+            t1, _, _ = timed_steps(solo, el, args.steps, args.warmup, 1, [])
             one_rank = {"per_gpu_batch": B, "clouds/s": round(B * args.steps / t1, 2),
                         "ms_per_step": round(t1 / args.steps * 1e3, 4)}
         dist.barrier()
@@ -510,6 +523,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "step_ms_min": spread.get("step_ms_min"), "step_ms_median": spread.get("step_ms_median"),
+            "step_ms_max": spread.get("step_ms_max"),       # per-step HIP events of this rank, inside the timed region
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

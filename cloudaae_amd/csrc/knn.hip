@@ -1445,7 +1445,10 @@ __global__ __launch_bounds__(1024) void knn3_wide_kernel(int n, int ld, int k, c
         const float *row = X + (size_t)min(j, n - 1) * ld;
         const float cx = row[0], cy = row[1], cz = row[2];
         const float a = cx * cx, b = cy * cy, c = cz * cz;
-        float sq = 0.0f + a;                               // the un-fused sequential sum the oracle defines
+        // the un-fused sequential sum the oracle defines.  (This file is compiled WITHOUT packed-fp32 instructions, csrc/Makefile:
+        //  the v_pk_add_f32 with op_sel the compiler made of these three lines is the instruction behind the wrong neighbour
+        //  lists of two processes sharing a GPU -- profiles/notes_two_processes_one_gpu.md, round 6; tests/test_isa_rules.py)
+        float sq = 0.0f + a;
         sq = sq + b;
         sq = sq + c;
         cand[j] = j < n ? float4v{cx, cy, cz, sq} : float4v{0.0f, 0.0f, 0.0f, __builtin_inff()};

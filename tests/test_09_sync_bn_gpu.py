@@ -121,23 +121,9 @@ def _compare_once(B, N, replay, steps):
                                                (64, 128, True, 3)])
 def test_sync_bn_two_ranks_equal_one_rank_of_the_global_batch(hip, B, N, replay, steps):
     """Two ranks with SyncBN against one rank on the global batch.  BOTH RANKS SHARE THE ONE GPU of the test box, which is
-    not the deployment (one rank per GPU): steps of two processes running side by side on one GPU have shown a rare
-    nondeterminism in a step's first kNN (about one step in a hundred, clouds below 256 points: the layer-1 kernels for
-    small clouds; never in one process; profiles/notes_two_processes_one_gpu.md -- round 5 showed that AMD_OPT_FLUSH=0,
-    which round 4 set here, does NOT remove it).  The default runtime configuration is what runs; a run that trips over it
-    is repeated ONCE and the trip is reported -- test_sync_bn_two_ranks_first_attempt (not strict) keeps it visible."""
+    not the deployment (one rank per GPU).  Rounds 4 and 5 repeated a failed first attempt here: about one step in a hundred of
+    two processes on one GPU came out with a wrong first kNN.  Round 6 found the instruction (a packed-fp32 add with op_sel
+    in the candidate norms, profiles/notes_two_processes_one_gpu.md) and the library no longer contains it
+    (tests/test_isa_rules.py): ONE attempt, no retry, no xfail canary."""
     bad = _compare_once(B, N, replay, steps)
-    if bad is not None:
-        import warnings
-        warnings.warn("two ranks on one GPU: first attempt outside the bounds (the known two-process flake?): %r" % (bad,))
-        bad = _compare_once(B, N, replay, steps)
-    assert bad is None, bad
-
-
-@pytest.mark.xfail(strict=False, reason="two processes on ONE GPU: ~1 % of steps see a nondeterministic first kNN "
-                                        "(profiles/notes_two_processes_one_gpu.md); one rank per GPU is unaffected")
-def test_sync_bn_two_ranks_first_attempt(hip):
-    """The same comparison without the second chance, on the shape that trips most often: stays in the report as XPASS /
-    XFAIL so the issue is not forgotten."""
-    bad = _compare_once(64, 128, True, 3)
     assert bad is None, bad

@@ -1,0 +1,34 @@
+"""Instruction-level rules on the library as BUILT (the gfx950 code objects inside cloudaae_amd/libcloudaae_hip.so are
+disassembled; no GPU needed)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools import isa_scan  # noqa: E402
+
+LIB = os.path.join(ROOT, "cloudaae_amd", "libcloudaae_hip.so")
+
+
+@pytest.fixture(scope="module")
+def instructions():
+    if not isa_scan.tools_present():
+        pytest.skip("no ROCm LLVM tools on this machine")
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    return isa_scan.disassemble(LIB)
+
+
+def test_no_packed_fp32_instruction_takes_its_low_half_from_a_high_register(instructions):
+    """The cause of the wrong neighbour lists under two processes on one GPU (profiles/notes_two_processes_one_gpu.md, round 6):
+    `v_pk_add_f32 ... op_sel:[0,1]`, formed by the compiler for the candidate norms x*x + y*y + z*z of the layer-1 kNN kernels,
+    returned `src0 + 0` in lanes 48-63 about once in 6000 executions when a wave of another process shared the SIMD.  csrc/Makefile
+    compiles the files where the compiler forms such instructions without the packed-fp32 feature; this test keeps every file
+    honest, whatever a later compiler or a later edit does."""
+    assert len(instructions) > 100000, "disassembly looks empty"
+    kernels = set(fn for fn, _ in instructions)
+    assert any("knn3_wide_kernel" in k for k in kernels) and any("adam_tf_kernel" in k for k in kernels)
+    bad = isa_scan.packed_f32_low_from_high(instructions)
+    assert not bad, "packed-fp32 instructions with op_sel on a low half:\n" + "\n".join("%s | %s" % b for b in bad[:20])
