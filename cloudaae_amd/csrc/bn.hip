@@ -670,10 +670,19 @@ static int bn_backward_impl(const char *name, int M, int C, const float *y, int 
     int parts = bn_parts(M);
     const int cb = ceil_div(C, 64);
     const int groups = pool_mode == 1 ? M / pool_rows : 0;
+    bool finalised = false;
     if (pool_stats != nullptr && pool_mode == 1 && dout == nullptr && relu && training) {
         parts = groups < BN_MAX_PARTS ? groups : BN_MAX_PARTS;     // partial-sum rows from what the forward pass counted
-        hipLaunchKernelGGL(bn_bwd_pool_partials_kernel, dim3(ceil_div(C, 256), parts), dim3(256), 0, s, C, groups,
-                           pool_rows, dpooled, pool_stats, partial);
+        if (sync == nullptr) {
+            // no exchange between the rows and their sums: the finalise forms the rows itself (one launch, same bits)
+            hipLaunchKernelGGL(bn_bwd_finalize_pool_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C, groups,
+                               pool_rows, parts, dpooled, pool_stats, (double)M, training, dgamma, dbeta,
+                               accumulate_param_grads, m12, dbias, gamma, save_var);
+            finalised = true;
+        } else {
+            hipLaunchKernelGGL(bn_bwd_pool_partials_kernel, dim3(ceil_div(C, 256), parts), dim3(256), 0, s, C, groups,
+                               pool_rows, dpooled, pool_stats, partial);
+        }
     } else {
         hipLaunchKernelGGL(bn_bwd_colsum_kernel, dim3(cb, parts), dim3(256), 0, s, a, partial, parts);
     }
@@ -685,9 +694,10 @@ static int bn_backward_impl(const char *name, int M, int C, const float *y, int 
         gsums = sync->buf;
         gcount = (double)M * (double)sync->world;
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts,
-                       (double)M, training, dgamma, dbeta, accumulate_param_grads, m12, dbias, gamma, save_var, gsums,
-                       gcount);
+    if (!finalised)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts,
+                           (double)M, training, dgamma, dbeta, accumulate_param_grads, m12, dbias, gamma, save_var, gsums,
+                           gcount);
     const int slab = 64;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cb, ceil_div(M, slab)), dim3(256), 0, s, a, m12, dy, lddy,
                        slab);

@@ -230,15 +230,14 @@ CLOUDAAE_API int cloudaae_bn_meanpool_backward16(int M, int C, const uint16_t *y
                      "null argument");
     CLOUDAAE_REQUIRE(((uintptr_t)y & 15) == 0 && ((uintptr_t)dy & 15) == 0, name, "y and dy must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    double *partial = (double *)workspace;
-    float *scratch = (float *)(partial + (size_t)BN_MAX_PARTS * 4 * C);
+    float *scratch = (float *)((double *)workspace + (size_t)BN_MAX_PARTS * 4 * C);
     float *m12 = scratch + 2 * (size_t)C;
     const int groups = M / pool_rows;
     const int parts = groups < BN_MAX_PARTS ? groups : BN_MAX_PARTS;
-    hipLaunchKernelGGL(bn_bwd_pool_partials_kernel, dim3(ceil_div(C, 256), parts), dim3(256), 0, s, C, groups, pool_rows,
-                       dpooled, pool_stats, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C, partial, parts,
-                       (double)M, 1, dgamma, dbeta, accumulate_param_grads, m12, dbias, gamma, save_var, nullptr, 0.0);
+    // (the partial-sum rows are formed inside the finalise: bn_common.h)
+    hipLaunchKernelGGL(bn_bwd_finalize_pool_kernel, dim3(ceil_div(C, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, C, groups,
+                       pool_rows, parts, dpooled, pool_stats, (double)M, 1, dgamma, dbeta, accumulate_param_grads, m12, dbias,
+                       gamma, save_var);
     const int slab = 64;
     hipLaunchKernelGGL(bn_bwd_apply_meanpool16_kernel, dim3(C / 256, M / slab), dim3(256), 0, s, C, y, ldy, gamma, beta,
                        save_mean, save_var, m12, pool_rows, dpooled, dy, lddy, slab);

@@ -38,38 +38,44 @@ constexpr int BN_FIN_THREADS = BN_FIN_CH * BN_FIN_LANES;
 __device__ __forceinline__ int bn_fin_channel() { return blockIdx.x * BN_FIN_CH + (int)(threadIdx.x % BN_FIN_CH); }
 __device__ __forceinline__ int bn_fin_lane() { return (int)(threadIdx.x / BN_FIN_CH); }
 
-// s = sum_p partial[p][0][c], s2 = sum_p partial[p][1][c]; with partial3 != nullptr also
-// s3 = sum_p partial3[p][0][c] in the same pass (its loads travel with the others)
-__device__ __forceinline__ void bn_reduce_partials(const double *__restrict__ partial, int parts, int C, int c,
-                                                   int pl, double &s, double &s2,
-                                                   const double *__restrict__ partial3 = nullptr,
-                                                   double *s3 = nullptr)
+// The reduction itself, over any source of partial-sum rows: A(p), B(p), C3(p) give row p's three terms for this thread's
+// channel (C3 only with THREE).  Fixed shape -- two accumulators per lane over rows pl, pl + 32, ... (bn_accumulate_rows), then
+// the tree over the lanes (bn_reduce_lanes) -- so every caller (the finalise kernels, a finalise folded into the producing
+// kernel, the pooled backward that forms its rows on the fly) gets the same bits from the same rows.
+struct BnLaneSums {
+    double a, b, c;
+};
+template <bool THREE, class FA, class FB, class FC>
+__device__ __forceinline__ BnLaneSums bn_accumulate_rows(int parts, bool active, int pl, FA A, FB B, FC C3)
 {
-    __shared__ double red[3][BN_FIN_LANES][BN_FIN_CH];
     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, c0 = 0.0, c1 = 0.0;
-    if (c < C) {
+    if (active) {
         int p = pl;
         for (; p + BN_FIN_LANES < parts; p += 2 * BN_FIN_LANES) {
-            a0 += partial[((size_t)p * 2 + 0) * C + c];
-            b0 += partial[((size_t)p * 2 + 1) * C + c];
-            a1 += partial[((size_t)(p + BN_FIN_LANES) * 2 + 0) * C + c];
-            b1 += partial[((size_t)(p + BN_FIN_LANES) * 2 + 1) * C + c];
-            if (partial3 != nullptr) {
-                c0 += partial3[((size_t)p * 2 + 0) * C + c];
-                c1 += partial3[((size_t)(p + BN_FIN_LANES) * 2 + 0) * C + c];
+            a0 += A(p);
+            b0 += B(p);
+            a1 += A(p + BN_FIN_LANES);
+            b1 += B(p + BN_FIN_LANES);
+            if constexpr (THREE) {
+                c0 += C3(p);
+                c1 += C3(p + BN_FIN_LANES);
             }
         }
         for (; p < parts; p += BN_FIN_LANES) {
-            a0 += partial[((size_t)p * 2 + 0) * C + c];
-            b0 += partial[((size_t)p * 2 + 1) * C + c];
-            if (partial3 != nullptr)
-                c0 += partial3[((size_t)p * 2 + 0) * C + c];
+            a0 += A(p);
+            b0 += B(p);
+            if constexpr (THREE)
+                c0 += C3(p);
         }
     }
-    const int l = threadIdx.x % BN_FIN_CH;
-    red[0][pl][l] = a0 + a1;
-    red[1][pl][l] = b0 + b1;
-    red[2][pl][l] = c0 + c1;
+    return BnLaneSums{a0 + a1, b0 + b1, c0 + c1};
+}
+__device__ __forceinline__ void bn_reduce_lanes(const BnLaneSums &v, int pl, int l, double &s, double &s2, double &s3)
+{
+    __shared__ double red[3][BN_FIN_LANES][BN_FIN_CH];
+    red[0][pl][l] = v.a;
+    red[1][pl][l] = v.b;
+    red[2][pl][l] = v.c;
     __syncthreads();
     double t0 = 0.0, t1 = 0.0, t2 = 0.0;
 #pragma unroll
@@ -80,25 +86,42 @@ __device__ __forceinline__ void bn_reduce_partials(const double *__restrict__ pa
     }
     s = t0;
     s2 = t1;
+    s3 = t2;
+}
+template <bool THREE, class FA, class FB, class FC>
+__device__ __forceinline__ void bn_reduce_rows(int parts, bool active, int pl, int l, FA A, FB B, FC C3, double &s, double &s2,
+                                               double &s3)
+{
+    bn_reduce_lanes(bn_accumulate_rows<THREE>(parts, active, pl, A, B, C3), pl, l, s, s2, s3);
+}
+
+// s = sum_p partial[p][0][c], s2 = sum_p partial[p][1][c]; with partial3 != nullptr also
+// s3 = sum_p partial3[p][0][c] in the same pass (its loads travel with the others)
+__device__ __forceinline__ void bn_reduce_partials(const double *__restrict__ partial, int parts, int C, int c,
+                                                   int pl, double &s, double &s2,
+                                                   const double *__restrict__ partial3 = nullptr,
+                                                   double *s3 = nullptr)
+{
+    const int l = threadIdx.x % BN_FIN_CH;
+    auto A = [&](int p) { return partial[((size_t)p * 2 + 0) * C + c]; };
+    auto B = [&](int p) { return partial[((size_t)p * 2 + 1) * C + c]; };
+    auto C3 = [&](int p) { return partial3[((size_t)p * 2 + 0) * C + c]; };
+    double t2 = 0.0;
+    if (partial3 != nullptr)
+        bn_reduce_rows<true>(parts, c < C, pl, l, A, B, C3, s, s2, t2);
+    else
+        bn_reduce_rows<false>(parts, c < C, pl, l, A, B, C3, s, s2, t2);
     if (s3 != nullptr)
         *s3 = t2;
 }
 
-// per-channel finalise (grid = ceil(C/BN_FIN_CH) blocks of BN_FIN_THREADS threads).  training: moments from
-// the partial sums + EMA update; inference: moments = EMA shadows.  Also derives inv/shift
-// for the apply pass.
-static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_kernel(
-    int C, const double *__restrict__ partial, int parts, double count, int training,
-    const float *__restrict__ decay, float *__restrict__ ema_mean, float *__restrict__ ema_var,
-    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ save_mean,
-    float *__restrict__ save_var, float *__restrict__ scale_shift)
+// what one channel's forward finalise writes, from its two sums
+__device__ __forceinline__ void bn_finalize_channel(int C, int c, double s, double s2, double count, int training,
+                                                    const float *__restrict__ decay, float *__restrict__ ema_mean,
+                                                    float *__restrict__ ema_var, const float *__restrict__ gamma,
+                                                    const float *__restrict__ beta, float *__restrict__ save_mean,
+                                                    float *__restrict__ save_var, float *__restrict__ scale_shift)
 {
-    const int c = bn_fin_channel(), pl = bn_fin_lane();
-    double s = 0.0, s2 = 0.0;
-    if (training)
-        bn_reduce_partials(partial, parts, C, c, pl, s, s2);
-    if (c >= C || pl != 0)
-        return;
     float mean, var;
     if (training) {
         const double mu = s / count;
@@ -122,6 +145,47 @@ static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_kernel(
     scale_shift[C + c] = beta[c] - mean * inv;
 }
 
+// per-channel finalise (grid = ceil(C/BN_FIN_CH) blocks of BN_FIN_THREADS threads).  training: moments from
+// the partial sums + EMA update; inference: moments = EMA shadows.  Also derives inv/shift
+// for the apply pass.
+static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize_kernel(
+    int C, const double *__restrict__ partial, int parts, double count, int training,
+    const float *__restrict__ decay, float *__restrict__ ema_mean, float *__restrict__ ema_var,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ save_mean,
+    float *__restrict__ save_var, float *__restrict__ scale_shift)
+{
+    const int c = bn_fin_channel(), pl = bn_fin_lane();
+    double s = 0.0, s2 = 0.0;
+    if (training)
+        bn_reduce_partials(partial, parts, C, c, pl, s, s2);
+    if (c >= C || pl != 0)
+        return;
+    bn_finalize_channel(C, c, s, s2, count, training, decay, ema_mean, ema_var, gamma, beta, save_mean, save_var, scale_shift);
+}
+
+// what one channel's backward finalise writes, from its three sums
+__device__ __forceinline__ void bn_bwd_finalize_channel(int C, int c, double s, double s2, double s3, double count, int training,
+                                                        float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate,
+                                                        float *__restrict__ m12, float *__restrict__ dbias,
+                                                        const float *__restrict__ gamma, const float *__restrict__ save_var,
+                                                        const double *__restrict__ gsums, double gcount)
+{
+    if (dbeta != nullptr)
+        dbeta[c] = (accumulate ? dbeta[c] : 0.0f) + (float)s;
+    if (dgamma != nullptr)
+        dgamma[c] = (accumulate ? dgamma[c] : 0.0f) + (float)s2;
+    const float m1 = training ? (gsums != nullptr ? (float)(gsums[c] / gcount) : (float)(s / count)) : 0.0f;
+    const float m2 = training ? (gsums != nullptr ? (float)(gsums[C + c] / gcount) : (float)(s2 / count)) : 0.0f;
+    m12[c] = m1;
+    m12[C + c] = m2;
+    if (dbias != nullptr) {
+        // gradient of a bias added right in front of this BN = sum_r dy = gamma*rstd*((sum dz - M*m1) -
+        // m2 * sum xhat): analytically zero, numerically the same round-off a column sum of dy gives
+        const double gr = (double)gamma[c] * (double)bn_rsqrt(save_var[c] + BN_EPS);
+        dbias[c] = (accumulate ? dbias[c] : 0.0f) + (float)(gr * ((s - count * (double)m1) - (double)m2 * s3));
+    }
+}
+
 // dbeta = sum dz, dgamma = sum dz*xhat; m1/m2 = their means (0 in inference mode,
 // where the statistics do not depend on the batch).  grid = ceil(C/BN_FIN_CH) x BN_FIN_THREADS threads.
 static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_bwd_finalize_kernel(
@@ -138,20 +202,8 @@ static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_bwd_finalize_kernel(
                        dbias != nullptr ? partial + (size_t)BN_MAX_PARTS * 2 * C : nullptr, &s3);
     if (c >= C || pl != 0)
         return;
-    if (dbeta != nullptr)
-        dbeta[c] = (accumulate ? dbeta[c] : 0.0f) + (float)s;
-    if (dgamma != nullptr)
-        dgamma[c] = (accumulate ? dgamma[c] : 0.0f) + (float)s2;
-    const float m1 = training ? (gsums != nullptr ? (float)(gsums[c] / gcount) : (float)(s / count)) : 0.0f;
-    const float m2 = training ? (gsums != nullptr ? (float)(gsums[C + c] / gcount) : (float)(s2 / count)) : 0.0f;
-    m12[c] = m1;
-    m12[C + c] = m2;
-    if (dbias != nullptr) {
-        // gradient of a bias added right in front of this BN = sum_r dy = gamma*rstd*((sum dz - M*m1) -
-        // m2 * sum xhat): analytically zero, numerically the same round-off a column sum of dy gives
-        const double gr = (double)gamma[c] * (double)bn_rsqrt(save_var[c] + BN_EPS);
-        dbias[c] = (accumulate ? dbias[c] : 0.0f) + (float)(gr * ((s - count * (double)m1) - (double)m2 * s3));
-    }
+    bn_bwd_finalize_channel(C, c, s, s2, s3, count, training, dgamma, dbeta, accumulate, m12, dbias, gamma, save_var, gsums,
+                            gcount);
 }
 
 // Mean pool over groups of `rows` rows with nothing else consuming the activation: the upstream gradient
@@ -182,6 +234,44 @@ static __global__ __launch_bounds__(256) void bn_bwd_pool_partials_kernel(int C,
     double *p3 = partial + (size_t)BN_MAX_PARTS * 2 * C;
     p3[((size_t)blockIdx.y * 2 + 0) * C + c] = s2;
     p3[((size_t)blockIdx.y * 2 + 1) * C + c] = 0.0;
+}
+
+// The two kernels above in one (no SyncBN exchange between them): the finalise forms partial-sum row p on the fly -- the
+// same products in the same order as bn_bwd_pool_partials_kernel stores them -- and reduces the rows as ever: same bits,
+// one launch less.
+static __global__ __launch_bounds__(BN_FIN_THREADS) void bn_bwd_finalize_pool_kernel(
+    int C, int groups, int rows, int parts, const float *__restrict__ dpooled, const double *__restrict__ pool_stats,
+    double count, int training, float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate,
+    float *__restrict__ m12, float *__restrict__ dbias, const float *__restrict__ gamma, const float *__restrict__ save_var)
+{
+    const int c = bn_fin_channel(), pl = bn_fin_lane(), l = threadIdx.x % BN_FIN_CH;
+    auto A = [&](int p) {
+        double acc = 0.0;
+        for (int g = p; g < groups; g += parts)
+            acc += (double)(dpooled[(size_t)g * C + c] / (float)rows) * pool_stats[(size_t)g * 3 * C + c];
+        return acc;
+    };
+    auto B = [&](int p) {
+        double acc = 0.0;
+        for (int g = p; g < groups; g += parts)
+            acc += (double)(dpooled[(size_t)g * C + c] / (float)rows) * pool_stats[(size_t)g * 3 * C + C + c];
+        return acc;
+    };
+    auto C3 = [&](int p) {
+        double acc = 0.0;
+        for (int g = p; g < groups; g += parts)
+            acc += pool_stats[(size_t)g * 3 * C + 2 * (size_t)C + c];
+        return acc;
+    };
+    double s, s2, s3;
+    if (dbias != nullptr)
+        bn_reduce_rows<true>(parts, c < C, pl, l, A, B, C3, s, s2, s3);
+    else
+        bn_reduce_rows<false>(parts, c < C, pl, l, A, B, C3, s, s2, s3);
+    if (c >= C || pl != 0)
+        return;
+    bn_bwd_finalize_channel(C, c, s, s2, s3, count, training, dgamma, dbeta, accumulate, m12, dbias, gamma, save_var, nullptr,
+                            0.0);
 }
 
 // ---- SyncBN: the sums of a layer leave for the other ranks between its statistics pass and its finalise ----
