@@ -6,6 +6,8 @@ this module.  Nothing under cloudaae_amd/ does.
   liboracle.so               our C restatement (oracle/cloudaae_oracle.c)
   _ref/libref_nndistance.so  the reference's own Chamfer lines, when built
                              (oracle/build_ref.sh); `ref_*` raise if absent.
+  _ref/libref_gpu.so         the reference's own GPU kernels (tf_sampling_g.cu, tf_nndistance_g.cu) compiled for gfx950
+                             (oracle/ref_gpu_shim.hip); `ref_gpu_*` take torch CUDA tensors, GPU tests only.
 """
 import ctypes
 import os
@@ -199,3 +201,102 @@ def pairwise_distance(x, channels=None):
     D = np.zeros((n, n), np.float32)
     lib().oracle_pairwise_distance(n, c, ld, p, D.ctypes.data_as(_c_f))
     return D
+
+
+# ---- the reference's GPU kernels, compiled for gfx950 (oracle/ref_gpu_shim.hip; needs a GPU) --------------------------
+_ref_gpu = None
+
+
+def ref_gpu():
+    """oracle/_ref/libref_gpu.so (tf_sampling_g.cu whole, tf_nndistance_g.cu:5-151, built by oracle/build_ref.sh where
+    /root/reference exists), or None."""
+    global _ref_gpu
+    if _ref_gpu is None:
+        _ref_gpu = _load(os.path.join(_HERE, "_ref", "libref_gpu.so"))
+    return _ref_gpu
+
+
+def have_ref_gpu():
+    return ref_gpu() is not None
+
+
+def _dev(t, dtype):
+    import torch
+    assert t.is_cuda and t.is_contiguous() and t.dtype == dtype, (t.device, t.dtype)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _ok(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s: the reference kernel's launch failed (%d)" % (what, rc))
+
+
+def ref_gpu_farthest_point_sample(npoint, inp):
+    """farthestpointsamplingLauncher (tf_sampling_g.cu:203) on torch CUDA tensors: inp [b,n,3] f32 -> [b,npoint] i32"""
+    import torch
+    b, n, _ = inp.shape
+    temp = torch.empty((32, n), dtype=torch.float32, device=inp.device)          # tf_sampling.cpp:115
+    out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
+    _ok(ref_gpu().ref_gpu_farthest_point_sample(b, n, int(npoint), _dev(inp, torch.float32), _dev(temp, torch.float32),
+                                                _dev(out, torch.int32)), "farthestpointsamplingLauncher")
+    return out
+
+
+def ref_gpu_gather_point(inp, idx):
+    import torch
+    b, n, _ = inp.shape
+    m = idx.shape[1]
+    out = torch.empty((b, m, 3), dtype=torch.float32, device=inp.device)
+    _ok(ref_gpu().ref_gpu_gather_point(b, n, m, _dev(inp, torch.float32), _dev(idx, torch.int32), _dev(out, torch.float32)),
+        "gatherpointLauncher")
+    return out
+
+
+def ref_gpu_gather_point_grad(n, idx, out_g):
+    import torch
+    b, m = idx.shape
+    inp_g = torch.zeros((b, n, 3), dtype=torch.float32, device=idx.device)       # tf_sampling.cpp:174 clears it
+    _ok(ref_gpu().ref_gpu_scatter_add_point(b, n, m, _dev(out_g, torch.float32), _dev(idx, torch.int32),
+                                            _dev(inp_g, torch.float32)), "scatteraddpointLauncher")
+    return inp_g
+
+
+def ref_gpu_prob_sample(inp, inpr):
+    """probsampleLauncher (tf_sampling_g.cu:198): inp [b,n] weights, inpr [b,m] uniform numbers -> ([b,m] i32, cumsum [b,n])"""
+    import torch
+    b, n = inp.shape
+    m = inpr.shape[1]
+    temp = torch.empty((b, n), dtype=torch.float32, device=inp.device)
+    out = torch.empty((b, m), dtype=torch.int32, device=inp.device)
+    _ok(ref_gpu().ref_gpu_prob_sample(b, n, m, _dev(inp, torch.float32), _dev(inpr, torch.float32), _dev(temp, torch.float32),
+                                      _dev(out, torch.int32)), "probsampleLauncher")
+    return out, temp
+
+
+def ref_gpu_nn_distance(xyz1, xyz2):
+    """NmDistanceKernelLauncher (tf_nndistance_g.cu:128)"""
+    import torch
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    d1 = torch.empty((b, n), dtype=torch.float32, device=xyz1.device)
+    i1 = torch.empty((b, n), dtype=torch.int32, device=xyz1.device)
+    d2 = torch.empty((b, m), dtype=torch.float32, device=xyz1.device)
+    i2 = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    _ok(ref_gpu().ref_gpu_nn_distance(b, n, _dev(xyz1, torch.float32), m, _dev(xyz2, torch.float32), _dev(d1, torch.float32),
+                                      _dev(i1, torch.int32), _dev(d2, torch.float32), _dev(i2, torch.int32)),
+        "NmDistanceKernelLauncher")
+    return d1, i1, d2, i2
+
+
+def ref_gpu_nn_distance_grad(xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2):
+    """NmDistanceGradKernel (tf_nndistance_g.cu:132-151) as its launcher issues it (:153-156)"""
+    import torch
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    g1 = torch.empty_like(xyz1)
+    g2 = torch.empty_like(xyz2)
+    _ok(ref_gpu().ref_gpu_nn_distance_grad(b, n, _dev(xyz1, torch.float32), m, _dev(xyz2, torch.float32),
+                                           _dev(grad_dist1, torch.float32), _dev(idx1, torch.int32),
+                                           _dev(grad_dist2, torch.float32), _dev(idx2, torch.int32), _dev(g1, torch.float32),
+                                           _dev(g2, torch.float32)), "NmDistanceGradKernel")
+    return g1, g2
