@@ -9,12 +9,12 @@
 // running minimum distance in registers (the reference round-trips the running
 // minimum through a global `temp` array, tf_sampling_g.cu:139,144), the cloud is
 // mirrored in LDS only to fetch the last pick's coordinates, and the arg-max is
-// a single order-independent u64 max-reduction per round:
-//      key = bits(d2) << 32 | (511 - t) << 23 | p          (k = t + 512 p)
+// an order-independent u64 max per round over keys
+//      bits(d2) << 32 | tie-break code of k
 // d2 >= 0, so its bit pattern orders like the float.  The largest key is the
 // reference's winner -- max value, then lowest k mod 512, then lowest k -- which
 // its thread-strided scan + left-biased tree (:130-165) produces.  One barrier
-// per round (ping-pong LDS slots).
+// per round.  fps_kernel (clouds up to 16384 points) below; fps_big_kernel beyond.
 #include "common.h"
 #include "../../include/cloudaae_hip.h"
 
@@ -30,15 +30,33 @@ __device__ __forceinline__ float fps_sqdist(float x2, float y2, float z2, float 
     return dx * dx + dy * dy + dz * dz;
 }
 
-// PPT = points per thread held in registers (n <= 512*PPT).
-// LDS_XYZ: cloud mirrored in dynamic LDS (12 n bytes) for the last-pick fetch.
+// PPT = points per thread held in registers (n <= 512*PPT).  Round 6: a round is ONE chain of dependent steps, and it is as
+// fast as that chain is short --
+//   per lane   : the maximum of its PPT running minima (v_max3_f32); their bit patterns order like integers (minima are >= +0;
+//                a slot past the cloud holds -1 and +inf coordinates: it stays -1 for ever)
+//   per wave   : six v_max_i32 with DPP modifiers leave the wave's maximum in lane 63; every lane that holds it (one, unless
+//                distances tie) finds its lowest slot holding it and sends ONE LDS atomic, ds_max_u64 of
+//                    bits(maximum) << 32 | (511 - t) << 16 | 65535 - p            (k = t + 512 p)
+//                to this round's cell: the largest key is the reference's winner -- max value, then lowest k mod 512, then
+//                lowest k (its thread-strided scan + left-biased tree, tf_sampling_g.cu:130-165)
+//   one barrier
+//   every lane : reads the cell (a broadcast), decodes k, reads the winner's coordinates from the cloud's copy in LDS.
+// Three cells in rotation: the one of round j + 1 is cleared while round j runs.  No 64-bit compares in registers, no
+// table of per-wave candidates to reduce, two scalar-register hops per round.  (profiles/notes_fps_r6.md)
+#define FPS_DPP_MAX(v, ctrl) asm("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 " ctrl : "+v"(v))
+__device__ __forceinline__ float fps_min(float a, float b)      // v_min_f32 as is (fminf first canonicalises b: one more instruction)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// LDS_XYZ: the cloud copied to dynamic LDS (12 n bytes) for the winner's coordinates; else they come from memory.
 template <int PPT, bool LDS_XYZ>
-__global__ __launch_bounds__(FPS_THREADS) void fps_reg_kernel(int n, int m,
-                                                              const float *__restrict__ inp,
-                                                              int *__restrict__ out)
+__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, const float *__restrict__ inp, int *__restrict__ out)
 {
     extern __shared__ float lds_xyz[];
-    __shared__ unsigned long long slot[2][FPS_WAVES];
+    __shared__ unsigned long long cell[3];
 
     const int t = threadIdx.x;
     const int cloud = blockIdx.x;
@@ -50,22 +68,58 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_reg_kernel(int n, int m,
     for (int p = 0; p < PPT; ++p) {
         const int k = t + FPS_THREADS * p;
         const bool ok = k < n;
-        px[p] = ok ? P[3 * k] : 0.0f;
-        py[p] = ok ? P[3 * k + 1] : 0.0f;
-        pz[p] = ok ? P[3 * k + 2] : 0.0f;
-        run[p] = 1e38f;  // tf_sampling_g.cu:117
+        px[p] = ok ? P[3 * k] : __builtin_inff();
+        py[p] = ok ? P[3 * k + 1] : __builtin_inff();
+        pz[p] = ok ? P[3 * k + 2] : __builtin_inff();
+        run[p] = ok ? 1e38f : -1.0f;  // tf_sampling_g.cu:117
     }
     if (LDS_XYZ) {
         for (int f = t; f < n * 3; f += FPS_THREADS)
             lds_xyz[f] = P[f];
     }
+    if (t < 3)
+        cell[t] = 0;
     if (t == 0)
         O[0] = 0;
+    float ox = P[0], oy = P[1], oz = P[2];      // idx_0 = 0 (:114)
     __syncthreads();
 
-    int last = 0;
+    int slot = 1;                               // j % 3
     for (int j = 1; j < m; ++j) {
-        float ox, oy, oz;
+        float lm = -1.0f;
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            const float d = fps_sqdist(px[p], py[p], pz[p], ox, oy, oz);
+            run[p] = fps_min(d, run[p]);
+            lm = fmaxf(lm, run[p]);
+        }
+        int v = __float_as_int(lm);
+        FPS_DPP_MAX(v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+        FPS_DPP_MAX(v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+        FPS_DPP_MAX(v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+        FPS_DPP_MAX(v, "row_shr:8 row_mask:0xf bank_mask:0xf");        // lane 15 of a row: the row's maximum
+        FPS_DPP_MAX(v, "row_bcast:15 row_mask:0xa bank_mask:0xf");     // rows 1, 3 take in rows 0, 2
+        FPS_DPP_MAX(v, "row_bcast:31 row_mask:0xc bank_mask:0xf");     // rows 2, 3 take in lane 31: lane 63 has the wave's
+        const int umax = __builtin_amdgcn_readlane(v, 63);
+        const int next = slot == 2 ? 0 : slot + 1;
+        if (__float_as_int(lm) == umax && umax >= 0) {                 // (a wave wholly past the cloud holds -1: no key)
+            int ps = PPT - 1;
+#pragma unroll
+            for (int p = PPT - 2; p >= 0; --p)
+                ps = __float_as_int(run[p]) == umax ? p : ps;          // this thread's lowest k holding the maximum (:146)
+            const unsigned long long key = ((unsigned long long)(unsigned)umax << 32) |
+                                           (unsigned)(((FPS_THREADS - 1 - t) << 16) | (65535 - ps));
+            // (the cell's index through a register the compiler cannot see through: with a uniform address it first combines the
+            //  wave's lanes in a readlane loop -- longer than the one ds_max_u64 of the one lane that usually gets here)
+            int opaque = slot;
+            asm volatile("" : "+v"(opaque));
+            __hip_atomic_fetch_max(&cell[opaque], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (t == 0)
+            cell[next] = 0;
+        __syncthreads();
+        const unsigned code = (unsigned)cell[slot];
+        const int last = (FPS_THREADS - 1 - (int)(code >> 16)) + FPS_THREADS * (65535 - (int)(code & 0xffffu));
         if (LDS_XYZ) {
             ox = lds_xyz[3 * last];
             oy = lds_xyz[3 * last + 1];
@@ -75,43 +129,9 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_reg_kernel(int n, int m,
             oy = P[3 * last + 1];
             oz = P[3 * last + 2];
         }
-        unsigned bestv = 0;
-        unsigned bestp = 0;
-        bool any = false;
-#pragma unroll
-        for (int p = 0; p < PPT; ++p) {
-            const int k = t + FPS_THREADS * p;
-            if (k < n) {
-                const float d = fps_sqdist(px[p], py[p], pz[p], ox, oy, oz);
-                const float d2 = fminf(d, run[p]);
-                run[p] = d2;
-                const unsigned u = __float_as_uint(d2);
-                // strict '>' keeps the first maximum of this thread (:146)
-                if (!any || u > bestv) {
-                    bestv = u;
-                    bestp = p;
-                    any = true;
-                }
-            }
-        }
-        unsigned long long key = 0;
-        if (any)
-            key = ((unsigned long long)bestv << 32) |
-                  ((unsigned long long)(FPS_THREADS - 1 - t) << 23) | bestp;
-        key = wave_max_u64(key);
-        if ((t & 63) == 0)
-            slot[j & 1][t >> 6] = key;
-        __syncthreads();
-        unsigned long long w = slot[j & 1][0];
-#pragma unroll
-        for (int i = 1; i < FPS_WAVES; ++i) {
-            const unsigned long long o = slot[j & 1][i];
-            w = o > w ? o : w;
-        }
-        const unsigned lo = (unsigned)w;
-        last = (FPS_THREADS - 1 - (int)((lo >> 23) & 511u)) + FPS_THREADS * (int)(lo & 0x7fffffu);
         if (t == 0)
             O[j] = last;
+        slot = next;
     }
 }
 
@@ -211,20 +231,20 @@ template <int PPT>
 static int launch_fps_reg(int b, int n, int m, const float *inp, int *out, hipStream_t s)
 {
     const size_t lds = (size_t)n * 3 * sizeof(float);
-    if (lds <= 96 * 1024) {
+    if (lds <= 144 * 1024) {
         // opt in to > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU)
         if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void *)fps_reg_kernel<PPT, true>,
+            hipError_t e = hipFuncSetAttribute((const void *)fps_kernel<PPT, true>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) {
                 set_error("cloudaae_farthest_point_sample: %s", hipGetErrorString(e));
                 return (int)e;
             }
         }
-        hipLaunchKernelGGL((fps_reg_kernel<PPT, true>), dim3(b), dim3(FPS_THREADS), lds, s, n, m,
+        hipLaunchKernelGGL((fps_kernel<PPT, true>), dim3(b), dim3(FPS_THREADS), lds, s, n, m,
                            inp, out);
     } else {
-        hipLaunchKernelGGL((fps_reg_kernel<PPT, false>), dim3(b), dim3(FPS_THREADS), 0, s, n, m,
+        hipLaunchKernelGGL((fps_kernel<PPT, false>), dim3(b), dim3(FPS_THREADS), 0, s, n, m,
                            inp, out);
     }
     return 0;
