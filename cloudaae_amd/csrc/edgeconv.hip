@@ -1088,8 +1088,7 @@ static int ec_backward_impl(const char *name, int b, int n, int k, int cin, int 
         return rc;
     }
     const bool quads = pool_mode == 1 && training && edge_stats != nullptr && (cout == 64 || cout == 128) && lddo % 4 == 0 &&
-                       (((uintptr_t)a.pq | (uintptr_t)a.dout | (uintptr_t)dpq | (uintptr_t)edge_stats) & 15) == 0 &&
-                       CLOUDAAE_KNOB("CLOUDAAE_EC_BWD_QUADS", 1) != 0;
+                       (((uintptr_t)a.pq | (uintptr_t)a.dout | (uintptr_t)dpq | (uintptr_t)edge_stats) & 15) == 0;
     if (quads && cout == 64) {
         hipLaunchKernelGGL(ec_bwd_apply_mean4_kernel<64>, dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src,
                            dpq, edge_stats);

@@ -950,17 +950,13 @@ static FcFwdPlan fc_fwd_plan(int M, int K, int N, bool bn, bool no_scratch)
 {
     FcFwdPlan p;
     p.rts = ceil_div(M, FC_ROWS);
-    p.cq = bn ? CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_CQ_BN", 2) : CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_CQ_PLAIN", 4);
-    p.cq = p.cq == 2 ? 2 : 4;
-    const int want = bn ? CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_BLOCKS_BN", 64) : CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_BLOCKS", 256);
-    const int forced = CLOUDAAE_KNOB("CLOUDAAE_FC_FWD_SPLITS", 0);
+    p.cq = bn ? 2 : 4;
+    const int want = bn ? 64 : 256;
     p.tiles = ceil_div(N, 32 * p.cq);
     int splits = want / (p.tiles * p.rts);
     const int most = K / (16 * FC_NW);
     splits = splits > most ? most : splits;
     splits = splits < 1 ? 1 : splits;
-    if (forced)
-        splits = forced;
     if (no_scratch)
         splits = 1;
     p.kslice = ceil_div(ceil_div(K, splits), 8) * 8;
@@ -1080,14 +1076,14 @@ CLOUDAAE_API int cloudaae_fc_backward_group(int M, int count, const cloudaae_fc_
         const int slices = ceil_div(l.N, FC_TN), ktiles = ceil_div(l.K, 32);
         // Few tiles (every layer but the wide output one): one tile per workgroup, its four waves share
         // it, everything resident at once.  Many tiles: a wave per tile, workgroups for the resident set.
-        const bool fine = (long long)slices * ktiles <= CLOUDAAE_KNOB("CLOUDAAE_FC_BWD_FINE", 1024);
+        const bool fine = (long long)slices * ktiles <= 1024;
         int by;
         if (fine) {
             // (several row tiles: every workgroup of a slice derives dY for all rows of the slice again -- 128 KB of
             // L2 reads at 128 rows -- so a workgroup keeps two tiles)
-            by = ceil_div(ktiles, rts > 1 ? CLOUDAAE_KNOB("CLOUDAAE_FC_BWD_FINE_TILES_TALL", 2) : CLOUDAAE_KNOB("CLOUDAAE_FC_BWD_FINE_TILES", 1));
+            by = ceil_div(ktiles, rts > 1 ? 2 : 1);
         } else {
-            const int want = rts > 1 ? CLOUDAAE_KNOB("CLOUDAAE_FC_BWD_BLOCKS_TALL", 384) : CLOUDAAE_KNOB("CLOUDAAE_FC_BWD_BLOCKS", 384);
+            const int want = 384;
             by = ceil_div(want, slices);
             const int most = ceil_div(ktiles, 4);
             by = by > most ? most : by;
@@ -1098,7 +1094,7 @@ CLOUDAAE_API int cloudaae_fc_backward_group(int M, int count, const cloudaae_fc_
         FcBwdArgs &a = g.p[i];
         a.M = M; a.K = l.K; a.N = l.N; a.ldx = l.ldx; a.lddo = l.lddo; a.lddx = l.lddx; a.tiles_per_block = tpb;
         a.acc_dw = l.accumulate_dw; a.acc_pg = l.accumulate_param_grads; a.training = training; a.relu = l.relu;
-        a.block0 = blocks; a.slices = slices; a.parts = fine ? 4 : (CLOUDAAE_KNOB("CLOUDAAE_FC_BWD_ROLES", 1) ? 2 : 1);
+        a.block0 = blocks; a.slices = slices; a.parts = fine ? 4 : 2;
         a.vec = l.N % 4 == 0 && aligned16(l.w) && (l.dw == nullptr || aligned16(l.dw));
         a.x = l.x; a.w = l.w; a.y = l.y; a.gamma = l.gamma; a.beta = l.beta; a.save_mean = l.save_mean;
         a.save_var = l.save_var; a.dout = l.dout; a.dx = l.dx; a.dw = l.dw; a.dgamma = l.dgamma;

@@ -457,13 +457,13 @@ static void gemm_plan(int M, int N, int K, int &BM, int &BN, int &splits, bool o
     if (M <= 32) {
         BM = 32;
         BN = 128;
-    } else if (M <= 128 && !CLOUDAAE_KNOB_SET("CLOUDAAE_GEMM_SKINNY128")) {
+    } else if (M <= 128) {
         // the fully connected stack at 33..128 clouds per GPU (the fused kernels of fc.hip take at most 32 rows): one or
         // two row tiles, so the parallelism has to come from N and K -- 64 x 64 tiles (six workgroups per CU) instead of
         // 128 x 128: [128 x 1024] x [1024 x 12288] 69 -> 48 us, [128 x 1024] x [1024 x 1024] 15.6 -> 10.7 us
         BM = 64;
         BN = 64;
-    } else if (N % 160 == 0 && N % 128 != 0 && M >= 1024 && K >= 512 && !CLOUDAAE_KNOB_SET("CLOUDAAE_F32_TILE64")) {
+    } else if (N % 160 == 0 && N % 128 != 0 && M >= 1024 && K >= 512) {
         // dX of dgcnn_agg (N = 320): 160-wide tiles, five 32 x 32 accumulators per wave -- 1.2 LDS fragment reads per
         // MFMA instead of 1.5 and 512 workgroups instead of 1280: 214 -> 208 us (B=32), 830 -> 807 us (B=128)
         BM = 128;
@@ -484,8 +484,7 @@ static void gemm_plan(int M, int N, int K, int &BM, int &BN, int &splits, bool o
     // Halve the tile height until there are two workgroups per CU.
     // (not the 160-wide tiles: they exist as 128 x 160 only -- a 64-row grid over them would start half the
     //  workgroups past the end of the matrix)
-    if (BM == 128 && BN != 160 && M >= 1024 && K <= 512 && (long long)ceil_div(M, 128) * ceil_div(N, BN) < 512 &&
-        !CLOUDAAE_KNOB_SET("CLOUDAAE_GEMM_TALL128"))
+    if (BM == 128 && BN != 160 && M >= 1024 && K <= 512 && (long long)ceil_div(M, 128) * ceil_div(N, BN) < 512)
         BM = 64;
     // (32-row tiles for these shapes, four workgroups per CU: 11.5 vs 11.9 us at [32768 x 64] x [64 x 128] -- not worth a
     //  second rule)
@@ -510,7 +509,6 @@ static void gemm_plan(int M, int N, int K, int &BM, int &BN, int &splits, bool o
             splits = 1;
         if (splits > 8)
             splits = splits / 8 * 8;      // whole slices per XCD (the kernel then keeps a slice's tiles on one XCD)
-        splits = CLOUDAAE_KNOB("CLOUDAAE_GEMM_SPLITS", splits);
     }
     // deterministic mode (cloudaae_set_knob("CLOUDAAE_DETERMINISTIC", 1)): a product that would add its K slices with
     // atomics stays whole (and pays with idle CUs); the slice-ordered variant (cloudaae_gemm_f32_ordered) keeps its cut
@@ -722,8 +720,8 @@ CLOUDAAE_API int cloudaae_gemm_f32_tn_group(int count, const cloudaae_gemm_tn_jo
         // (every slice adds its whole tile to the same 32 KB with atomics: at K = 32768 the 320 slices of 112 k that fill
         //  the chip take 53 us, 128 of 256 k 44 us (step 1.590 -> 1.582 ms); at K = 131072 320 slices of 416 k stay best:
         //  profiles/notes_gemm_f32.md)
-        const int kmin = CLOUDAAE_KNOB("CLOUDAAE_GEMM_GROUP_KMIN", 256);
-        int splits = (CLOUDAAE_KNOB("CLOUDAAE_GEMM_GROUP_WGS", 256 * 5) / count) / j.tiles;
+        const int kmin = 256;
+        int splits = ((256 * 5) / count) / j.tiles;
         if (splits > q.K / kmin)
             splits = q.K / kmin;
         if (splits > 8)

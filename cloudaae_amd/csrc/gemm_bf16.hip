@@ -430,8 +430,7 @@ static void launch_bf16(bool ta, bool tb, dim3 grid, hipStream_t s, int M, int N
     // whole tiles, whole slabs in every K slice, 16-byte aligned rows: the lean loop
     // (a folded k-contiguous B: every 32-wide slab inside one fold block)
     const bool fold_ok = fb.shift < 0 || !tb || (1 << fb.shift) % GB_BK == 0;
-    const bool fast = M % BM == 0 && N % BN == 0 && K % GB_BK == 0 && vecA && vecB && fold_ok &&
-                      CLOUDAAE_KNOB("CLOUDAAE_BF16_FAST", 1) != 0;
+    const bool fast = M % BM == 0 && N % BN == 0 && K % GB_BK == 0 && vecA && vecB && fold_ok;
     if (fast)
         launch_bf16_as<BM, BN, WM, WN, true>(ta, tb, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, vecA,
                                              vecB, fb, fc, cs, cslice);
@@ -447,15 +446,14 @@ static void gemm_bf16_plan(int M, int N, int K, int &BM, int &BN, int &splits, b
     // 160 but not of 128 (the 320 concat channels of dgcnn_agg: N of dX, M of dW) takes 160-wide tiles of five 32 x 32
     // accumulators per wave: the big operand (dY, 1.07 GB at B=256) is then re-read twice instead of five times
     // (measured, dW / dX: B=256 987 -> 716 / 563 -> 542 us, B=128 494 -> 372 / 288 -> 276 us, B=32 139 -> 152 / 79 -> 64 us:
-    // the transposed product keeps 64-row tiles below 65536 rows of K).  CLOUDAAE_BF16_TILE160=0 switches the rule off.
-    const bool t160 = CLOUDAAE_KNOB("CLOUDAAE_BF16_TILE160", 1) != 0;
+    // the transposed product keeps 64-row tiles below 65536 rows of K).
     if (M <= 32) {
         BM = 32;
         BN = 128;
-    } else if (t160 && N % 160 == 0 && N % 128 != 0 && M >= 1024) {
+    } else if (N % 160 == 0 && N % 128 != 0 && M >= 1024) {
         BM = 128;
         BN = 160;
-    } else if (t160 && M % 160 == 0 && M % 128 != 0 && N % 128 == 0 && K >= 65536) {
+    } else if (M % 160 == 0 && M % 128 != 0 && N % 128 == 0 && K >= 65536) {
         BM = 160;
         BN = 128;
     } else if (N <= 64 || (N % 128 != 0 && N % 64 == 0)) {

@@ -688,7 +688,7 @@ static bool gemm_x3s_plan(int M, int N, int K, int &TM, int &TN)
         return false;
     // 256-row tiles (a wave's 64 x 128 tile reads each small-operand fragment for two row tiles) when they still give
     // every CU its two workgroups; 160-column tiles keep 128 rows (five accumulator tiles per row tile: 256 registers)
-    TM = (TN == 4 && M % 256 == 0 && (long long)(M / 256) * (N / 128) >= 512 && CLOUDAAE_KNOB("CLOUDAAE_X3_TM", 2) == 2) ? 2 : 1;
+    TM = (TN == 4 && M % 256 == 0 && (long long)(M / 256) * (N / 128) >= 512) ? 2 : 1;
     return true;
 }
 
@@ -757,17 +757,13 @@ CLOUDAAE_API int cloudaae_gemm_bf16x3p(int M, int N, int K, const float *A, int 
     CLOUDAAE_REQUIRE(colstats == nullptr || accumulate == 0, name, "column statistics need an overwriting product");
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    const bool deep = CLOUDAAE_KNOB("CLOUDAAE_X3_AS", 2) == 2;
+    // (128-row tiles keep two slabs of the big operand in flight: AS = 2)
     if (TM == 2)
         rc = launch_x3s<2, 4, 1>(name, s, M, N, K, A, lda, planes, C, ldc, bias, accumulate, colstats);
-    else if (TN == 4 && deep)
-        rc = launch_x3s<1, 4, 2>(name, s, M, N, K, A, lda, planes, C, ldc, bias, accumulate, colstats);
     else if (TN == 4)
-        rc = launch_x3s<1, 4, 1>(name, s, M, N, K, A, lda, planes, C, ldc, bias, accumulate, colstats);
-    else if (deep)
-        rc = launch_x3s<1, 5, 2>(name, s, M, N, K, A, lda, planes, C, ldc, bias, accumulate, colstats);
+        rc = launch_x3s<1, 4, 2>(name, s, M, N, K, A, lda, planes, C, ldc, bias, accumulate, colstats);
     else
-        rc = launch_x3s<1, 5, 1>(name, s, M, N, K, A, lda, planes, C, ldc, bias, accumulate, colstats);
+        rc = launch_x3s<1, 5, 2>(name, s, M, N, K, A, lda, planes, C, ldc, bias, accumulate, colstats);
     if (rc != 0)
         return rc;
     CLOUDAAE_CHECK_LAUNCH(name);
@@ -786,7 +782,7 @@ CLOUDAAE_API int cloudaae_gemm_bf16x3_colstats_parts(int M, int N, int K)
     if (!gemm_x3_plan(0, 0, M, N, K, BM, BN, splits) || splits != 1)
         return 0;
     int TMs, TNs;
-    if (CLOUDAAE_KNOB("CLOUDAAE_X3_GEN1", 0) == 0 && gemm_x3s_plan(M, N, K, TMs, TNs) &&
+    if (gemm_x3s_plan(M, N, K, TMs, TNs) &&
         (long long)(M / (128 * TMs)) * (N / (32 * TNs)) >= 192)
         return M / (128 * TMs);
     return M / BM;
@@ -807,8 +803,7 @@ CLOUDAAE_API int cloudaae_gemm_bf16x3(int trans_a, int trans_b, int M, int N, in
     hipStream_t s = (hipStream_t)stream;
     int TMs, TNs;
     // (a product with few output tiles is cut over K by the first-generation kernel below; the streamed one keeps K whole)
-    if (!trans_a && gemm_x3s_plan(M, N, K, TMs, TNs) && (long long)(M / (128 * TMs)) * (N / (32 * TNs)) >= 192 &&
-        CLOUDAAE_KNOB("CLOUDAAE_X3_GEN1", 0) == 0) {
+    if (!trans_a && gemm_x3s_plan(M, N, K, TMs, TNs) && (long long)(M / (128 * TMs)) * (N / (32 * TNs)) >= 192) {
         // the streamed kernel wants the second operand as planes: split it into scratch of this call (stream ordered).
         // A caller that multiplies by the same matrix more than once splits it itself (cloudaae_x3_split) and calls
         // cloudaae_gemm_bf16x3p.
@@ -834,26 +829,18 @@ CLOUDAAE_API int cloudaae_gemm_bf16x3(int trans_a, int trans_b, int M, int N, in
     CLOUDAAE_REQUIRE(M / BM <= 65535, name, "M too large");
     dim3 grid(N / BN, M / BM, splits);
     int rc;
-    // CLOUDAAE_X3_DEPTH2=1: two slabs in flight for the 128 x 128 tiles (every K slice an even number of slabs).  Measured
-    // equal to one slab in flight (forward 146 vs 150 us at B = 32): the kernel is not waiting for memory -- per slab a
-    // wave spends ~640 cycles splitting, ~1540 in its 48 MFMAs, and the two waves of a SIMD contend for both pipes.
-    const bool deep = K % kchunk == 0 && (kchunk / X3_BK) % 2 == 0 && CLOUDAAE_KNOB("CLOUDAAE_X3_DEPTH2", 0) != 0;
-    if (!trans_a && !trans_b && !deep)
+    // (one slab in flight: two measured equal -- forward 146 vs 150 us at B = 32 --, the kernel is not waiting for memory: per slab
+    //  a wave spends ~640 cycles splitting, ~1540 in its 48 MFMAs, and the two waves of a SIMD contend for both pipes)
+    if (!trans_a && !trans_b)
         rc = launch_x3<128, 128, 2, 2, false, false, 1>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
-    else if (!trans_a && !trans_b)
-        rc = launch_x3<128, 128, 2, 2, false, false, 2>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
     else if (!trans_a && BN == 160)
         rc = launch_x3<128, 160, 4, 1, false, true, 1>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
-    else if (!trans_a && !deep)
-        rc = launch_x3<128, 128, 2, 2, false, true, 1>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
     else if (!trans_a)
-        rc = launch_x3<128, 128, 2, 2, false, true, 2>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
+        rc = launch_x3<128, 128, 2, 2, false, true, 1>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
     else if (BM == 160)
         rc = launch_x3<160, 128, 1, 4, true, false, 1>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
-    else if (!deep)
-        rc = launch_x3<128, 128, 2, 2, true, false, 1>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
     else
-        rc = launch_x3<128, 128, 2, 2, true, false, 2>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
+        rc = launch_x3<128, 128, 2, 2, true, false, 1>(name, grid, s, M, N, K, A, lda, B, ldb, C, ldc, bias, epi, kchunk, colstats);
     if (rc != 0)
         return rc;
     CLOUDAAE_CHECK_LAUNCH(name);

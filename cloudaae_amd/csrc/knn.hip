@@ -12,9 +12,8 @@
 //   <,>   : channel-ordered fp32 fma chain from +0 (what v_mfma_f32 computes)
 //   |.|^2 : sequential un-fused sum of rounded squares
 //   order : ascending D, ties -> lower j (TopKV2)
-// A workgroup is 4 waves x 64 queries; wave w scans candidate quarter w in
-// ascending j, then wave 0 merges the four sorted lists in wave order with the
-// same stable insertion, which preserves the tie rule.
+// Candidate ranges of a query are scanned by different waves; their sorted lists are merged
+// lexicographically by (distance, index), which preserves the tie rule.
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
@@ -164,102 +163,6 @@ __device__ __forceinline__ int knn_key_low16(double key)
     return (int)(__double_as_longlong(key + 4503599627370496.0) & 0xffff);
 }
 
-template <int K>
-__device__ __forceinline__ void merge_and_store(TopK<K> &top, float *mbuf_d, int *mbuf_i, int wave,
-                                                int lane, bool valid, int k, int *dst)
-{
-    // lists of waves 1..3 go through LDS, [wave-1][p][lane]; the buffer aliases
-    // the scan buffers, so every wave must have finished scanning first
-    __syncthreads();
-    if (wave > 0) {
-#pragma unroll
-        for (int p = 0; p < K; ++p) {
-            mbuf_d[((wave - 1) * K + p) * 64 + lane] = top.d[p];
-            mbuf_i[((wave - 1) * K + p) * 64 + lane] = top.i[p];
-        }
-    }
-    __syncthreads();
-    if (wave == 0) {
-        for (int w = 0; w < KNN_WAVES - 1; ++w) {
-#pragma unroll
-            for (int p = 0; p < K; ++p)
-                top.insert(mbuf_d[(w * K + p) * 64 + lane], mbuf_i[(w * K + p) * 64 + lane]);
-        }
-        if (valid) {
-#pragma unroll
-            for (int p = 0; p < K; ++p)
-                if (p < k)
-                    dst[p] = top.i[p];
-        }
-    }
-}
-
-// ---- C = 3 (xyz slice of a [*, ld] row) -----------------------------------
-constexpr int KNN3_CHUNK = 256;  // candidates per wave per LDS refill
-
-template <int K>
-__global__ __launch_bounds__(KNN_THREADS) void knn3_kernel(int n, int ld, int k,
-                                                           const float *__restrict__ x,
-                                                           int *__restrict__ nn_idx)
-{
-    // scan buffer (x, y, z, |.|^2 per candidate) and merge buffer share LDS
-    constexpr int SCAN_BYTES = KNN_WAVES * KNN3_CHUNK * 16;
-    constexpr int MERGE_BYTES = (KNN_WAVES - 1) * K * 64 * 8;
-    __shared__ __attribute__((aligned(16))) char smem[SCAN_BYTES > MERGE_BYTES ? SCAN_BYTES : MERGE_BYTES];
-    float4v(*cand)[KNN3_CHUNK] = reinterpret_cast<float4v(*)[KNN3_CHUNK]>(smem);
-    float *mbuf_d = reinterpret_cast<float *>(smem);
-    int *mbuf_i = reinterpret_cast<int *>(smem) + (KNN_WAVES - 1) * K * 64;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int tile, cloud;
-    xcd_cloud_tile(tile, cloud);   // a cloud's candidate rows stay in ONE XCD's L2
-    const float *X = x + (size_t)cloud * n * ld;
-    const int i = tile * 64 + lane;
-    const bool valid = i < n;
-    const int ii = valid ? i : 0;
-    const float qx = X[(size_t)ii * ld], qy = X[(size_t)ii * ld + 1], qz = X[(size_t)ii * ld + 2];
-    float sqi;
-    {
-        const float a = qx * qx, b = qy * qy, c = qz * qz;
-        sqi = 0.0f + a;
-        sqi = sqi + b;
-        sqi = sqi + c;
-    }
-    TopK<K> top;
-    top.init();
-
-    const int per = (n + KNN_WAVES - 1) / KNN_WAVES;
-    const int j_begin = min(wave * per, n), j_end = min(j_begin + per, n);
-    const int rounds = (per + KNN3_CHUNK - 1) / KNN3_CHUNK;  // same for all waves
-    for (int r = 0; r < rounds; ++r) {
-        const int c0 = j_begin + r * KNN3_CHUNK;
-        const int cnt = max(0, min(KNN3_CHUNK, j_end - c0));
-        __syncthreads();
-        for (int s = lane; s < cnt; s += 64) {
-            const float *row = X + (size_t)(c0 + s) * ld;
-            const float cx = row[0], cy = row[1], cz = row[2];
-            const float a = cx * cx, b = cy * cy, c = cz * cz;
-            float sq = 0.0f + a;
-            sq = sq + b;
-            sq = sq + c;
-            cand[wave][s] = float4v{cx, cy, cz, sq};
-        }
-        __syncthreads();
-        for (int s = 0; s < cnt; ++s) {
-            const float4v c = cand[wave][s];
-            float inner = fmaf(qx, c.x, 0.0f);
-            inner = fmaf(qy, c.y, inner);
-            inner = fmaf(qz, c.z, inner);
-            const float m2 = -2.0f * inner;
-            const float t = sqi + m2;
-            const float d = t + c.w;
-            top.insert(d, c0 + s);
-        }
-    }
-    merge_and_store<K>(top, mbuf_d, mbuf_i, wave, lane, valid, k,
-                       nn_idx + ((size_t)cloud * n + ii) * k);
-}
-
 // ---- any other channel count (model variants outside the named configs) ----
 // one lane per query, features re-read from global per candidate; slow, exact.
 template <int K>
@@ -299,167 +202,17 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_generic_kernel(int n, int c, 
 // ---- C = 64 on the matrix cores -----------------------------------------------------------
 // The inner products of a 32-candidate x 32-query tile are ONE chain of 32
 // v_mfma_f32_32x32x2_f32 (channels (2s, 2s+1) in step s): bitwise the channel-ordered fma
-// chain of the oracle, at the matrix-pipe rate and with almost no LDS traffic (the VALU
-// kernel above is LDS-bound: 16 broadcast ds_read_b128 per candidate per wave).  A
-// workgroup = 4 waves = the SAME 32 queries; wave w scans candidate quarter w.  In the
+// chain of the oracle, at the matrix-pipe rate and with almost no LDS traffic.  In the
 // accumulator layout a lane holds query column (lane & 31) and 16 candidate rows, so lanes l
 // and l+32 keep separate sorted k-lists for the same query over disjoint candidates; the
-// 8 lists of a query (4 waves x 2 half-waves) are merged lexicographically by
-// (distance, index) at the end, which is exactly "ascending distance, ties -> lower index".
-// The selection (VALU) of one wave overlaps the MFMA chain of the others.
+// lists of a query are merged lexicographically by (distance, index) at the end, which is
+// exactly "ascending distance, ties -> lower index".
+// (Round 6 retired the first generation of this file -- knn3_kernel and knn64_mfma_kernel, a sorted insert per candidate --
+//  and round 5's knn64_split_kernel, the scan on the bf16 matrix pipe that lost inside a training step
+//  (profiles/notes_knn_split_r5.md; the kernel is kept as profiles/r06_knn_retired_kernels.diff).  Five kernels remain:
+//  knn3_wide / knn3_scan (xyz), knn64_wide / knn64_scan (64 channels), knn_generic (anything else).)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KM_TILE = 32;
-constexpr int KM_LD = 65;   // LDS row stride of a staged candidate tile (odd: conflict-free column reads)
-
-template <int K>
-__global__ __launch_bounds__(KNN_THREADS) void knn64_mfma_kernel(int n, int ld, int k,
-                                                                 const float *__restrict__ x,
-                                                                 int *__restrict__ nn_idx)
-{
-    constexpr int TILE_FLOATS = KM_TILE * KM_LD + KM_TILE;            // rows + their |.|^2
-    constexpr int SCAN_BYTES = KNN_WAVES * TILE_FLOATS * 4;
-    constexpr int MERGE_BYTES = 2 * KNN_WAVES * K * 32 * 8;           // 8 lists x K x 32 queries x (d, idx)
-    __shared__ __attribute__((aligned(16))) char smem[SCAN_BYTES > MERGE_BYTES ? SCAN_BYTES : MERGE_BYTES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *tile = reinterpret_cast<float *>(smem) + wave * TILE_FLOATS;
-    float *csq = tile + KM_TILE * KM_LD;
-
-    int qtile, cloud;
-    xcd_cloud_tile(qtile, cloud);
-    const float *X = x + (size_t)cloud * n * ld;
-    const int col = lane & 31, half = lane >> 5;
-    const int qi = qtile * KM_TILE + col;               // this lane's query
-    const bool qvalid = qi < n;
-    const int qs = qvalid ? qi : 0;
-
-    // B operand: query channels of parity `half`, one register per MFMA step; and |x_q|^2
-    float bq[32];
-    float sqi = 0.0f;
-    {
-        const float *row = X + (size_t)qs * ld;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const float4v v = *reinterpret_cast<const float4v *>(row + 4 * g);
-            const float a = v.x * v.x, b = v.y * v.y, c = v.z * v.z, d = v.w * v.w;
-            sqi = sqi + a;
-            sqi = sqi + b;
-            sqi = sqi + c;
-            sqi = sqi + d;
-            bq[2 * g] = half ? v.y : v.x;               // channels 4g + half, 4g + 2 + half
-            bq[2 * g + 1] = half ? v.w : v.z;
-        }
-    }
-    TopK<K> top;
-    top.init();
-
-    const int per = ((n + KNN_WAVES - 1) / KNN_WAVES + KM_TILE - 1) / KM_TILE * KM_TILE;
-    const int j_begin = min(wave * per, n), j_end = min(j_begin + per, n);
-    const int rounds = per / KM_TILE;                    // identical for all waves
-    const int srow = lane >> 1, shalf = lane & 1;        // two lanes stage one candidate row
-    for (int r = 0; r < rounds; ++r) {
-        const int c0 = j_begin + r * KM_TILE;
-        const int cnt = max(0, min(KM_TILE, j_end - c0));
-        __syncthreads();
-        {
-            const bool ok = srow < cnt;
-            const float *row = X + (size_t)(ok ? c0 + srow : 0) * ld + 32 * shalf;
-            float4v v[8];
-#pragma unroll
-            for (int g = 0; g < 8; ++g)
-                v[g] = ok ? *reinterpret_cast<const float4v *>(row + 4 * g) : float4v{0, 0, 0, 0};
-            float lo = 0.0f;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const float a = v[g].x * v[g].x, b = v[g].y * v[g].y, c = v[g].z * v[g].z, d = v[g].w * v[g].w;
-                lo = lo + a;
-                lo = lo + b;
-                lo = lo + c;
-                lo = lo + d;
-            }
-            float part = __shfl(lo, lane & ~1, 64);      // the odd lane continues the even lane's sum
-            if (shalf) {
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const float a = v[g].x * v[g].x, b = v[g].y * v[g].y, c = v[g].z * v[g].z,
-                                d = v[g].w * v[g].w;
-                    part = part + a;
-                    part = part + b;
-                    part = part + c;
-                    part = part + d;
-                }
-                csq[srow] = part;
-            }
-            float *dst = tile + srow * KM_LD + 32 * shalf;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                dst[4 * g + 0] = v[g].x;
-                dst[4 * g + 1] = v[g].y;
-                dst[4 * g + 2] = v[g].z;
-                dst[4 * g + 3] = v[g].w;
-            }
-        }
-        __syncthreads();
-        if (cnt > 0) {
-            f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                acc[e] = 0.0f;
-            const float *arow = tile + col * KM_LD + half;   // A operand: candidate row `col`, parity `half`
-#pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                // step s covers channels 2s (lanes 0-31) and 2s+1 (lanes 32-63); bq[] is stored in
-                // the same order: bq[s] = channel 2s + half
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * s], bq[s], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rr = (e & 3) + 8 * (e >> 2) + 4 * half;    // candidate row of acc[e]
-                if (rr < cnt) {
-                    const float m2 = -2.0f * acc[e];
-                    const float t = sqi + m2;
-                    top.insert(t + csq[rr], c0 + rr);
-                }
-            }
-        }
-    }
-
-    // merge the 8 sorted lists of every query: [list][p][query]
-    __syncthreads();
-    float *md = reinterpret_cast<float *>(smem);
-    int *mi = reinterpret_cast<int *>(smem) + 2 * KNN_WAVES * K * 32;
-    const int list = wave * 2 + half;
-#pragma unroll
-    for (int p = 0; p < K; ++p) {
-        md[(list * K + p) * 32 + col] = top.d[p];
-        mi[(list * K + p) * 32 + col] = top.i[p];
-    }
-    __syncthreads();
-    if (wave == 0 && half == 0 && qvalid) {
-        int head[2 * KNN_WAVES];
-#pragma unroll
-        for (int l = 0; l < 2 * KNN_WAVES; ++l)
-            head[l] = 0;
-        int *dst = nn_idx + ((size_t)cloud * n + qi) * k;
-        for (int p = 0; p < k; ++p) {
-            float bd = __builtin_inff();
-            int bi = 0x7fffffff, bl = 0;
-#pragma unroll
-            for (int l = 0; l < 2 * KNN_WAVES; ++l) {
-                const int h = head[l];
-                const float d = h < K ? md[(l * K + h) * 32 + col] : __builtin_inff();
-                const int i = h < K ? mi[(l * K + h) * 32 + col] : 0x7fffffff;
-                const bool better = d < bd || (d == bd && i < bi);
-                bd = better ? d : bd;
-                bi = better ? i : bi;
-                bl = better ? l : bl;
-            }
-#pragma unroll
-            for (int l = 0; l < 2 * KNN_WAVES; ++l)
-                head[l] += (l == bl) ? 1 : 0;
-            dst[p] = bi == 0x7fffffff ? 0 : bi;
-        }
-    }
-}
 
 // ---- C = 64, second generation: one wave per 32-query tile scans the WHOLE cloud -------------
 // The kernel above gives every query eight short lists (4 candidate quarters x 2 lane halves); each
@@ -816,17 +569,14 @@ static size_t knn_wide_lds_bytes(int n)
 // 1.5 x for K = 20 (half of the tiles sampled), 1.125 x instead of 1.25 x for K = 10.  The second merge finds the queue
 // area occupied, so its lists (the 8 smallest of every lane: the K-th over fewer values is still a bound) go through the
 // tile buffers, which are idle at that point.
-template <int K, int QPQ, bool REUSE, bool TWO>
+template <int K, int QPQ, bool REUSE, bool TWO, bool HINT = false>
 __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, const float *__restrict__ x,
-                                                          int *__restrict__ nn_idx, const unsigned char *__restrict__ only)
+                                                          int *__restrict__ nn_idx, const float *__restrict__ hint_tau = nullptr)
 {
-    // only != nullptr: the launch repairs the query groups knn64_split_kernel flagged (a byte per workgroup of this grid)
-    if (only != nullptr) {
-        int qg, cl;
-        xcd_cloud_tile(qg, cl);
-        if (only[cl * gridDim.x + qg] == 0)
-            return;
-    }
+    // HINT (round 6): the bound comes with the call -- hint_tau[cloud][query] = the largest distance from the query to k
+    // distinct points somebody already suspects of being near it (the previous layer's neighbours:
+    // knn64_hint_bound_kernel) -- so there is no pass A: every tile goes through pass B's filter once, 1.0 x the products.
+    static_assert(!HINT || (!REUSE && !TWO), "the hinted form has no sample");
     constexpr int QW = 4, CS = 4, THREADS = 1024;
     constexpr int KS_LD = 68;                              // staged row: [32 even channels | 32 odd | 4 pad]
     constexpr int TILE_FLOATS = KM_TILE * KS_LD;
@@ -859,8 +609,8 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     const bool qvalid = qi0 < n;
     const int qs = qvalid ? qi0 : qgroup * QW * KM_TILE;   // (a row whose norm the prologue computes)
     // pass A's sample: S tiles, every stride-th one (a quarter of the tiles; half of them for K > 10)
-    const int S = min(ntiles, max((ntiles + (K > 10 ? 1 : 3)) / (K > 10 ? 2 : 4), 4));
-    const int stride = ntiles / S;
+    const int S = HINT ? 0 : min(ntiles, max((ntiles + (K > 10 ? 1 : 3)) / (K > 10 ? 2 : 4), 4));
+    const int stride = HINT ? 1 : ntiles / S;
     static_assert(!(REUSE && TWO), "one or the other");
     const int SA1 = TWO ? (S + 1) / 2 : S, SA2 = TWO ? S / 2 : 0;         // sample slots of pass A1 (TWO: the even ones) / A2
     // pass B's tile list = the tiles whose distances are not kept, ascending: all but the sample (REUSE) / all but A2's
@@ -986,7 +736,11 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
     // ---------------- pass A: tau ----------------
     const int roundsA = (SA1 + CS - 1) / CS;
     stage_rows(2, 0);                                      // the workgroup's 4 query tiles, staged like candidate tiles
-    stage_rows(1, 0);                                      // (the first sample tiles travel with them)
+    stage_rows(HINT ? 0 : 1, 0);                           // (the first sample tiles -- HINT: pass B's first tiles -- travel with them)
+    if (HINT && tid < QW * 32) {                           // the bounds that came with the call (rows past the end: nothing passes)
+        const int q = qgroup * QW * KM_TILE + tid;
+        tauv[tid] = q < n ? fminf(hint_tau[(size_t)cloud * n + q], 3.4028234664e38f) : -1.0f;
+    }
     staged();
     norms(2, 0);
     {
@@ -1074,52 +828,54 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
             }
         }
     }
-    // K-th smallest unit minimum over the query's 2*CS lists, through the query tile's share of the queue area
-    float *md = reinterpret_cast<float *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6));
-    // (UL values and a +inf behind them per list: a head that has taken a whole list reads the sentinel)
-    static_assert(2 * CS * (UL + 1) * 32 * 4 <= 32 * QPQ * 6 && (32 * QPQ * 6) % 8 == 0,
-                  "scratch lists must fit the queue area of one query tile");
     const int list = cs * 2 + half;
-    __syncthreads();
-    int slot0 = list * (UL + 1) * 32 + col;                // (opaque: keeps the compiler from deriving these addresses
-    asm volatile("" : "+v"(slot0));                        //  before the scan loop and spilling them across it)
-#pragma unroll
-    for (int p = 0; p < UL; ++p)
-        md[slot0 + p * 32] = um.d[p];
-    md[slot0 + UL * 32] = __builtin_inff();
     const int roundsB = (nB + CS - 1) / CS;
     const int roundsA2 = (SA2 + CS - 1) / CS;
-    if (TWO ? roundsA2 > 0 : roundsB > 0)
-        stage_rows(TWO ? 4 : 0, 0);                        // the next pass's first tiles travel during the merge below
-    __syncthreads();
-    // K-th smallest over the query's lists: ONE wave per query tile merges (waves 0, 5, 10, 15: one per SIMD), the bound
-    // reaches the other lanes through LDS after the next barrier
-    if (cs == qt) {
-        float t = __builtin_inff();
-        // K steps of "smallest head, advance it" over the 2*CS sorted lists.  Equal heads advance together, which can
-        // only make the bound larger (it stays valid).
-        int head[2 * CS];
-#pragma unroll
-        for (int l = 0; l < 2 * CS; ++l)
-            head[l] = (l * (UL + 1)) * 32 + col;
-#pragma unroll
-        for (int p = 0; p < K; ++p) {
-            float hv[2 * CS];
-#pragma unroll
+    if constexpr (!HINT) {
+        // K-th smallest unit minimum over the query's 2*CS lists, through the query tile's share of the queue area
+        float *md = reinterpret_cast<float *>(reinterpret_cast<char *>(qd_all) + qt * (32 * QPQ * 6));
+        // (UL values and a +inf behind them per list: a head that has taken a whole list reads the sentinel)
+        static_assert(2 * CS * (UL + 1) * 32 * 4 <= 32 * QPQ * 6 && (32 * QPQ * 6) % 8 == 0,
+                      "scratch lists must fit the queue area of one query tile");
+        __syncthreads();
+        int slot0 = list * (UL + 1) * 32 + col;                // (opaque: keeps the compiler from deriving these addresses
+        asm volatile("" : "+v"(slot0));                        //  before the scan loop and spilling them across it)
+    #pragma unroll
+        for (int p = 0; p < UL; ++p)
+            md[slot0 + p * 32] = um.d[p];
+        md[slot0 + UL * 32] = __builtin_inff();
+        if (TWO ? roundsA2 > 0 : roundsB > 0)
+            stage_rows(TWO ? 4 : 0, 0);                        // the next pass's first tiles travel during the merge below
+        __syncthreads();
+        // K-th smallest over the query's lists: ONE wave per query tile merges (waves 0, 5, 10, 15: one per SIMD), the bound
+        // reaches the other lanes through LDS after the next barrier
+        if (cs == qt) {
+            float t = __builtin_inff();
+            // K steps of "smallest head, advance it" over the 2*CS sorted lists.  Equal heads advance together, which can
+            // only make the bound larger (it stays valid).
+            int head[2 * CS];
+    #pragma unroll
             for (int l = 0; l < 2 * CS; ++l)
-                hv[l] = md[head[l]];                       // (a head stops at its list's sentinel: +inf is never the minimum
-                                                           //  unless every list is exhausted, and then it stays the answer)
-            float m = hv[0];
-#pragma unroll
-            for (int l = 1; l < 2 * CS; ++l)
-                m = fminf(m, hv[l]);
-#pragma unroll
-            for (int l = 0; l < 2 * CS; ++l)
-                head[l] += hv[l] == m ? 32 : 0;
-            t = m;
+                head[l] = (l * (UL + 1)) * 32 + col;
+    #pragma unroll
+            for (int p = 0; p < K; ++p) {
+                float hv[2 * CS];
+    #pragma unroll
+                for (int l = 0; l < 2 * CS; ++l)
+                    hv[l] = md[head[l]];                       // (a head stops at its list's sentinel: +inf is never the minimum
+                                                               //  unless every list is exhausted, and then it stays the answer)
+                float m = hv[0];
+    #pragma unroll
+                for (int l = 1; l < 2 * CS; ++l)
+                    m = fminf(m, hv[l]);
+    #pragma unroll
+                for (int l = 0; l < 2 * CS; ++l)
+                    head[l] += hv[l] == m ? 32 : 0;
+                t = m;
+            }
+            if (half == 0)
+                tauv[qt * 32 + col] = fminf(t, 3.4028234664e38f);                 // rows past the end (+inf) never pass
         }
-        if (half == 0)
-            tauv[qt * 32 + col] = fminf(t, 3.4028234664e38f);                 // rows past the end (+inf) never pass
     }
 
     if constexpr (TWO) {
@@ -1376,32 +1132,95 @@ __global__ __launch_bounds__(1024) void knn64_wide_kernel(int n, int ld, int k, 
 }
 
 template <int K, int QPQ, bool REUSE, bool TWO>
-static hipError_t launch_knn_wide_q(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s,
-                                    const unsigned char *only = nullptr)
+static hipError_t launch_knn_wide_q(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
     const size_t lds = knn_wide_lds_bytes(n);
     static bool raised[64] = {};
     if (hipError_t e = raise_lds_limit(&knn64_wide_kernel<K, QPQ, REUSE, TWO>, raised); e != hipSuccess)
         return e;
     hipLaunchKernelGGL((knn64_wide_kernel<K, QPQ, REUSE, TWO>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s, n, ld,
-                       k, x, nn_idx, only);
+                       k, x, nn_idx);
     return hipSuccess;
 }
 template <int K>
-static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s,
-                                  const unsigned char *only = nullptr)
+static hipError_t launch_knn_wide(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
     if constexpr (K <= 10) {
         // pass A of at most two rounds (n <= 1024): its distances are kept and pass B skips the sampled tiles
-        if (ceil_div(n, KM_TILE) <= 32 && CLOUDAAE_KNOB("CLOUDAAE_KNN_REUSE", 1) != 0)
-            return launch_knn_wide_q<K, 144, true, false>(b, n, ld, k, x, nn_idx, s, only);
+        if (ceil_div(n, KM_TILE) <= 32)
+            return launch_knn_wide_q<K, 144, true, false>(b, n, ld, k, x, nn_idx, s);
     }
-    // otherwise the bound in two stages (knob CLOUDAAE_KNN_TWO = 0: one stage, the sample scanned twice)
-    if (CLOUDAAE_KNOB("CLOUDAAE_KNN_TWO", 1) != 0)
-        return knn_wide_qpq(n) == 144 ? launch_knn_wide_q<K, 144, false, true>(b, n, ld, k, x, nn_idx, s, only)
-                                      : launch_knn_wide_q<K, 128, false, true>(b, n, ld, k, x, nn_idx, s, only);
-    return knn_wide_qpq(n) == 144 ? launch_knn_wide_q<K, 144, false, false>(b, n, ld, k, x, nn_idx, s, only)
-                                  : launch_knn_wide_q<K, 128, false, false>(b, n, ld, k, x, nn_idx, s, only);
+    // otherwise the bound in two stages (one stage, the sample scanned twice, was round 4's: 1.5 x instead of 1.25 x the products)
+    return knn_wide_qpq(n) == 144 ? launch_knn_wide_q<K, 144, false, true>(b, n, ld, k, x, nn_idx, s)
+                                  : launch_knn_wide_q<K, 128, false, true>(b, n, ld, k, x, nn_idx, s);
+}
+
+// ---- the bound from a hint (round 6) --------------------------------------------------------------------------------------
+// tau[cloud][q] = max over the k hinted points j of D(q, j), D in the arithmetic of the kernels above (the channel-ordered fma
+// chain of -2 x_q . x_j from +0, then + |x_q|^2, then + |x_j|^2; norms = un-fused sequential sums of squares).  The hinted
+// points are k DISTINCT indices (somebody's neighbour list), so at least k candidates lie at or below tau: it bounds the
+// k-th distance, and the filtered scan that takes it (knn64_wide_kernel<..., HINT>) returns exactly what every other kernel
+// returns -- a bad hint only costs queue slots (and, when a queue overflows, the flagged rescan).  Half a wave per query,
+// a lane per hinted point (the lanes past k take the query itself: distance ~0), the row gathers hit L2 (a cloud's features
+// are 256 bytes x n: resident).
+__global__ __launch_bounds__(256) void knn64_hint_bound_kernel(int n, int ld, int k, const float *__restrict__ x,
+                                                               const int *__restrict__ hint, float *__restrict__ tau)
+{
+    const int cloud = blockIdx.y, q = blockIdx.x * 8 + ((int)threadIdx.x >> 5), j = threadIdx.x & 31;
+    if (q >= n)
+        return;                                            // (whole half-waves leave together)
+    const float *X = x + (size_t)cloud * n * ld;
+    int c = j < k ? hint[((size_t)cloud * n + q) * k + j] : q;
+    c = min(max(c, 0), n - 1);
+    const float4v *qr = reinterpret_cast<const float4v *>(X + (size_t)q * ld);
+    const float4v *cr = reinterpret_cast<const float4v *>(X + (size_t)c * ld);
+    float acc = 0.0f, sqq = 0.0f, sqc = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const float4v a = qr[u], b = cr[u];
+        acc = fmaf(b.x, -2.0f * a.x, acc);
+        acc = fmaf(b.y, -2.0f * a.y, acc);
+        acc = fmaf(b.z, -2.0f * a.z, acc);
+        acc = fmaf(b.w, -2.0f * a.w, acc);
+        const float a0 = a.x * a.x, a1 = a.y * a.y, a2 = a.z * a.z, a3 = a.w * a.w;
+        const float b0 = b.x * b.x, b1 = b.y * b.y, b2 = b.z * b.z, b3 = b.w * b.w;
+        sqq = sqq + a0;
+        sqq = sqq + a1;
+        sqq = sqq + a2;
+        sqq = sqq + a3;
+        sqc = sqc + b0;
+        sqc = sqc + b1;
+        sqc = sqc + b2;
+        sqc = sqc + b3;
+    }
+    float d = (acc + sqq) + sqc;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)
+        d = fmaxf(d, __shfl_xor(d, o, 32));
+    if (j == 0)
+        tau[(size_t)cloud * n + q] = d;
+}
+
+template <int K>
+static hipError_t launch_knn_wide_hinted(int b, int n, int ld, int k, const float *x, const int *hint, float *tau, int *nn_idx,
+                                         hipStream_t s)
+{
+    hipLaunchKernelGGL(knn64_hint_bound_kernel, dim3(ceil_div(n, 8), b), dim3(256), 0, s, n, ld, k, x, hint, tau);
+    const size_t lds = knn_wide_lds_bytes(n);
+    static bool raised[64] = {};
+    if (knn_wide_qpq(n) == 144) {
+        if (hipError_t e = raise_lds_limit(&knn64_wide_kernel<K, 144, false, false, true>, raised); e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL((knn64_wide_kernel<K, 144, false, false, true>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s,
+                           n, ld, k, x, nn_idx, tau);
+    } else {
+        static bool raised128[64] = {};
+        if (hipError_t e = raise_lds_limit(&knn64_wide_kernel<K, 128, false, false, true>, raised128); e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL((knn64_wide_kernel<K, 128, false, false, true>), dim3(ceil_div(n, KM_TILE * 4), b), dim3(1024), lds, s,
+                           n, ld, k, x, nn_idx, tau);
+    }
+    return hipSuccess;
 }
 
 // ---- C = 3 on the matrix cores: the bound pass + filtered scan of knn64_wide_kernel without its rounds ----------------
@@ -1807,521 +1626,18 @@ static hipError_t launch_knn3_scan(int b, int n, int ld, int k, const float *x, 
     return hipSuccess;
 }
 
-// ---- C = 64, fourth generation (round 5; NOT the default -- see the end of this comment): the scan on the bf16 matrix pipe -----
-// knn64_wide_kernel computes every one of the N x N distances the way the oracle defines them (a k-ordered fp32 fma chain =
-// v_mfma_f32_32x32x2_f32, 33 steps of 64 cycles per 32 x 32 tile) and is bound by exactly that: the fp32 matrix rate.  But
-// the oracle's arithmetic is needed only for the candidates that can be among the k nearest.  Here:
-//   planes  : every point once, minus a centre of its cloud, as two bf16 pieces per channel, h = bf16(y), m = bf16(y - h)
-//             (y - h - m is below 2^-18 |y|); |x|^2 in the oracle's order (fp32, exact), |y|^2, and -|y|^2 / 2 as two bf16
-//             pieces (knn64_planes_kernel).
-//   scores  : s~_ij = y_i.y_j - (|y_i|^2 + |y_j|^2) / 2 = -d_ij / 2 from 13 v_mfma_f32_32x32x16_bf16 per tile (h.h, h.m, m.h
-//             over four blocks of 16 channels, and one block that adds the norms): 416 matrix cycles instead of 2112, and
-//             |s~ - s| <= E_i for the s the oracle's arithmetic gives (the bound is spelled out in the kernel).
-//   pass A  : every tile; per lane the maximum of its rows of the tile goes into a sorted list of K values; the k-th largest
-//             over the query's two lanes is tau~ (k DISTINCT candidates score at least that).
-//   pass B  : every tile again; a candidate with s~ >= tau~ - 2 E_i goes to its lane's queue in LDS (the index only).  Every
-//             candidate the oracle ranks among the k nearest is there: its s is >= the oracle's k-th largest >= tau~ - E_i.
-//   select  : the oracle's distance (the fma chain over the 64 channels, (|x_i|^2 + -2 inner) + |x_j|^2) for every queued
-//             candidate, sorted keys, a lane pair per query.
-//   A queue that overflows flags the query group; a gated launch of knn64_wide_kernel (workgroups leave at once unless
-//   flagged) recomputes those: correctness never depends on the margins being small, only on E_i being a bound.
-// Bit-exact on every case of tests/test_00_ops_gpu.py (CLOUDAAE_KNN_SPLIT = 2 forces it).  Measured (profiles/
-// notes_knn_split_r5.md): post-ReLU Gaussian features, [128, 1024, k = 10] 229 -> 163 us and [32, 4096, k = 20] 1036 -> 542 us with
-// a first version of the selection (the oracle's distance only for neighbours the scores cannot order).  INSIDE a training
-// step it loses: the features of a freshly initialised encoder sit in a ball a tenth of their own size (|x - centre|^2 =
-// 0.01 |x|^2), neighbours' distances are 1e-3 |x|^2 and 5e-5 |x|^2 apart -- the level of the oracle's OWN rounding (its fma chain
-// is good to 2e-6 |x|^2 a term), so half of all neighbours have to be settled by the oracle's arithmetic anyway; config 5's
-// clouds repeat points (visible points re-drawn to 4096 rows), whose exact ties overflow the per-lane queues.
-// B = 128: 241 us against 236; config 5: the queues overflow.  The fp32 kernel stays the default.
-constexpr int KSP_T = 2;             // candidate tiles per round
-constexpr int KSP_NB = 4;            // ring of round buffers: the tiles of round r + 3 travel while round r computes
-constexpr int KSP_TILE_BYTES = KM_TILE * 256;
-typedef __bf16 ksp_bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned ksp_u4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned ksp_bf16_rne(float v)           // finite v
-{
-    const unsigned u = __float_as_uint(v);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-
-struct KspScratch {                  // one call's scratch (scratch_alloc): offsets in bytes
-    size_t flags, rows, ext, sqx, sqc, total;
-    int npad, gq;                    // rows per cloud in the planes (whole 256-query workgroups); 128-query groups per cloud
-};
-static KspScratch ksp_layout(int b, int n)
-{
-    KspScratch L;
-    L.gq = ceil_div(n, 4 * KM_TILE);
-    L.npad = ceil_div(n, 256) * 256;
-    L.flags = 0;
-    L.rows = ((size_t)b * L.gq + 255) / 256 * 256;
-    L.ext = L.rows + (size_t)b * L.npad * 256;
-    L.sqx = L.ext + (size_t)b * L.npad * 4;
-    L.sqc = L.sqx + (size_t)b * L.npad * 4;
-    L.total = L.sqc + (size_t)b * L.npad * 4;
-    return L;
-}
-
-// grid (npad / 32, b), 256 threads: thread (row r = t / 8, unit u = t % 8) splits channels 8u .. 8u + 7 of its row -- of the row
-// MINUS a centre of the cloud: distances do not change, and the error of a score is relative to the norms of what was
-// split.  Features behind a ReLU are all positive: their spread around the centre is a fraction of their size (at the
-// first training steps a twentieth), and neighbours whose distances differ by 1e-4 of |x|^2 -- most of them, there -- are
-// told apart by scores on centred rows but not by scores on the rows themselves.  The centre is the mean of 64 rows spread
-// over the cloud, summed in one fixed order by every workgroup (ANY centre is valid; it only has to be the same for the whole
-// cloud).  The norm in the oracle's order (of the row itself: squares rounded, then summed channel by channel) is a chain
-// through the row's eight threads: thread u continues the sum where thread u - 1 stopped (eight steps of eight additions;
-// every thread runs all of them, one keeps the result); the norm of the centred row likewise.  Also clears the flag bytes
-// of the query groups (a byte per 128 rows).
-__global__ __launch_bounds__(256) void knn64_planes_kernel(int n, int ld, int npad, int gq, const float *__restrict__ x,
-                                                          unsigned char *__restrict__ rows, unsigned *__restrict__ ext,
-                                                          float *__restrict__ sqx, float *__restrict__ sqc,
-                                                          unsigned char *__restrict__ flags)
-{
-    __shared__ float part[4][64];
-    const int cloud = blockIdx.y, t = threadIdx.x, lane = t & 63;
-    const int row = blockIdx.x * KM_TILE + (t >> 3), u = t & 7;
-    const float *X = x + (size_t)cloud * n * ld;
-    if (t == 0 && (blockIdx.x & 3) == 0 && (int)(blockIdx.x >> 2) < gq)
-        flags[cloud * gq + (blockIdx.x >> 2)] = 0;
-    {
-        float sum = 0.0f;
-        for (int i = 0; i < 16; ++i) {
-            const int r = (int)(((long long)((t >> 6) * 16 + i) * n) >> 6);     // sample row (t / 64) * 16 + i of 64
-            sum += X[(size_t)r * ld + lane];
-        }
-        part[t >> 6][lane] = sum;
-    }
-    __syncthreads();
-    float mu[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = 8 * u + e;
-        mu[e] = (((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]) * (1.0f / 64.0f);
-    }
-    unsigned h[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0};
-    float v2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, w2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (row < n) {
-        const float4v a = *reinterpret_cast<const float4v *>(X + (size_t)row * ld + 8 * u);
-        const float4v c = *reinterpret_cast<const float4v *>(X + (size_t)row * ld + 8 * u + 4);
-        const float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float w = v[e] - mu[e];
-            const unsigned hb = ksp_bf16_rne(w);
-            const unsigned mb = ksp_bf16_rne(w - __uint_as_float(hb << 16));         // (the difference is exact)
-            h[e >> 1] |= hb << (16 * (e & 1));
-            m[e >> 1] |= mb << (16 * (e & 1));
-            v2[e] = v[e] * v[e];
-            w2[e] = w * w;
-        }
-    }
-    unsigned char *R = rows + ((size_t)cloud * npad + row) * 256;
-    *reinterpret_cast<ksp_u4 *>(R + 16 * u) = ksp_u4{h[0], h[1], h[2], h[3]};
-    *reinterpret_cast<ksp_u4 *>(R + 128 + 16 * u) = ksp_u4{m[0], m[1], m[2], m[3]};
-    float sq = 0.0f, sc = 0.0f;
-#pragma unroll
-    for (int step = 0; step < 8; ++step) {
-        float c = sq, d = sc;                               // (step 0: the chains start from +0, like the oracle's)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            c = c + v2[e];
-            d = d + w2[e];
-        }
-        sq = __shfl(c, (lane & ~7) | step, 64);             // what the row's thread `step` computed goes on
-        sc = __shfl(d, (lane & ~7) | step, 64);
-    }
-    if (u == 0) {
-        unsigned e = 0xff80u;                               // (-inf, 0): a row past the end never scores
-        if (row < n) {
-            const float hs = -0.5f * sc;
-            const unsigned a0 = ksp_bf16_rne(hs);
-            const unsigned a1 = ksp_bf16_rne(hs - __uint_as_float(a0 << 16));
-            e = a0 | (a1 << 16);
-        }
-        ext[(size_t)cloud * npad + row] = e;
-        sqx[(size_t)cloud * npad + row] = row < n ? sq : __builtin_inff();
-        sqc[(size_t)cloud * npad + row] = row < n ? sc : 0.0f;
-    }
-}
-
-template <int K>
-struct MaxK {                        // the K largest values seen, descending
-    float d[K];
-    __device__ __forceinline__ void init()
-    {
-#pragma unroll
-        for (int p = 0; p < K; ++p)
-            d[p] = -__builtin_inff();
-    }
-    __device__ __forceinline__ void insert(float nd)
-    {
-        d[K - 1] = fmaxf(d[K - 1], nd);
-#pragma unroll
-        for (int p = K - 1; p > 0; --p) {
-            const float a = d[p - 1], b = d[p];
-            d[p - 1] = fmaxf(a, b);
-            d[p] = fminf(a, b);
-        }
-    }
-};
-
-// queue slots per LANE (a query's two lanes keep their own: no counters in LDS, no atomics) + one slot that takes every write
-// that is not a hit
-constexpr int KSP_QH = 32;
-template <int QW>
-static size_t ksp_lds_bytes()
-{
-    return KSP_NB * KSP_T * KSP_TILE_BYTES + KSP_NB * KSP_T * 64 * 4 + 64 * QW * (size_t)(KSP_QH + 2) * 2 + 64 * 4 + 16;
-}
-
-// QW waves per workgroup, a 32-query tile each (8 where that still fills the chip: two waves per SIMD, and the cloud passes
-// through LDS half as often; every workgroup streams the whole cloud through its own LDS either way)
-template <int K, int QW>
-__global__ __launch_bounds__(64 * QW) void knn64_split_kernel(int n, int ld, int k, int npad, int gq,
-                                                             const float *__restrict__ x,
-                                                             const unsigned char *__restrict__ rows,
-                                                             const unsigned *__restrict__ ext, const float *__restrict__ sqx,
-                                                             const float *__restrict__ sqc, unsigned char *__restrict__ flags,
-                                                             int *__restrict__ nn_idx)
-{
-    constexpr int QH = KSP_QH, T = KSP_T, NB = KSP_NB, NQ = 32 * QW;
-    extern __shared__ __attribute__((aligned(16))) char ksp_smem[];
-    char *tiles = ksp_smem;                                               // [NB][T][32 rows x 256 bytes], units XOR-swizzled
-    unsigned *extb = reinterpret_cast<unsigned *>(tiles + NB * T * KSP_TILE_BYTES);   // [NB][T][64]
-    unsigned short *qj = reinterpret_cast<unsigned short *>(extb + NB * T * 64);      // [64 QW lanes][QH + 2] candidate indices
-    float *red = reinterpret_cast<float *>(qj + 64 * QW * (QH + 2));      // [64]
-    int *flag = reinterpret_cast<int *>(red + 64);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 31, half = lane >> 5;
-    int wg, cloud;
-    xcd_cloud_tile(wg, cloud);
-    const int ntiles = (n + KM_TILE - 1) / KM_TILE;
-    const unsigned char *R = rows + (size_t)cloud * npad * 256;
-    const unsigned *EX = ext + (size_t)cloud * npad;
-    const float *SQ = sqx + (size_t)cloud * npad;
-    const float *SC = sqc + (size_t)cloud * npad;
-    if (tid == 0)
-        *flag = 0;
-    // the largest norms of the cloud, of the rows and of the centred rows (the error bound of a score needs them)
-    float sqmax = 0.0f, scmax = 0.0f;
-    for (int j = tid; j < n; j += 64 * QW) {
-        sqmax = fmaxf(sqmax, SQ[j]);
-        scmax = fmaxf(scmax, SC[j]);
-    }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        sqmax = fmaxf(sqmax, __shfl_xor(sqmax, off, 64));
-        scmax = fmaxf(scmax, __shfl_xor(scmax, off, 64));
-    }
-    if (lane == 0) {
-        red[wave] = sqmax;
-        red[32 + wave] = scmax;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < QW; ++w) {
-        sqmax = fmaxf(sqmax, red[w]);
-        scmax = fmaxf(scmax, red[32 + w]);
-    }
-
-    const int qrow = wg * NQ + wave * 32 + col;             // (< npad)
-    const bool qvalid = qrow < n;
-    // B operands: the query's pieces (this lane's half of every block of 16 channels), and the block that adds the norms
-    ksp_u4 bh[4], bm[4];
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        bh[kb] = *reinterpret_cast<const ksp_u4 *>(R + (size_t)qrow * 256 + 16 * (2 * kb + half));
-        bm[kb] = *reinterpret_cast<const ksp_u4 *>(R + (size_t)qrow * 256 + 128 + 16 * (2 * kb + half));
-    }
-    const ksp_u4 bext = half == 0 ? ksp_u4{0x3f803f80u, EX[qrow], 0u, 0u} : ksp_u4{0u, 0u, 0u, 0u};
-    const float sq_i = SQ[qrow];
-    // How far a score can be from the oracle's -d / 2, with y = x - centre the rows that were split:
-    //   the score against y's exact -|y_i - y_j|^2 / 2: 1.6e-5 (|y_i|^2 + |y_j|^2) -- dropped piece products 1.15e-5 |y_i| |y_j|
-    //     (m.m', r.y', y.r' with |m| <= 2^-9 |y|, |r| <= 2^-18 |y| per channel), the norms' pieces 2^-19 each and the norms' own
-    //     fp32 sums (64 ulp), the matrix pipe's fp32 accumulation (13 instructions, taken as 4 ulp of the running magnitude
-    //     each: 3e-6); y is x - centre ROUNDED, off by an ulp of itself: 1.2e-7 more;
-    //   the oracle's fp32 distance against the exact one: its fma chain and sums are off by up to 64 ulp of |x_i| |x_j|, the size
-    //     of the rows themselves: 2.1e-6 (|x_i|^2 + |x_j|^2).
-    const float Es = 1.8e-5f * ((qvalid ? SC[qrow] : 0.0f) + scmax) + 2.1e-6f * ((qvalid ? sq_i : 0.0f) + sqmax);
-
-    // staging: a tile = 32 rows of 256 bytes = 8 wave instructions of 1 KB (global_load_lds, 16 bytes per lane, lane-linear
-    // in LDS).  The rows are read back a row per lane, so the 16-byte units of a row are XOR-swizzled with the row number: the
-    // lane that fills physical unit p of row r fetches logical unit p ^ (r & 15).
-    auto stage = [&](auto tile_of, int slot0, int nslots, int buf) {
-#pragma unroll
-        for (int mth = 0; mth < T * 8 / QW; ++mth) {
-            const int ii = wave + QW * mth, t = ii >> 3, part = ii & 7;
-            const int tile = tile_of(min(slot0 + t, nslots - 1));
-            const int r = part * 4 + (lane >> 4), pu = lane & 15;
-            const unsigned char *src = R + ((size_t)(tile * KM_TILE + r) * 256 + 16 * (pu ^ (r & 15)));
-            __builtin_amdgcn_global_load_lds(src, tiles + (buf * T + t) * KSP_TILE_BYTES + part * 1024, 16, 0, 0);
-        }
-        static_assert(T <= 2 && QW >= 2, "a wave per tile brings the norms' pieces");
-        if (wave < T) {
-            const int tile = tile_of(min(slot0 + wave, nslots - 1));
-            __builtin_amdgcn_global_load_lds(EX + tile * KM_TILE + col, extb + (buf * T + wave) * 64, 4, 0, 0);
-        }
-    };
-    struct Ops {
-        ksp_u4 a[9];                                        // the norms' block, then (h, m) of the four blocks of 16 channels
-    };
-    auto operands = [&](int buf, int t) {
-        const char *tb = tiles + (buf * T + t) * KSP_TILE_BYTES + col * 256;
-        Ops o;
-        o.a[0] = half == 0 ? ksp_u4{extb[(buf * T + t) * 64 + col], 0x3f803f80u, 0u, 0u} : ksp_u4{0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            o.a[1 + 2 * kb] = *reinterpret_cast<const ksp_u4 *>(tb + 16 * ((2 * kb + half) ^ (col & 15)));
-            o.a[2 + 2 * kb] = *reinterpret_cast<const ksp_u4 *>(tb + 16 * ((8 + 2 * kb + half) ^ (col & 15)));
-        }
-        return o;
-    };
-    auto mm = [](const ksp_u4 &a, const ksp_u4 &b, const f32x16 &c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ksp_bf16x8, a), __builtin_bit_cast(ksp_bf16x8, b), c, 0, 0, 0);
-    };
-    // matrix instruction `step` (0 .. 12) of a tile: the norms, then h.h, h.m, m.h of every block
-    auto mstep = [&](const Ops &o, auto step, const f32x16 &c) {
-        constexpr int st = decltype(step)::value;
-        if constexpr (st == 0)
-            return mm(o.a[0], bext, c);
-        else {
-            constexpr int kb = (st - 1) / 3, w = (st - 1) % 3;
-            return w == 0 ? mm(o.a[1 + 2 * kb], bh[kb], c) : w == 1 ? mm(o.a[1 + 2 * kb], bm[kb], c) : mm(o.a[2 + 2 * kb], bh[kb], c);
-        }
-    };
-    // A pass: `nslots` tiles in rounds of T through a ring of NB round buffers.  One barrier per round: behind it the round's
-    // tiles have landed (every wave waited for its own part) and nobody reads the buffer of the round before any more -- the
-    // tiles of round r + NB - 1 travel into it; the loads of the NB - 2 rounds in between stay in flight (loads are issued for
-    // rounds past the end as well -- the last tile again -- so the count a wave may leave outstanding never changes).
-    // A wave alone on its SIMD issues in order: an accumulating matrix instruction waits ~32 cycles for the one before it,
-    // and nothing else of the wave issues meanwhile.  So the visitor's work on tile t - 1 is cut into 13 pieces that sit
-    // BETWEEN the 13 matrix instructions of tile t in program order (pinned by scheduling barriers).
-    constexpr int LPR = T * 8 / QW;                         // a wave's loads per round (+ 1 for the waves that bring the norms)
-    f32x16 zero16;
-#pragma unroll
-    for (int e = 0; e < 16; ++e)
-        zero16[e] = 0.0f;
-    asm volatile("" : "+v"(zero16));                        // (opaque: not rebuilt in front of every tile)
-    auto pass = [&](auto tile_of, int nslots, auto piece) {
-        const int rounds = (nslots + T - 1) / T;
-#pragma unroll
-        for (int r = 0; r < NB - 1; ++r)
-            stage(tile_of, r * T, nslots, r);
-        f32x16 cur = zero16;
-        int cur_tile = 0;
-        bool cur_valid = false;
-        for (int r = 0; r < rounds; ++r) {
-            if (wave < T)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * (LPR + 1)) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * LPR) : "memory");
-            __syncthreads();
-            stage(tile_of, (r + NB - 1) * T, nslots, (r + NB - 1) % NB);
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const Ops o = operands(r % NB, t);
-                f32x16 nxt = zero16;                      // (a register set that stays zero: the first instruction's addend)
-                static_for<13>([&](auto st) {
-                    nxt = mstep(o, st, nxt);
-                    piece(cur, cur_tile, cur_valid, st);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                cur = nxt;
-                cur_tile = tile_of(min(r * T + t, nslots - 1));
-                cur_valid = r * T + t < nslots;
-            }
-        }
-        static_for<13>([&](auto st) { piece(cur, cur_tile, cur_valid, st); });
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                    // (the buffers are free for the next pass)
-    };
-
-    // ---------------- pass A: tau~ ----------------
-    // every tile once: per lane the maximum of its sixteen rows of the tile (of two blocks of eight, of four units of four,
-    // where the cloud has few tiles) goes into a sorted list of K; the k-th largest over the query's two lanes is reached by
-    // k DISTINCT candidates, and with 2 ntiles blocks to choose from it sits just below the k-th best score (about 1.2 k
-    // candidates pass it).  The pass costs a third of pass B per tile (no queue writes).
-    MaxK<K> best;
-    best.init();
-    const int units = 2 * ntiles >= 4 * K ? 1 : (4 * ntiles >= 4 * K ? 2 : 4);
-    float um[4];
-    pass([](int s) { return s; }, ntiles, [&](const f32x16 &acc, int, bool valid, auto step) {
-        constexpr int st = decltype(step)::value;
-        if constexpr (st < 4) {
-            um[st] = fmaxf(fmaxf(acc[4 * st], acc[4 * st + 1]), fmaxf(acc[4 * st + 2], acc[4 * st + 3])) +
-                     (valid ? 0.0f : -__builtin_inff());
-        } else if constexpr (st == 4) {
-            if (units <= 2) {
-                um[0] = fmaxf(um[0], um[1]);
-                um[2] = fmaxf(um[2], um[3]);
-            }
-            if (units == 1)
-                um[0] = fmaxf(um[0], um[2]);
-        } else if constexpr (st == 5) {
-            best.insert(um[0]);
-        } else if constexpr (st == 9) {
-            if (units >= 2)
-                best.insert(um[2]);
-        } else if constexpr (st == 7 || st == 11) {
-            if (units == 4)
-                best.insert(um[st == 7 ? 1 : 3]);
-        }
-    });
-    {
-        float other[K];
-#pragma unroll
-        for (int p = 0; p < K; ++p)
-            other[p] = __shfl_xor(best.d[p], 32, 64);
-#pragma unroll
-        for (int p = 0; p < K; ++p)
-            best.insert(other[p]);
-    }
-    float tau = best.d[K - 1];
-#pragma unroll
-    for (int p = 0; p < K; ++p)
-        tau = p == k - 1 ? best.d[p] : tau;
-    const float thr = qvalid ? tau - 2.0f * Es : __builtin_inff();          // (a row past the end asks for nothing)
-
-    // ---------------- pass B: the candidates at or above the bound ----------------
-    // branch free: every candidate's index is written -- a hit to the lane's next queue slot, anything else to the slot behind
-    // the queue
-    unsigned short *myqj = qj + (wave * 64 + lane) * (QH + 2);
-    int cnt = 0;                                            // hits so far (the queue keeps the first QH)
-    pass([](int s) { return s; }, ntiles, [&](const f32x16 &acc, int tile, bool valid, auto step) {
-        constexpr int st = decltype(step)::value;
-        const float th = valid ? thr : __builtin_inff();
-        auto one = [&](auto ee) {
-            constexpr int e = decltype(ee)::value;
-            const bool hit = acc[e] >= th;
-            const int slot = hit ? min(cnt, QH) : QH;
-            myqj[slot] = (unsigned short)(tile * KM_TILE + 4 * half + (e & 3) + 8 * (e >> 2));
-            cnt += hit ? 1 : 0;
-        };
-        one(std::integral_constant<int, st>{});
-        if constexpr (st >= 10)
-            one(std::integral_constant<int, st + 3>{});
-    });
-    const int cnt_pair = cnt + __shfl_xor(cnt, 32, 64);
-    if (qvalid && (cnt > QH || cnt_pair < k))               // (fewer than k: only NaN scores do that)
-        *flag = 1;
-
-    // ---------------- select: the oracle's distance for every queued candidate, a lane pair per query ----------------
-    // (Round 5 first ordered the queue by score and gave only neighbours closer than the two evaluations can differ the oracle's
-    //  distance.  On features as a training step has them -- |x - centre|^2 a hundredth of |x|^2, neighbours' distances 1e-3 |x|^2
-    //  and 5e-5 |x|^2 apart -- half of all neighbours are that close: the ORACLE's own fma chain is only good to 2e-6 |x|^2 a
-    //  term.  So every candidate of the queue, about 1.2 k per query, gets the fma chain; the bound keeps the queue that short
-    //  whatever the data.)
-    TopKey<K> top;
-    top.init();
-    {
-        const float *X = x + (size_t)cloud * n * ld;
-        const float4v *xi = reinterpret_cast<const float4v *>(X + (size_t)(qvalid ? qrow : 0) * ld);
-        const int L = min(cnt, QH);
-        int e = 0;
-        while (__any(e < L)) {
-            const int j = e < L ? (int)myqj[min(e, QH - 1)] : (qvalid ? qrow : 0);
-            const float4v *xj = reinterpret_cast<const float4v *>(X + (size_t)j * ld);
-            float inner = 0.0f;
-#pragma unroll
-            for (int c4 = 0; c4 < 16; c4 += 4) {
-                float4v a[4], b[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    a[u] = xi[c4 + u];
-                    b[u] = xj[c4 + u];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    inner = __builtin_fmaf(a[u].x, b[u].x, inner);
-                    inner = __builtin_fmaf(a[u].y, b[u].y, inner);
-                    inner = __builtin_fmaf(a[u].z, b[u].z, inner);
-                    inner = __builtin_fmaf(a[u].w, b[u].w, inner);
-                }
-            }
-            const float m2 = -2.0f * inner;
-            const float tt = sq_i + m2;
-            const float d = tt + SQ[j];
-            top.insert(e < L ? knn_key(d, j) : __builtin_inf());
-            e += 1;
-        }
-        double other[K];
-#pragma unroll
-        for (int p = 0; p < K; ++p)
-            other[p] = __shfl_xor(top.key[p], 32, 64);
-#pragma unroll
-        for (int p = 0; p < K; ++p)
-            top.insert(other[p]);
-    }
-    __syncthreads();
-    if (*flag != 0) {
-        if (tid < (NQ + 127) / 128 && (wg * NQ) / 128 + tid < gq)
-            flags[cloud * gq + (wg * NQ) / 128 + tid] = 1;
-        return;
-    }
-    if (qvalid && half == 0) {
-        int *dst = nn_idx + ((size_t)cloud * n + qrow) * k;
-#pragma unroll
-        for (int p = 0; p < K; ++p)
-            if (p < k)
-                dst[p] = knn_key_low16(top.key[p]);
-    }
-}
-
-template <int K>
-static hipError_t launch_knn_split(int b, int n, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
-{
-    const KspScratch L = ksp_layout(b, n);
-    void *scratch = nullptr;
-    if (hipError_t e = scratch_alloc(&scratch, L.total, s); e != hipSuccess)
-        return e;
-    unsigned char *base = (unsigned char *)scratch;
-    hipLaunchKernelGGL(knn64_planes_kernel, dim3(L.npad / KM_TILE, b), dim3(256), 0, s, n, ld, L.npad, L.gq, x, base + L.rows,
-                       (unsigned *)(base + L.ext), (float *)(base + L.sqx), (float *)(base + L.sqc), base + L.flags);
-    // 256-query workgroups (two waves per SIMD, the cloud streamed through LDS half as often) where that still fills the
-    // chip; 128-query ones otherwise (knob CLOUDAAE_KNN_SPLIT_QW)
-    const long long groups = (long long)(L.npad / 128) * b;
-    const int qw = CLOUDAAE_KNOB_SET("CLOUDAAE_KNN_SPLIT_QW") ? CLOUDAAE_KNOB("CLOUDAAE_KNN_SPLIT_QW", 4) : (groups >= 1024 ? 8 : 4);
-    if (qw == 8) {
-        static bool raised[64] = {};
-        auto kern = &knn64_split_kernel<K, 8>;
-        const size_t lds = ksp_lds_bytes<8>();
-        if (hipError_t e = raise_lds_limit(kern, raised); e != hipSuccess)
-            return e;
-        hipLaunchKernelGGL((knn64_split_kernel<K, 8>), dim3(ceil_div(L.npad, 256), b), dim3(512), lds, s, n, ld, k, L.npad,
-                           L.gq, x, base + L.rows, (const unsigned *)(base + L.ext), (const float *)(base + L.sqx),
-                           (const float *)(base + L.sqc), base + L.flags, nn_idx);
-    } else {
-        static bool raised[64] = {};
-        auto kern = &knn64_split_kernel<K, 4>;
-        const size_t lds = ksp_lds_bytes<4>();
-        if (hipError_t e = raise_lds_limit(kern, raised); e != hipSuccess)
-            return e;
-        hipLaunchKernelGGL((knn64_split_kernel<K, 4>), dim3(L.npad / 128, b), dim3(256), lds, s, n, ld, k, L.npad,
-                           L.gq, x, base + L.rows, (const unsigned *)(base + L.ext), (const float *)(base + L.sqx),
-                           (const float *)(base + L.sqc), base + L.flags, nn_idx);
-    }
-    // the flagged query groups once more, the oracle's arithmetic throughout (a byte per workgroup of THAT grid)
-    // (development knob CLOUDAAE_KNN_SPLIT_FIXUP = 0 leaves them unwritten: tools/dev/chk_knn_split.py counts them)
-    if (CLOUDAAE_KNOB("CLOUDAAE_KNN_SPLIT_FIXUP", 1) != 0)
-        if (hipError_t e = launch_knn_wide<K>(b, n, ld, k, x, nn_idx, s, base + L.flags); e != hipSuccess)
-            return e;
-    return hipFreeAsync(scratch, s);
-}
-
-
-// Which C = 64 kernel for `tiles` 32-query tiles (measured, B x N = 1024 points, k = 10, us):
+// Which C = 64 kernel for `tiles` 32-query tiles (measured, B x N = 1024 points, k = 10, us; knn64_mfma = the retired first
+// generation):
 //   tiles      knn64_mfma   scan, 1 wave/tile   scan, 2 waves/tile   wide (bound pass, 16 waves; round 3 -> end of round 4)
+//    128 (B=4)      53.5                                                  57.5
 //    256 (B=8)      55            152                100                  73 -> 58
 //    512 (B=16)     66            152                101                  74 -> 58
-//    640 (B=20)     85                                                    75 -> 59
 //   1024 (B=32)    138            134                102                  76 -> 58
 //   4096 (B=128)                  414                397                 289 -> 228
 //   8192 (B=256)   780            631                788                 571 -> 455
-// Return value / knob CLOUDAAE_KNN_SCAN (forces a choice; the tests cover all of them): 0 = knn64_mfma_kernel,
-// 1 / 2 = knn64_scan_kernel with one / two waves per query tile, 5 = knn64_wide_kernel (where it applies: see
-// knn_wide_fits; otherwise 5 means 1).  (3 / 4 were the 8-wave bound kernel of round 2, superseded by the wide one.)
+// The wide kernel wherever it fits (clouds of 256 points and more whose queues fit LDS), else the scan kernel with two
+// waves per query tile (one from 4096 tiles).  Knob CLOUDAAE_KNN_SCAN forces a choice (the tests cover all of them):
+// 1 / 2 = knn64_scan_kernel with one / two waves per query tile, 5 = knn64_wide_kernel (where it fits; otherwise 5 means 2).
 static bool knn_wide_fits(int n, int k)
 {
     return k <= 20 && n >= 256 && knn_wide_lds_bytes(n) <= 158 * 1024;
@@ -2329,22 +1645,21 @@ static bool knn_wide_fits(int n, int k)
 
 static int knn_scan_waves(long long tiles, int n, int k)
 {
-    if (CLOUDAAE_KNOB_SET("CLOUDAAE_KNN_SCAN"))
-        return CLOUDAAE_KNOB("CLOUDAAE_KNN_SCAN", 0);
-    // (re-measured at the end of round 4, k = 10, wide / first generation: 256 tiles 57.7 / 59.3 us at n = 1024, 22.5 / 23.6 at
-    //  n = 256, 35.4 / 35.1 at n = 512; 512 tiles 58.2 / 70.1, 22.7 / 27.6, 35.7 / 42.9, 114.8 / 117.4 at n = 2048; 128 tiles
-    //  57.5 / 53.5)
-    if (tiles >= 256 && knn_wide_fits(n, k))
+    if (CLOUDAAE_KNOB_SET("CLOUDAAE_KNN_SCAN")) {
+        const int forced = CLOUDAAE_KNOB("CLOUDAAE_KNN_SCAN", 0);
+        if (forced == 1 || forced == 2 || forced == 5)
+            return forced;
+    }
+    if (knn_wide_fits(n, k))
         return 5;
-    return tiles >= 4096 ? 1 : tiles >= 1024 ? 2 : 0;
+    return tiles >= 4096 ? 1 : 2;
 }
 
 template <int K>
 static hipError_t launch_knn(int b, int n, int c, int ld, int k, const float *x, int *nn_idx, hipStream_t s)
 {
-    const bool first_gen = CLOUDAAE_KNOB_SET("CLOUDAAE_KNN_SCAN") && CLOUDAAE_KNOB("CLOUDAAE_KNN_SCAN", 0) == 0;
     const bool vec = ld % 4 == 0 && ((uintptr_t)x & 15) == 0;
-    if (c == 3 && K <= 20 && n <= 6144 && !first_gen) {
+    if (c == 3 && K <= 20 && n <= 6144) {
         if constexpr (K <= 20) {
             // the matrix-core form wherever it fits (n >= 256, the cloud and the queues in LDS); knob CLOUDAAE_KNN3_WIDE = 0
             // / 1 forces the choice (the tests cover both).  Measured, k = 10, continuous coordinates, wide / scan: n = 1024:
@@ -2363,31 +1678,20 @@ static hipError_t launch_knn(int b, int n, int c, int ld, int k, const float *x,
                 return launch_knn3_scan<K, 2>(b, n, ld, k, x, nn_idx, s);
             return launch_knn3_scan<K, 4>(b, n, ld, k, x, nn_idx, s);
         }
-    } else if (c == 3) {
-        hipLaunchKernelGGL(knn3_kernel<K>, dim3(ceil_div(n, 64), b), dim3(KNN_THREADS), 0, s, n, ld, k, x, nn_idx);
     } else if (c == 64 && vec && K <= 20 && n <= 16384) {
         if constexpr (K <= 20) {
             const long long tiles = (long long)ceil_div(n, KM_TILE) * b;
             const int mode = knn_scan_waves(tiles, n, K);
-            if (mode == 5 && knn_wide_fits(n, K)) {
-                // development knob CLOUDAAE_KNN_SPLIT: 2 = the scan on the bf16 matrix pipe (knn64_split_kernel), 1 = the same where
-                // 256-query workgroups fill the chip, 0 (default) = the fp32 matrix pipe throughout: see knn64_split_kernel
-                const int split = CLOUDAAE_KNOB("CLOUDAAE_KNN_SPLIT", 0);
-                if (n <= 65536 && k >= 2 && (split == 2 || (split == 1 && (long long)ceil_div(n, 128) * b >= 1024)))
-                    return launch_knn_split<K>(b, n, ld, k, x, nn_idx, s);
+            if (mode == 5 && knn_wide_fits(n, K))
                 return launch_knn_wide<K>(b, n, ld, k, x, nn_idx, s);
-            } else if (mode == 2) {
-                return launch_knn_scan<K, 4, 2>(b, n, ld, k, x, nn_idx, s);
-            } else if (mode > 0) {
+            if (mode == 1)
                 return launch_knn_scan<K, 4, 1>(b, n, ld, k, x, nn_idx, s);
-            }
-            hipLaunchKernelGGL(knn64_mfma_kernel<K>, dim3(ceil_div(n, KM_TILE), b), dim3(KNN_THREADS), 0, s, n, ld, k, x,
-                               nn_idx);
+            return launch_knn_scan<K, 4, 2>(b, n, ld, k, x, nn_idx, s);
         }
-    } else {
-        hipLaunchKernelGGL(knn_generic_kernel<K>, dim3(ceil_div(n, KNN_THREADS), b), dim3(KNN_THREADS), 0, s, n, c, ld, k, x,
-                           nn_idx);
     }
+    // anything else (other channel counts, k above 20, clouds beyond the LDS-resident forms): one lane per query, exact, slow
+    hipLaunchKernelGGL(knn_generic_kernel<K>, dim3(ceil_div(n, KNN_THREADS), b), dim3(KNN_THREADS), 0, s, n, c, ld, k, x,
+                       nn_idx);
     return hipSuccess;
 }
 
@@ -2411,6 +1715,26 @@ CLOUDAAE_API int cloudaae_knn(int b, int n, int c, int ld, int k, const float *x
     const hipError_t e = k <= 10 ? launch_knn<10>(b, n, c, ld, k, x, nn_idx, s)
                        : k <= 20 ? launch_knn<20>(b, n, c, ld, k, x, nn_idx, s)
                                  : launch_knn<32>(b, n, c, ld, k, x, nn_idx, s);
+    CLOUDAAE_CHECK_HIP(e, name);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
+}
+
+// cloudaae_knn over 64 channels with a HINT: hint[b, n, k] = k distinct indices per point that are likely to be near it (the
+// neighbour lists of the layer before).  Same result as cloudaae_knn, whatever the hint holds; tau_scratch: b * n floats.
+// Shapes the hinted kernel does not take (other channel counts, k above 20, clouds below 256 points or beyond the
+// LDS-resident form) go through cloudaae_knn unchanged.
+CLOUDAAE_API int cloudaae_knn_hinted(int b, int n, int c, int ld, int k, const float *x, const int *hint, float *tau_scratch,
+                                     int *nn_idx, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_knn_hinted";
+    const bool vec = ld % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    if (hint == nullptr || tau_scratch == nullptr || c != 64 || !vec || k > 20 || b <= 0 || n <= 0 || k < 1 || k > n ||
+        b > 65535 || !knn_wide_fits(n, k <= 10 ? 10 : 20))
+        return cloudaae_knn(b, n, c, ld, k, x, nn_idx, stream);
+    hipStream_t s = (hipStream_t)stream;
+    const hipError_t e = k <= 10 ? launch_knn_wide_hinted<10>(b, n, ld, k, x, hint, tau_scratch, nn_idx, s)
+                                 : launch_knn_wide_hinted<20>(b, n, ld, k, x, hint, tau_scratch, nn_idx, s);
     CLOUDAAE_CHECK_HIP(e, name);
     CLOUDAAE_CHECK_LAUNCH(name);
     return 0;

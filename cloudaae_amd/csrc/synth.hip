@@ -136,119 +136,19 @@ __global__ __launch_bounds__(256) void spherical_flip_kernel(int na, int nb, con
 // ---- spatial order of a flipped cloud -------------------------------------------------------
 // Seidel's LP is exact for ANY constraint order; its cost is not.  In a random order the violated
 // constraints turn up at random positions i and each costs a 1-D re-solve over i earlier constraints.
-// But the planes that decide whether p is a hull vertex are those of p's angular neighbours on the
-// shell.  So every cloud is sorted once by direction from its centroid (cube-map face, then a 16x16
-// grid in Morton order), a point's LP sees its neighbours in sorted order FIRST (j+1, j-1, j+2, ...)
-// and then everything in the bit-reversed order: after the short local pass the optimum is almost
-// always final (or the LP already infeasible), so the full pass is one scan without re-solves.
-constexpr int HS_CELLS = 6 * 256;
+// But the planes that decide whether p is a hull vertex are those of p's neighbours on the shell.  So every
+// cloud is sorted once, a point's LP sees its neighbours in sorted order FIRST (j+1, j-1, j+2, ...) and then
+// everything else: after the short local pass the optimum is almost always final (or the LP already
+// infeasible).  (Round 4 sorted by direction from the centroid -- cube-map face, then a 16 x 16 grid in Morton
+// order; retired in round 6, profiles/notes_hull_vertex.md.)
 constexpr int HS_THREADS = 1024;
 
-__device__ __forceinline__ unsigned hs_morton8(unsigned x, unsigned y)     // 4 + 4 bits interleaved
-{
-    x = (x | (x << 2)) & 0x33u;
-    x = (x | (x << 1)) & 0x55u;
-    y = (y | (y << 2)) & 0x33u;
-    y = (y | (y << 1)) & 0x55u;
-    return x | (y << 1);
-}
-
-// sorted[h][pos] = points[h][perm[h][pos]]; one workgroup per cloud, counting sort on the cell id
-__global__ __launch_bounds__(HS_THREADS) void hpr_sort_kernel(int n1, const float *__restrict__ points,
-                                                              float *__restrict__ sorted, int *__restrict__ perm,
-                                                              int *__restrict__ next_point)
-{
-    if (threadIdx.x == 0)
-        next_point[blockIdx.x] = 0;         // (the hull kernel's queue of this cloud)
-    __shared__ int cell_cnt[HS_CELLS];
-    __shared__ double cen[3][HS_THREADS / 64];
-    __shared__ int wsum[HS_THREADS / 64];
-    const float *P = points + (size_t)blockIdx.x * n1 * 3;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    double sx = 0.0, sy = 0.0, sz = 0.0;
-    for (int q = t; q < n1; q += HS_THREADS) {
-        sx += (double)P[3 * q];
-        sy += (double)P[3 * q + 1];
-        sz += (double)P[3 * q + 2];
-    }
-    sx = wave_sum(sx);
-    sy = wave_sum(sy);
-    sz = wave_sum(sz);
-    if (lane == 0) {
-        cen[0][wave] = sx;
-        cen[1][wave] = sy;
-        cen[2][wave] = sz;
-    }
-    for (int c = t; c < HS_CELLS; c += HS_THREADS)
-        cell_cnt[c] = 0;
-    __syncthreads();
-    double cx = 0.0, cy = 0.0, cz = 0.0;
-    for (int w = 0; w < HS_THREADS / 64; ++w) {
-        cx += cen[0][w];
-        cy += cen[1][w];
-        cz += cen[2][w];
-    }
-    const float fx = (float)(cx / n1), fy = (float)(cy / n1), fz = (float)(cz / n1);
-    auto cell_of = [&](int q) {
-        const float x = P[3 * q] - fx, y = P[3 * q + 1] - fy, z = P[3 * q + 2] - fz;
-        const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
-        int face;
-        float u, v, m;
-        if (ax >= ay && ax >= az) {
-            face = x >= 0.f ? 0 : 1; u = y; v = z; m = ax;
-        } else if (ay >= az) {
-            face = y >= 0.f ? 2 : 3; u = x; v = z; m = ay;
-        } else {
-            face = z >= 0.f ? 4 : 5; u = x; v = y; m = az;
-        }
-        const float inv = m > 0.f ? 1.0f / m : 0.f;
-        const int ui = min(15, max(0, (int)((u * inv * 0.5f + 0.5f) * 16.0f)));
-        const int vi = min(15, max(0, (int)((v * inv * 0.5f + 0.5f) * 16.0f)));
-        return face * 256 + (int)hs_morton8((unsigned)ui, (unsigned)vi);
-    };
-    for (int q = t; q < n1; q += HS_THREADS)
-        atomicAdd(&cell_cnt[cell_of(q)], 1);
-    __syncthreads();
-    // exclusive prefix over the 1536 cells (2 per thread for the first 768 threads)
-    int c0 = 0, c1 = 0;
-    if (2 * t < HS_CELLS) {
-        c0 = cell_cnt[2 * t];
-        c1 = cell_cnt[2 * t + 1];
-    }
-    int incl = c0 + c1;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d, 64);
-        if (lane >= d)
-            incl += o;
-    }
-    if (lane == 63)
-        wsum[wave] = incl;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w)
-        base += wsum[w];
-    if (2 * t < HS_CELLS) {
-        cell_cnt[2 * t] = base + incl - c0 - c1;
-        cell_cnt[2 * t + 1] = base + incl - c1;
-    }
-    __syncthreads();
-    float *S = sorted + (size_t)blockIdx.x * n1 * 3;
-    int *PM = perm + (size_t)blockIdx.x * n1;
-    for (int q = t; q < n1; q += HS_THREADS) {
-        const int pos = atomicAdd(&cell_cnt[cell_of(q)], 1);
-        PM[pos] = q;
-        S[3 * pos] = P[3 * q];
-        S[3 * pos + 1] = P[3 * q + 1];
-        S[3 * pos + 2] = P[3 * q + 2];
-    }
-}
-
-// The same counting sort on a 32 x 32 x 32 grid over the cloud's bounding box, cells in Morton order (round 5): consecutive
-// sorted points are neighbours in SPACE, whatever the shape of the cloud.  The cube map above sorts by direction from the
-// centroid; a flipped cloud is a thin, almost flat patch of a huge sphere (radius 10^2.5 x its distance) with its centroid
-// inside, so nearly all of its directions fall into the two rows of cells next to the patch's plane and a cell is a long
-// radial sliver -- fine as "some neighbours first", useless as a bounding volume (hpr_lp2d_wave_culled below).
+// sorted[h][pos] = points[h][perm[h][pos]]; one workgroup per cloud, a counting sort on a 32 x 32 x 32 grid over the cloud's
+// bounding box, cells in Morton order (round 5): consecutive sorted points are neighbours in SPACE, whatever the shape of
+// the cloud.  (A flipped cloud is a thin, almost flat patch of a huge sphere -- radius 10^2.5 x its distance -- with its
+// centroid inside: sorted by DIRECTION from the centroid, nearly all of it falls into the two rows of cells next to the
+// patch's plane and a cell is a long radial sliver -- fine as "some neighbours first", useless as a bounding volume
+// (hpr_lp2d_wave_culled below).)
 constexpr int HG_BITS = 5, HG_CELLS = 1 << (3 * HG_BITS);
 
 __device__ __forceinline__ unsigned hg_spread(unsigned v)          // 5 bits -> every third bit
@@ -948,7 +848,10 @@ __global__ __launch_bounds__(64 * HPR_WAVES) void hull_vertex_kernel(int n1, con
             if (lane == 0)
                 j = atomicAdd(&next_point[blockIdx.y], 1);
             j = __builtin_amdgcn_readfirstlane(j);      // (uniform for the compiler as well: with __shfl(j, 0) the kernel hung)
-        } else {                             // (knob CLOUDAAE_HPR_QUEUE = 0: a fixed share per wave)
+        } else {
+            // (a fixed share per wave: round 4's hand-out.  The host always passes the queue since round 6 -- but WITHOUT this
+            //  branch around the atomic the compiled kernel hangs (hipcc 7.2; as it did with __shfl(j, 0) in place of the
+            //  readfirstlane): the form that is known to work stays)
             j = blockIdx.x * HPR_WAVES + wave + turn * HPR_WAVES * gridDim.x;
         }
         if (j >= n1)
@@ -1156,7 +1059,18 @@ CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *
     const char *name = "cloudaae_hidden_point_removal";
     CLOUDAAE_REQUIRE(b >= 0 && n1 >= 5 && b <= 65535 && workspace, name, "bad size (need >= 4 points + viewpoint)");
     CLOUDAAE_REQUIRE(rows >= 1, name, "bad number of output rows");
-    CLOUDAAE_REQUIRE((size_t)n1 * 12 <= 150 * 1024, name, "cloud too large for the LDS-resident hull test");
+    // the cloud (12 bytes a point, dynamic LDS) next to the kernel's own static LDS (group slabs, working-set lists, the
+    // centroid sums: ~10 KB, read from the code object) must fit the CU's 160 KB
+    static size_t static_lds[2] = {0, 0};
+    if (static_lds[0] == 0) {
+        hipFuncAttributes a8, a16;
+        CLOUDAAE_CHECK_HIP(hipFuncGetAttributes(&a8, (const void *)hull_vertex_kernel<8>), name);
+        CLOUDAAE_CHECK_HIP(hipFuncGetAttributes(&a16, (const void *)hull_vertex_kernel<16>), name);
+        static_lds[1] = a16.sharedSizeBytes;
+        static_lds[0] = a8.sharedSizeBytes;
+    }
+    const size_t lds = (size_t)n1 * 3 * sizeof(float);
+    CLOUDAAE_REQUIRE(lds + static_lds[1] <= 160 * 1024, name, "cloud too large for the LDS-resident hull test");
     if (b == 0)
         return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -1165,8 +1079,8 @@ CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *
     float *sorted = (float *)(flags + (pts + 15) / 16 * 16);
     int *perm = (int *)(sorted + pts * 3);
     int *next_point = perm + pts;
-    // spatial order of every cloud: the 3-D grid in Morton order (knob CLOUDAAE_HPR_SORT = 0: the cube map of directions)
-    if (CLOUDAAE_KNOB("CLOUDAAE_HPR_SORT", 1) != 0) {
+    // spatial order of every cloud: the 3-D grid in Morton order
+    {
         static bool raised = false;
         if (!raised) {
             CLOUDAAE_CHECK_HIP(hipFuncSetAttribute((const void *)hpr_sort_grid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1175,38 +1089,19 @@ CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *
         }
         hipLaunchKernelGGL(hpr_sort_grid_kernel, dim3(b), dim3(HS_THREADS), HG_CELLS * sizeof(int), s, n1, flipped, sorted, perm,
                            next_point);
-    } else {
-        hipLaunchKernelGGL(hpr_sort_kernel, dim3(b), dim3(HS_THREADS), 0, s, n1, flipped, sorted, perm, next_point);
     }
-    const size_t lds = (size_t)n1 * 3 * sizeof(float);
-    // a cloud of more than ~6800 points leaves room for ONE workgroup per CU: it then takes 16 waves instead of 8
-    const bool wide = lds > 74 * 1024;          // (6 KB of group boxes and working-set lists next to the cloud)
+    // a cloud that leaves room for ONE workgroup per CU (more than ~5900 points) takes 16 waves instead of 8
+    const bool wide = 2 * (lds + static_lds[0]) > 160 * 1024;
     const int waves = wide ? 16 : 8;
     if (lds > 48 * 1024)
         CLOUDAAE_CHECK_HIP(hipFuncSetAttribute(wide ? (const void *)hull_vertex_kernel<16> : (const void *)hull_vertex_kernel<8>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), name);
     // workgroups per cloud: two 8-wave workgroups fit a CU (512 on the chip), one of the 16-wave form (256).  The points of a
     // cloud come from its queue, so a workgroup lives as long as its cloud has points: exactly the resident number is launched.
-    // (knob CLOUDAAE_HPR_WG_ROUNDS: 2 / 3 / 4 x as many -- late workgroups joining the clouds that still have points -- cost
-    // more in set-up than they balance: 4.18 / 4.52 / 6.56 / 7.64 ms per config-5 batch; a fixed share per wave 6.55 ms.)
-    int gx = 1;
-    const bool queue = CLOUDAAE_KNOB("CLOUDAAE_HPR_QUEUE", 1) != 0;
-    if (queue) {
-        const long long resident = wide ? 256 : 512;
-        const long long rounds = std::max(1, CLOUDAAE_KNOB("CLOUDAAE_HPR_WG_ROUNDS", 1));
-        gx = (int)std::min<long long>(std::max<long long>(1, (rounds * resident + b - 1) / b), ceil_div(n1, waves * 2));
-    } else {                                 // a fixed share per wave: the split whose (rounds x points per wave) is smallest
-        const long long resident = wide ? 256 : 512;
-        long long best = -1;
-        for (int cand = ceil_div(n1, waves * 32); cand <= ceil_div(n1, waves * 4); ++cand) {
-            const long long rounds = ((long long)cand * b + resident - 1) / resident;
-            const long long cost = rounds * ceil_div(n1, waves * cand);
-            if (best < 0 || cost < best) {
-                best = cost;
-                gx = cand;
-            }
-        }
-    }
+    // (2 / 3 / 4 x as many -- late workgroups joining the clouds that still have points -- cost more in set-up than they
+    // balance: 4.18 / 4.52 / 6.56 / 7.64 ms per config-5 batch; a fixed share of points per wave, round 4's: 6.55 ms.)
+    const long long resident = wide ? 256 : 512;
+    const int gx = (int)std::min<long long>(std::max<long long>(1, (resident + b - 1) / b), ceil_div(n1, waves * 2));
     // the scan behind the local problem as culled verification passes (knob CLOUDAAE_HPR_CULL = 0: the full strided scan; a value
     // of 2 .. 32 caps the points that may join a working set -- HPR_EXTRA = 32 by default -- so that the tests can send
     // points through the fallback, 1 = the default)
@@ -1214,10 +1109,10 @@ CLOUDAAE_API int cloudaae_hidden_point_removal_rows(int b, int n1, const float *
     const int culled = cull_knob <= 0 ? 0 : (cull_knob == 1 ? HPR_EXTRA + 1 : cull_knob - 1);    // 0 = off, else the cap + 1
     if (wide)
         hipLaunchKernelGGL(hull_vertex_kernel<16>, dim3(gx, b), dim3(64 * 16), lds, s, n1, sorted, perm, hpr_stride(n1), culled,
-                           queue ? next_point : nullptr, flags);
+                           next_point, flags);
     else
         hipLaunchKernelGGL(hull_vertex_kernel<8>, dim3(gx, b), dim3(64 * 8), lds, s, n1, sorted, perm, hpr_stride(n1), culled,
-                           queue ? next_point : nullptr, flags);
+                           next_point, flags);
     hipLaunchKernelGGL(hpr_gather_kernel, dim3(b), dim3(512), (size_t)n1 * sizeof(int), s, n1, flags, org, seed,
                        visible, num_vis, visible_id, row_src, rows);
     CLOUDAAE_CHECK_LAUNCH(name);

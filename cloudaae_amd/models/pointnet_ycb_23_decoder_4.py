@@ -35,9 +35,11 @@ def _dgcnn_encoder(point_cloud, is_training_pl_encoder, k, bn_decay, pool, prefi
                                    device=point_cloud.device))
     net = point_cloud                      # [B,N,C]; kNN metric = xyz slice (tf_util.py:608)
     nets, off = [], 0
+    nn_idx = None
     for i, width in enumerate(widths):
         adj_matrix = tf_util.pairwise_xyz_distance(net)
-        nn_idx = tf_util.knn(adj_matrix, k=k)
+        # (the lists of the layer before go along as a hint: they bound this layer's k-th distance, the result is the same)
+        nn_idx = tf_util.knn(adj_matrix, k=k, hint=nn_idx)
         if nn_out is not None:
             nn_out.append(nn_idx)
         net = tf_util.edge_conv(net, nn_idx, width, scope='%sdgcnn%d' % (prefix, i + 1), pool=pool,

@@ -362,11 +362,20 @@ def pairwise_xyz_distance(point_cloud):
     return PairwiseDistance(pts, channels)
 
 
-def knn(adj_matrix, k=9):
+# hint=...: which layers may take the neighbour lists of the layer before as a bound (cloudaae_knn_hinted).  The RESULT
+# does not depend on it; it pays where the bound pass of the plain kernel is long (k = 20 at 4096 points: BASELINE
+# configs[4]) and costs a launch where it is short.  None = by shape (KNN_HINT_MIN_WORK), True / False = always / never.
+KNN_HINT = None
+KNN_HINT_MIN_WORK = 4096 * 20
+
+
+def knn(adj_matrix, k=9, hint=None):
     """Get KNN based on the pairwise distance (tf_util.py:621-632).
     Args:
       pairwise distance: (batch_size, num_points, num_points)
       k: int
+      hint (not in the reference): (batch_size, num_points, k) int32, k distinct indices per point that are likely to be
+        near it -- the result of this function on the previous layer's features.  Same result with or without.
 
     Returns:
       nearest neighbors: (batch_size, num_points, k)   int32, ascending distance,
@@ -389,8 +398,15 @@ def knn(adj_matrix, k=9):
             rec = None
     if rec is not None:
         _lib.host(F._mark, rec)
-    _lib.check(_lib.lib().cloudaae_knn(b, n, adj_matrix.channels, ld, int(k), x.data_ptr(), ptr(nn_idx),
-                                       stream()), "cloudaae_knn")
+    use_hint = (hint is not None and adj_matrix.channels == 64 and tuple(hint.shape) == (b, n, int(k)) and
+                (KNN_HINT if KNN_HINT is not None else n * int(k) >= KNN_HINT_MIN_WORK))
+    if use_hint:
+        tau = _lib.empty((b, n), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().cloudaae_knn_hinted(b, n, adj_matrix.channels, ld, int(k), x.data_ptr(), ptr(hint), ptr(tau),
+                                                  ptr(nn_idx), stream()), "cloudaae_knn_hinted")
+    else:
+        _lib.check(_lib.lib().cloudaae_knn(b, n, adj_matrix.channels, ld, int(k), x.data_ptr(), ptr(nn_idx),
+                                           stream()), "cloudaae_knn")
     if rec is not None:
         _lib.host(F._mark, rec)
     return nn_idx

@@ -44,8 +44,8 @@ typedef void *cloudaae_stream_t; /* hipStream_t */
 /* The ABI revision this header describes: argument lists and struct layouts.  A caller built against another
  * revision must not call in -- check cloudaae_version() == CLOUDAAE_ABI_VERSION after loading (the Python host
  * does, cloudaae_amd/_lib.py).  500: round 5 (fully connected entry points take up to 128 rows; tickets / partials
- * queries take M; no y_zeroed argument). */
-#define CLOUDAAE_ABI_VERSION 500
+ * queries take M; no y_zeroed argument).  600: round 6 (cloudaae_knn_hinted added; nothing else changed). */
+#define CLOUDAAE_ABI_VERSION 600
 int cloudaae_version(void);
 const char *cloudaae_last_error(void);
 /* Development knobs (kernel A/B choices and launch shapes for tests and sweeps; none is needed in normal use):
@@ -183,6 +183,13 @@ int cloudaae_prob_sample(int b, int n, int m, const float *inp_p, const float *i
  * fp32 fma chain and |.|^2 a sequential un-fused sum (oracle_knn). */
 int cloudaae_knn(int b, int n, int c, int ld, int k, const float *x, int *nn_idx,
                  cloudaae_stream_t stream);
+/* The same with a HINT (revision 600): hint [b,n,k] int32 = k DISTINCT indices per point that are likely to be near it -- the
+ * neighbour lists of the layer before (models/pointnet_ycb_23_decoder_4.py:337-404 recomputes the lists layer by layer on
+ * features that change little).  Their largest distance bounds the k-th distance, so the scan needs no bound pass of its
+ * own.  The RESULT is cloudaae_knn's whatever the hint holds (a bad one costs time only).  tau_scratch: b * n floats.
+ * Shapes outside the hinted kernel (c != 64, k > 20, clouds below 256 points, hint == NULL) take cloudaae_knn's path. */
+int cloudaae_knn_hinted(int b, int n, int c, int ld, int k, const float *x, const int *hint, float *tau_scratch,
+                        int *nn_idx, cloudaae_stream_t stream);
 
 /* ---- utils/tf_util.py: dense layers ------------------------------------- */
 

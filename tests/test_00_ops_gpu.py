@@ -243,7 +243,7 @@ def test_knn_vs_oracle(hip, oracle, b, n, c, ld, k):
 
 
 @pytest.mark.parametrize("b,n,k,mode", [(2, 333, 10, 1), (40, 1024, 10, 1), (3, 1500, 20, 2), (33, 1024, 10, 2),
-                                          (2, 700, 20, 0), (140, 1024, 10, None), (2, 257, 20, 1), (5, 1000, 5, 2),
+                                          (2, 700, 20, None), (140, 1024, 10, None), (2, 257, 20, 1), (5, 1000, 5, 2),
                                           (32, 1024, 10, None), (2, 4096, 20, 2), (2, 4096, 20, None), (2, 260, 10, 2),
                                           (40, 1024, 10, 5), (3, 1500, 10, 5), (2, 260, 5, 5), (2, 2048, 10, 5), (9, 3000, 10, None),
                                           (1, 3300, 7, 5),
@@ -251,22 +251,20 @@ def test_knn_vs_oracle(hip, oracle, b, n, c, ld, k):
                                           (2, 4096, 20, 5), (3, 1500, 20, 5), (2, 300, 15, 5), (1, 4500, 20, 5), (1, 6000, 10, 5),
                                           (5, 4096, 20, None), (33, 1024, 20, None), (1, 3400, 10, 5),
                                           # sampled tiles reused, pass B over the rest: tile counts 17 / 25 / 29 / 9 / 32
-                                          (3, 530, 10, 5), (2, 800, 10, 5), (2, 900, 7, 5), (3, 270, 10, 5), (2, 1024, 1, 5)])
-@pytest.mark.parametrize("split", [2, 0])
-def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, knobs, b, n, k, mode, split):
-    """All C = 64 kernels (knob CLOUDAAE_KNN_SCAN = 0: knn64_mfma, 1 / 2: whole-cloud scan with one / two waves
-    per query tile, 5: bound pass + filtered scan in 16-wave workgroups; None: the launcher's own choice; where 5 applies,
-    knob CLOUDAAE_KNN_SPLIT = 2: the scan on the bf16 matrix pipe, the oracle's arithmetic for undecided neighbours (1, the
-    default: the same where 256-query workgroups fill the chip), = 0: the fp32 matrix pipe throughout) keep the same
-    bit-exact contract."""
+                                          (3, 530, 10, 5), (2, 800, 10, 5), (2, 900, 7, 5), (3, 270, 10, 5), (2, 1024, 1, 5),
+                                          # clouds below 256 points (the scan kernel since round 6 retired knn64_mfma_kernel),
+                                          # k up to the cloud's size, and k above 20 (the generic kernel)
+                                          (3, 5, 5, None), (2, 31, 10, None), (4, 64, 20, None), (2, 130, 10, 1), (2, 255, 20, None),
+                                          (2, 40, 32, None), (1, 1030, 25, None)])
+def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, knobs, b, n, k, mode):
+    """The C = 64 kernels (knob CLOUDAAE_KNN_SCAN = 1 / 2: whole-cloud scan with one / two waves per query tile, 5: bound
+    pass + filtered scan in 16-wave workgroups; None: the launcher's own choice) keep the same bit-exact contract."""
     from cloudaae_amd import _lib
-    if split == 0 and mode not in (5, None):
-        pytest.skip("the knob only matters where the 16-wave kernel applies")
     knobs("CLOUDAAE_KNN_SCAN", mode)
-    knobs("CLOUDAAE_KNN_SPLIT", split)
     rng = np.random.default_rng(n + k)
     x = np.maximum(rng.standard_normal((b, n, 64)), -0.5).astype(np.float32) * 0.1
-    x[:, n // 2:n // 2 + 30] = x[:, :30]
+    dup = min(30, n - n // 2)
+    x[:, n // 2:n // 2 + dup] = x[:, :dup]
     want = oracle.knn(x, k, channels=64, threads=8)
     xd = _dev(x)
     got = torch.empty((b, n, k), dtype=torch.int32, device="cuda")
@@ -274,16 +272,14 @@ def test_knn_c64_kernel_choices_vs_oracle(hip, oracle, knobs, b, n, k, mode, spl
     assert np.array_equal(want, got.cpu().numpy())
 
 
-@pytest.mark.parametrize("mode,k,two,split", [(1, 10, 1, 1), (5, 10, 1, 0), (5, 20, 1, 0), (5, 20, 0, 0), (5, 10, 1, 2), (5, 20, 1, 2)])
+@pytest.mark.parametrize("mode,k", [(1, 10), (2, 20), (5, 10), (5, 20)])
 @pytest.mark.parametrize("case", ["all_equal", "few_distinct", "lattice", "large_finite", "far_cluster", "near_ties"])
-def test_knn_c64_bound_kernel_adversarial(hip, oracle, knobs, mode, k, two, split, case):
+def test_knn_c64_bound_kernel_adversarial(hip, oracle, knobs, mode, k, case):
     """The bound kernel's correctness must not depend on its bound being tight: clouds where (nearly) every
     candidate ties with the k-th distance (the queue overflows and is drained over and over), where the sampled
     tiles are unrepresentative, and where distances are huge."""
     from cloudaae_amd import _lib
     knobs("CLOUDAAE_KNN_SCAN", mode)
-    knobs("CLOUDAAE_KNN_TWO", two)          # the bound in two stages (default) / one
-    knobs("CLOUDAAE_KNN_SPLIT", split)      # the scan on the bf16 matrix pipe / the fp32 pipe throughout
     rng = np.random.default_rng(7)
     b, n = 3, 1024
     if case == "near_ties":
@@ -314,11 +310,56 @@ def test_knn_c64_bound_kernel_adversarial(hip, oracle, knobs, mode, k, two, spli
     assert np.array_equal(want, got.cpu().numpy())
 
 
+@pytest.mark.parametrize("b,n,k", [(3, 256, 10), (2, 1024, 10), (2, 1500, 20), (2, 4096, 20), (1, 4500, 20), (5, 700, 7), (2, 3400, 10)])
+@pytest.mark.parametrize("hint_kind", ["previous_layer", "exact", "random", "one_point", "far"])
+def test_knn_hinted_vs_oracle(hip, oracle, b, n, k, hint_kind):
+    """cloudaae_knn_hinted (round 6): the largest distance to k hinted points bounds the k-th distance, the filtered scan takes
+    it instead of a bound pass of its own -- and returns cloudaae_knn's answer WHATEVER the hint holds: the lists of slightly
+    different features (what the encoder passes: the layer before), the exact answer (the bound IS the k-th distance: the
+    filter's `<=`), random points (a loose bound: the queues overflow, the flagged rescan answers), k copies of one index
+    (not distinct: the bound may be too tight -- the caller's contract is k DISTINCT indices, so this case only has to
+    stay in bounds and return k valid indices) and the k farthest points."""
+    from cloudaae_amd import _lib
+    rng = np.random.default_rng(n + k)
+    x = np.maximum(rng.standard_normal((b, n, 64)), -0.5).astype(np.float32) * 0.1
+    x[:, n // 2:n // 2 + 30] = x[:, :30]
+    want = oracle.knn(x, k, channels=64, threads=8)
+    if hint_kind == "previous_layer":
+        hint = oracle.knn((x + rng.standard_normal(x.shape).astype(np.float32) * 0.01).astype(np.float32), k, channels=64, threads=8)
+    elif hint_kind == "exact":
+        hint = want.copy()
+    elif hint_kind == "random":
+        hint = np.stack([np.stack([rng.permutation(n)[:k] for _ in range(n)]) for _ in range(b)])
+    elif hint_kind == "one_point":
+        hint = np.repeat(rng.integers(0, n, (b, n, 1)), k, axis=2)
+    else:
+        far = oracle.knn(-x, k, channels=64, threads=8)       # (some other k distinct points)
+        hint = far
+    hint = np.ascontiguousarray(hint.astype(np.int32))
+    xd, hd = _dev(x), _dev(hint)
+    tau = torch.empty((b, n), device="cuda")
+    got = torch.full((b, n, k), -1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().cloudaae_knn_hinted(b, n, 64, 64, k, _lib.ptr(xd), _lib.ptr(hd), _lib.ptr(tau), _lib.ptr(got),
+                                              _lib.stream()), "knn_hinted")
+    g = got.cpu().numpy()
+    if hint_kind == "one_point":
+        assert g.min() >= 0 and g.max() < n
+    else:
+        assert np.array_equal(want, g)
+        # the bound really is one: at least k candidates at or below it
+        d = oracle.knn(x, k, channels=64, threads=8, return_dist=True)[1]
+        assert (tau.cpu().numpy() >= d[:, :, k - 1]).all()
+
+
 @pytest.mark.parametrize("wide", [1, 0])
 @pytest.mark.parametrize("b,n,ld,k,case", [(2, 300, 24, 10, "dup"), (3, 1024, 24, 10, "dup"), (2, 1000, 3, 20, "dup"),
                                             (2, 4096, 24, 20, "dup"), (1, 2500, 3, 7, "dup"), (5, 257, 24, 1, "dup"),
                                             (2, 1024, 24, 10, "all_equal"), (2, 1024, 24, 20, "lattice"),
-                                            (2, 1024, 24, 10, "far_cluster"), (2, 1024, 3, 10, "large_finite")])
+                                            (2, 1024, 24, 10, "far_cluster"), (2, 1024, 3, 10, "large_finite"),
+                                            # clouds below 256 points (always the scan kernel), k above 20 and clouds beyond
+                                            # the LDS-resident forms (the generic kernel since round 6 retired knn3_kernel)
+                                            (3, 5, 24, 5, "dup"), (2, 64, 3, 20, "lattice"), (4, 200, 24, 10, "dup"),
+                                            (2, 300, 24, 27, "dup"), (1, 6500, 3, 10, "dup")])
 def test_knn_c3_kernel_choices_vs_oracle(hip, oracle, knobs, wide, b, n, ld, k, case):
     """C = 3 (layer 1): knn3_wide_kernel (three MFMAs per 32 x 32 tile, bound pass + queues; CLOUDAAE_KNN3_WIDE=1) and
     knn3_scan_kernel (=0) keep the same bit-exact contract, also where (nearly) every candidate ties with the k-th
@@ -328,7 +369,8 @@ def test_knn_c3_kernel_choices_vs_oracle(hip, oracle, knobs, wide, b, n, ld, k, 
     rng = np.random.default_rng(n + k + ld)
     if case == "dup":
         x = np.maximum(rng.standard_normal((b, n, ld)), -0.5) * 0.1
-        x[:, n // 2:n // 2 + 30] = x[:, :30]      # duplicates -> exact ties
+        dup = min(30, n - n // 2)
+        x[:, n // 2:n // 2 + dup] = x[:, :dup]    # duplicates -> exact ties
     elif case == "all_equal":
         x = np.tile(rng.standard_normal((b, 1, ld)), (1, n, 1))
     elif case == "lattice":

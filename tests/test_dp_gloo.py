@@ -1,4 +1,4 @@
-"""CPU: the N>1 path's host logic with world_size 2 over gloo -- flat-buffer gradient
+"""CPU: the N>1 path's host logic with world_size 2 and 8 over gloo -- flat-buffer gradient
 exchange (early bucket + remainder), averaging scale, parameter broadcast, batch sharding,
 and the VariableStore's flat layout.  No HIP compute is involved (there is no GPU here)."""
 import os
@@ -76,11 +76,14 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_grad_exchange_world2():
+@pytest.mark.parametrize("world", [2, 8])
+def test_grad_exchange(world):
+    """world 8 = the deployment's rank count (BASELINE configs[3]: 8 x 128 clouds): shard ranges, the early bucket, the
+    remainder and the averaging scale at eight ranks -- the cheapest rehearsal of the run only the driver can make."""
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    assert dict(out) == {0: True, 1: True}
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {r: True for r in range(world)}
 
 
 def _replica_worker(rank, world, port, out):
@@ -109,14 +112,15 @@ def _replica_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_bench_replica_check_world2():
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_replica_check(world):
     """bench.py's N > 1 self-check: identical replicas pass, a one-ulp difference on one rank fails, the per-rank loss
-    spread is reported (world 2 over gloo)."""
+    spread is reported (world 2 and 8 over gloo)."""
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_replica_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    want = (True, 0.25, False, True, 2, 0x3f800000 + 0xbf800000 - (1 << 32))
-    assert dict(out) == {0: want, 1: want}
+    mp.spawn(_replica_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    want = (True, 0.25 * (world - 1), False, True, world, 0x3f800000 + 0xbf800000 - (1 << 32))
+    assert dict(out) == {r: want for r in range(world)}
 
 
 def test_shard_range_errors():
