@@ -26,27 +26,6 @@ def shard_range(global_batch, world, rank):
     return rank * per, (rank + 1) * per
 
 
-def warn_if_ranks_share_a_device(device, group=None):
-    """One rank per GPU is the deployment.  Two ranks on ONE GPU work, but steps running side by side
-    in two processes have shown a rare nondeterminism in a step's first kNN (about 1 step in 100; never with one process
-    per GPU: profiles/notes_two_processes_one_gpu.md) -- say so once instead of letting a run drift silently."""
-    import socket
-    import warnings
-    try:
-        props = torch.cuda.get_device_properties(device)
-        ident = (socket.gethostname(), str(getattr(props, "uuid", "")) or str(torch.device(device).index))
-        every = [None] * dist.get_world_size(group)
-        dist.all_gather_object(every, ident, group=group)
-    except Exception:       # (a backend that cannot gather objects: nothing to say)
-        return False
-    shared = len(set(every)) < len(every)
-    if shared and dist.get_rank(group) == 0:
-        warnings.warn("cloudaae_amd: %d ranks share %d device(s) -- supported, but steps of two processes on one GPU have shown "
-                      "a rare (1e-2 per step) nondeterministic first kNN; run one rank per GPU "
-                      "(profiles/notes_two_processes_one_gpu.md)" % (len(every), len(set(every))), RuntimeWarning)
-    return shared
-
-
 class GradExchange(object):
     def __init__(self, flat_grads, early=None, group=None, world=None, early_count=1):
         self.g = flat_grads
@@ -67,8 +46,6 @@ class GradExchange(object):
         self._early_seen = 0
         self._pending = []
         self._early_sent = False
-        if world > 1 and dist.is_initialized() and flat_grads.is_cuda:
-            warn_if_ranks_share_a_device(flat_grads.device, group)
 
     @property
     def scale(self):

@@ -33,7 +33,7 @@ _OWN_GROUPS = {}
 
 def close_communicators():
     """Destroy the communicators BnSync created (end of a process that builds many graphs, tests)."""
-    for g in _OWN_GROUPS.values():
+    for _, g in _OWN_GROUPS.values():
         try:
             dist.destroy_process_group(g)
         except Exception:      # noqa: BLE001 -- already gone with the default group
@@ -53,12 +53,14 @@ class BnSync(object):
             # first BnSync over these ranks (ranks outside `group` included), in the same order relative to other
             # new_group calls.  Later BnSyncs over the same ranks reuse the communicator: no further collective, no leak.
             ranks = tuple(dist.get_process_group_ranks(group) if group is not None else range(dist.get_world_size()))
-            # (keyed by the default group as well: after destroy_process_group + init_process_group in one process --
-            # tests, notebooks, an elastic restart -- a handle made under the old default group is dead)
-            key = (id(dist.group.WORLD), ranks)
-            if key not in _OWN_GROUPS:
-                _OWN_GROUPS[key] = dist.new_group(ranks=list(ranks))
-            group = _OWN_GROUPS[key]
+            # (a handle made under an earlier default group -- destroy_process_group + init_process_group in one process:
+            # tests, notebooks, an elastic restart -- is dead: an entry is good only for the default group OBJECT it was made
+            # under, which the entry keeps alive so that its identity cannot be handed to a new one)
+            made = _OWN_GROUPS.get(ranks)
+            if made is None or made[0] is not dist.group.WORLD:
+                made = (dist.group.WORLD, dist.new_group(ranks=list(ranks)))
+                _OWN_GROUPS[ranks] = made
+            group = made[1]
         self.group = group
         self.calls = 0               # all-reduces issued (tests and bench read it)
         self.error = None            # exception raised inside the callback (ctypes cannot propagate it)

@@ -13,6 +13,8 @@ torch host forces:
 `edge_conv` is the fused form of get_edge_feature -> conv2d(bn) -> reduce_mean/max that
 the model builders use; the unfused functions remain available.
 """
+import os
+
 import torch
 
 from .. import _lib
@@ -365,7 +367,7 @@ def pairwise_xyz_distance(point_cloud):
 # hint=...: which layers may take the neighbour lists of the layer before as a bound (cloudaae_knn_hinted).  The RESULT
 # does not depend on it; it pays where the bound pass of the plain kernel is long (k = 20 at 4096 points: BASELINE
 # configs[4]) and costs a launch where it is short.  None = by shape (KNN_HINT_MIN_WORK), True / False = always / never.
-KNN_HINT = None
+KNN_HINT = {"0": False, "1": True}.get(os.environ.get("CLOUDAAE_KNN_HINT", ""), None)
 KNN_HINT_MIN_WORK = 4096 * 20
 
 

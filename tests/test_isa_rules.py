@@ -32,3 +32,14 @@ def test_no_packed_fp32_instruction_takes_its_low_half_from_a_high_register(inst
     assert any("knn3_wide_kernel" in k for k in kernels) and any("adam_tf_kernel" in k for k in kernels)
     bad = isa_scan.packed_f32_low_from_high(instructions)
     assert not bad, "packed-fp32 instructions with op_sel on a low half:\n" + "\n".join("%s | %s" % b for b in bad[:20])
+
+
+def test_chamfer_digest_reads_no_xdl_result_too_early(instructions):
+    """csrc/nn_distance.hip's digest (`v_min3_f32` in inline assembly) reads accumulators of
+    v_mfma_f32_32x32x16_bf16, an XDL operation whose result needs 11 wait states before a vector instruction may read it; the
+    compiler's hazard recogniser does not see inline assembly (a stale read already happened once: a few wrong neighbours per
+    thousand).  The source pins the order with scheduling barriers; this checks the built code."""
+    reads = [i for fn, i in instructions if "nn_distance_filter_kernel" in fn and i.startswith("v_min3_f32")]
+    assert len(reads) >= 16, "the digest's v_min3_f32 were not found in the disassembly"
+    early = isa_scan.xdl_results_read_too_early(instructions, "nn_distance_filter_kernel")
+    assert not early, early[:5]

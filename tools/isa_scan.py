@@ -72,6 +72,47 @@ def packed_f32_low_from_high(instructions):
     return bad
 
 
+_MFMA = re.compile(r"^(v_mfma_\S+)\s+([av])\[(\d+):(\d+)\]")
+_REG = re.compile(r"\b([av])(?:\[(\d+):(\d+)\]|(\d+))\b")
+_NOP = re.compile(r"^s_nop\s+(\d+)")
+
+
+def xdl_results_read_too_early(instructions, kernel_substring, reader=r"^v_min3_f32\b", need=11):
+    """Rule 2 (csrc/nn_distance.hip, the digest of the Chamfer scores): the `v_min3_f32` there are inline assembly, which the
+    compiler's hazard recogniser does not see -- it neither counts the wait states an XDL result needs before a vector
+    instruction may read it (v_mfma_f32_32x32x16_bf16: 11) nor keeps its scheduler from placing the read right behind the
+    write.  The source pins the order in groups; this checks the BUILT code: between a v_mfma that writes a register and the
+    first `reader` instruction that reads it (in text order, inside the named kernels) lie at least `need` wait states --
+    an instruction counts 1, `s_nop N` N + 1, another v_mfma its 8 passes.  -> [(kernel, mfma, reader, wait states)]"""
+    rd = re.compile(reader)
+    bad = []
+    by_fn = {}
+    for fn, ins in instructions:
+        if kernel_substring in fn:
+            by_fn.setdefault(fn, []).append(ins)
+    for fn, body in by_fn.items():
+        wrote = {}                      # register -> (clock at the write's issue, text of the mfma)
+        clock = 0
+        for ins in body:
+            m = _MFMA.match(ins)
+            if rd.match(ins):
+                srcs = ins.split(",", 1)[1] if "," in ins else ""
+                for kind, lo, hi, one in _REG.findall(srcs):
+                    regs = range(int(lo), int(hi) + 1) if one == "" else (int(one),)
+                    for r in regs:
+                        w = wrote.get((kind, r))
+                        if w is not None and clock - w[0] - w[2] < need:
+                            bad.append((fn, w[1], ins, clock - w[0] - w[2]))
+            if m:
+                for r in range(int(m.group(3)), int(m.group(4)) + 1):
+                    wrote[(m.group(2), r)] = (clock, ins, 8)
+                clock += 8
+            else:
+                n = _NOP.match(ins)
+                clock += int(n.group(1)) + 1 if n else 1
+    return bad
+
+
 def main():
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "cloudaae_amd", "libcloudaae_hip.so")
@@ -83,7 +124,12 @@ def main():
           % (lib, len(ins), kernels, pk, len(bad)))
     for fn, i in bad[:40]:
         print("   ", fn, "|", i)
-    return 1 if bad else 0
+    early = xdl_results_read_too_early(ins, "nn_distance_filter_kernel")
+    reads = sum(1 for fn, i in ins if "nn_distance_filter_kernel" in fn and i.startswith("v_min3_f32"))
+    print("nn_distance_filter_kernel: %d v_min3_f32, %d of them read an XDL result less than 11 wait states after its v_mfma" % (reads, len(early)))
+    for e in early[:10]:
+        print("   ", e)
+    return 1 if (bad or early) else 0
 
 
 if __name__ == "__main__":
