@@ -183,7 +183,7 @@ def conv2d_full_width(x, cout, scope, V, is_training, bn_decay):
 # must agree with it, which is asserted -- the analogue of nn_override for the neighbour sets.
 RELU_OVERRIDE = None
 RELU_TIE = 1e-4
-RELU_REPORT = None      # a list: (scope, ambiguous units, units that took the other side)
+RELU_REPORT = None      # a list: (scope, ambiguous units, units that took the other side, the largest |value| among those)
 
 
 def fully_connected(x, cout, scope, V, bn=False, is_training=None, bn_decay=None, relu=True):
@@ -205,7 +205,9 @@ def fully_connected(x, cout, scope, V, bn=False, is_training=None, bn_decay=None
             raise AssertionError("%s: activation patterns differ away from the ReLU corner" % scope)
         out = torch.where(tie & other, y, torch.where(tie, torch.zeros_like(y), out))
         if RELU_REPORT is not None:
-            RELU_REPORT.append((scope, int(tie.sum()), int((tie & (mine != other)).sum())))
+            flipped = tie & (mine != other)
+            RELU_REPORT.append((scope, int(tie.sum()), int(flipped.sum()),
+                                float(y.detach().abs()[flipped].max()) if bool(flipped.any()) else 0.0))
     return out
 
 

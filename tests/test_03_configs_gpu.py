@@ -27,6 +27,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# largest |normalised value| of a fully connected unit whose ReLU the bf16 step and the fp32-activation oracle may decide
+# differently (their inputs agree to ~1e-3): measured in round 6 at B = 256: ten units, the largest at 1.5e-4 (round 5 allowed 3e-2)
+RELU_FLIP_MAX_BF16 = 1e-3
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEP0 = 2            # the step counter (`batch`, train...:192) the compared iteration starts from
 
@@ -190,13 +194,18 @@ def test_config_replayed_step_vs_oracle(hip, name, B, N, dtype, kn):
     MO.RELU_REPORT = []
     tie0 = MO.RELU_TIE
     if bf16:
-        MO.RELU_TIE = 3e-2          # (bf16 operands below the stack: its inputs agree to ~1e-3, not to round-off)
+        MO.RELU_TIE = RELU_FLIP_MAX_BF16   # (bf16 operands below the stack: its inputs agree to ~1e-3, not to round-off)
     try:
         ref, grads = MO.train_step(batch, V, opt, STEP0, N, B, k=kn, nn_override=rep["idx"])
-        took = [(s_, a_, c_) for s_, a_, c_ in MO.RELU_REPORT if c_]
+        took = [(s_, a_, c_, "%.1e" % v_) for s_, a_, c_, v_ in MO.RELU_REPORT if c_]
         print("%s: fully connected units within %.0e of the ReLU corner: %d, of which the oracle took the GPU's side: %s"
-              % (name, MO.RELU_TIE, sum(a_ for _, a_, _ in MO.RELU_REPORT), took or "none"))
+              % (name, MO.RELU_TIE, sum(r_[1] for r_ in MO.RELU_REPORT), took or "none"))
         assert len(MO.RELU_REPORT) >= 6, MO.RELU_REPORT          # the six batch-normalised layers were compared
+        # the override is for a HANDFUL of units on the corner, not a licence: measured (round 6) 0 or 1 unit in fp32 at every
+        # size, 10 of 917 504 in bf16 mode (B = 256); more than that, or a flipped unit far from the corner, is a regression
+        n_took = sum(r_[2] for r_ in MO.RELU_REPORT)
+        assert n_took <= (30 if bf16 else 4), MO.RELU_REPORT
+        assert max(r_[3] for r_ in MO.RELU_REPORT) <= (RELU_FLIP_MAX_BF16 if bf16 else 1e-4), MO.RELU_REPORT
     finally:
         MO.GEMM_BF16 = MO.ACT_BF16 = False
         MO.RELU_OVERRIDE = MO.RELU_REPORT = None
