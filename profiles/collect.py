@@ -51,7 +51,7 @@ SITES = [
     ("agg_fwd_bf16", r"^gemm_bf16_kernel<128, ?128", "largest", ["cloudaae_amd/csrc/gemm_bf16.hip", "cloudaae_amd/csrc/gemm.h"]),
     ("agg_fwd_b16", r"^gemm_b16_kernel<128, ?128, ?2, ?2, ?false, ?false, ?true", "largest", ["cloudaae_amd/csrc/gemm_b16.hip"]),
     ("agg_dw", r"^gemm_f32_kernel<64, ?128, ?2, ?2, ?true, ?false", "largest", ["cloudaae_amd/csrc/gemm.hip", "cloudaae_amd/csrc/gemm.h"]),
-    ("knn64", r"^knn64_(wide|scan|bound|mfma)_kernel", "largest", ["cloudaae_amd/csrc/knn.hip"]),
+    ("knn64", r"^knn64_(wide|scan)_kernel", "largest", ["cloudaae_amd/csrc/knn.hip", "cloudaae_amd/csrc/Makefile"]),
 ]
 
 
