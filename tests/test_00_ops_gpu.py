@@ -163,10 +163,16 @@ def test_nn_distance_full_size_properties(hip):
     # (3) a cloud against itself: zero distance; index = first duplicate = itself for distinct points
     z1, k1, _, _ = tf_nndistance.nn_distance(a, a)
     assert (z1 == 0).all() and torch.equal(k1, torch.arange(4096, device="cuda", dtype=torch.int32).expand(32, -1))
-    # (4) brute force on a sample of rows (tf_nndistance.py:77-85)
+    # (4) brute force on a sample of rows (tf_nndistance.py:77-85), in the reference's arithmetic -- the un-fused expression of
+    # tf_nndistance.cpp:30-33, one rounding per operation (elementwise torch kernels do not contract) -- and its tie rule
+    # (strict <: the FIRST minimum): distance and index must be EQUAL, no tolerance
     rows = torch.randint(0, 4096, (64,), device="cuda")
-    D = ((a[:, rows, None, :] - c[:, None, :, :]) ** 2).sum(-1)
-    assert torch.equal(D.argmin(-1).int(), i1[:, rows]) or (D.min(-1).values - d1[:, rows]).abs().max() < 1e-5
+    df = a[:, rows, None, :] - c[:, None, :, :]
+    D = (df[..., 0] * df[..., 0] + df[..., 1] * df[..., 1]) + df[..., 2] * df[..., 2]
+    dmin = D.min(-1, keepdim=True).values
+    first = torch.where(D == dmin, torch.arange(4096, device="cuda").expand_as(D), torch.full_like(D, 4096, dtype=torch.int64)).min(-1).values
+    assert torch.equal(dmin[..., 0], d1[:, rows])
+    assert torch.equal(first.int(), i1[:, rows])
 
 
 @pytest.mark.parametrize("name", ["fps_rand_2x1024_to_256", "fps_dup_2x700_to_128",
