@@ -950,8 +950,11 @@ static FcFwdPlan fc_fwd_plan(int M, int K, int N, bool bn, bool no_scratch)
 {
     FcFwdPlan p;
     p.rts = ceil_div(M, FC_ROWS);
-    p.cq = bn ? 2 : 4;
-    const int want = bn ? 64 : 256;
+    // a layer without batch norm (the 12288-column output layer): at ONE row tile 64-column tiles with K whole -- 192 workgroups,
+    // no publish / ticket / read-back episode: 25.7 -> 20.7 us in the B = 32 step (round 6; 128-column tiles cut over K twice
+    // were 208 workgroups and an episode of 5-7 us) --, at several row tiles 128-column tiles as before
+    p.cq = bn ? 2 : (p.rts == 1 ? 2 : 4);
+    const int want = bn ? 64 : (p.rts == 1 ? 192 : 256);
     p.tiles = ceil_div(N, 32 * p.cq);
     int splits = want / (p.tiles * p.rts);
     const int most = K / (16 * FC_NW);
