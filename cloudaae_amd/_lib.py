@@ -29,6 +29,7 @@ _SIGNATURES = {
     "cloudaae_prob_sample": [_I, _I, _I, _P, _P, _P, _P, _P],
     "cloudaae_knn": [_I, _I, _I, _I, _I, _P, _P, _P],
     "cloudaae_knn_hinted": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "cloudaae_selftest_div_by": [_F, _I, _P, _P],
     "cloudaae_gemm_f32": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "cloudaae_gemm_bf16": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P],
     "cloudaae_gemm_f32_ordered": [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _L, _P],
@@ -142,7 +143,7 @@ _LONGLONG_RESULTS = ["cloudaae_x3_planes_bytes", "cloudaae_loss_tail_workspace_b
                      "cloudaae_gemm_bf16_ordered_workspace"]
 
 
-ABI_VERSION = 600     # CLOUDAAE_ABI_VERSION of include/cloudaae_hip.h (tests/test_capi_symbols.py compares the two)
+ABI_VERSION = 601     # CLOUDAAE_ABI_VERSION of include/cloudaae_hip.h (tests/test_capi_symbols.py compares the two)
 
 
 class HipLibraryError(RuntimeError):

@@ -58,6 +58,32 @@ __device__ __forceinline__ unsigned short ec_bf16_bits(float v)
     return w;
 }
 
+// x / d for a divisor that is the same for a whole launch (the neighbour count k), rd = 1.0f / d computed once: the
+// IEEE sequence the compiler emits for `x / d` (scale both operands, quarter-rate reciprocal, two fma to refine it, product,
+// two remainder / correction pairs, the last one as div_fmas, fix-up: eleven instructions) with the part that only
+// depends on d taken out: rd is the correctly rounded reciprocal (better than the refined estimate), and d itself needs
+// no scaling (1 <= d <= 2^20), so what is left per quotient is: scale the numerator, did that change it, product, FIX
+// remainder / correction pairs (the last as div_fmas), fix-up: 6 or 8 instructions.  The gradient pass below divides once
+// per gathered element and is bound by its vector instructions.
+// Same quotient as `x / d`, bit for bit, for EVERY float x -- subnormal quotients, zeros, infinities, NaN included:
+// cloudaae_selftest_div_by walks all 2^32 numerators (tests/test_01_layers_gpu.py).  FIX = 2: no difference for any
+// divisor tried (1 .. 64 and a dozen others).  FIX = 1: none for most, k = 10 and k = 20 among them (what the model
+// families use; the launcher takes FIX = 1 for exactly these), but e.g. d = 26 rounds 209 724 subnormal quotients the other
+// way (a quotient that is exactly half way between two subnormals needs the first correction to land on it exactly).
+// (The flag for div_fmas is "the scaling changed the numerator", not div_scale's own: that one is also set where the
+//  hardware sequence expects a scaled DENOMINATOR, |x| >= 2^96 d.)
+template <int FIX>
+__device__ __forceinline__ float ec_div_by(float x, float d, float rd)
+{
+    bool unused;
+    const float xs = __builtin_amdgcn_div_scalef(x, d, true, &unused);
+    float q = xs * rd;
+    if (FIX == 2)
+        q = __builtin_fmaf(__builtin_fmaf(-d, q, xs), rd, q);
+    return __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(__builtin_fmaf(-d, q, xs), rd, q, xs != x), d, x);
+}
+static int ec_div_corrections(int k) { return (k == 10 || k == 20) ? 1 : 2; }
+
 // all k pre-activation rows of one point, for this lane's CPL channels
 // US: the P' half of pq already holds U = P' - Q + bias (true in the backward kernels: every forward
 // call leaves it so)
@@ -738,7 +764,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
 // loads per array keeps 16 (8) rows = 8 KB of U and dOut in flight per wave.  ec_bwd_apply_kernel moves 256 bytes
 // per load instruction (one row, four bytes per lane) and is bound by the latency of its dependent gathers.  The
 // partial sums of the row groups meet in two (one) cross-lane steps; S is evaluated exactly as above.
-template <int COUT>
+template <int COUT, int FIX>
 __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_mean4_kernel(
     EcArgs a, const float *__restrict__ m12, const int *__restrict__ rev_off, const int *__restrict__ rev_src,
     float *__restrict__ dpq, const float *__restrict__ edge_stats)
@@ -759,7 +785,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_mean4_kernel(
         m1[e] = m12[c];
         m2[e] = m12[COUT + c];
     }
-    const float fk = (float)a.k;
+    const float fk = (float)a.k, rk = 1.0f / fk;
     ec_for_each_point<EC_WAVES>(a, wave, [&](int pt) {
         const int cloud = pt / a.N, m = pt - cloud * a.N;
         const int *off = rev_off + (size_t)cloud * (a.N + 1);
@@ -774,7 +800,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_mean4_kernel(
         float S[4], T[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float gk = go[e] / fk;
+            const float gk = ec_div_by<FIX>(go[e], fk, rk);
             S[e] = gr[e] * ((gk * es0[e] - fk * m1[e]) - es2[e] * m2[e]);
             T[e] = 0.0f;
         }
@@ -800,7 +826,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_mean4_kernel(
                         for (int e = 0; e < 4; ++e) {
                             const float y = ui[u][e] + qm[e];   // U of the source point + Q of this one
                             const float z = fmaxf(y * sc[e] + sh[e], 0.0f);
-                            float d = gi[u][e] / fk;
+                            float d = ec_div_by<FIX>(gi[u][e], fk, rk);      // == gi / k, bit for bit
                             if (!(z > 0.0f))
                                 d = 0.0f;
                             const float xh = (y - mean[e]) * rstd[e];
@@ -891,6 +917,43 @@ CLOUDAAE_API int cloudaae_edgeconv_revlists(int count, int b, int n, int k, cons
     const char *name = "cloudaae_edgeconv_revlists";
     CLOUDAAE_REQUIRE(b > 0 && n > 0 && k > 0 && nn_idx && rev_scratch, name, "bad argument");
     return ec_launch_revlists(name, count, b, n, k, nn_idx, rev_scratch, (hipStream_t)stream);
+}
+
+// every float as the numerator of ec_div_by: count[0] = arguments whose quotient differs in its bits from x / d
+// (two NaNs count as equal), count[1] = the largest magnitude among them (its bits)
+template <int FIX>
+__global__ __launch_bounds__(256) void ec_selftest_div_kernel(float d, unsigned long long *__restrict__ count)
+{
+    const float rd = 1.0f / d;
+    unsigned long long bad = 0, largest = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < (1ull << 32); i += 256ull * gridDim.x) {
+        const float x = __uint_as_float((unsigned)i);
+        const float want = x / d, got = ec_div_by<FIX>(x, d, rd);
+        if (__float_as_uint(want) != __float_as_uint(got) && !(want != want && got != got)) {
+            largest = max(largest, i & 0x7fffffffull);
+            ++bad;
+        }
+    }
+    if (bad) {
+        atomicAdd(&count[0], bad);
+        atomicMax(&count[1], largest);
+    }
+}
+
+CLOUDAAE_API int cloudaae_selftest_div_by(float d, int corrections, unsigned long long *count, cloudaae_stream_t stream)
+{
+    const char *name = "cloudaae_selftest_div_by";
+    CLOUDAAE_REQUIRE(count != nullptr && d >= 1.0f && d <= 1048576.0f && corrections >= 0 && corrections <= 2, name, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (corrections == 0)       // what the launcher takes for a layer with d neighbours
+        corrections = d == (float)(int)d ? ec_div_corrections((int)d) : 2;
+    CLOUDAAE_CHECK_HIP(hipMemsetAsync(count, 0, 2 * sizeof(unsigned long long), s), name);
+    if (corrections == 1)
+        hipLaunchKernelGGL(ec_selftest_div_kernel<1>, dim3(4096), dim3(256), 0, s, d, count);
+    else
+        hipLaunchKernelGGL(ec_selftest_div_kernel<2>, dim3(4096), dim3(256), 0, s, d, count);
+    CLOUDAAE_CHECK_LAUNCH(name);
+    return 0;
 }
 
 CLOUDAAE_API long long cloudaae_edgeconv_workspace_bytes(int cout)
@@ -1089,12 +1152,14 @@ static int ec_backward_impl(const char *name, int b, int n, int k, int cin, int 
     }
     const bool quads = pool_mode == 1 && training && edge_stats != nullptr && (cout == 64 || cout == 128) && lddo % 4 == 0 &&
                        (((uintptr_t)a.pq | (uintptr_t)a.dout | (uintptr_t)dpq | (uintptr_t)edge_stats) & 15) == 0;
-    if (quads && cout == 64) {
-        hipLaunchKernelGGL(ec_bwd_apply_mean4_kernel<64>, dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src,
-                           dpq, edge_stats);
-    } else if (quads) {
-        hipLaunchKernelGGL(ec_bwd_apply_mean4_kernel<128>, dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src,
-                           dpq, edge_stats);
+    if (quads) {
+        const bool one = ec_div_corrections(k) == 1;
+#define EC_BA4(COUT_, FIX_) hipLaunchKernelGGL((ec_bwd_apply_mean4_kernel<COUT_, FIX_>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src, dpq, edge_stats)
+        if (cout == 64 && one) EC_BA4(64, 1);
+        else if (cout == 64) EC_BA4(64, 2);
+        else if (one) EC_BA4(128, 1);
+        else EC_BA4(128, 2);
+#undef EC_BA4
     } else if (pool_mode == 1) {
 #define EC_BA(CPL_, KC_) hipLaunchKernelGGL((ec_bwd_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, m12, rev_off, rev_src, out, ldo, tie_count, dpq, training ? edge_stats : nullptr)
         EC_DISPATCH(EC_BA);

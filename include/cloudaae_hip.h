@@ -44,8 +44,9 @@ typedef void *cloudaae_stream_t; /* hipStream_t */
 /* The ABI revision this header describes: argument lists and struct layouts.  A caller built against another
  * revision must not call in -- check cloudaae_version() == CLOUDAAE_ABI_VERSION after loading (the Python host
  * does, cloudaae_amd/_lib.py).  500: round 5 (fully connected entry points take up to 128 rows; tickets / partials
- * queries take M; no y_zeroed argument).  600: round 6 (cloudaae_knn_hinted added; nothing else changed). */
-#define CLOUDAAE_ABI_VERSION 600
+ * queries take M; no y_zeroed argument).  600: round 6 (cloudaae_knn_hinted added; nothing else changed).
+ * 601: cloudaae_selftest_div_by added. */
+#define CLOUDAAE_ABI_VERSION 601
 int cloudaae_version(void);
 const char *cloudaae_last_error(void);
 /* Development knobs (kernel A/B choices and launch shapes for tests and sweeps; none is needed in normal use):
@@ -515,6 +516,13 @@ int cloudaae_fc_backward_group(int M, int count, const cloudaae_fc_layer *layers
  * (centre term of every edge of the point) and the last cout columns Q = X W_neighbour, which is how
  * cloudaae_edgeconv_backward expects to find it. */
 long long cloudaae_edgeconv_workspace_bytes(int cout);
+/* Self-test of the gradient pass's division by the neighbour count (mean pooling, utils/tf_util.py reduce_mean over k:
+ * models/pointnet_ycb_23_decoder_4.py:350): the kernels divide by a launch-wide constant d with the IEEE sequence's
+ * d-only part (reciprocal and its refinement, scaling of d) computed once -- six or eight instructions per quotient
+ * instead of eleven.  Walks ALL 2^32 float numerators x: count[0] = those whose quotient differs in its bits from x / d
+ * (two NaNs are equal), count[1] = bits of the largest magnitude among them.  count: 2 x u64, device memory.
+ * corrections: 1 or 2 remainder steps; 0 = what cloudaae_edgeconv_backward takes for k = d.  1 <= d <= 2^20. */
+int cloudaae_selftest_div_by(float d, int corrections, unsigned long long *count, cloudaae_stream_t stream);
 int cloudaae_edgeconv_forward(int b, int n, int k, int cin, int cout, const float *x, int ldx,
                               const int *nn_idx, const float *weights, const float *biases,
                               const float *gamma, const float *beta, int training, const float *decay,

@@ -281,6 +281,25 @@ def test_edge_conv_into_slot_and_eval_mode(hip, oracle):
     assert float(buf[:, :, :64].abs().max()) == 0 and float(buf[:, :, 128:].abs().max()) == 0
 
 
+def test_division_by_the_neighbour_count_is_the_division(hip):
+    """the mean-pool gradient pass divides by k once per gathered element with the IEEE sequence's k-only part taken out of
+    the loop (edgeconv.hip: ec_div_by): the quotient of EVERY float -- all 2^32 numerators, subnormal quotients, zeros,
+    infinities, NaN -- equals `x / k` in its bits.  Two correction steps: for every k a layer can have and a few other
+    divisors; one step: for the k the launcher uses it with (10 and 20) -- and not for every k, which is why there are two."""
+    from cloudaae_amd import _lib
+    count = torch.zeros(2, dtype=torch.int64, device="cuda")
+
+    def differing(d, corrections):
+        _lib.check(_lib.lib()._cdll.cloudaae_selftest_div_by(float(d), corrections, count.data_ptr(), _lib.stream()), "cloudaae_selftest_div_by")
+        return tuple(int(v) for v in count.cpu())
+    for d in list(range(1, 65)) + [100.0, 1000.0, 7.5, 123.456, 1.0000001, 1.9999999, 999999.0, 1048576.0]:
+        assert differing(d, 2) == (0, 0), d
+        assert differing(d, 0) == (0, 0), d          # the launcher's choice for k = d
+    assert differing(10, 1) == (0, 0) and differing(20, 1) == (0, 0)
+    bad, largest = differing(26, 1)
+    assert bad > 0 and largest < 0x01000000          # (only quotients in the subnormal range)
+
+
 def test_losses_vs_oracle(hip):
     from cloudaae_amd.losses import angular_distance_taylor, chamfer_loss, trans_distance
     from oracle import model_oracle as MO
