@@ -87,7 +87,13 @@ static int ec_div_corrections(int k) { return (k == 10 || k == 20) ? 1 : 2; }
 // all k pre-activation rows of one point, for this lane's CPL channels
 // US: the P' half of pq already holds U = P' - Q + bias (true in the backward kernels: every forward
 // call leaves it so)
-template <int CPL, int KCAP, bool US = false>
+//
+// FAST (the launcher takes it when k == KCAP: every configuration of the model): the loops over the neighbours carry no
+// `j < k` test, and the j-th neighbour's index comes out of lane j with v_readlane -- a constant lane, so the index and the
+// row address built from it live in SCALAR registers: a gather costs the vector unit nothing but the load itself.  (The
+// general form asks for the index with a cross-lane shuffle and forms a 64-bit address per lane and gather: the forward
+// kernels issued 27 vector instructions per edge value and were bound by that: `r06_step_all_pmc.json`.)
+template <int CPL, int KCAP, bool US = false, bool FAST = false>
 struct EcPoint {
     float y[KCAP][CPL];
     int nb[KCAP];
@@ -105,12 +111,12 @@ struct EcPoint {
         }
 #pragma unroll
         for (int j = 0; j < KCAP; ++j) {
-            if (j < a.k) {
-                nb[j] = base + __shfl(mine, j, 64);
-                const float *q = a.pq + (size_t)nb[j] * a.ldpq + a.cout + lane;
+            if (FAST || j < a.k) {
+                nb[j] = base + (FAST ? __builtin_amdgcn_readlane(mine, j) : __shfl(mine, j, 64));
+                const float *q = a.pq + (size_t)nb[j] * a.ldpq + a.cout;
 #pragma unroll
                 for (int e = 0; e < CPL; ++e)
-                    y[j][e] = u[e] + q[64 * e];
+                    y[j][e] = u[e] + q[(unsigned)lane + 64u * e];     // (unsigned: scalar base + 32-bit lane offset, no 64-bit vector address)
             }
         }
     }
@@ -120,9 +126,9 @@ struct EcPoint {
 // memory round trips for the PAIR.  A wave that handles its points one after the other pays the two
 // round trips per point, and (vmcnt retires in order) the stores of one point in front of the loads of
 // the next: ec_apply_kernel went from 11.5 to 26 us per layer when it got four more rows to store.
-template <int CPL, int KCAP, bool US>
-__device__ __forceinline__ void ec_load_pair(const EcArgs &a, int pt0, int pt1, int lane, EcPoint<CPL, KCAP, US> &p0,
-                                             EcPoint<CPL, KCAP, US> &p1)
+template <int CPL, int KCAP, bool US, bool FAST>
+__device__ __forceinline__ void ec_load_pair(const EcArgs &a, int pt0, int pt1, int lane, EcPoint<CPL, KCAP, US, FAST> &p0,
+                                             EcPoint<CPL, KCAP, US, FAST> &p1)
 {
     const int mine0 = lane < a.k ? a.nn_idx[(size_t)pt0 * a.k + lane] : 0;
     const int mine1 = lane < a.k ? a.nn_idx[(size_t)pt1 * a.k + lane] : 0;
@@ -140,15 +146,15 @@ __device__ __forceinline__ void ec_load_pair(const EcArgs &a, int pt0, int pt1, 
     float q0[KCAP][CPL], q1[KCAP][CPL];
 #pragma unroll
     for (int j = 0; j < KCAP; ++j)
-        if (j < a.k) {
-            p0.nb[j] = base0 + __shfl(mine0, j, 64);
-            p1.nb[j] = base1 + __shfl(mine1, j, 64);
-            const float *g0 = a.pq + (size_t)p0.nb[j] * a.ldpq + a.cout + lane;
-            const float *g1 = a.pq + (size_t)p1.nb[j] * a.ldpq + a.cout + lane;
+        if (FAST || j < a.k) {
+            p0.nb[j] = base0 + (FAST ? __builtin_amdgcn_readlane(mine0, j) : __shfl(mine0, j, 64));
+            p1.nb[j] = base1 + (FAST ? __builtin_amdgcn_readlane(mine1, j) : __shfl(mine1, j, 64));
+            const float *g0 = a.pq + (size_t)p0.nb[j] * a.ldpq + a.cout;
+            const float *g1 = a.pq + (size_t)p1.nb[j] * a.ldpq + a.cout;
 #pragma unroll
             for (int e = 0; e < CPL; ++e) {
-                q0[j][e] = g0[64 * e];
-                q1[j][e] = g1[64 * e];
+                q0[j][e] = g0[(unsigned)lane + 64u * e];
+                q1[j][e] = g1[(unsigned)lane + 64u * e];
             }
         }
 #pragma unroll
@@ -159,7 +165,7 @@ __device__ __forceinline__ void ec_load_pair(const EcArgs &a, int pt0, int pt1, 
     }
 #pragma unroll
     for (int j = 0; j < KCAP; ++j)
-        if (j < a.k) {
+        if (FAST || j < a.k) {
 #pragma unroll
             for (int e = 0; e < CPL; ++e) {
                 p0.y[j][e] = u0[e] + q0[j][e];
@@ -231,10 +237,10 @@ __device__ __forceinline__ void ec_block_reduce_store(double (&s)[CPL], double (
     }
 }
 
-template <int CPL, int KCAP>
+template <int CPL, int KCAP, bool FAST>
 __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_stats_kernel(EcArgs a, double *__restrict__ partial)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (the wave index in a scalar register: what follows from it -- point, cloud, row addresses -- is scalar arithmetic)
     double s[CPL], s2[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e)
@@ -245,11 +251,11 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_stats_kernel(EcArgs a, 
         // One point at a time: forty gathers in flight per lane are enough, and the sums take the same order.  (At 64
         // channels x 20 neighbours the pair form stays: 86 against 96 us.)
         ec_for_each_point<EC_STAT_WAVES>(a, wave, [&](int pt) {
-            EcPoint<CPL, KCAP> p;
+            EcPoint<CPL, KCAP, false, FAST> p;
             p.load(a, pt, lane);
 #pragma unroll
             for (int j = 0; j < KCAP; ++j)
-                if (j < a.k) {
+                if (FAST || j < a.k) {
 #pragma unroll
                     for (int e = 0; e < CPL; ++e) {
                         s[e] += (double)p.y[j][e];
@@ -261,12 +267,12 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_stats_kernel(EcArgs a, 
         return;
     }
     ec_for_each_pair<EC_STAT_WAVES>(a, wave, [&](int pt0, int pt1) {
-        EcPoint<CPL, KCAP> p0, p1;
+        EcPoint<CPL, KCAP, false, FAST> p0, p1;
         ec_load_pair(a, pt0, pt1 >= 0 ? pt1 : pt0, lane, p0, p1);
         const double w1 = pt1 >= 0 ? 1.0 : 0.0;
 #pragma unroll
         for (int j = 0; j < KCAP; ++j)
-            if (j < a.k) {
+            if (FAST || j < a.k) {
 #pragma unroll
                 for (int e = 0; e < CPL; ++e) {
                     s[e] += (double)p0.y[j][e];
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_stats_kernel(EcArgs a, 
             }
 #pragma unroll
         for (int j = 0; j < KCAP; ++j)
-            if (j < a.k) {
+            if (FAST || j < a.k) {
 #pragma unroll
                 for (int e = 0; e < CPL; ++e) {
                     s[e] += w1 * (double)p1.y[j][e];
@@ -286,18 +292,18 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_stats_kernel(EcArgs a, 
     ec_block_reduce_store<CPL>(s, s2, partial, a.cout, lane, wave);
 }
 
-template <int CPL, int KCAP, int POOL>
+template <int CPL, int KCAP, int POOL, bool FAST, bool STATS>
 __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float *__restrict__ out, int ldo,
                                                                 float *__restrict__ ties,
                                                                 float *__restrict__ edge_stats,
                                                                 float *__restrict__ u_out)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (the wave index in a scalar register: what follows from it -- point, cloud, row addresses -- is scalar arithmetic)
     // mean pool in training mode: per point and channel, what the backward statistics need of its k
     // edges -- how many pass the ReLU, the sum of their x_hat, the sum of all x_hat (edge_stats[P][3][cout]).
     // The upstream gradient of every edge of a point is the same number, so backward gets its column
     // sums from these without gathering a single neighbour (ec_bwd_stats_pool_kernel).
-    const bool stats = POOL == 1 && edge_stats != nullptr;
+    constexpr bool stats = STATS;      // (the launcher: POOL == 1 && edge_stats != nullptr)
     float sc[CPL], sh[CPL], mean[CPL], rstd[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e) {
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
         mean[e] = stats ? a.save_mean[lane + 64 * e] : 0.0f;
         rstd[e] = stats ? bn_rsqrt(a.save_var[lane + 64 * e] + BN_EPS) : 0.0f;
     }
-    auto finish = [&](const EcPoint<CPL, KCAP> &p, int pt, bool store) {
+    auto finish = [&](const EcPoint<CPL, KCAP, false, FAST> &p, int pt, bool store) {
         float acc[CPL], cnt[CPL], sx[CPL], sall[CPL];
 #pragma unroll
         for (int e = 0; e < CPL; ++e) {
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
         }
 #pragma unroll
         for (int j = 0; j < KCAP; ++j)
-            if (j < a.k) {
+            if (FAST || j < a.k) {
 #pragma unroll
                 for (int e = 0; e < CPL; ++e) {
                     const float z = fmaxf(p.y[j][e] * sc[e] + sh[e], 0.0f);
@@ -363,14 +369,14 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
         // form needs 113 / 135 registers (64 / 128 channels: four / three waves per SIMD).  Measured at [32, 4096, k = 20]:
         // 103 -> 86 us (64 channels), 215 -> 169 us (128); at k = 10 the pair form stays (16.7 against 17.7 us at [32, 1024])
         ec_for_each_point<EC_WAVES>(a, wave, [&](int pt) {
-            EcPoint<CPL, KCAP> p;
+            EcPoint<CPL, KCAP, false, FAST> p;
             p.load(a, pt, lane);
             finish(p, pt, true);
         });
         return;
     }
     ec_for_each_pair<EC_WAVES>(a, wave, [&](int pt0, int pt1) {
-        EcPoint<CPL, KCAP> p0, p1;
+        EcPoint<CPL, KCAP, false, FAST> p0, p1;
         ec_load_pair(a, pt0, pt1 >= 0 ? pt1 : pt0, lane, p0, p1);
         finish(p0, pt0, true);
         finish(p1, pt1, pt1 >= 0);
@@ -424,7 +430,7 @@ __device__ __forceinline__ void ec_upstream(const EcArgs &a, const EcPoint<CPL, 
 template <int CPL, int KCAP, int POOL>
 __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_bwd_stats_kernel(EcArgs a, double *__restrict__ partial)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (the wave index in a scalar register: what follows from it -- point, cloud, row addresses -- is scalar arithmetic)
     float sc[CPL], sh[CPL], mean[CPL], rstd[CPL];
     double s[CPL], s2[CPL], s3[CPL], zero[CPL];
 #pragma unroll
@@ -467,7 +473,7 @@ __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_bwd_stats_pool_kernel(E
                                                                               const float *__restrict__ edge_stats,
                                                                               double *__restrict__ partial)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (the wave index in a scalar register: what follows from it -- point, cloud, row addresses -- is scalar arithmetic)
     double s[CPL], s2[CPL], s3[CPL], zero[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e)
@@ -649,7 +655,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_kernel(
     const float *__restrict__ fwd_out, int ldo, const float *__restrict__ ties, float *__restrict__ dpq,
     const float *__restrict__ edge_stats)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (the wave index in a scalar register: what follows from it -- point, cloud, row addresses -- is scalar arithmetic)
     float sc[CPL], sh[CPL], mean[CPL], rstd[CPL], gr[CPL], m1[CPL], m2[CPL], bias[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e) {
@@ -772,7 +778,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_mean4_kernel(
     constexpr int LPR = COUT / 4;          // lanes per row
     constexpr int SPI = 64 / LPR;          // source rows per load instruction
     constexpr int RU = 4;                  // load instructions per array in flight
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (the wave index in a scalar register: what follows from it -- point, cloud, row addresses -- is scalar arithmetic)
     const int grp = lane / LPR, c0 = 4 * (lane % LPR);
     float sc[4], sh[4], mean[4], rstd[4], gr[4], m1[4], m2[4];
 #pragma unroll
@@ -1001,7 +1007,11 @@ static int ec_forward_impl(const char *name, int b, int n, int k, int cin, int c
     const int cpl = cout / 64, kcap = k <= 10 ? 10 : (k <= 20 ? 20 : 32);
     const int grid = ec_stat_grid(P), agrid = ec_apply_grid(P);
     if (training) {
-#define EC_STATS(CPL_, KC_) hipLaunchKernelGGL((ec_stats_kernel<CPL_, KC_>), dim3(grid), dim3(64 * EC_STAT_WAVES), 0, s, a, partial)
+#define EC_STATS(CPL_, KC_)                                                                                                     \
+    do {                                                                                                                         \
+        if (k == KC_) hipLaunchKernelGGL((ec_stats_kernel<CPL_, KC_, true>), dim3(grid), dim3(64 * EC_STAT_WAVES), 0, s, a, partial); \
+        else hipLaunchKernelGGL((ec_stats_kernel<CPL_, KC_, false>), dim3(grid), dim3(64 * EC_STAT_WAVES), 0, s, a, partial);   \
+    } while (0)
         EC_DISPATCH(EC_STATS);
 #undef EC_STATS
     }
@@ -1018,11 +1028,21 @@ static int ec_forward_impl(const char *name, int b, int n, int k, int cin, int c
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(cout, BN_FIN_CH)), dim3(BN_FIN_THREADS), 0, s, cout, sums, fin_parts,
                        count, training, decay, ema_mean, ema_var, gamma, beta, save_mean, save_var, scale_shift);
     if (pool_mode == 1) {
-#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 1>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, es, pq)
+#define EC_APPLY(CPL_, KC_)                                                                                                     \
+    do {                                                                                                                         \
+        if (k == KC_ && es != nullptr) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 1, true, true>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, es, pq); \
+        else if (k == KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 1, true, false>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, es, pq); \
+        else if (es != nullptr) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 1, false, true>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, es, pq); \
+        else hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 1, false, false>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, es, pq);   \
+    } while (0)
         EC_DISPATCH(EC_APPLY);
 #undef EC_APPLY
     } else {
-#define EC_APPLY(CPL_, KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 2>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, nullptr, pq)
+#define EC_APPLY(CPL_, KC_)                                                                                                     \
+    do {                                                                                                                         \
+        if (k == KC_) hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 2, true, false>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, nullptr, pq); \
+        else hipLaunchKernelGGL((ec_apply_kernel<CPL_, KC_, 2, false, false>), dim3(agrid), dim3(64 * EC_WAVES), 0, s, a, out, ldo, tie_count, nullptr, pq);   \
+    } while (0)
         EC_DISPATCH(EC_APPLY);
 #undef EC_APPLY
     }
