@@ -21,6 +21,16 @@
 // dX and dW.
 // This is an algebraic refactoring of the reference arithmetic: results agree with
 // the edge-tensor formulation to fp32 round-off, not bitwise.
+// The file is compiled TWICE (csrc/Makefile): edgeconv.o holds the forward kernels and entry points
+// (-DCLOUDAAE_EC_PART=1, without the packed-fp32 feature: the compiler paired the two channels of a lane in
+// ec_stats_kernel<2, ...> with an `op_sel` form -- Makefile, tests/test_isa_rules.py), edgeconv_bwd.o the backward
+// ones (-DCLOUDAAE_EC_PART=2, with packed arithmetic: the gradient pass is bound by its vector instructions and 15 % of
+// them are packed; the ISA test reads that object too).  Without the macro everything is in one object.
+#ifndef CLOUDAAE_EC_PART
+#define CLOUDAAE_EC_PART 0
+#endif
+#define EC_FWD (CLOUDAAE_EC_PART != 2)
+#define EC_BWD (CLOUDAAE_EC_PART != 1)
 #include "bn_common.h"
 #include "gemm.h"
 #include "../../include/cloudaae_hip.h"
@@ -237,6 +247,7 @@ __device__ __forceinline__ void ec_block_reduce_store(double (&s)[CPL], double (
     }
 }
 
+#if EC_FWD
 template <int CPL, int KCAP, bool FAST>
 __global__ __launch_bounds__(64 * EC_STAT_WAVES) void ec_stats_kernel(EcArgs a, double *__restrict__ partial)
 {
@@ -383,6 +394,9 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_apply_kernel(EcArgs a, float
     });
 }
 
+#endif   // EC_FWD
+
+#if EC_BWD
 // upstream gradient of z_ij for one point: mean -> dout/k; max -> dout shared among
 // the equal maxima (tf.reduce_max gradient), both masked by ReLU.
 template <int CPL, int KCAP, int POOL>
@@ -854,6 +868,8 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_mean4_kernel(
     });
 }
 
+#endif   // EC_BWD
+
 static int ec_stat_grid(int P)
 {
     int g = ceil_div(ceil_div(P, EC_STAT_WAVES * 2), 8) * 8;   // multiple of 8: one share per XCD
@@ -896,6 +912,7 @@ static int ec_gemm(const char *name, int bf16, int ta, int tb, int M, int N, int
                                   (hipStream_t)stream);
 }
 
+#if EC_BWD
 static int ec_launch_revlists(const char *name, int count, int b, int n, int k, const int *const *nn_idx,
                               int *const *rev, hipStream_t s)
 {
@@ -962,10 +979,15 @@ CLOUDAAE_API int cloudaae_selftest_div_by(float d, int corrections, unsigned lon
     return 0;
 }
 
+#endif   // EC_BWD
+
+#if EC_FWD
 CLOUDAAE_API long long cloudaae_edgeconv_workspace_bytes(int cout)
 {
     return (long long)(ec_ws_doubles(cout) * sizeof(double));
 }
+
+#endif   // EC_FWD
 
 static int ec_check(const char *name, int b, int n, int k, int cin, int cout, int pool_mode)
 {
@@ -976,6 +998,7 @@ static int ec_check(const char *name, int b, int n, int k, int cin, int cout, in
     return 0;
 }
 
+#if EC_FWD
 static int ec_forward_impl(const char *name, int b, int n, int k, int cin, int cout, const float *x, int ldx,
                            const int *nn_idx, const float *weights, const float *biases,
                            const float *gamma, const float *beta, int training,
@@ -1093,6 +1116,9 @@ CLOUDAAE_API int cloudaae_edgeconv_forward_sync(int b, int n, int k, int cin, in
                            tie_count, edge_stats, gemm_bf16, workspace, sync, stream);
 }
 
+#endif   // EC_FWD
+
+#if EC_BWD
 static int ec_backward_impl(const char *name, int b, int n, int k, int cin, int cout, const float *x, int ldx,
                             const int *nn_idx, const float *weights, const float *biases,
                             const float *gamma, const float *beta, int training,
@@ -1245,3 +1271,5 @@ CLOUDAAE_API int cloudaae_edgeconv_backward_sync(int b, int n, int k, int cin, i
                             rev_scratch, rev_ready, dx, lddx, accumulate_dx, dweights, dweights_zeroed, dbiases, dgamma,
                             dbeta, edge_stats, gemm_bf16, workspace, sync, stream, side_stream);
 }
+
+#endif   // EC_BWD
