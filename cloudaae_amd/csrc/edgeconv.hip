@@ -845,7 +845,7 @@ __global__ __launch_bounds__(64 * EC_WAVES) void ec_bwd_apply_mean4_kernel(
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float y = ui[u][e] + qm[e];   // U of the source point + Q of this one
-                            const float z = fmaxf(y * sc[e] + sh[e], 0.0f);
+                            const float z = y * sc[e] + sh[e];  // (ReLU passes the edge iff this is positive: no max needed to ask)
                             float d = ec_div_by<FIX>(gi[u][e], fk, rk);      // == gi / k, bit for bit
                             if (!(z > 0.0f))
                                 d = 0.0f;
