@@ -354,7 +354,14 @@ def test_knn_hinted_vs_oracle(hip, oracle, b, n, k, hint_kind):
         assert np.array_equal(want, g)
         # the bound really is one: at least k candidates at or below it
         d = oracle.knn(x, k, channels=64, threads=8, return_dist=True)[1]
-        assert (tau.cpu().numpy() >= d[:, :, k - 1]).all()
+        t = tau.cpu().numpy()
+        assert (t >= d[:, :, k - 1]).all()
+        if hint_kind == "exact":
+            # the hinted points ARE the neighbours: the bound is their largest distance plus the rounding allowance of
+            # knn64_hint_bound_kernel (1.25 x 2^-17 of the two squared norms), no looser
+            norms = (x.astype(np.float64) ** 2).sum(-1)
+            slack = 2.0 ** -16 * (norms + norms.max(axis=1, keepdims=True)) + 1e-30
+            assert (t <= d[:, :, k - 1] * (1 + 1e-5) + slack).all()
 
 
 @pytest.mark.parametrize("wide", [1, 0])
