@@ -982,6 +982,82 @@ CLOUDAAE_API int cloudaae_selftest_div_by(float d, int corrections, unsigned lon
 #endif   // EC_BWD
 
 #if EC_FWD
+// [P' | Q] = X [W_centre | W_neighbour] for 64 input channels, streamed.  The general fp32 product (gemm.hip) runs these
+// shapes -- 32768 x 64 times 64 x 128 -- at 2.0 - 2.3 TB/s: a workgroup is one chain load -> stage -> 32 MFMAs -> store and
+// fetches its own copy of the weights (`notes_gemm_f32.md`).  Here a wave keeps its 32 (64) columns of the folded kernel in
+// REGISTERS for the whole launch (32 (64) B operands of v_mfma_f32_32x32x2_f32), the workgroup walks 32-row tiles of X:
+// global -> registers one tile ahead, registers -> LDS as [32 even channels | 32 odd | pad] (the layout the A operand reads
+// with eight ds_read_b128: lane = row, half = parity), two LDS buffers so that one barrier per tile is enough.  The k order
+// of the accumulation is the general kernel's (0, 1, ..., 63 in pairs), so the product has the same bits
+// (tests/test_01_layers_gpu.py: test_edge_conv_streamed_product_equals_the_general_one).  11.5 -> 9.6 us (128 columns) and
+// 19.1 -> 15.6 us (256) at 32768 rows, whatever the grid: a launch that moves 25 MB does not get much below that.
+typedef float ec_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int EC_PQ_LD = 68;
+template <int NOUT>
+__global__ __launch_bounds__(256) void ec_pq_stream_kernel(int P, const float *__restrict__ x, int ldx,
+                                                          const float *__restrict__ w, int cout, float *__restrict__ pq)
+{
+    constexpr int CIN = 64, TN = NOUT / 128;                 // 32 x 32 tiles per wave
+    __shared__ __attribute__((aligned(16))) float lds[2][32 * EC_PQ_LD];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int n0 = wave * (NOUT / 4);
+    // B operands: step s, tile j: Bf[2 s + half][n0 + 32 j + col], Bf(kk, c) = w[((c / cout) * CIN + kk) * cout + c % cout]
+    float b[32][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = n0 + 32 * j + col;
+        const float *wc = w + ((size_t)(c / cout) * CIN) * cout + c % cout;
+#pragma unroll
+        for (int st = 0; st < 32; ++st)
+            b[st][j] = wc[(size_t)(2 * st + half) * cout];
+    }
+    const int ntiles = P / 32;
+    // staging share of a thread: two 16-byte pieces of the tile's 32 x 64 floats (16 lanes per row: coalesced)
+    const int r0 = threadIdx.x >> 4, f = threadIdx.x & 15;     // rows r0 and r0 + 16, floats 4 f .. 4 f + 3
+    float4v g0, g1;
+    int t = blockIdx.x;
+    if (t < ntiles) {
+        g0 = *reinterpret_cast<const float4v *>(x + (size_t)(32 * t + r0) * ldx + 4 * f);
+        g1 = *reinterpret_cast<const float4v *>(x + (size_t)(32 * t + r0 + 16) * ldx + 4 * f);
+    }
+    for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
+        float *buf = lds[it & 1];
+        *reinterpret_cast<float2 *>(buf + r0 * EC_PQ_LD + 2 * f) = float2{g0.x, g0.z};
+        *reinterpret_cast<float2 *>(buf + r0 * EC_PQ_LD + 32 + 2 * f) = float2{g0.y, g0.w};
+        *reinterpret_cast<float2 *>(buf + (r0 + 16) * EC_PQ_LD + 2 * f) = float2{g1.x, g1.z};
+        *reinterpret_cast<float2 *>(buf + (r0 + 16) * EC_PQ_LD + 32 + 2 * f) = float2{g1.y, g1.w};
+        __syncthreads();
+        const int tn = t + (int)gridDim.x;
+        if (tn < ntiles) {                                   // the next tile travels under this one's products
+            g0 = *reinterpret_cast<const float4v *>(x + (size_t)(32 * tn + r0) * ldx + 4 * f);
+            g1 = *reinterpret_cast<const float4v *>(x + (size_t)(32 * tn + r0 + 16) * ldx + 4 * f);
+        }
+        float4v a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            a[u] = *reinterpret_cast<const float4v *>(buf + col * EC_PQ_LD + 32 * half + 4 * u);
+        ec_f32x16 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[j][r] = 0.0f;
+#pragma unroll
+        for (int st = 0; st < 32; ++st)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st >> 2][st & 3], b[st][j], acc[j], 0, 0, 0);
+        // lane holds column (lane & 31), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        float *c0 = pq + (size_t)(32 * t + 4 * half) * NOUT + n0 + col;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                c0[(size_t)((r & 3) + 8 * (r >> 2)) * NOUT + 32 * j] = acc[j][r];
+    }
+}
+
 CLOUDAAE_API long long cloudaae_edgeconv_workspace_bytes(int cout)
 {
     return (long long)(ec_ws_doubles(cout) * sizeof(double));
@@ -1016,7 +1092,16 @@ static int ec_forward_impl(const char *name, int b, int n, int k, int cin, int c
     hipStream_t s = (hipStream_t)stream;
     const int P = b * n;
     // [P' | Q] = X [W_centre | W_neighbour]: ONE product over the folded kernel (cout is 64 or 128)
-    int rc = ec_gemm(name, gemm_bf16, 0, 0, P, 2 * cout, cin, x, ldx, weights, cout, pq, 2 * cout, 0, cout, 0, stream);
+    int rc = 0;
+    if (!gemm_bf16 && cin == 64 && P % 32 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0) {
+        const int grid = P / 32 < 512 ? P / 32 : 512;          // two workgroups per CU, tiles in turn (256 .. 2048: the same time)
+        if (cout == 64)
+            hipLaunchKernelGGL(ec_pq_stream_kernel<128>, dim3(grid), dim3(256), 0, s, P, x, ldx, weights, cout, pq);
+        else
+            hipLaunchKernelGGL(ec_pq_stream_kernel<256>, dim3(grid), dim3(256), 0, s, P, x, ldx, weights, cout, pq);
+    } else {
+        rc = ec_gemm(name, gemm_bf16, 0, 0, P, 2 * cout, cin, x, ldx, weights, cout, pq, 2 * cout, 0, cout, 0, stream);
+    }
     if (rc)
         return rc;
     double *partial = (double *)workspace;

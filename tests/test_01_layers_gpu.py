@@ -300,6 +300,27 @@ def test_division_by_the_neighbour_count_is_the_division(hip):
     assert bad > 0 and largest < 0x01000000          # (only quotients in the subnormal range)
 
 
+@pytest.mark.parametrize("cout", [64, 128])
+def test_edge_conv_streamed_product_equals_the_general_one(hip, cout):
+    """[P' | Q] = X [W_c | W_n] at 64 input channels goes through ec_pq_stream_kernel (weights in registers, rows streamed);
+    rows that are not 16-byte aligned take the general fp32 product.  Same k order in both: the same bits."""
+    from cloudaae_amd.utils import _functions as F
+    B, N, c, k = 2, 512, 64, 10
+    g = torch.Generator(device="cuda").manual_seed(cout)
+    wide = torch.randn((B, N, c + 1), generator=g, device="cuda")
+    x_odd = wide[:, :, :c]                                   # row stride 65 floats: the general product
+    x = x_odd.contiguous()                                   # row stride 64: the streamed one
+    W = torch.randn((2 * c, cout), generator=g, device="cuda") * 0.1
+    idx = torch.randint(0, N, (B, N, k), generator=g, device="cuda", dtype=torch.int32)
+    gamma, beta = torch.rand(cout, generator=g, device="cuda") + 0.5, torch.randn(cout, generator=g, device="cuda") * 0.1
+
+    def fwd(xx):
+        return F.EdgeConvFn.apply(xx, idx, W, torch.zeros(cout, device="cuda"), gamma, beta, torch.zeros(cout, device="cuda"),
+                                  torch.ones(cout, device="cuda"), torch.full((1,), 0.5, device="cuda"), True, 1, None)
+    assert x_odd.stride(1) == c + 1 and x.stride(1) == c
+    assert torch.equal(fwd(x), fwd(x_odd))
+
+
 def test_losses_vs_oracle(hip):
     from cloudaae_amd.losses import angular_distance_taylor, chamfer_loss, trans_distance
     from oracle import model_oracle as MO
