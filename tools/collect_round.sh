@@ -14,6 +14,9 @@ timeout 400 bash tools/profile_step.sh ${R}_trainstep_b32_n1024 "B=32,N=1024"
 timeout 400 bash tools/profile_step.sh ${R}_trainstep_b128_n1024 "B=128,N=1024" --per-gpu-batch 128
 timeout 500 bash tools/profile_step.sh ${R}_trainstep_b256_n1024_bf16 "B=256,N=1024" --per-gpu-batch 256 --gemm-dtype bf16
 timeout 500 bash tools/profile_step.sh ${R}_config5_b32_n4096_k20 "B=32,N=4096" --config5
+# (the bench lines below take `roofline.traffic` from profiles/roofline_traffic.json: put THIS run's file there first, so that a
+#  collection made right after a priced source changed carries the number in its own lines)
+[ -f "$ROOT/gpurun_out/${R}_trainstep_b32_n1024/summary/roofline_traffic.json" ] && cp "$ROOT/gpurun_out/${R}_trainstep_b32_n1024/summary/roofline_traffic.json" "$ROOT/profiles/roofline_traffic.json"
 # kernel sequences of one replayed step
 bash tools/kernel_sequence.sh > "$OUT/${R}_step_kernel_sequence_b32.txt" 2>&1
 bash tools/kernel_sequence.sh --config5 > "$OUT/${R}_step_kernel_sequence_config5.txt" 2>&1
